@@ -1,0 +1,167 @@
+"""Shared by make_golden.py (runs where /root/reference exists) and the tests.
+
+Fixtures hold only arrays: inputs and the reference's outputs.  Weights are NOT
+stored: both sides regenerate them from a seeded NumPy stream with a fixed draw
+order (``make_params``), which keeps the fixtures to a few hundred KB.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+CFG_DEFAULTS = dict(
+    n_embed=128, n_position=256, n_layer=2, n_head=4, n_inner=None, pre_lnorm=False, mem_len=256,
+    same_length=True, untie_r=False, text_vocab_size=32000, num_discrete_values=1024,
+    num_continuous_bin=1024, overlap_with_text=True, embd_pdrop=0.0, drop=0.0, dropattn=0.0,
+    activation_fn="geglu", layer_norm_epsilon=1e-5, share_input_output_embedding=True,
+    use_deepnorm=False, fp16=False, vision_patch_size=16, vision_num_input_channels=3,
+    vision_position_vocab_size=128, vision_hidden_dropout_prob=0.0,
+)
+
+# the fixture cases: name -> config overrides
+CASES = {
+    # BASELINE.json configs[0]: DB1-tiny text-only seq-len 256
+    "tiny_nlp": dict(),
+    # mixed RL(+image) / NLP / caption batch, small vocabulary
+    "small_mixed": dict(n_embed=64, n_head=2, n_position=48, mem_len=48, text_vocab_size=300,
+                        num_continuous_bin=64, num_discrete_values=64),
+    # sliding-window mask (0 < mem_len < L)
+    "small_window": dict(n_embed=64, n_head=2, n_position=48, mem_len=16, text_vocab_size=300,
+                         num_continuous_bin=64, num_discrete_values=64),
+    # the other flag values: gelu FF, untied u/v, separate lm_head, deepnorm, no vocabulary overlap
+    "small_flags": dict(n_embed=64, n_head=4, n_position=40, mem_len=40, text_vocab_size=200,
+                        num_continuous_bin=32, num_discrete_values=16, overlap_with_text=False,
+                        activation_fn="gelu", untie_r=True, share_input_output_embedding=False,
+                        use_deepnorm=True, n_inner=96),
+    "small_prelnorm": dict(n_embed=64, n_head=2, n_position=40, mem_len=40, text_vocab_size=200,
+                           num_continuous_bin=32, num_discrete_values=32, pre_lnorm=True, same_length=False),
+    # inference with Transformer-XL memory (evaluate_rl.py:157-266 call pattern)
+    "small_mems": dict(n_embed=64, n_head=2, n_position=24, mem_len=24, text_vocab_size=300,
+                       num_continuous_bin=64, num_discrete_values=64, n_layer=3),
+}
+
+
+def case_cfg(name: str) -> dict:
+    c = dict(CFG_DEFAULTS)
+    c.update(CASES[name])
+    return c
+
+
+def param_shapes(cfg: dict):
+    """state_dict names/shapes in a fixed order (ic_encoder.* aliases and tied per-layer
+    r_*_bias aliases omitted; pos_emb.inv_freq is a buffer and is stored in the fixture)."""
+    d, H = cfg["n_embed"], cfg["n_head"]
+    D = d // H
+    di = 4 * d if cfg["n_inner"] is None else cfg["n_inner"]
+    V = cfg["text_vocab_size"] + cfg["num_continuous_bin"] + (0 if cfg["overlap_with_text"] else cfg["num_discrete_values"]) + 1
+    ps, C = cfg["vision_patch_size"], cfg["vision_num_input_channels"]
+    out = []
+    if not cfg["untie_r"]:
+        out += [("r_w_bias", (H, D)), ("r_r_bias", (H, D))]
+    out += [("word_embedding.weight", (V, d))]
+    pe = "vision_encoder.patch_embeddings."
+    out += [(pe + "conv1.weight", (64, C, 3, 3)), (pe + "conv1.bias", (64,)),
+            (pe + "projection.weight", (d, 64, ps, ps)), (pe + "projection.bias", (d,)),
+            (pe + "residual_path.0.weight", (64,)), (pe + "residual_path.0.bias", (64,)),
+            (pe + "residual_path.2.weight", (64, 64, 3, 3)), (pe + "residual_path.2.bias", (64,)),
+            (pe + "residual_path.3.weight", (64,)), (pe + "residual_path.3.bias", (64,)),
+            (pe + "residual_path.5.weight", (64, 64, 3, 3)), (pe + "residual_path.5.bias", (64,)),
+            ("vision_encoder.row_position_embeddings.weight", (cfg["vision_position_vocab_size"], d)),
+            ("vision_encoder.col_position_embeddings.weight", (cfg["vision_position_vocab_size"], d)),
+            ("rl_local_timestep_embedding.weight", (513, d))]
+    for i in range(cfg["n_layer"]):
+        p = f"h.{i}."
+        if cfg["untie_r"]:
+            out += [(p + "dec_attn.r_r_bias", (H, D)), (p + "dec_attn.r_w_bias", (H, D))]
+        out += [(p + "dec_attn.qkv_net.weight", (3 * d, d)), (p + "dec_attn.o_net.weight", (d, d)),
+                (p + "dec_attn.r_net.weight", (d, d)),
+                (p + "dec_attn.layer_norm.weight", (d,)), (p + "dec_attn.layer_norm.bias", (d,)),
+                (p + "pos_ff.CoreNet.0.weight", (di, d)), (p + "pos_ff.CoreNet.0.bias", (di,)),
+                (p + "pos_ff.CoreNet.2.weight", (d, di // 2 if cfg["activation_fn"] == "geglu" else di)),
+                (p + "pos_ff.CoreNet.2.bias", (d,)),
+                (p + "pos_ff.layer_norm.weight", (d,)), (p + "pos_ff.layer_norm.bias", (d,))]
+    if not cfg["share_input_output_embedding"]:
+        out += [("lm_head.weight", (V, d))]
+    return out
+
+
+def make_params(cfg: dict, seed: int):
+    """Deterministic float32 weights.  Larger std than the reference's 0.02 init and
+    non-trivial LN/GN/bias values so every term of the forward/backward is exercised."""
+    rng = np.random.default_rng(seed)
+    params = {}
+    for name, shape in param_shapes(cfg):
+        if name.endswith("layer_norm.weight") or ("residual_path" in name and name.endswith(".weight") and len(shape) == 1):
+            a = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif name.endswith(".bias") or name.endswith("r_w_bias") or name.endswith("r_r_bias"):
+            a = 0.05 * rng.standard_normal(shape)
+        elif "projection.weight" in name:
+            a = 0.01 * rng.standard_normal(shape)
+        elif "conv" in name or "residual_path" in name:
+            a = 0.06 * rng.standard_normal(shape)
+        else:
+            a = 0.05 * rng.standard_normal(shape)
+        params[name] = a.astype(np.float32)
+    return params
+
+
+def sample_idx(n: int, k: int = 256):
+    """Fixed subsample of a flat tensor of n elements (<= k entries)."""
+    if n <= k:
+        return np.arange(n)
+    return (np.arange(k, dtype=np.int64) * (n // k)) + (np.arange(k) % 7) % max(1, n // k)
+
+
+def make_batch(name: str, cfg: dict, seed: int):
+    """Synthetic task inputs for a case: list of dicts with the reference's field names."""
+    rng = np.random.default_rng(seed + 1000)
+    L = cfg["n_position"]
+    V_text = cfg["text_vocab_size"]
+    sep = cfg["text_vocab_size"] + cfg["num_continuous_bin"] + (0 if cfg["overlap_with_text"] else cfg["num_discrete_values"])
+    tasks = []
+
+    def nlp(B):
+        ids = rng.integers(0, V_text, size=(B, L + 1))
+        lm = (rng.random((B, L)) > 0.2).astype(np.float32)
+        lm[:, -1] = 1.0
+        return dict(kind="nlp", text_seq=ids[:, :-1].copy(), label=ids[:, 1:].copy(), loss_mask=lm)
+
+    if name == "tiny_nlp":
+        ids = rng.integers(0, 32000, size=(8, L + 1))
+        tasks.append(dict(kind="nlp", text_seq=ids[:, :-1].copy(), label=ids[:, 1:].copy(),
+                          loss_mask=np.ones((8, L), np.float32)))
+    elif name in ("small_mixed",):
+        # RL: obs = one 32x32 image (4 patches) + 2 tensor tokens, SEP, 1 action -> 8 tokens/transition
+        B, ntr = 2, L // 8
+        seq = np.zeros((B, L + 1), np.int64)
+        for b in range(B):
+            row = []
+            for t in range(ntr + 1):
+                row += [-1] * 4 + list(V_text + rng.integers(0, cfg["num_continuous_bin"], 2)) + [sep] + [int(rng.integers(0, 18))]
+            seq[b] = np.array(row[:L + 1])
+        inp, lab = seq[:, :-1].copy(), seq[:, 1:].copy()
+        step = 8
+        within = np.arange(L) % step
+        pos = np.where(within <= 6, within + 1, 0)
+        lm = np.zeros((B, L), np.float32)
+        lm[:, within == 6] = 1.0  # label at the separator position is the action token
+        nimg = int((inp[0] == -1).sum()) // 4
+        vision = rng.random((B, nimg, 3, 32, 32)).astype(np.float32) * 255.0
+        tasks.append(dict(kind="rl", tensor_seq=inp, vision_seq=vision, position_id=np.tile(pos, (B, 1)),
+                          label=lab, loss_mask=lm))
+        tasks.append(nlp(2))
+        # caption: prompt 4 + image 32x48 (6 patches) + text
+        Bc, P, nv = 2, 4, 6
+        T = L - P - nv
+        prompt = rng.integers(0, V_text, size=(Bc, P))
+        text = rng.integers(0, V_text, size=(Bc, T))
+        img = rng.standard_normal((Bc, 3, 32, 48)).astype(np.float32)
+        label = rng.integers(0, V_text, size=(Bc, L))
+        lm = np.zeros((Bc, L), np.float32)
+        lm[:, P + nv - 1:] = (rng.random((Bc, T + 1)) > 0.3)
+        lm[:, P + nv - 1] = 1.0
+        tasks.append(dict(kind="ic", prompt_seq=prompt, img_seq=img, text_seq=text, label=label, loss_mask=lm))
+    elif name in ("small_window", "small_flags", "small_prelnorm"):
+        tasks.append(nlp(3))
+    elif name == "small_mems":
+        pass
+    return tasks

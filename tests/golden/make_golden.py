@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from /root/reference).
+
+Run only in the build container (the reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Nothing from the reference is copied: the fixtures contain input arrays and the
+reference's output arrays only.  Weights are regenerated on both sides from
+``golden_util.make_params``.
+"""
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("DB1_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+
+import torch  # noqa: E402
+from golden_util import CASES, case_cfg, make_params, make_batch, sample_idx  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def build_ref_model(cfg, params):
+    from src.model import TransformerXL
+    m = TransformerXL(SimpleNamespace(**cfg))
+    sd = m.state_dict()
+    new = {}
+    for k, v in sd.items():
+        k2 = k.replace("ic_encoder.", "vision_encoder.")
+        if k2 in params:
+            new[k] = torch.from_numpy(params[k2])
+        elif not cfg["untie_r"] and (k.endswith("dec_attn.r_w_bias") or k.endswith("dec_attn.r_r_bias")):
+            new[k] = torch.from_numpy(params[k.split(".")[-1]])
+        else:
+            assert k == "pos_emb.inv_freq", k
+            new[k] = v
+    m.load_state_dict(new)
+    m.eval()  # deterministic vision position ids; all dropout p are 0 anyway
+    return m
+
+
+def to_ref_inputs(tasks):
+    from src.data.input_specs import NLPTaskInput, RLTaskInput, ICTaskInput
+    T = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+    out = []
+    for t in tasks:
+        base = dict(position_id=T(t.get("position_id")), attention_mask=None, loss_mask=T(t.get("loss_mask")), label=T(t.get("label")))
+        if t["kind"] == "nlp":
+            out.append(NLPTaskInput(text_seq=T(t["text_seq"]), text_len=None, **base))
+        elif t["kind"] == "rl":
+            out.append(RLTaskInput(text_seq=None, vision_seq=T(t["vision_seq"]), tensor_seq=T(t["tensor_seq"]), **base))
+        elif t["kind"] == "ic":
+            out.append(ICTaskInput(prompt_seq=T(t["prompt_seq"]), img_seq=T(t["img_seq"]), text_seq=T(t["text_seq"]), img_id_seq=None, **base))
+    return out
+
+
+def gen_model_case(name, seed):
+    cfg = case_cfg(name)
+    params = make_params(cfg, seed)
+    m = build_ref_model(cfg, params)
+    out = {"inv_freq": m.pos_emb.inv_freq.numpy().copy()}
+    if name == "small_mems":
+        # 3 consecutive calls with memory, qlen 5 / 1 / 7
+        rng = np.random.default_rng(seed + 7)
+        mems = m.init_mem(2)
+        for step, q in enumerate((5, 1, 7)):
+            ids = rng.integers(0, cfg["text_vocab_size"], size=(2, q))
+            from src.data.input_specs import NLPTaskInput
+            x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None,
+                             text_seq=torch.from_numpy(ids), text_len=None)
+            with torch.no_grad():
+                logits, _, mems = m([x], compute_loss=False, mems=mems)
+            out[f"ids{step}"] = ids
+            out[f"logits{step}"] = logits.numpy()
+            out[f"mem_last{step}"] = mems[-1].numpy()
+        return out
+    tasks = make_batch(name, cfg, seed)
+    logits, loss = m(to_ref_inputs(tasks))
+    loss.backward()
+    lg = logits.detach().numpy()
+    out["loss"] = np.float64(loss.item())
+    out["logits_shape"] = np.array(lg.shape)
+    out["logits_sample"] = lg.reshape(-1)[sample_idx(lg.size, 4096)]
+    out["logits_norm"] = np.float64(np.sqrt((lg.astype(np.float64) ** 2).sum()))
+    for k, p in m.named_parameters():
+        if k.startswith("ic_encoder."):
+            continue
+        if not cfg["untie_r"] and ("dec_attn.r_w_bias" in k or "dec_attn.r_r_bias" in k):
+            continue
+        g = p.grad
+        g = np.zeros(p.shape, np.float32) if g is None else g.numpy()
+        out["gnorm/" + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        out["gsample/" + k] = g.reshape(-1)[sample_idx(g.size)]
+    return out
+
+
+def gen_patch_embed(seed):
+    from src.tokenizer.vision_embedding import PatchEmbeddings
+    cfg = case_cfg("small_mixed")
+    params = make_params(cfg, seed)
+    pe = PatchEmbeddings(16, 3, cfg["n_embed"], data_type=torch.float32)
+    pe.load_state_dict({k.replace("vision_encoder.patch_embeddings.", ""): torch.from_numpy(v)
+                        for k, v in params.items() if k.startswith("vision_encoder.patch_embeddings.")})
+    rng = np.random.default_rng(seed + 3)
+    img = (rng.random((3, 3, 32, 48)) * 255).astype(np.float32)
+    y = pe(torch.from_numpy(img))
+    G = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    (y * torch.from_numpy(G)).sum().backward()
+    out = {"img": img, "G": G, "y": y.detach().numpy()}
+    for k, p in pe.named_parameters():
+        out["grad/" + k] = p.grad.numpy()
+    return out
+
+
+def gen_scalar_tokenizer(seed):
+    from src.tokenizer.scalar_tokenizer import ContinuousScalarTokenizer
+    tok = ContinuousScalarTokenizer()
+    rng = np.random.default_rng(seed)
+    known_obs = np.array([-300, -1, -.01, 0, .01, .5, 1, 10, 256, 1e4], np.float32)
+    known_act = np.array([-1, -.5, 0, .5, .999, 1], np.float32)
+    # random sweep over several magnitudes + exact bin boundaries of the action path and their fp32 neighbours
+    sweep = np.concatenate([
+        rng.standard_normal(40000) * s for s in (0.01, 0.3, 3.0, 50.0, 400.0)]).astype(np.float32)
+    edges = (np.arange(0, 1025, dtype=np.float64) / 512.0 - 1.0).astype(np.float32)
+    act = np.concatenate([edges, np.nextafter(edges, np.float32(2)), np.nextafter(edges, np.float32(-2)),
+                          rng.uniform(-1.2, 1.2, 20000).astype(np.float32)])
+    # mu-law bin boundaries mapped back to observation space, and neighbours
+    t = edges.astype(np.float64)
+    xb = (np.sign(t) * (np.power(25601.0, np.abs(t)) - 1.0) / 100.0).astype(np.float32)
+    nb = [xb]
+    for _ in range(3):
+        nb.append(np.nextafter(nb[-1], np.float32(1e9)))
+    lo = xb
+    for _ in range(3):
+        lo = np.nextafter(lo, np.float32(-1e9))
+        nb.append(lo)
+    obs = np.concatenate([sweep] + nb)
+    D = lambda x, a: tok.discretize(torch.from_numpy(x.copy()), a).numpy().astype(np.int32)
+    ids = np.arange(0, 1024, dtype=np.int64)
+    return dict(known_obs=known_obs, known_obs_ids=D(known_obs, False), known_act=known_act, known_act_ids=D(known_act, True),
+                obs=obs, obs_ids=D(obs, False), act=act, act_ids=D(act, True),
+                dec_ids=ids, dec_obs=tok.decode(torch.from_numpy(ids), False).numpy(), dec_act=tok.decode(torch.from_numpy(ids), True).numpy())
+
+
+def gen_adam(seed):
+    rng = np.random.default_rng(seed)
+    out = {}
+    for mode in ("adam", "adamw"):
+        p0 = rng.standard_normal(257).astype(np.float32)
+        gs = [rng.standard_normal(257).astype(np.float32) * s for s in (1.0, 0.1, 3.0)]
+        p = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+        cls = torch.optim.Adam if mode == "adam" else torch.optim.AdamW
+        opt = cls([p], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+        out[f"{mode}/p0"] = p0
+        for i, g in enumerate(gs):
+            p.grad = torch.from_numpy(g.copy())
+            norm = torch.nn.utils.clip_grad_norm_([p], 1.0)
+            opt.step()
+            out[f"{mode}/g{i}"] = g
+            out[f"{mode}/norm{i}"] = np.float64(norm.item())
+            out[f"{mode}/p{i + 1}"] = p.detach().numpy().copy()
+            st = opt.state[p]
+            out[f"{mode}/m{i + 1}"] = st["exp_avg"].numpy().copy()
+            out[f"{mode}/v{i + 1}"] = st["exp_avg_sq"].numpy().copy()
+    return out
+
+
+def gen_scheduler():
+    import src.mpu  # noqa: F401  (print_rank_0)
+    from src.train_utils.optimizer_param_scheduler import OptimizerParamScheduler
+    out = {}
+    steps = np.array([0, 1, 5, 10, 11, 50, 99, 100, 101, 150], np.int64)
+    for style in ("constant", "linear", "cosine"):
+        for wstyle in ("constant", "linear", "cosine"):
+            opt = SimpleNamespace(param_groups=[{"lr": 0.0, "weight_decay": 0.0}])
+            s = OptimizerParamScheduler(opt, max_lr=1e-3, min_lr=1e-5, lr_warmup_steps=10, lr_decay_steps=100,
+                                        lr_decay_style=style, start_wd=0.01 if wstyle == "constant" else 0.0, end_wd=0.01,
+                                        wd_incr_steps=80, wd_incr_style=wstyle)
+            lrs, wds = [], []
+            prev = 0
+            for st in steps:
+                s.step(int(st - prev))
+                prev = st
+                lrs.append(opt.param_groups[0]["lr"])
+                wds.append(opt.param_groups[0]["weight_decay"])
+            out[f"lr/{style}/{wstyle}"] = np.array(lrs)
+            out[f"wd/{style}/{wstyle}"] = np.array(wds)
+    out["steps"] = steps
+    return out
+
+
+def gen_rl_packing():
+    for n in ("gym", "d4rl", "tree"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    try:
+        from src.data.rl_dataset import _get_action_flag_and_position_id, _truncate_or_pad_to_match_seq_len
+    except Exception as e:  # pragma: no cover
+        print("rl_dataset helpers not importable:", repr(e))
+        return None
+    out = {}
+    cases = [(0, 63, 6, 1, 0), (0, 1023, 20, 1, 0), (0, 99, 7, 3, 2), (0, 10, 4, 2, 0), (22, 1046, 20, 1, 3)]
+    for i, c in enumerate(cases):
+        f, p = _get_action_flag_and_position_id(*c)
+        out[f"args{i}"] = np.array(c)
+        out[f"flag{i}"] = f
+        out[f"pos{i}"] = p
+    out["pad_in"] = np.arange(5)
+    out["pad8"] = _truncate_or_pad_to_match_seq_len(np.arange(5), 8)
+    out["pad3"] = _truncate_or_pad_to_match_seq_len(np.arange(5), 3)
+    return out
+
+
+def main():
+    torch.manual_seed(0)
+    for i, name in enumerate(CASES):
+        d = gen_model_case(name, seed=100 + i)
+        np.savez_compressed(os.path.join(HERE, f"model_{name}.npz"), **d)
+        print("wrote", name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in list(d.items())[:4]})
+    np.savez_compressed(os.path.join(HERE, "patch_embed.npz"), **gen_patch_embed(7))
+    np.savez_compressed(os.path.join(HERE, "scalar_tokenizer.npz"), **gen_scalar_tokenizer(11))
+    np.savez_compressed(os.path.join(HERE, "adam.npz"), **gen_adam(13))
+    np.savez_compressed(os.path.join(HERE, "scheduler.npz"), **gen_scheduler())
+    r = gen_rl_packing()
+    if r is not None:
+        np.savez_compressed(os.path.join(HERE, "rl_packing.npz"), **r)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
