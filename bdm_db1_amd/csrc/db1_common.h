@@ -1,0 +1,104 @@
+// Shared device/host helpers for libdb1_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/db1_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+void db1_set_error(const char* fmt, ...);
+
+#define DB1_FAIL(code, ...)           \
+    do {                              \
+        db1_set_error(__VA_ARGS__);   \
+        return (code);                \
+    } while (0)
+
+#define DB1_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int db1_elt_size(int dt) { return dt == DB1_F32 ? 4 : 2; }
+static inline bool db1_dt_ok(int dt) { return dt == DB1_F32 || dt == DB1_BF16; }
+static inline bool db1_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                        // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 16-byte vector access: VEC = 4 floats or 8 bf16
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) { float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    float v[8];
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        uint4 t = *reinterpret_cast<const uint4*>(p);
+        unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    __device__ __forceinline__ void store(bf16_t* p) const {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+// block-wide sum for blockDim.x == 256 (4 waves); sm must hold >= 4 floats
+__device__ __forceinline__ float block_sum256(float x, float* sm) {
+    x = wave_sum(x);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+__device__ __forceinline__ float block_max256(float x, float* sm) {
+    x = wave_max(x);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * __expf(-0.5f * x * x) * 0.39894228040143267794f;
+}
+
+// dtype dispatch helpers (host)
+#define DB1_DISPATCH_DT(dt, T, ...)                          \
+    do {                                                     \
+        if ((dt) == DB1_F32) { using T = float; __VA_ARGS__; } \
+        else { using T = bf16_t; __VA_ARGS__; }               \
+    } while (0)

@@ -1,0 +1,684 @@
+// HBM-bound kernels of the DB1 hot path: residual+LayerNorm, FF activation, column sums,
+// embedding gather / scatter-add, RL sequence assembly, masked cross-entropy, fused Adam,
+// global-norm, mu-law tokenizer.  All are one-pass (or L2-resident re-read) streaming kernels
+// with 16-byte vector accesses and wave-shuffle reductions; roofline = HBM bytes.
+#include "db1_common.h"
+
+// =====================================================================================
+// residual + LayerNorm      (reference: transformer_xl.py:231-238, 288-290)
+// one wave per row, 4 rows per 256-thread block; the row (<= 8 KB) is re-read from L1/L2
+// =====================================================================================
+template <typename T, typename TP>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ r, float alpha,
+                                                     const TP* __restrict__ gamma, const TP* __restrict__ beta,
+                                                     T* __restrict__ y, T* s_out, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int64_t rows, int d, float eps) {
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int V = Vec16<T>::N;
+    const T* xr = x + row * d;
+    const T* rr = r ? r + row * d : nullptr;
+    auto load_s = [&](int i, Vec16<T>& a) {
+        a.load(xr + i);
+        if (rr) {
+            Vec16<T> b;
+            b.load(rr + i);
+#pragma unroll
+            for (int j = 0; j < V; j++) a.v[j] = alpha * a.v[j] + b.v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; j++) a.v[j] = alpha * a.v[j];
+        }
+        if (sizeof(T) == 2) {  // s is a tensor of dtype T in the reference: round before the statistics
+#pragma unroll
+            for (int j = 0; j < V; j++) a.v[j] = bf2f(f2bf(a.v[j]));
+        }
+    };
+    float sum = 0.f;
+    for (int i = lane * V; i < d; i += 64 * V) {
+        Vec16<T> a;
+        load_s(i, a);
+#pragma unroll
+        for (int j = 0; j < V; j++) sum += a.v[j];
+    }
+    const float mu = wave_sum(sum) / (float)d;
+    float sq = 0.f;
+    for (int i = lane * V; i < d; i += 64 * V) {
+        Vec16<T> a;
+        load_s(i, a);
+#pragma unroll
+        for (int j = 0; j < V; j++) { float c = a.v[j] - mu; sq += c * c; }
+    }
+    const float rs = rsqrtf(wave_sum(sq) / (float)d + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    T* yr = y + row * d;
+    T* sr = s_out ? s_out + row * d : nullptr;
+    for (int i = lane * V; i < d; i += 64 * V) {
+        Vec16<T> a, o;
+        load_s(i, a);
+        if (sr) a.store(sr + i);
+#pragma unroll
+        for (int j = 0; j < V; j++) o.v[j] = (a.v[j] - mu) * rs * ldf(gamma + i + j) + ldf(beta + i + j);
+        o.store(yr + i);
+    }
+}
+
+template <typename T, typename TP>
+__global__ __launch_bounds__(256) void ln_bwd_ds_kernel(const T* __restrict__ dy, const T* __restrict__ s,
+                                                        const TP* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, T* __restrict__ ds,
+                                                        int64_t rows, int d) {
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int V = Vec16<T>::N;
+    const T* dyr = dy + row * d;
+    const T* sr = s + row * d;
+    const float mu = mean[row], rs = rstd[row];
+    float c1 = 0.f, c2 = 0.f;
+    for (int i = lane * V; i < d; i += 64 * V) {
+        Vec16<T> a, b;
+        a.load(dyr + i);
+        b.load(sr + i);
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            float g = a.v[j] * ldf(gamma + i + j);
+            c1 += g;
+            c2 += g * (b.v[j] - mu) * rs;
+        }
+    }
+    c1 = wave_sum(c1) / (float)d;
+    c2 = wave_sum(c2) / (float)d;
+    T* dsr = ds + row * d;
+    for (int i = lane * V; i < d; i += 64 * V) {
+        Vec16<T> a, b, o;
+        a.load(dyr + i);
+        b.load(sr + i);
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            float g = a.v[j] * ldf(gamma + i + j);
+            float xh = (b.v[j] - mu) * rs;
+            o.v[j] = rs * (g - c1 - xh * c2);
+        }
+        o.store(dsr + i);
+    }
+}
+
+// dgamma[c] += sum_r dy*xhat ; dbeta[c] += sum_r dy.  thread per column, a chunk of rows per block
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_param_kernel(const T* __restrict__ dy, const T* __restrict__ s,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           float* dgamma, float* dbeta, int64_t rows, int d, int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float ag = 0.f, ab = 0.f;
+    for (int64_t r = r0; r < r1; r++) {
+        float g = ldf(dy + r * d + c);
+        float xh = (ldf(s + r * d + c) - mean[r]) * rstd[r];
+        ag += g * xh;
+        ab += g;
+    }
+    atomicAdd(dgamma + c, ag);
+    atomicAdd(dbeta + c, ab);
+}
+
+extern "C" int db1_layernorm_residual_fwd(const void* x, const void* r, float alpha, const void* gamma, const void* beta,
+                                          void* y, void* s_out, float* mean, float* rstd, int64_t rows, int d, float eps,
+                                          int dt, int dtParam, void* stream) {
+    if (!db1_dt_ok(dt) || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "layernorm fwd: dtype");
+    const int V = dt == DB1_F32 ? 4 : 8;
+    if (rows <= 0 || d <= 0 || d % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm fwd: d=%d must be a multiple of %d", d, V);
+    if (!db1_aligned16(x) || !db1_aligned16(y) || (r && !db1_aligned16(r)) || (s_out && !db1_aligned16(s_out)))
+        DB1_FAIL(DB1_ERR_BAD_ALIGN, "layernorm fwd: pointers must be 16-byte aligned");
+    dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+#define LN_FWD(T, TP) ln_fwd_kernel<T, TP><<<grid, 256, 0, st>>>((const T*)x, (const T*)r, alpha, (const TP*)gamma, (const TP*)beta, (T*)y, (T*)s_out, mean, rstd, rows, d, eps)
+    if (dt == DB1_F32 && dtParam == DB1_F32) LN_FWD(float, float);
+    else if (dt == DB1_BF16 && dtParam == DB1_BF16) LN_FWD(bf16_t, bf16_t);
+    else if (dt == DB1_BF16 && dtParam == DB1_F32) LN_FWD(bf16_t, float);
+    else LN_FWD(float, bf16_t);
+#undef LN_FWD
+    DB1_CHECK_LAUNCH("layernorm fwd");
+    return DB1_OK;
+}
+
+extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
+                                          void* ds, float* dgamma_acc, float* dbeta_acc, int64_t rows, int d, int dt,
+                                          int dtParam, void* stream) {
+    if (!db1_dt_ok(dt) || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "layernorm bwd: dtype");
+    const int V = dt == DB1_F32 ? 4 : 8;
+    if (rows <= 0 || d <= 0 || d % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd: d=%d must be a multiple of %d", d, V);
+    if (!db1_aligned16(dy) || !db1_aligned16(s) || !db1_aligned16(ds)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "layernorm bwd: alignment");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((rows + 3) / 4));
+#define LN_BWD(T, TP) ln_bwd_ds_kernel<T, TP><<<grid, 256, 0, st>>>((const T*)dy, (const T*)s, (const TP*)gamma, mean, rstd, (T*)ds, rows, d)
+    if (dt == DB1_F32 && dtParam == DB1_F32) LN_BWD(float, float);
+    else if (dt == DB1_BF16 && dtParam == DB1_BF16) LN_BWD(bf16_t, bf16_t);
+    else if (dt == DB1_BF16 && dtParam == DB1_F32) LN_BWD(bf16_t, float);
+    else LN_BWD(float, bf16_t);
+#undef LN_BWD
+    DB1_CHECK_LAUNCH("layernorm bwd ds");
+    if (dgamma_acc && dbeta_acc) {
+        const int rpb = 128;
+        dim3 g2((unsigned)((d + 255) / 256), (unsigned)((rows + rpb - 1) / rpb));
+        if (dt == DB1_F32) ln_bwd_param_kernel<float><<<g2, 256, 0, st>>>((const float*)dy, (const float*)s, mean, rstd, dgamma_acc, dbeta_acc, rows, d, rpb);
+        else ln_bwd_param_kernel<bf16_t><<<g2, 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)s, mean, rstd, dgamma_acc, dbeta_acc, rows, d, rpb);
+        DB1_CHECK_LAUNCH("layernorm bwd param");
+    }
+    return DB1_OK;
+}
+
+// =====================================================================================
+// feed-forward activation (GEGLU = a * gelu_erf(b), activations.py:19-32)
+// =====================================================================================
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const T* __restrict__ z, T* __restrict__ out, int64_t rows, int n) {
+    constexpr int V = Vec16<T>::N;
+    const int64_t nv = (int64_t)rows * (n / V);
+    const int ld = ACT == DB1_ACT_GEGLU ? 2 * n : n;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nv; idx += (int64_t)gridDim.x * 256) {
+        int64_t r = idx / (n / V);
+        int c = (int)(idx % (n / V)) * V;
+        Vec16<T> a, o;
+        a.load(z + r * ld + c);
+        if (ACT == DB1_ACT_GEGLU) {
+            Vec16<T> b;
+            b.load(z + r * ld + n + c);
+#pragma unroll
+            for (int j = 0; j < V; j++) o.v[j] = a.v[j] * gelu_erf(b.v[j]);
+        } else if (ACT == DB1_ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < V; j++) o.v[j] = gelu_erf(a.v[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; j++) o.v[j] = fmaxf(a.v[j], 0.f);
+        }
+        o.store(out + r * n + c);
+    }
+}
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dout, T* __restrict__ dz,
+                                                      int64_t rows, int n) {
+    constexpr int V = Vec16<T>::N;
+    const int64_t nv = (int64_t)rows * (n / V);
+    const int ld = ACT == DB1_ACT_GEGLU ? 2 * n : n;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nv; idx += (int64_t)gridDim.x * 256) {
+        int64_t r = idx / (n / V);
+        int c = (int)(idx % (n / V)) * V;
+        Vec16<T> a, g, o;
+        a.load(z + r * ld + c);
+        g.load(dout + r * n + c);
+        if (ACT == DB1_ACT_GEGLU) {
+            Vec16<T> b, o2;
+            b.load(z + r * ld + n + c);
+#pragma unroll
+            for (int j = 0; j < V; j++) { o.v[j] = g.v[j] * gelu_erf(b.v[j]); o2.v[j] = g.v[j] * a.v[j] * gelu_erf_grad(b.v[j]); }
+            o.store(dz + r * ld + c);
+            o2.store(dz + r * ld + n + c);
+        } else {
+            if (ACT == DB1_ACT_GELU) {
+#pragma unroll
+                for (int j = 0; j < V; j++) o.v[j] = g.v[j] * gelu_erf_grad(a.v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < V; j++) o.v[j] = a.v[j] > 0.f ? g.v[j] : 0.f;
+            }
+            o.store(dz + r * ld + c);
+        }
+    }
+}
+
+static inline unsigned grid_for(int64_t work_items) {
+    int64_t b = (work_items + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;  // 16 blocks per CU, grid-stride beyond
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+extern "C" int db1_ffn_act_fwd(const void* z, void* out, int64_t rows, int n, int act, int dt, void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "ffn_act_fwd: dtype");
+    const int V = dt == DB1_F32 ? 4 : 8;
+    if (rows <= 0 || n <= 0 || n % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "ffn_act_fwd: n=%d must be a multiple of %d", n, V);
+    if (act < 0 || act > 2) DB1_FAIL(DB1_ERR_UNSUPPORTED, "ffn_act_fwd: act %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned g = grid_for(rows * (n / V));
+#define L(T, A) act_fwd_kernel<T, A><<<g, 256, 0, st>>>((const T*)z, (T*)out, rows, n)
+    DB1_DISPATCH_DT(dt, T, { if (act == 0) L(T, 0); else if (act == 1) L(T, 1); else L(T, 2); });
+#undef L
+    DB1_CHECK_LAUNCH("ffn_act_fwd");
+    return DB1_OK;
+}
+
+extern "C" int db1_ffn_act_bwd(const void* z, const void* dout, void* dz, int64_t rows, int n, int act, int dt, void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "ffn_act_bwd: dtype");
+    const int V = dt == DB1_F32 ? 4 : 8;
+    if (rows <= 0 || n <= 0 || n % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "ffn_act_bwd: n=%d must be a multiple of %d", n, V);
+    if (act < 0 || act > 2) DB1_FAIL(DB1_ERR_UNSUPPORTED, "ffn_act_bwd: act %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned g = grid_for(rows * (n / V));
+#define L(T, A) act_bwd_kernel<T, A><<<g, 256, 0, st>>>((const T*)z, (const T*)dout, (T*)dz, rows, n)
+    DB1_DISPATCH_DT(dt, T, { if (act == 0) L(T, 0); else if (act == 1) L(T, 1); else L(T, 2); });
+#undef L
+    DB1_CHECK_LAUNCH("ffn_act_bwd");
+    return DB1_OK;
+}
+
+// =====================================================================================
+// column sums, add, cast
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* out, int64_t rows, int cols, int64_t ldx, int rpb) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    int64_t r0 = (int64_t)blockIdx.y * rpb;
+    int64_t r1 = r0 + rpb < rows ? r0 + rpb : rows;
+    float a = 0.f;
+    for (int64_t r = r0; r < r1; r++) a += ldf(x + r * ldx + c);
+    atomicAdd(out + c, a);
+}
+
+extern "C" int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int cols, int64_t ldx, int dt, void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "colsum: dtype");
+    if (rows <= 0 || cols <= 0 || ldx < cols) DB1_FAIL(DB1_ERR_BAD_SHAPE, "colsum: shape");
+    const int rpb = 128;
+    dim3 g((unsigned)((cols + 255) / 256), (unsigned)((rows + rpb - 1) / rpb));
+    DB1_DISPATCH_DT(dt, T, (colsum_kernel<T><<<g, 256, 0, (hipStream_t)stream>>>((const T*)x, out_acc, rows, cols, ldx, rpb)));
+    DB1_CHECK_LAUNCH("colsum");
+    return DB1_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) stf(y + i, ldf(a + i) + ldf(b + i));
+}
+extern "C" int db1_add(const void* a, const void* b, void* y, int64_t n, int dt, void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "add: dtype");
+    if (n <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "add: n");
+    DB1_DISPATCH_DT(dt, T, (add_kernel<T><<<grid_for(n), 256, 0, (hipStream_t)stream>>>((const T*)a, (const T*)b, (T*)y, n)));
+    DB1_CHECK_LAUNCH("add");
+    return DB1_OK;
+}
+
+template <typename TA, typename T>
+__global__ __launch_bounds__(256) void add2d_kernel(const TA* __restrict__ a, int64_t lda, const T* b, int64_t ldb, T* y, int64_t ldy,
+                                                    int64_t rows, int cols) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols;
+        const int c = (int)(i % cols);
+        stf(y + r * ldy + c, ldf(a + r * lda + c) + ldf(b + r * ldb + c));
+    }
+}
+extern "C" int db1_add2d(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows, int cols, int dtA,
+                         int dt, void* stream) {
+    if (!db1_dt_ok(dt) || !db1_dt_ok(dtA)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "add2d: dtype");
+    if (rows <= 0 || cols <= 0 || lda < cols || ldb < cols || ldy < cols) DB1_FAIL(DB1_ERR_BAD_SHAPE, "add2d: shape");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned g = grid_for(rows * cols);
+#define L_(TA, T) add2d_kernel<TA, T><<<g, 256, 0, st>>>((const TA*)a, lda, (const T*)b, ldb, (T*)y, ldy, rows, cols)
+    if (dtA == DB1_F32 && dt == DB1_F32) L_(float, float);
+    else if (dtA == DB1_BF16 && dt == DB1_BF16) L_(bf16_t, bf16_t);
+    else if (dtA == DB1_F32) L_(float, bf16_t);
+    else L_(bf16_t, float);
+#undef L_
+    DB1_CHECK_LAUNCH("add2d");
+    return DB1_OK;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) stf(y + i, ldf(x + i));
+}
+extern "C" int db1_cast(const void* x, void* y, int64_t n, int dtIn, int dtOut, void* stream) {
+    if (!db1_dt_ok(dtIn) || !db1_dt_ok(dtOut)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "cast: dtype");
+    if (n <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "cast: n");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned g = grid_for(n);
+    if (dtIn == DB1_F32 && dtOut == DB1_BF16) cast_kernel<float, bf16_t><<<g, 256, 0, st>>>((const float*)x, (bf16_t*)y, n);
+    else if (dtIn == DB1_BF16 && dtOut == DB1_F32) cast_kernel<bf16_t, float><<<g, 256, 0, st>>>((const bf16_t*)x, (float*)y, n);
+    else if (dtIn == DB1_F32) cast_kernel<float, float><<<g, 256, 0, st>>>((const float*)x, (float*)y, n);
+    else cast_kernel<bf16_t, bf16_t><<<g, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, n);
+    DB1_CHECK_LAUNCH("cast");
+    return DB1_OK;
+}
+
+// =====================================================================================
+// embeddings (transformer_xl.py:621-672)
+// =====================================================================================
+template <typename TT, typename TO>
+__global__ __launch_bounds__(256) void gather_kernel(const TT* __restrict__ table, const int64_t* __restrict__ ids, TO* __restrict__ out,
+                                                     int64_t n_tokens, int d, int64_t ld_out) {
+    int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tokens) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t id = ids[t];
+    for (int i = lane; i < d; i += 64) stf(out + t * ld_out + i, id >= 0 ? ldf(table + id * d + i) : 0.f);
+}
+extern "C" int db1_embed_gather_fwd(const void* table, const int64_t* ids, void* out, int64_t n_tokens, int d, int64_t ld_out,
+                                    int dtTable, int dtOut, void* stream) {
+    if (!db1_dt_ok(dtTable) || !db1_dt_ok(dtOut)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "embed_gather: dtype");
+    if (n_tokens <= 0 || d <= 0 || ld_out < d) DB1_FAIL(DB1_ERR_BAD_SHAPE, "embed_gather: shape");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g((unsigned)((n_tokens + 3) / 4));
+#define L(A, B) gather_kernel<A, B><<<g, 256, 0, st>>>((const A*)table, ids, (B*)out, n_tokens, d, ld_out)
+    if (dtTable == DB1_F32 && dtOut == DB1_F32) L(float, float);
+    else if (dtTable == DB1_BF16 && dtOut == DB1_BF16) L(bf16_t, bf16_t);
+    else if (dtTable == DB1_F32) L(float, bf16_t);
+    else L(bf16_t, float);
+#undef L
+    DB1_CHECK_LAUNCH("embed_gather");
+    return DB1_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_add_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids, float* dtable,
+                                                          int64_t n_tokens, int d, int64_t ld) {
+    int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tokens) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t id = ids[t];
+    if (id < 0) return;
+    for (int i = lane; i < d; i += 64) atomicAdd(dtable + id * d + i, ldf(dout + t * ld + i));
+}
+extern "C" int db1_embed_scatter_add_bwd(const void* dout, const int64_t* ids, float* dtable_acc, int64_t n_tokens, int d,
+                                         int64_t ld_dout, int dt, void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "embed_scatter: dtype");
+    if (n_tokens <= 0 || d <= 0 || ld_dout < d) DB1_FAIL(DB1_ERR_BAD_SHAPE, "embed_scatter: shape");
+    dim3 g((unsigned)((n_tokens + 3) / 4));
+    DB1_DISPATCH_DT(dt, T, (scatter_add_kernel<T><<<g, 256, 0, (hipStream_t)stream>>>((const T*)dout, ids, dtable_acc, n_tokens, d, ld_dout)));
+    DB1_CHECK_LAUNCH("embed_scatter");
+    return DB1_OK;
+}
+
+// RL assembly: one 256-thread block per sequence row.  The rank of each -1 placeholder inside its row
+// is a prefix count (ballot + popcount per 64-token chunk, chunk offsets through LDS).
+template <typename TT, typename T, bool BWD>
+__global__ __launch_bounds__(256) void rl_assemble_kernel(const TT* __restrict__ word_table, const TT* __restrict__ pos_table,
+                                                          const T* vis, const int64_t* __restrict__ ids,
+                                                          const int64_t* __restrict__ position_id, int64_t* labels, T* out,
+                                                          float* dword, float* dpos, T* dvis, int L, int d, int nvis) {
+    extern __shared__ int rank_sm[];  // [L] rank of placeholder or -1
+    __shared__ int wave_cnt[4];
+    __shared__ int base_sm;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t* row = ids + (int64_t)b * L;
+    if (tid == 0) base_sm = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < L; c0 += 256) {
+        const int t = c0 + tid;
+        const bool ph = t < L && row[t] == -1;
+        const unsigned long long m = __ballot(ph);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[w] = __popcll(m);
+        __syncthreads();
+        int off = base_sm;
+        for (int k = 0; k < w; k++) off += wave_cnt[k];
+        if (t < L) rank_sm[t] = ph ? off + before : -1;
+        __syncthreads();
+        if (tid == 0) base_sm += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (!BWD && labels) {
+        for (int t = tid; t < L; t += 256) if (labels[(int64_t)b * L + t] == -1) labels[(int64_t)b * L + t] = 0;
+    }
+    if (BWD && dvis) {
+        for (int64_t i = tid; i < (int64_t)nvis * d; i += 256) stf(dvis + (int64_t)b * nvis * d + i, 0.f);
+        __syncthreads();
+    }
+    for (int t = w; t < L; t += 4) {
+        const int64_t id = row[t];
+        const int rk = rank_sm[t];
+        const int64_t pid = position_id[(int64_t)b * L + t];
+        const int64_t o = ((int64_t)b * L + t) * d;
+        for (int i = lane; i < d; i += 64) {
+            if (!BWD) {
+                float v = 0.f;
+                if (id >= 0) v = ldf(word_table + id * d + i);
+                else if (rk >= 0 && rk < nvis && vis) v = ldf(vis + ((int64_t)b * nvis + rk) * d + i);
+                v += ldf(pos_table + pid * d + i);
+                stf(out + o + i, v);
+            } else {
+                const float g = ldf(out + o + i);  // 'out' carries dout in the backward
+                if (id >= 0) atomicAdd(dword + id * d + i, g);
+                else if (rk >= 0 && rk < nvis && dvis) stf(dvis + ((int64_t)b * nvis + rk) * d + i, g);
+                atomicAdd(dpos + pid * d + i, g);
+            }
+        }
+    }
+}
+
+extern "C" int db1_rl_assemble_fwd(const void* word_table, const void* pos_table, const void* vis, const int64_t* ids,
+                                   const int64_t* position_id, int64_t* labels, void* out, int B, int L, int d,
+                                   int n_vis_per_row, int dtTable, int dt, void* stream) {
+    if (!db1_dt_ok(dt) || !db1_dt_ok(dtTable)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "rl_assemble_fwd: dtype");
+    if (B <= 0 || L <= 0 || d <= 0 || L > 12288) DB1_FAIL(DB1_ERR_BAD_SHAPE, "rl_assemble_fwd: shape");
+    hipStream_t st = (hipStream_t)stream;
+    size_t sm = (size_t)L * sizeof(int);
+#define L_(TT, T) rl_assemble_kernel<TT, T, false><<<B, 256, sm, st>>>((const TT*)word_table, (const TT*)pos_table, (const T*)vis, ids, position_id, labels, (T*)out, nullptr, nullptr, nullptr, L, d, n_vis_per_row)
+    if (dtTable == DB1_F32 && dt == DB1_F32) L_(float, float);
+    else if (dtTable == DB1_BF16 && dt == DB1_BF16) L_(bf16_t, bf16_t);
+    else if (dtTable == DB1_F32) L_(float, bf16_t);
+    else L_(bf16_t, float);
+#undef L_
+    DB1_CHECK_LAUNCH("rl_assemble_fwd");
+    return DB1_OK;
+}
+
+extern "C" int db1_rl_assemble_bwd(const void* dout, const int64_t* ids, const int64_t* position_id, float* dword_acc,
+                                   float* dpos_acc, void* dvis, int B, int L, int d, int n_vis_per_row, int dt, void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "rl_assemble_bwd: dtype");
+    if (B <= 0 || L <= 0 || d <= 0 || L > 12288) DB1_FAIL(DB1_ERR_BAD_SHAPE, "rl_assemble_bwd: shape");
+    hipStream_t st = (hipStream_t)stream;
+    size_t sm = (size_t)L * sizeof(int);
+    DB1_DISPATCH_DT(dt, T, (rl_assemble_kernel<float, T, true><<<B, 256, sm, st>>>(nullptr, nullptr, nullptr, ids, position_id, nullptr,
+                                                                                  (T*)const_cast<void*>(dout), dword_acc, dpos_acc, (T*)dvis, L, d, n_vis_per_row)));
+    DB1_CHECK_LAUNCH("rl_assemble_bwd");
+    return DB1_OK;
+}
+
+// =====================================================================================
+// masked cross-entropy over materialised logits (transformer_xl.py:602-609)
+// one 256-thread block per token row, online (max, sum-exp) per thread, block reduction
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                     const float* __restrict__ mask, float* __restrict__ lse, float* sums,
+                                                     int V, int64_t ld, int vec_ok) {
+    __shared__ float sm[4];
+    const int64_t t = blockIdx.x;
+    const T* row = logits + t * ld;
+    const int tid = threadIdx.x;
+    float m = -3.0e38f, s = 0.f;
+    constexpr int VN = Vec16<T>::N;
+    if (vec_ok) {
+        for (int c = tid * VN; c < V; c += 256 * VN) {
+            Vec16<T> a;
+            a.load(row + c);
+#pragma unroll
+            for (int j = 0; j < VN; j++) {
+                if (c + j < V) {
+                    float x = a.v[j];
+                    if (x > m) { s = s * __expf(m - x) + 1.f; m = x; } else s += __expf(x - m);
+                }
+            }
+        }
+    } else {
+        for (int c = tid; c < V; c += 256) {
+            float x = ldf(row + c);
+            if (x > m) { s = s * __expf(m - x) + 1.f; m = x; } else s += __expf(x - m);
+        }
+    }
+    const float M = block_max256(m, sm);
+    const float S = block_sum256(s * __expf(m - M), sm);
+    if (tid == 0) {
+        const float l = M + logf(S);
+        lse[t] = l;
+        const float mk = mask[t];
+        int64_t y = labels[t];
+        const float nll = l - ldf(row + y);
+        atomicAdd(sums + 0, mk * nll);
+        atomicAdd(sums + 1, mk);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, const int64_t* __restrict__ labels, const float* __restrict__ mask,
+                                                     const float* __restrict__ lse, const float* __restrict__ sums, T* dlogits,
+                                                     int V, int64_t ld, float gscale, int vec_ok) {
+    const int64_t t = blockIdx.x;
+    const T* row = logits + t * ld;
+    T* drow = dlogits + t * ld;
+    const int tid = threadIdx.x;
+    const float l = lse[t];
+    const float w = mask[t] / sums[1] * gscale;
+    const int y = (int)labels[t];
+    constexpr int VN = Vec16<T>::N;
+    if (vec_ok) {
+        for (int c = tid * VN; c < ld; c += 256 * VN) {
+            Vec16<T> a, o;
+            a.load(row + c);
+#pragma unroll
+            for (int j = 0; j < VN; j++) o.v[j] = (c + j < V) ? w * (__expf(a.v[j] - l) - (c + j == y ? 1.f : 0.f)) : 0.f;
+            o.store(drow + c);
+        }
+    } else {
+        for (int c = tid; c < ld; c += 256) stf(drow + c, c < V ? w * (__expf(ldf(row + c) - l) - (c == y ? 1.f : 0.f)) : 0.f);
+    }
+}
+
+extern "C" int db1_masked_ce_fwd(const void* logits, const int64_t* labels, const float* mask, float* lse, float* sums,
+                                 int64_t T_, int V, int64_t ld, int dt, void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "masked_ce_fwd: dtype");
+    if (T_ <= 0 || V <= 0 || ld < V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "masked_ce_fwd: shape");
+    const int VN = dt == DB1_F32 ? 4 : 8;
+    const int vec_ok = (ld % VN == 0) && db1_aligned16(logits);
+    DB1_DISPATCH_DT(dt, T, (ce_fwd_kernel<T><<<(unsigned)T_, 256, 0, (hipStream_t)stream>>>((const T*)logits, labels, mask, lse, sums, V, ld, vec_ok)));
+    DB1_CHECK_LAUNCH("masked_ce_fwd");
+    return DB1_OK;
+}
+extern "C" int db1_masked_ce_bwd(const void* logits, const int64_t* labels, const float* mask, const float* lse, const float* sums,
+                                 void* dlogits, int64_t T_, int V, int64_t ld, float gscale, int dt, void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "masked_ce_bwd: dtype");
+    if (T_ <= 0 || V <= 0 || ld < V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "masked_ce_bwd: shape");
+    const int VN = dt == DB1_F32 ? 4 : 8;
+    const int vec_ok = (ld % VN == 0) && db1_aligned16(logits) && db1_aligned16(dlogits);
+    DB1_DISPATCH_DT(dt, T, (ce_bwd_kernel<T><<<(unsigned)T_, 256, 0, (hipStream_t)stream>>>((const T*)logits, labels, mask, lse, sums, (T*)dlogits, V, ld, gscale, vec_ok)));
+    DB1_CHECK_LAUNCH("masked_ce_bwd");
+    return DB1_OK;
+}
+
+// =====================================================================================
+// optimizer: global-norm and fused Adam / AdamW (28-30 B per parameter per step, HBM-bound)
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ x, float* acc, int64_t n) {
+    __shared__ float sm[4];
+    float a = 0.f;
+    constexpr int V = Vec16<T>::N;
+    const int64_t nv = n / V;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        Vec16<T> v;
+        v.load(x + i * V);
+#pragma unroll
+        for (int j = 0; j < V; j++) a += v.v[j] * v.v[j];
+    }
+    if (blockIdx.x == 0) for (int64_t i = nv * V + threadIdx.x; i < n; i += 256) { float f = ldf(x + i); a += f * f; }
+    a = block_sum256(a, sm);
+    if (threadIdx.x == 0) atomicAdd(acc, a);
+}
+extern "C" int db1_sumsq_acc(const void* x, float* acc, int64_t n, int dt, void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "sumsq: dtype");
+    if (n <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "sumsq: n");
+    if (!db1_aligned16(x)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "sumsq: alignment");
+    const int V = dt == DB1_F32 ? 4 : 8;
+    DB1_DISPATCH_DT(dt, T, (sumsq_kernel<T><<<grid_for(n / V + 1), 256, 0, (hipStream_t)stream>>>((const T*)x, acc, n)));
+    DB1_CHECK_LAUNCH("sumsq");
+    return DB1_OK;
+}
+
+template <bool HAS_WORK>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, bf16_t* __restrict__ pw, int64_t n, float lr, float b1,
+                                                   float b2, float omb1, float omb2, float eps, float wd, int adamw, float bc1, float rsqrt_bc2,
+                                                   float gscale, float clip, const float* norm_sq) {
+    float gs = gscale;
+    if (clip > 0.f && norm_sq) {
+        const float nrm = sqrtf(*norm_sq) * gscale;
+        gs *= fminf(1.f, clip / (nrm + 1e-6f));
+    }
+    const float step_size = lr / bc1;
+    const int64_t nv = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i], Vv = reinterpret_cast<float4*>(v)[i];
+        float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {Vv.x, Vv.y, Vv.z, Vv.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float gr = gg[j] * gs;
+            if (adamw) pp[j] *= (1.f - lr * wd); else gr += wd * pp[j];
+            mm[j] = b1 * mm[j] + omb1 * gr;
+            vv[j] = b2 * vv[j] + omb2 * gr * gr;
+            const float denom = sqrtf(vv[j]) * rsqrt_bc2 + eps;
+            pp[j] -= step_size * mm[j] / denom;
+        }
+        reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (HAS_WORK) {
+            uint2 o;
+            o.x = (unsigned)f2bf(pp[0]) | ((unsigned)f2bf(pp[1]) << 16);
+            o.y = (unsigned)f2bf(pp[2]) | ((unsigned)f2bf(pp[3]) << 16);
+            reinterpret_cast<uint2*>(pw)[i] = o;
+        }
+    }
+}
+extern "C" int db1_adam_step(float* p32, const float* g, float* m, float* v, void* p_work, int64_t n, double lr, double beta1,
+                             double beta2, double eps, double wd, int adamw, int step, float gscale, float clip,
+                             const float* norm_sq, int dtWork, void* stream) {
+    if (n <= 0 || (n & 3)) DB1_FAIL(DB1_ERR_BAD_SHAPE, "adam: n=%lld must be a positive multiple of 4", (long long)n);
+    if (step < 1) DB1_FAIL(DB1_ERR_BAD_SHAPE, "adam: step must be >= 1");
+    if (!db1_aligned16(p32) || !db1_aligned16(g) || !db1_aligned16(m) || !db1_aligned16(v) || (p_work && (((uintptr_t)p_work) & 7)))
+        DB1_FAIL(DB1_ERR_BAD_ALIGN, "adam: alignment");
+    if (p_work && dtWork != DB1_BF16) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "adam: working copy must be bf16");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned gr = grid_for(n / 4);
+    if (p_work) adam_kernel<true><<<gr, 256, 0, st>>>(p32, g, m, v, (bf16_t*)p_work, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd, adamw, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, clip, norm_sq);
+    else adam_kernel<false><<<gr, 256, 0, st>>>(p32, g, m, v, nullptr, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd, adamw, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, clip, norm_sq);
+    DB1_CHECK_LAUNCH("adam");
+    return DB1_OK;
+}
+
+// =====================================================================================
+// mu-law scalar tokenizer (scalar_tokenizer.py:28-45): float32 op order of the reference with a
+// correctly rounded logarithm (float64 log rounded once) -> ids identical to torch-CPU.
+// =====================================================================================
+__global__ __launch_bounds__(256) void mulaw_kernel(const float* __restrict__ x, int32_t* __restrict__ ids, int64_t n, int is_action,
+                                                    int nb, float mu, float den) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = x[i];
+        if (!is_action) {
+            const float t = __fadd_rn(__fmul_rn(fabsf(v), mu), 1.0f);
+            const float lg = (float)log((double)t);
+            const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+            float y = __fdiv_rn(__fmul_rn(sg, lg), den);
+            if (v != v) y = v;
+            v = fminf(fmaxf(y, -1.f), 1.f);
+        }
+        const float z = __fmul_rn(__fdiv_rn(__fadd_rn(v, 1.0f), 2.0f), (float)nb);
+        int id = (int)z;  // truncation toward zero, as torch .int()
+        id = id < 0 ? 0 : (id > nb - 1 ? nb - 1 : id);
+        ids[i] = id;
+    }
+}
+extern "C" int db1_mulaw_discretize(const float* x, int32_t* ids, int64_t n, int is_action, int num_bins, float mu, float M, void* stream) {
+    if (n <= 0 || num_bins <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "mulaw: shape");
+    const float den = (float)log((double)(float)(mu * M + 1.0f));
+    mulaw_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(x, ids, n, is_action, num_bins, mu, den);
+    DB1_CHECK_LAUNCH("mulaw");
+    return DB1_OK;
+}

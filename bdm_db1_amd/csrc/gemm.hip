@@ -1,0 +1,290 @@
+// bf16 MFMA tile GEMM for gfx950 + the GEMM dispatcher of the C ABI.
+//
+//   C[M,N] = alpha * A.B + beta * C + bias[n],  fp32 accumulate on v_mfma_f32_16x16x32_bf16.
+//
+// Operand tiles come in two storage forms (this is what makes NT / NN / TN one kernel):
+//   K-major : memory is [row][k] (k contiguous)  -> LDS image [128 rows][64 k], fragments by ds_read_b128
+//   M-major : memory is [k][row] (row contiguous) -> LDS image [64 k][128 rows], fragments by
+//             ds_read_b64_tr_b16 (hardware transpose read; lane map verified in profiles/r01_probe_*.txt)
+//     NT (y = x W^T)   : A K-major, B K-major
+//     NN (dx = dy W)   : A K-major, B M-major
+//     TN (dW = dy^T x) : A M-major, B M-major
+// Staging is global_load_lds (16 B per lane, LDS destination lane-linear), double-buffered over BK = 64;
+// bank conflicts are removed by swizzling the per-lane SOURCE chunk and applying the same XOR on the read
+// (cdna_hip_programming.md rule 21).  The MFMA is issued with the operands swapped (mfma(Bfrag, Afrag))
+// so that each lane ends up with 4 CONSECUTIVE n of one row m: the epilogue stores 8-byte (bf16) or
+// 16-byte (fp32) vectors.  Workgroup = 256 threads = 2x2 waves, wave tile 64x64 = 4x4 fragments.
+// Workgroup ids are remapped so that each XCD (private L2) owns a contiguous band of output tiles.
+#include "db1_common.h"
+#include "gemm_args.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+int db1_gemm_strided_generic(const GemmStridedArgs& a, int dtA, int dtB, int dtC, int dtBias, int batch, hipStream_t st);
+
+#define TBM 128
+#define TBN 128
+#define TBK 64
+#define TILE_BYTES (128 * 64 * 2)  // 16 KiB per operand per stage
+
+struct GemmTileArgs {
+    const bf16_t* A; const bf16_t* B; void* C; const void* bias;
+    int M, N, K;
+    int64_t lda, ldb, ldc;  // leading dimensions in elements
+    int batch1;
+    int64_t a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
+    float alpha, beta;
+    int tiles_m, tiles_n;
+};
+
+// ---- staging: one 16 KiB operand tile, 16 wave-instructions of 1 KiB, 4 per wave
+template <bool KMAJOR>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, int row0, int k0, char* lds, int wave, int lane) {
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int q = wave * 4 + it;  // which 1 KiB piece
+        const bf16_t* src;
+        if (KMAJOR) {
+            // piece q = rows [8q, 8q+8), 128 B per row: lane -> (r = lane/8, cp = lane%8); holds global chunk cp ^ (r & 7)
+            const int r = q * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            src = g + (int64_t)(row0 + r) * ld + k0 + c * 8;
+        } else {
+            // piece q = k-rows [4q, 4q+4), 256 B per k-row: lane -> (kr = lane/16, cp = lane%16); holds chunk cp ^ f(kr)
+            const int kr = q * 4 + (lane >> 4);
+            const int f = ((kr & 3) << 1) | (kr & 8);
+            const int c = (lane & 15) ^ f;
+            src = g + (int64_t)(k0 + kr) * ld + row0 + c * 8;
+        }
+        __builtin_amdgcn_global_load_lds(src, LDS_PTR(void, lds + q * 1024), 16, 0, 0);
+    }
+}
+
+// ---- fragment: 8 consecutive k (k = ks*32 + g*8 + 0..7) for tile row (rbase + lane&15)
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8_t load_frag(const char* lds, int rbase, int ks, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    if (KMAJOR) {
+        const int row = rbase + i;
+        const int chunk = (ks * 4 + g) ^ (row & 7);
+        return *reinterpret_cast<const bf16x8_t*>(lds + row * 128 + chunk * 16);
+    } else {
+        // tr16_b64: lane t of a 16-lane group passes the address of (k-row kb + t/4, 4 rows-elements at rbase + (t%4)*4)
+        // and receives k-rows kb..kb+3 of tile row rbase + t.
+        const int kb = ks * 32 + g * 8;
+        const int q = (rbase >> 2) + (i & 3);  // 8-byte granule index inside the k-row
+        bf16x8_t out;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int kr = kb + h * 4 + (i >> 2);
+            const int f = ((kr & 3) << 1) | (kr & 8);
+            const int off = kr * 256 + ((((q >> 1) ^ f)) << 4) + (q & 1) * 8;
+            bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4_t, const_cast<char*>(lds) + off));
+            out[h * 4 + 0] = v[0]; out[h * 4 + 1] = v[1]; out[h * 4 + 2] = v[2]; out[h * 4 + 3] = v[3];
+        }
+        return out;
+    }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR, typename TC, typename TBIAS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tile_kernel(GemmTileArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware remap: consecutive hardware block ids round-robin over 8 XCDs; give each XCD a contiguous span
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // column-major walk over tiles inside a band of 8 tile-rows keeps the B panel L2-resident
+    const int band = 8;
+    const int tiles_per_band = band * p.tiles_n;
+    const int b0 = bid / tiles_per_band, rem = bid % tiles_per_band;
+    const int band_rows = (p.tiles_m - b0 * band) < band ? (p.tiles_m - b0 * band) : band;
+    const int tm = b0 * band + rem % band_rows, tn = rem / band_rows;
+    const int z = blockIdx.y, z0 = z / p.batch1, z1 = z % p.batch1;
+    const bf16_t* A = p.A + z0 * p.a_bs0 + z1 * p.a_bs1;
+    const bf16_t* B = p.B + z0 * p.b_bs0 + z1 * p.b_bs1;
+    const int m0 = tm * TBM, n0 = tn * TBN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt = p.K / TBK;
+    stage_tile<A_KMAJOR>(A, p.lda, m0, 0, smem, wave, lane);
+    stage_tile<B_KMAJOR>(B, p.ldb, n0, 0, smem + TILE_BYTES, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nt; t++) {
+        char* sa = smem + cur * 2 * TILE_BYTES;
+        char* sb = sa + TILE_BYTES;
+        if (t + 1 < nt) {
+            char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            stage_tile<A_KMAJOR>(A, p.lda, m0, (t + 1) * TBK, na, wave, lane);
+            stage_tile<B_KMAJOR>(B, p.ldb, n0, (t + 1) * TBK, na + TILE_BYTES, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8_t af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) af[i] = load_frag<A_KMAJOR>(sa, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; j++) bfr[j] = load_frag<B_KMAJOR>(sb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // swapped: D[n][m]
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    // epilogue.  swapped-operand layout: lane holds m = lane & 15, n = (lane >> 4) * 4 + r
+    TC* C = (TC*)p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = p.alpha * acc[i][j][r];
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] += ldf((const TBIAS*)p.bias + n + r);
+            }
+            TC* c = C + (int64_t)m * p.ldc + n;
+            if (sizeof(TC) == 4) {
+                if (p.beta != 0.f) {
+                    float4 o = *reinterpret_cast<const float4*>(c);
+                    v[0] += p.beta * o.x; v[1] += p.beta * o.y; v[2] += p.beta * o.z; v[3] += p.beta * o.w;
+                }
+                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                if (p.beta != 0.f) {
+                    uint2 o = *reinterpret_cast<const uint2*>(c);
+                    v[0] += p.beta * __uint_as_float(o.x << 16); v[1] += p.beta * __uint_as_float(o.x & 0xffff0000u);
+                    v[2] += p.beta * __uint_as_float(o.y << 16); v[3] += p.beta * __uint_as_float(o.y & 0xffff0000u);
+                }
+                uint2 o;
+                o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(c) = o;
+            }
+        }
+    }
+}
+
+// storage form of an operand from its strides: returns 0 = K-major, 1 = M-major, -1 = neither
+static int operand_form(int64_t row_stride, int64_t k_stride, int64_t* ld) {
+    if (k_stride == 1 && row_stride >= 1) { *ld = row_stride; return 0; }
+    if (row_stride == 1 && k_stride >= 1) { *ld = k_stride; return 1; }
+    return -1;
+}
+
+static bool fast_ok(int M, int N, int K, int dtA, int dtB, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs,
+                    int64_t c_cs, int* fa, int* fb, int64_t* lda, int64_t* ldb) {
+    if (dtA != DB1_BF16 || dtB != DB1_BF16) return false;
+    if (M % TBM || N % TBN || K % TBK || M <= 0 || N <= 0 || K <= 0) return false;
+    if (c_cs != 1 || (c_rs % 4)) return false;
+    *fa = operand_form(a_rs, a_cs, lda);  // A: rows = m, k stride = a_cs
+    *fb = operand_form(b_cs, b_rs, ldb);  // B: rows = n (stride b_cs), k stride = b_rs
+    if (*fa < 0 || *fb < 0) return false;
+    if (*fa == 1 && *fb == 0) return false;  // "TT" never occurs on the path
+    if ((*lda % 8) || (*ldb % 8)) return false;
+    return true;
+}
+
+extern "C" int db1_gemm_would_use_fast(int M, int N, int K, int dtA, int dtB, int dtC, int64_t a_rs, int64_t a_cs, int64_t b_rs,
+                                       int64_t b_cs, int64_t c_rs, int64_t c_cs) {
+    int fa, fb;
+    int64_t lda, ldb;
+    (void)dtC;
+    return fast_ok(M, N, K, dtA, dtB, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, &fa, &fb, &lda, &ldb) ? 1 : 0;
+}
+
+template <bool AK, bool BK_>
+static void launch_tile(const GemmTileArgs& t, int dtC, int dtBias, dim3 grid, hipStream_t st) {
+    const size_t sm = 4 * TILE_BYTES;
+    if (dtC == DB1_F32) {
+        if (dtBias == DB1_BF16) gemm_bf16_tile_kernel<AK, BK_, float, bf16_t><<<grid, 256, sm, st>>>(t);
+        else gemm_bf16_tile_kernel<AK, BK_, float, float><<<grid, 256, sm, st>>>(t);
+    } else {
+        if (dtBias == DB1_BF16) gemm_bf16_tile_kernel<AK, BK_, bf16_t, bf16_t><<<grid, 256, sm, st>>>(t);
+        else gemm_bf16_tile_kernel<AK, BK_, bf16_t, float><<<grid, 256, sm, st>>>(t);
+    }
+}
+
+static int g_force_generic = 0;
+extern "C" void db1_gemm_force_generic(int on) { g_force_generic = on; }
+
+extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int dtA, int dtB,
+                                int dtC, int dtBias, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs,
+                                int64_t c_cs, int batch0, int batch1, int64_t a_bs0, int64_t a_bs1, int64_t b_bs0,
+                                int64_t b_bs1, int64_t c_bs0, int64_t c_bs1, float alpha, float beta, void* stream) {
+    if (!db1_dt_ok(dtA) || !db1_dt_ok(dtB) || !db1_dt_ok(dtC) || (bias && !db1_dt_ok(dtBias)))
+        DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "gemm: dtype codes %d %d %d", dtA, dtB, dtC);
+    if (M <= 0 || N <= 0 || K <= 0 || batch0 <= 0 || batch1 <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "gemm: M=%d N=%d K=%d batch=%dx%d", M, N, K, batch0, batch1);
+    if (!A || !B || !C) DB1_FAIL(DB1_ERR_BAD_SHAPE, "gemm: null operand");
+    hipStream_t st = (hipStream_t)stream;
+    int fa, fb;
+    int64_t lda, ldb;
+    const int64_t batch = (int64_t)batch0 * batch1;
+    const bool aligned = db1_aligned16(A) && db1_aligned16(B) && db1_aligned16(C) && !(a_bs0 % 8) && !(a_bs1 % 8) && !(b_bs0 % 8) &&
+                         !(b_bs1 % 8) && !(c_bs0 % 4) && !(c_bs1 % 4);
+    if (!g_force_generic && aligned && batch <= 65535 &&
+        fast_ok(M, N, K, dtA, dtB, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, &fa, &fb, &lda, &ldb)) {
+        GemmTileArgs t;
+        t.A = (const bf16_t*)A; t.B = (const bf16_t*)B; t.C = C; t.bias = bias;
+        t.M = M; t.N = N; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = c_rs;
+        t.batch1 = batch1; t.a_bs0 = a_bs0; t.a_bs1 = a_bs1; t.b_bs0 = b_bs0; t.b_bs1 = b_bs1; t.c_bs0 = c_bs0; t.c_bs1 = c_bs1;
+        t.alpha = alpha; t.beta = beta; t.tiles_m = M / TBM; t.tiles_n = N / TBN;
+        dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch);
+        static bool attr_set = false;
+        if (!attr_set) {
+            // 64 KiB of dynamic LDS needs the opt-in attribute on every instantiation
+#define SET_ATTR(AK, BK_, TC, TB) hipFuncSetAttribute((const void*)gemm_bf16_tile_kernel<AK, BK_, TC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES)
+#define SET_ALL(AK, BK_) SET_ATTR(AK, BK_, float, float); SET_ATTR(AK, BK_, float, bf16_t); SET_ATTR(AK, BK_, bf16_t, float); SET_ATTR(AK, BK_, bf16_t, bf16_t)
+            SET_ALL(true, true); SET_ALL(true, false); SET_ALL(false, false);
+#undef SET_ALL
+#undef SET_ATTR
+            attr_set = true;
+        }
+        if (fa == 0 && fb == 0) launch_tile<true, true>(t, dtC, dtBias, grid, st);
+        else if (fa == 0 && fb == 1) launch_tile<true, false>(t, dtC, dtBias, grid, st);
+        else launch_tile<false, false>(t, dtC, dtBias, grid, st);
+        DB1_CHECK_LAUNCH("gemm_bf16_tile");
+        return DB1_OK;
+    }
+    GemmStridedArgs a;
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.M = M; a.N = N; a.K = K;
+    a.a_rs = a_rs; a.a_cs = a_cs; a.b_rs = b_rs; a.b_cs = b_cs; a.c_rs = c_rs; a.c_cs = c_cs;
+    a.batch1 = batch1; a.a_bs0 = a_bs0; a.a_bs1 = a_bs1; a.b_bs0 = b_bs0; a.b_bs1 = b_bs1; a.c_bs0 = c_bs0; a.c_bs1 = c_bs1;
+    a.alpha = alpha; a.beta = beta;
+    return db1_gemm_strided_generic(a, dtA, dtB, dtC, dtBias, (int)batch, st);
+}
+
+extern "C" int db1_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                           int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream) {
+    return db1_gemm_strided(A, B, C, bias, M, N, K, dtAB, dtAB, dtC, dtAB, lda, 1, 1, ldb, ldc, 1, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, stream);
+}
+extern "C" int db1_gemm_nn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                           int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream) {
+    return db1_gemm_strided(A, B, C, bias, M, N, K, dtAB, dtAB, dtC, dtAB, lda, 1, ldb, 1, ldc, 1, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, stream);
+}
+extern "C" int db1_gemm_tn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                           int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream) {
+    return db1_gemm_strided(A, B, C, bias, M, N, K, dtAB, dtAB, dtC, dtAB, 1, lda, ldb, 1, ldc, 1, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, stream);
+}

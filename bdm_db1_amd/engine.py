@@ -1,0 +1,229 @@
+"""Training / inference engine with the surface the reference's drivers use on the DeepSpeed engine
+(src/train_utils/train.py:216-232, src/evaluation/evaluate_rl.py:192,344,508-512, src/checkpointing.py:17-22):
+
+    engine, optimizer, _, lr_scheduler = initialize(args, model, mpu=mpu)
+    logits, loss = engine(inputs); engine.backward(loss); engine.step()
+
+What the external runtime did around the model is done here MI355X-first:
+  * gradients live in ONE flat float32 arena laid out in backward-completion order; as each decoder layer
+    finishes its backward, its contiguous bucket (46.2 M elements for DB1-1.3B) is all-reduced with RCCL
+    (torch.distributed "nccl" on ROCm) asynchronously, overlapping the remaining backward;
+  * the data-parallel mean, the global-norm clip and 1/grad-accumulation are folded into the fused Adam
+    kernel's gradient scale (no extra pass over 1.2 G gradients), and the clip coefficient is computed on
+    the device (no host sync);
+  * one fused Adam launch updates fp32 master weights + moments and writes the bf16 working copy.
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .optim import OptimizerParamScheduler
+
+
+class GradSync:
+    """Bucketed asynchronous all-reduce (SUM) over slices of one flat gradient tensor.
+    Backend-agnostic (RCCL on the GPUs; gloo in the CPU tests of the sharding logic)."""
+
+    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[str, int, int]], group=None):
+        self.flat = flat_grad
+        self.buckets = {n: (s, e) for n, s, e in buckets}
+        self.order = [n for n, _, _ in buckets]
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.handles = []
+        self.launched = set()
+
+    def launch(self, name: str):
+        if self.world == 1 or name in self.launched:
+            return
+        s, e = self.buckets[name]
+        self.launched.add(name)
+        self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """launch whatever was not launched by a hook, then wait for everything"""
+        for n in self.order:
+            self.launch(n)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        self.launched = set()
+
+
+class _Optimizer:
+    """What callers see as ``optimizer``: param_groups for the LR scheduler + state for checkpoints."""
+
+    def __init__(self, lr, wd):
+        self.param_groups = [{"lr": lr, "weight_decay": wd}]
+
+
+class DB1Engine:
+    def __init__(self, args, model, mpu=None, lr_scheduler=None):
+        g = lambda k, d=None: getattr(args, k, d) if args is not None else d
+        self.module = model
+        self.mpu = mpu
+        self.args = args
+        self.group = None
+        if mpu is not None and dist.is_available() and dist.is_initialized() and mpu.model_parallel_is_initialized():
+            self.group = mpu.get_data_parallel_group()
+        self.dp_world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        micro = g("micro_batch_size", None)
+        glob = g("global_batch_size", None)
+        ga = g("gradient_accumulation_steps", None)
+        if ga is None:
+            ga = max(1, glob // (micro * self.dp_world)) if (micro and glob) else 1
+        self._ga = int(ga)
+        self.micro_steps = 0
+        self.global_steps = 0
+        self.beta1, self.beta2 = float(g("adam_beta1", 0.9)), float(g("adam_beta2", 0.999))
+        self.eps = float(g("adam_eps", 1e-8))
+        self.clip = float(g("clip_grad", 1.0) or 0.0)
+        self.adamw = str(g("optimizer", "adam")).lower() == "adamw"
+        lr = g("lr", None)
+        self.optimizer = _Optimizer(float(lr) if lr is not None else 1e-4, float(g("weight_decay", 0.01)))
+        self.lr_scheduler = lr_scheduler
+        self.overlap_comm = bool(g("overlap_grad_reduce", True))
+        model.keep_logits = bool(g("keep_logits", False))
+        ar = model.arena
+        if ar.exp_avg is None:
+            ar.exp_avg = torch.zeros_like(ar.master)
+            ar.exp_avg_sq = torch.zeros_like(ar.master)
+        self._norm_sq = torch.zeros(1, device=model.device, dtype=torch.float32)
+        self.sync = GradSync(ar.grad, model.grad_buckets(), self.group)
+        self.last_grad_norm_sq = None
+
+    # ---- what the reference's drivers call
+    def __call__(self, *a, **k):
+        return self.module(*a, **k)
+
+    def __getattr__(self, name):  # attribute passthrough (model.init_mem, evaluate_rl.py:344)
+        mod = self.__dict__.get("module")
+        if mod is not None and hasattr(mod, name):
+            return getattr(mod, name)
+        raise AttributeError(name)
+
+    @property
+    def device(self):
+        return self.module.device
+
+    def train(self, mode: bool = True):
+        self.module.train(mode)
+        return self
+
+    def eval(self):
+        self.module.eval()
+        return self
+
+    def gradient_accumulation_steps(self):
+        return self._ga
+
+    def is_gradient_accumulation_boundary(self):
+        return (self.micro_steps + 1) % self._ga == 0
+
+    def backward(self, loss=None):
+        """DeepSpeed semantics: gradient of loss / grad_accumulation_steps; on the boundary micro-step the
+        per-layer buckets are all-reduced while the backward of the earlier layers is still running."""
+        boundary = self.is_gradient_accumulation_boundary()
+        hook = self.sync.launch if (boundary and self.overlap_comm and self.dp_world > 1) else None
+        self.module.backward(grad_scale=1.0 / self._ga, layer_done_hook=hook)
+        return loss
+
+    def step(self):
+        boundary = self.is_gradient_accumulation_boundary()
+        self.micro_steps += 1
+        if not boundary:
+            return
+        self.sync.finish()
+        ar = self.module.arena
+        gscale = 1.0 / self.dp_world  # arena holds the SUM over ranks
+        self._norm_sq.zero_()
+        if self.clip > 0:
+            ops.sumsq_acc(ar.grad, self._norm_sq)
+        self.global_steps += 1
+        grp = self.optimizer.param_groups[0]
+        ops.adam_step(ar.master, ar.grad, ar.exp_avg, ar.exp_avg_sq, None if ar.work is ar.master else ar.work,
+                      grp["lr"], self.beta1, self.beta2, self.eps, grp["weight_decay"], self.adamw, self.global_steps,
+                      gscale=gscale, clip=self.clip, norm_sq=self._norm_sq if self.clip > 0 else None)
+        ar.grad.zero_()
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step(1)
+
+    def get_global_grad_norm(self) -> float:
+        """host-synchronising convenience (not used in the step path)"""
+        return float(self._norm_sq.sqrt().item()) / self.dp_world
+
+    # ---- checkpoints (DeepSpeed file naming so the released loaders' paths make sense)
+    def save_checkpoint(self, save_dir, tag=None, client_state=None):
+        tag = tag or f"global_step{self.global_steps}"
+        path = os.path.join(save_dir, str(tag))
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        if rank == 0:
+            os.makedirs(path, exist_ok=True)
+            ar = self.module.arena
+            state = {"module": {k: v.detach().cpu() for k, v in self.module.state_dict().items()},
+                     "optimizer": {"exp_avg": ar.exp_avg.cpu(), "exp_avg_sq": ar.exp_avg_sq.cpu(), "step": self.global_steps},
+                     "lr_scheduler": self.lr_scheduler.state_dict() if self.lr_scheduler is not None else None,
+                     "global_steps": self.global_steps, "micro_steps": self.micro_steps}
+            state.update(client_state or {})
+            torch.save(state, os.path.join(path, "mp_rank_00_model_states.pt"))
+            with open(os.path.join(save_dir, "latest"), "w") as f:
+                f.write(str(tag))
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+        return True
+
+    def load_checkpoint(self, load_dir, tag=None, load_optimizer_states=True, **_):
+        if tag is None:
+            with open(os.path.join(load_dir, "latest")) as f:
+                tag = f.read().strip()
+        path = os.path.join(load_dir, str(tag), "mp_rank_00_model_states.pt")
+        state = torch.load(path, map_location="cpu", weights_only=False)
+        self.module.load_state_dict(state["module"], strict=False)
+        if load_optimizer_states and state.get("optimizer") and "exp_avg" in state["optimizer"]:
+            ar = self.module.arena
+            ar.exp_avg.copy_(state["optimizer"]["exp_avg"])
+            ar.exp_avg_sq.copy_(state["optimizer"]["exp_avg_sq"])
+            self.global_steps = int(state["optimizer"].get("step", 0))
+        if self.lr_scheduler is not None and state.get("lr_scheduler"):
+            self.lr_scheduler.load_state_dict(state["lr_scheduler"])
+        self.micro_steps = int(state.get("micro_steps", 0))
+        client = {k: v for k, v in state.items() if k not in ("module", "optimizer", "lr_scheduler")}
+        return path, client
+
+
+def init_distributed(dist_backend: str = "nccl", distributed_port: Optional[int] = None, **_):
+    """``deepspeed.init_distributed`` stand-in (evaluate_rl.py:492): one process per GPU, RCCL over xGMI."""
+    if dist.is_available() and dist.is_initialized():
+        return
+    if "RANK" not in os.environ:
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if distributed_port is not None:
+        os.environ.setdefault("MASTER_PORT", str(distributed_port))
+    if dist_backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    dist.init_process_group(backend=dist_backend)
+
+
+def initialize(args=None, model=None, mpu=None, lr_scheduler=None, **_):
+    """``deepspeed.initialize`` stand-in: returns the same 4-tuple shape (engine, optimizer, dataloader, lr_scheduler)."""
+    engine = DB1Engine(args, model, mpu=mpu, lr_scheduler=None)
+    g = lambda k, d=None: getattr(args, k, d) if args is not None else d
+    if lr_scheduler is None and g("lr", None) is not None and g("lr_decay_iters", None):
+        lr_scheduler = OptimizerParamScheduler(
+            engine.optimizer, max_lr=g("lr"), min_lr=g("min_lr", 0.0) or 0.0,
+            lr_warmup_steps=g("lr_warmup_iters", 0) or 0, lr_decay_steps=g("lr_decay_iters"),
+            lr_decay_style=g("lr_decay_style", "linear"), start_wd=g("start_weight_decay", g("weight_decay", 0.01)),
+            end_wd=g("end_weight_decay", g("weight_decay", 0.01)), wd_incr_steps=g("lr_decay_iters"),
+            wd_incr_style=g("weight_decay_incr_style", "constant"))
+    elif lr_scheduler is not None and hasattr(lr_scheduler, "optimizer"):
+        lr_scheduler.optimizer = engine.optimizer
+        lr_scheduler.step(0)
+    engine.lr_scheduler = lr_scheduler
+    return engine, engine.optimizer, None, lr_scheduler

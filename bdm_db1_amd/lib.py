@@ -1,0 +1,89 @@
+"""ctypes binding of libdb1_hip.so.  The prototypes are read from include/db1_hip.h so the
+Python side can never drift from the C ABI.  There is NO fallback: if the library is missing or a
+call fails, this raises (the product path must fail loudly, never route through a CPU path).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(HERE, "..", "include", "db1_hip.h")
+LIB_PATH = os.path.join(HERE, "libdb1_hip.so")
+
+DB1_F32, DB1_BF16 = 0, 1
+ACT_CODES = {"geglu": 0, "gelu": 1, "relu": 2}
+
+_CTYPES = {
+    "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32,
+    "void": None,
+}
+
+
+class Db1Error(RuntimeError):
+    pass
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
+    """Returns {name: (restype, [argtypes])} for every function declared in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    protos = {}
+    for m in re.finditer(r"(?:^|\n)\s*(const\s+char\s*\*|int|void)\s+(db1_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        restype = ctypes.c_char_p if "char" in ret else (None if ret == "void" else ctypes.c_int)
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    base = a.replace("const", "").split()[0]
+                    argtypes.append(_CTYPES[base])
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+_lib = None
+_protos = None
+
+
+def load():
+    """Load the shared library (build it first with bdm_db1_amd.build.build_lib())."""
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Db1Error(f"{LIB_PATH} is missing: run `python -m bdm_db1_amd.build` (or __graft_entry__.build()). "
+                       "There is no CPU fallback for the DB1 hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    _protos = parse_header()
+    for name, (restype, argtypes) in _protos.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def declared_symbols() -> List[str]:
+    return sorted(parse_header().keys())
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().db1_last_error()
+        raise Db1Error(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    fn = getattr(load(), name)
+    st = fn(*args)
+    if st != 0:
+        msg = _lib.db1_last_error()
+        raise Db1Error(f"{name} failed with status {st}: {msg.decode() if msg else ''}")

@@ -1,0 +1,726 @@
+"""MI355X-native TransformerXL for DB1: the reference's ``src/model/transformer_xl.py`` API
+(constructor attributes, ``forward(tasks_input, compute_loss, mems)``, ``init_mem``, state-dict names)
+over hand-written gfx950 kernels called through the C ABI (``include/db1_hip.h``).
+
+Design (MI355X-first, not a translation of the eager reference):
+  * one flat float32 parameter arena (+ Adam m/v, + float32 gradient arena laid out in
+    BACKWARD-COMPLETION order so per-layer all-reduce buckets are contiguous), and a bf16 working copy
+    written by the fused Adam kernel; ``nn.Parameter``s are views into the master arena so
+    ``state_dict()`` / ``load_state_dict()`` keep the reference's names and shapes;
+  * forward and backward are explicit sequences of kernel launches on the current HIP stream
+    (no autograd graph); activations are kept (288 GB of HBM: no recompute at DB1-1.3B sizes);
+  * the relative-position term uses the closed form score[i,j] = ((q_i+u).k_j + (q_i+v).R[i-j])/sqrt(d)
+    (transformer_xl.py:98-110,160-173); the attention mask is the index predicate
+    ``i - shift < j <= i + mlen`` (:551-567) and is never materialised;
+  * the vocabulary is padded to a multiple of 128 rows INSIDE the arena (33 025 -> 33 280); the padded
+    logits columns never enter the softmax.
+There is no CPU or torch-op fallback: without libdb1_hip.so or without a gfx950 device this raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import lib, ops
+
+
+def print_with_rank(message):
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        print(f"rank: {torch.distributed.get_rank()}", message, flush=True)
+    else:
+        print(message, flush=True)
+
+
+class _Node(nn.Module):
+    """Anonymous container: only there to reproduce the reference's dotted parameter names."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("container module")
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class ParamArena:
+    """Flat device storage for parameters, gradients and optimizer state."""
+
+    def __init__(self, entries: List[Tuple[str, Tuple[int, ...], int]], device, work_dtype):
+        # entries: (name, logical shape, allocated element count >= prod(shape))
+        self.offsets: Dict[str, Tuple[int, Tuple[int, ...], int]] = {}
+        off = 0
+        for name, shape, alloc in entries:
+            self.offsets[name] = (off, shape, alloc)
+            off += _round_up(alloc, 8)
+        self.numel = _round_up(off, 8)
+        self.master = torch.zeros(self.numel, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(self.numel, device=device, dtype=torch.float32)
+        self.work = self.master if work_dtype == torch.float32 else torch.zeros(self.numel, device=device, dtype=work_dtype)
+        self.work_dtype = work_dtype
+        self.exp_avg: Optional[torch.Tensor] = None
+        self.exp_avg_sq: Optional[torch.Tensor] = None
+
+    def view(self, buf: torch.Tensor, name: str, full: bool = False) -> torch.Tensor:
+        off, shape, alloc = self.offsets[name]
+        if full:
+            return buf[off:off + alloc]
+        n = int(np.prod(shape))
+        return buf[off:off + n].view(*shape)
+
+    def sync_work(self):
+        if self.work is not self.master:
+            ops.cast(self.master, self.work)
+
+
+class _Ctx:
+    pass
+
+
+class TransformerXL(nn.Module):
+    """Drop-in for ``src.model.TransformerXL`` (transformer_xl.py:356-748)."""
+
+    def __init__(self, config, device: Optional[torch.device] = None, compute_dtype: Optional[torch.dtype] = None):
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise lib.Db1Error("bdm_db1_amd.TransformerXL needs an MI355X (gfx950) device; there is no CPU path")
+        lib.load()
+        self.dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if lib.load().db1_device_is_gfx950() != 1:
+            raise lib.Db1Error("libdb1_hip.so is built for gfx950 only")
+        g = lambda k, dflt=None: getattr(config, k, dflt)
+        # ---- the attributes the reference constructor reads (transformer_xl.py:357-439)
+        self.n_embed = config.n_embed
+        self.n_position = config.n_position
+        self.n_layer = config.n_layer
+        self.n_head = config.n_head
+        self.d_head = self.n_embed // self.n_head
+        assert self.d_head * self.n_head == self.n_embed, (self.d_head, self.n_head, self.n_embed)
+        self.d_model = self.n_embed
+        self.d_inner = 4 * self.d_model if g("n_inner") is None else config.n_inner
+        self.pre_lnorm = bool(config.pre_lnorm)
+        self.mem_len = config.mem_len if g("mem_len") is not None else 0
+        self.same_length = bool(config.same_length)
+        self.clamp_len = self.n_position
+        self.untie_r = bool(config.untie_r)
+        self.text_vocab_size = config.text_vocab_size
+        self.discrete_vocab_size = config.num_discrete_values
+        self.continuous_vocab_size = config.num_continuous_bin
+        self.discrete_overlap_with_text = bool(config.overlap_with_text)
+        tv = self.text_vocab_size + self.continuous_vocab_size + (0 if self.discrete_overlap_with_text else self.discrete_vocab_size)
+        self.total_vocab_size = tv + 1
+        self.rl_separator_token_id = tv
+        self.activation_fn = config.activation_fn
+        if self.activation_fn not in ("geglu", "gelu", "relu"):
+            raise NotImplementedError(f"activation_fn={self.activation_fn!r}: the HIP path implements geglu / gelu / relu")
+        if self.activation_fn == "geglu":
+            assert self.d_inner % 2 == 0
+        self.d_ff = self.d_inner // 2 if self.activation_fn == "geglu" else self.d_inner
+        self.layer_norm_epsilon = float(config.layer_norm_epsilon)
+        self.share_input_output_embedding = bool(config.share_input_output_embedding)
+        self.use_deepnorm = bool(g("use_deepnorm", False))
+        self.deepnorm_alpha = (2 * self.n_layer) ** 0.25 if self.use_deepnorm else None
+        self.deepnorm_beta = (8 * self.n_layer) ** -0.25 if self.use_deepnorm else None
+        for pname in ("embd_pdrop", "drop", "dropattn"):
+            if float(g(pname, 0.0) or 0.0) != 0.0:
+                raise NotImplementedError(f"{pname} != 0: dropout is not part of the HIP hot path (parity and benchmarks run with p = 0)")
+        self.patch_size = int(g("vision_patch_size", 16))
+        self.vision_channels = int(g("vision_num_input_channels", 3))
+        self.vision_position_vocab_size = int(g("vision_position_vocab_size", 128))
+        if compute_dtype is None:
+            compute_dtype = g("compute_dtype", None)
+        if compute_dtype is None:
+            compute_dtype = torch.bfloat16 if bool(g("fp16", False)) else torch.float32
+        if isinstance(compute_dtype, str):
+            compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[compute_dtype]
+        assert compute_dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = compute_dtype
+        self.vocab_pad = _round_up(self.total_vocab_size, 128)
+        self.keep_logits = True          # False: the CE backward overwrites the logits buffer (training engines)
+        self.use_flash = True            # fused attention when the shape is supported
+        self._ctx: Optional[_Ctx] = None
+        self._tables: Dict[Tuple[int, int], torch.Tensor] = {}
+
+        # ---- parameters: arena in backward-completion order (last layer first, embeddings last)
+        d, H, D, di, dff = self.d_model, self.n_head, self.d_head, self.d_inner, self.d_ff
+        ent: List[Tuple[str, Tuple[int, ...], int]] = []
+        add = lambda n, s, alloc=None: ent.append((n, tuple(s), int(np.prod(s)) if alloc is None else alloc))
+        for i in reversed(range(self.n_layer)):
+            p = f"h.{i}."
+            add(p + "pos_ff.layer_norm.weight", (d,)); add(p + "pos_ff.layer_norm.bias", (d,))
+            add(p + "pos_ff.CoreNet.2.weight", (d, dff)); add(p + "pos_ff.CoreNet.2.bias", (d,))
+            add(p + "pos_ff.CoreNet.0.weight", (di, d)); add(p + "pos_ff.CoreNet.0.bias", (di,))
+            add(p + "dec_attn.layer_norm.weight", (d,)); add(p + "dec_attn.layer_norm.bias", (d,))
+            add(p + "dec_attn.o_net.weight", (d, d)); add(p + "dec_attn.r_net.weight", (d, d))
+            add(p + "dec_attn.qkv_net.weight", (3 * d, d))
+            if self.untie_r:
+                add(p + "dec_attn.r_r_bias", (H, D)); add(p + "dec_attn.r_w_bias", (H, D))
+        if not self.untie_r:
+            add("r_w_bias", (H, D)); add("r_r_bias", (H, D))
+        add("rl_local_timestep_embedding.weight", (513, d))
+        pe = "vision_encoder.patch_embeddings."
+        C, ps = self.vision_channels, self.patch_size
+        add(pe + "projection.weight", (d, 64, ps, ps)); add(pe + "projection.bias", (d,))
+        add(pe + "residual_path.5.weight", (64, 64, 3, 3)); add(pe + "residual_path.5.bias", (64,))
+        add(pe + "residual_path.3.weight", (64,)); add(pe + "residual_path.3.bias", (64,))
+        add(pe + "residual_path.2.weight", (64, 64, 3, 3)); add(pe + "residual_path.2.bias", (64,))
+        add(pe + "residual_path.0.weight", (64,)); add(pe + "residual_path.0.bias", (64,))
+        add(pe + "conv1.weight", (64, C, 3, 3)); add(pe + "conv1.bias", (64,))
+        add("vision_encoder.row_position_embeddings.weight", (self.vision_position_vocab_size, d))
+        add("vision_encoder.col_position_embeddings.weight", (self.vision_position_vocab_size, d))
+        if not self.share_input_output_embedding:
+            add("lm_head.weight", (self.total_vocab_size, d), self.vocab_pad * d)
+        add("word_embedding.weight", (self.total_vocab_size, d), self.vocab_pad * d)
+        self.arena = ParamArena(ent, self.dev, compute_dtype)
+        self._register_parameters()
+        inv_freq = 1 / (10000 ** (torch.arange(0.0, d, 2.0) / d))  # transformer_xl.py:40 (same float32 op order, on the host)
+        self.pos_emb = _Node()
+        self.pos_emb.register_buffer("inv_freq", inv_freq.to(self.dev))
+        self._init_weights()
+        self.arena.sync_work()
+        self.train()
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _register_parameters(self):
+        shared: Dict[str, nn.Parameter] = {}
+        for name in self.arena.offsets:
+            prm = nn.Parameter(self.arena.view(self.arena.master, name), requires_grad=True)
+            prm.grad = self.arena.view(self.arena.grad, name)
+            shared[name] = prm
+            node = self
+            parts = name.split(".")
+            for part in parts[:-1]:
+                if not hasattr(node, part):
+                    node.add_module(part, _Node())
+                node = getattr(node, part)
+            node.register_parameter(parts[-1], prm)
+        if not self.untie_r:  # tied u / v appear under every layer in the reference's state dict (:421-422)
+            for i in range(self.n_layer):
+                att = getattr(getattr(self.h, str(i)), "dec_attn")
+                att.register_parameter("r_r_bias", shared["r_r_bias"])
+                att.register_parameter("r_w_bias", shared["r_w_bias"])
+        self.ic_encoder = self.vision_encoder  # transformer_xl.py:403-404
+        self.lm_head_is_tied = self.share_input_output_embedding
+
+    def _init_weights(self):
+        """Distribution of the reference init (transformer_xl.py:444-468); values differ (different RNG)."""
+        gen = torch.Generator(device=self.dev)
+        gen.manual_seed(torch.initial_seed() % (2 ** 31))
+        with torch.no_grad():
+            for name in self.arena.offsets:
+                p = self.arena.view(self.arena.master, name)
+                leaf = name.split(".")[-1]
+                if "layer_norm" in name or ("residual_path" in name and p.dim() == 1):
+                    p.fill_(1.0 if leaf == "weight" else 0.0)
+                elif "patch_embeddings" in name:  # nn.Conv2d default init (kaiming_uniform, a = sqrt(5))
+                    wname = name.rsplit(".", 1)[0] + ".weight"
+                    wshape = self.arena.offsets[wname][1]
+                    bound = 1.0 / math.sqrt(int(np.prod(wshape[1:])))
+                    p.copy_((torch.rand(p.shape, device=self.dev, generator=gen) * 2 - 1) * bound)
+                elif leaf == "bias":
+                    p.zero_()
+                else:
+                    p.copy_(torch.randn(p.shape, device=self.dev, generator=gen) * 0.02)
+            if self.use_deepnorm:  # _deepnorm_init :444-454
+                for i in range(self.n_layer):
+                    for nm, gain in ((f"h.{i}.pos_ff.CoreNet.0.weight", self.deepnorm_beta), (f"h.{i}.pos_ff.CoreNet.2.weight", self.deepnorm_beta),
+                                     (f"h.{i}.dec_attn.o_net.weight", self.deepnorm_beta)):
+                        nn.init.xavier_uniform_(self.arena.view(self.arena.master, nm), gain=gain)
+                    w = self.arena.view(self.arena.master, f"h.{i}.dec_attn.qkv_net.weight")
+                    nn.init.xavier_uniform_(w, gain=1)
+                    nn.init.xavier_uniform_(w[2 * self.d_model:, :], gain=self.deepnorm_beta)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        sd = dict(state_dict)
+        res = super().load_state_dict(sd, strict=strict, **kw)
+        self.arena.sync_work()
+        return res
+
+    def sync_work_params(self):
+        """Refresh the bf16 working copy after the float32 master parameters were edited by hand."""
+        self.arena.sync_work()
+
+    def W(self, name: str) -> torch.Tensor:
+        """parameter in the compute dtype"""
+        return self.arena.view(self.arena.work, name)
+
+    def G(self, name: str) -> torch.Tensor:
+        return self.arena.view(self.arena.grad, name)
+
+    @property
+    def device(self):
+        return self.dev
+
+    # ------------------------------------------------------------------ helpers
+    def _new(self, *shape, dtype=None):
+        return torch.empty(*shape, device=self.dev, dtype=self.compute_dtype if dtype is None else dtype)
+
+    def _window(self, qlen: int, mlen: int) -> int:
+        """shift of the visibility predicate i - shift < j <= i + mlen (transformer_xl.py:551-567)."""
+        klen = qlen + mlen
+        if self.same_length:
+            mask_len = klen - self.mem_len
+            return qlen - mask_len if mask_len > 0 else qlen
+        return klen
+
+    def _sinusoid(self, klen: int) -> torch.Tensor:
+        """R_in[dist] = cat(sin, cos)(min(dist, clamp) * inv_freq), dist = 0..klen-1 (transformer_xl.py:43-45,569-574).
+        A constant table: built once per klen with the reference's float32 op order and cached on the device."""
+        key = (klen, 0)
+        if key not in self._tables:
+            dist = torch.arange(0, klen, 1.0, dtype=torch.float32)
+            if self.clamp_len > 0:
+                dist.clamp_(max=self.clamp_len)
+            inv = self.pos_emb.inv_freq.detach().float().cpu()
+            s = torch.ger(dist, inv)
+            tab = torch.cat([s.sin(), s.cos()], dim=-1)
+            self._tables[key] = tab.to(self.dev).to(self.compute_dtype).contiguous()
+        return self._tables[key]
+
+    def _dev_ids(self, t) -> torch.Tensor:
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(np.asarray(t))
+        return t.to(device=self.dev, dtype=torch.int64).contiguous()
+
+    # ------------------------------------------------------------------ vision encoder (vision_embedding.py:65-180)
+    def _vision_position_ids(self, h0: int, w0: int, n_img: int):
+        """eval: midpoint rule; train: uniform pick in [low, high) per (image, position) (vision_embedding.py:134-172)."""
+        vocab = self.vision_position_vocab_size
+        seq = torch.arange(h0 * w0)
+        row = torch.div(seq, w0, rounding_mode="trunc")
+        col = seq % w0
+        col_hi = ((col + 1) / w0 * vocab).to(torch.int32)
+        col_lo = (col / w0 * vocab).to(torch.int32)
+        row_hi = ((row + 1) / h0 * vocab).to(torch.int32)
+        row_lo = (row / h0 * vocab).to(torch.int32)
+        if self.training:
+            r = (torch.rand(n_img, h0 * w0) * (row_hi - row_lo) + row_lo).floor().to(torch.int64)
+            c = (torch.rand(n_img, h0 * w0) * (col_hi - col_lo) + col_lo).floor().to(torch.int64)
+        else:
+            r = ((row_lo + row_hi) / 2).int().to(torch.int64).unsqueeze(0).expand(n_img, -1)
+            c = ((col_lo + col_hi) / 2).int().to(torch.int64).unsqueeze(0).expand(n_img, -1)
+        return r.contiguous(), c.contiguous()
+
+    def _conv3x3_fwd(self, x_nchw, wname, bname, N, Cin):
+        """per-patch 3x3 conv as im2col + GEMM; returns NHWC output [N*256, 64] and the column matrix"""
+        hw = self.patch_size * self.patch_size
+        cols = self._new(N * hw, Cin * 9)
+        ops.im2col3x3(x_nchw, cols, N, Cin, self.patch_size)
+        out = self._new(N * hw, 64)
+        ops.gemm(cols, self.W(wname).view(64, Cin * 9).t(), out, bias=self.W(bname))
+        return out, cols
+
+    def _vision_fwd(self, pixels: torch.Tensor, row_ids=None, col_ids=None):
+        pixels = pixels.to(device=self.dev, dtype=torch.float32).contiguous()
+        n_img, C, Hh, Ww = pixels.shape
+        p, d = self.patch_size, self.d_model
+        hw = p * p
+        h0, w0 = Hh // p, Ww // p
+        N = n_img * h0 * w0
+        pe = "vision_encoder.patch_embeddings."
+        c = _Ctx()
+        patches = self._new(N, C, p, p)
+        ops.patch_normalize(pixels, patches, p)
+        c1, c.cols1 = self._conv3x3_fwd(patches, pe + "conv1.weight", pe + "conv1.bias", N, C)
+        c.c1n = self._new(N, 64, hw)
+        ops.nhwc_to_nchw(c1, c.c1n, N, 64, hw)
+        a0 = self._new(N, 64, hw)
+        c.m0, c.r0 = self._new(N * 32, dtype=torch.float32), self._new(N * 32, dtype=torch.float32)
+        ops.groupnorm_gelu_fwd(c.c1n, self.W(pe + "residual_path.0.weight"), self.W(pe + "residual_path.0.bias"), a0, c.m0, c.r0, N, 64, hw)
+        c2, c.cols2 = self._conv3x3_fwd(a0, pe + "residual_path.2.weight", pe + "residual_path.2.bias", N, 64)
+        c.c2n = self._new(N, 64, hw)
+        ops.nhwc_to_nchw(c2, c.c2n, N, 64, hw)
+        a1 = self._new(N, 64, hw)
+        c.m1, c.r1 = self._new(N * 32, dtype=torch.float32), self._new(N * 32, dtype=torch.float32)
+        ops.groupnorm_gelu_fwd(c.c2n, self.W(pe + "residual_path.3.weight"), self.W(pe + "residual_path.3.bias"), a1, c.m1, c.r1, N, 64, hw)
+        c3, c.cols3 = self._conv3x3_fwd(a1, pe + "residual_path.5.weight", pe + "residual_path.5.bias", N, 64)
+        ops.add(c1, c3, c3)                                   # residual (NHWC)
+        c.y = self._new(N, 64 * hw)                            # NCHW flatten = projection weight layout
+        ops.nhwc_to_nchw(c3, c.y, N, 64, hw)
+        emb = self._new(N, d)
+        ops.gemm(c.y, self.W(pe + "projection.weight").view(d, 64 * hw).t(), emb, bias=self.W(pe + "projection.bias"))
+        if row_ids is None:
+            row_ids, col_ids = self._vision_position_ids(h0, w0, n_img)
+        c.row_ids, c.col_ids = self._dev_ids(row_ids).reshape(-1), self._dev_ids(col_ids).reshape(-1)
+        assert c.row_ids.numel() == N
+        tmp = self._new(N, d)
+        ops.embed_gather(self.W("vision_encoder.row_position_embeddings.weight"), c.row_ids, tmp)
+        ops.add(emb, tmp, emb)
+        ops.embed_gather(self.W("vision_encoder.col_position_embeddings.weight"), c.col_ids, tmp)
+        ops.add(emb, tmp, emb)
+        c.N, c.C, c.n_img = N, C, n_img
+        return emb.view(n_img, h0 * w0, d), c
+
+    def _conv3x3_bwd(self, dy_nhwc, cols, wname, bname, N, Cin, need_dx):
+        ops.gemm(dy_nhwc.t(), cols, self.G(wname).view(64, Cin * 9), beta=1.0)
+        ops.colsum_acc(dy_nhwc, self.G(bname))
+        if not need_dx:
+            return None
+        dcols = self._new(cols.shape[0], cols.shape[1])
+        ops.gemm(dy_nhwc, self.W(wname).view(64, Cin * 9), dcols)
+        dx = self._new(N, Cin, self.patch_size * self.patch_size)
+        ops.col2im3x3(dcols, dx, N, Cin, self.patch_size)
+        return dx
+
+    def _vision_bwd(self, demb: torch.Tensor, c: _Ctx):
+        """demb [N, d] (compute dtype, contiguous)"""
+        p, d = self.patch_size, self.d_model
+        hw, N = p * p, c.N
+        pe = "vision_encoder.patch_embeddings."
+        ops.embed_scatter_add(demb, c.row_ids, self.G("vision_encoder.row_position_embeddings.weight"))
+        ops.embed_scatter_add(demb, c.col_ids, self.G("vision_encoder.col_position_embeddings.weight"))
+        ops.gemm(demb.t(), c.y, self.G(pe + "projection.weight").view(d, 64 * hw), beta=1.0)
+        ops.colsum_acc(demb, self.G(pe + "projection.bias"))
+        dy = self._new(N, 64 * hw)
+        ops.gemm(demb, self.W(pe + "projection.weight").view(d, 64 * hw), dy)
+        dy_nhwc = self._new(N * hw, 64)
+        ops.nchw_to_nhwc(dy, dy_nhwc, N, 64, hw)
+        da1 = self._conv3x3_bwd(dy_nhwc, c.cols3, pe + "residual_path.5.weight", pe + "residual_path.5.bias", N, 64, True)
+        dc2n = self._new(N, 64, hw)
+        ops.groupnorm_gelu_bwd(da1, c.c2n, self.W(pe + "residual_path.3.weight"), self.W(pe + "residual_path.3.bias"), c.m1, c.r1, dc2n,
+                               self.G(pe + "residual_path.3.weight"), self.G(pe + "residual_path.3.bias"), N, 64, hw)
+        dc2 = self._new(N * hw, 64)
+        ops.nchw_to_nhwc(dc2n, dc2, N, 64, hw)
+        da0 = self._conv3x3_bwd(dc2, c.cols2, pe + "residual_path.2.weight", pe + "residual_path.2.bias", N, 64, True)
+        dc1n = self._new(N, 64, hw)
+        ops.groupnorm_gelu_bwd(da0, c.c1n, self.W(pe + "residual_path.0.weight"), self.W(pe + "residual_path.0.bias"), c.m0, c.r0, dc1n,
+                               self.G(pe + "residual_path.0.weight"), self.G(pe + "residual_path.0.bias"), N, 64, hw)
+        dc1 = self._new(N * hw, 64)
+        ops.nchw_to_nhwc(dc1n, dc1, N, 64, hw)
+        ops.add(dc1, dy_nhwc, dc1)                             # residual branch
+        self._conv3x3_bwd(dc1, c.cols1, pe + "conv1.weight", pe + "conv1.bias", N, c.C, False)
+
+    # ------------------------------------------------------------------ per-modality embedding (transformer_xl.py:621-748)
+    def _embed_task(self, task, compute_loss: bool):
+        kind = type(task).__name__
+        d = self.d_model
+        E = self.W("word_embedding.weight")
+        c = _Ctx()
+        c.kind = kind
+        if kind == "NLPTaskInput":
+            ids = self._dev_ids(task.text_seq)
+            B, L = ids.shape
+            emb = self._new(B, L, d)
+            ops.embed_gather(E, ids.view(-1), emb.view(B * L, d))
+            c.ids = ids
+        elif kind == "RLTaskInput":
+            ids = self._dev_ids(task.tensor_seq)
+            B, L = ids.shape
+            pos = self._dev_ids(task.position_id)
+            vis = None
+            if task.vision_seq is not None:
+                img = task.vision_seq
+                img = img.reshape(-1, *img.shape[-3:])
+                v, c.vis = self._vision_fwd(img, getattr(task, "vision_row_ids", None), getattr(task, "vision_col_ids", None))
+                vis = v.reshape(B, -1, d).contiguous()
+                c.vis_shape = vis.shape
+            rl_label = None
+            if compute_loss and task.label is not None:
+                rl_label = self._dev_ids(task.label).clone()  # "-1 -> 0" (:644-645) is applied to a private copy by the kernel
+            emb = self._new(B, L, d)
+            ops.rl_assemble_fwd(E, self.W("rl_local_timestep_embedding.weight"), vis, ids, pos, rl_label, emb)
+            c.ids, c.pos = ids, pos
+        elif kind in ("ICTaskInput", "VQATaskInput"):
+            prompt, text = self._dev_ids(task.prompt_seq), self._dev_ids(task.text_seq)
+            v, c.vis = self._vision_fwd(task.img_seq, getattr(task, "vision_row_ids", None), getattr(task, "vision_col_ids", None))
+            B, P_, nv, Tt = prompt.shape[0], prompt.shape[1], v.shape[1], text.shape[1]
+            L = P_ + nv + Tt
+            emb = self._new(B, L, d)
+            e2 = emb.view(B * L, d)
+            # gather straight into the concatenated layout (row stride L*d per sample handled by per-sample calls)
+            for b in range(B):
+                ops.embed_gather(E, prompt[b], emb[b, :P_])
+                ops.embed_gather(E, text[b], emb[b, P_ + nv:])
+            emb[:, P_:P_ + nv].copy_(v)  # placement of the patch embeddings (data movement only)
+            c.prompt, c.text, c.nv = prompt, text, nv
+        else:
+            raise TypeError(f"unknown task input type {kind}")
+        label = mask = None
+        if compute_loss:
+            label = rl_label if kind == "RLTaskInput" else self._dev_ids(task.label)
+            mask = task.loss_mask.to(device=self.dev, dtype=torch.float32) if torch.is_tensor(task.loss_mask) \
+                else torch.as_tensor(np.asarray(task.loss_mask), dtype=torch.float32, device=self.dev)
+        return emb, label, mask, c
+
+    def _embed_bwd(self, dh: torch.Tensor, ecs: List[_Ctx], shapes):
+        d = self.d_model
+        gE = self.arena.view(self.arena.grad, "word_embedding.weight", full=True).view(self.vocab_pad, d)
+        b0 = 0
+        for c, (B, L) in zip(ecs, shapes):
+            de = dh[b0:b0 + B]
+            b0 += B
+            if c.kind == "NLPTaskInput":
+                ops.embed_scatter_add(de.reshape(B * L, d), c.ids.view(-1), gE)
+            elif c.kind == "RLTaskInput":
+                dvis = self._new(*c.vis_shape) if hasattr(c, "vis") else None
+                ops.rl_assemble_bwd(de.contiguous(), c.ids, c.pos, gE, self.G("rl_local_timestep_embedding.weight"), dvis)
+                if dvis is not None:
+                    self._vision_bwd(dvis.view(-1, d), c.vis)
+            else:
+                P_, nv = c.prompt.shape[1], c.nv
+                for b in range(B):
+                    ops.embed_scatter_add(de[b, :P_], c.prompt[b], gE)
+                    ops.embed_scatter_add(de[b, P_ + nv:], c.text[b], gE)
+                self._vision_bwd(de[:, P_:P_ + nv].contiguous().view(-1, d), c.vis)
+
+    # ------------------------------------------------------------------ attention
+    def _bias(self, name: str, i: int) -> torch.Tensor:
+        return self.W(f"h.{i}.dec_attn.{name}" if self.untie_r else name)
+
+    def _bias_grad(self, name: str, i: int) -> torch.Tensor:
+        return self.G(f"h.{i}.dec_attn.{name}" if self.untie_r else name)
+
+    def _attn_probs(self, qkv, R, u, vb, B, Lq, Lk, mlen, shift):
+        """materialised path: returns (P [H,B,Lq,Lk] f32, T buffer, qu, qv)"""
+        H, D = self.n_head, self.d_head
+        nd = R.shape[0]
+        qu, qv = self._new(B, Lq, H, D), self._new(B, Lq, H, D)
+        ops.relattn_add_head_bias(qkv, u, vb, qu, qv, B, Lq, Lk, H, D)
+        qkv5 = qkv.view(B, Lk, 3, H, D)
+        AC = self._new(H, B, Lq, Lk, dtype=torch.float32)
+        ops.gemm_batched(qu.permute(2, 0, 1, 3), qkv5[:, :, 1].permute(2, 0, 3, 1), AC)
+        T = self._new(H, B, Lq, nd, dtype=torch.float32)
+        ops.gemm_batched(qv.permute(2, 0, 1, 3), R.view(nd, H, D).permute(1, 2, 0).unsqueeze(1).expand(H, B, D, nd), T)
+        ops.relattn_softmax_fwd(AC, T, None, H, B, Lq, Lk, nd, mlen, shift, 1.0 / math.sqrt(D))
+        return AC, T, qu, qv
+
+    def _attention_fwd(self, qkv, R, i, B, Lq, Lk, mlen, shift, c: Optional[_Ctx]):
+        H, D = self.n_head, self.d_head
+        u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
+        av = self._new(B, Lq, H, D)
+        flash = (self.use_flash and mlen == 0 and Lq == Lk and ops.relattn_flash_supported(B, Lq, H, D, self.compute_dtype))
+        if flash:
+            lse = self._new(B, H, Lq, dtype=torch.float32)
+            ops.relattn_flash_fwd(qkv, R, u, vb, av, lse, B, Lq, H, D, shift, 1.0 / math.sqrt(D))
+            if c is not None:
+                c.lse = lse
+        else:
+            Pm, _, _, _ = self._attn_probs(qkv, R, u, vb, B, Lq, Lk, mlen, shift)
+            qkv5 = qkv.view(B, Lk, 3, H, D)
+            ops.gemm_batched(Pm, qkv5[:, :, 2].permute(2, 0, 1, 3), av.permute(2, 0, 1, 3))
+        if c is not None:
+            c.flash = flash
+        return av
+
+    def _attention_bwd(self, dav, c: _Ctx, i, B, L, shift):
+        """returns dqkv [B*L, 3d] and dR [L, d]; accumulates du / dv_bias"""
+        H, D, d = self.n_head, self.d_head, self.d_model
+        u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
+        qkv, R = c.qkv, c.R
+        nd = R.shape[0]
+        scale = 1.0 / math.sqrt(D)
+        dqkv = self._new(B * L, 3 * d)
+        dqkv5 = dqkv.view(B, L, 3, H, D)
+        qkv5 = qkv.view(B, L, 3, H, D)
+        dav4 = dav.view(B, L, H, D)
+        if c.flash:
+            qv = self._new(B, L, H, D)
+            qu = self._new(B, L, H, D)
+            ops.relattn_add_head_bias(qkv, u, vb, qu, qv, B, L, L, H, D)
+            dT = self._new(H, B, L, L)
+            delta = self._new(B, H, L, dtype=torch.float32)
+            ops.relattn_flash_bwd(qkv, R, u, vb, c.av, dav, c.lse, delta, dqkv, dT, B, L, H, D, shift, scale)
+        else:
+            Pm, T, qu, qv = self._attn_probs(qkv, R, u, vb, B, L, L, 0, shift)
+            dP = self._new(H, B, L, L, dtype=torch.float32)
+            ops.gemm_batched(dav4.permute(2, 0, 1, 3), qkv5[:, :, 2].permute(2, 0, 3, 1), dP)
+            ops.gemm_batched(Pm.transpose(2, 3), dav4.permute(2, 0, 1, 3), dqkv5[:, :, 2].permute(2, 0, 1, 3))          # dV
+            dT = T
+            ops.relattn_softmax_bwd(Pm, dP, dT, H, B, L, L, nd, 0, shift, scale)
+            dS = dP
+            ops.gemm_batched(dS, qkv5[:, :, 1].permute(2, 0, 1, 3), dqkv5[:, :, 0].permute(2, 0, 1, 3))                  # dq_k
+            ops.gemm_batched(dS.transpose(2, 3), qu.permute(2, 0, 1, 3), dqkv5[:, :, 1].permute(2, 0, 1, 3))             # dK
+        dq2d = dqkv.view(B * L, 3 * d)[:, :d]
+        ops.colsum_acc(dq2d, self._bias_grad("r_w_bias", i).view(-1))                                                    # du
+        dqv = self._new(B, L, H, D)
+        ops.gemm_batched(dT, R.view(nd, H, D).permute(1, 0, 2).unsqueeze(1).expand(H, B, nd, D), dqv.permute(2, 0, 1, 3))  # dq_r
+        ops.colsum_acc(dqv.view(B * L, d), self._bias_grad("r_r_bias", i).view(-1))                                      # dv_bias
+        dR = self._new(nd, d)
+        ops.gemm_batched(dT.view(H, B * L, nd).transpose(1, 2).unsqueeze(1), qv.view(B * L, H, D).permute(1, 0, 2).unsqueeze(1),
+                         dR.view(nd, H, D).permute(1, 0, 2).unsqueeze(1))
+        ops.add2d(dqv.view(B * L, d), dq2d, dq2d)
+        return dqkv, dR
+
+    # ------------------------------------------------------------------ one decoder layer (post-LN; transformer_xl.py:112-353)
+    def _layer_fwd(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool):
+        d, di, dff = self.d_model, self.d_inner, self.d_ff
+        a = 1.0 if self.deepnorm_alpha is None else self.deepnorm_alpha
+        p = f"h.{i}."
+        c = _Ctx() if keep else None
+        T = B * L
+        if mem is not None:
+            cat = torch.cat([mem.to(self.compute_dtype), x.view(B, L, d)], dim=1).contiguous()  # data movement only (:125)
+            Lk = cat.shape[1]
+            xin = cat.view(B * Lk, d)
+        else:
+            Lk, xin = L, x
+        qkv = self._new(B * Lk, 3 * d)
+        ops.gemm(xin, self.W(p + "dec_attn.qkv_net.weight").t(), qkv)
+        R = self._new(R_in.shape[0], d)
+        ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
+        av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c)
+        o = self._new(T, d)
+        ops.gemm(av.view(T, d), self.W(p + "dec_attn.o_net.weight").t(), o)
+        h1 = self._new(T, d)
+        m1, r1 = self._new(T, dtype=torch.float32), self._new(T, dtype=torch.float32)
+        ops.layernorm_residual_fwd(x, o, a, self.W(p + "dec_attn.layer_norm.weight"), self.W(p + "dec_attn.layer_norm.bias"),
+                                   h1, o if keep else None, m1, r1, self.layer_norm_epsilon)  # s1 overwrites o
+        z = self._new(T, di)
+        ops.gemm(h1, self.W(p + "pos_ff.CoreNet.0.weight").t(), z, bias=self.W(p + "pos_ff.CoreNet.0.bias"))
+        act = self._new(T, dff)
+        ops.ffn_act_fwd(z, act, self.activation_fn)
+        f = self._new(T, d)
+        ops.gemm(act, self.W(p + "pos_ff.CoreNet.2.weight").t(), f, bias=self.W(p + "pos_ff.CoreNet.2.bias"))
+        out = self._new(T, d)
+        m2, r2 = self._new(T, dtype=torch.float32), self._new(T, dtype=torch.float32)
+        ops.layernorm_residual_fwd(h1, f, a, self.W(p + "pos_ff.layer_norm.weight"), self.W(p + "pos_ff.layer_norm.bias"),
+                                   out, f if keep else None, m2, r2, self.layer_norm_epsilon)
+        if keep:
+            c.x, c.qkv, c.R, c.av, c.s1, c.m1, c.r1 = x, qkv, R, av, o, m1, r1
+            c.h1, c.z, c.act, c.s2, c.m2, c.r2 = h1, z, act, f, m2, r2
+        return out, c
+
+    def _layer_bwd(self, i, dout, c: _Ctx, R_in, B, L, shift):
+        d, di, dff = self.d_model, self.d_inner, self.d_ff
+        a = 1.0 if self.deepnorm_alpha is None else self.deepnorm_alpha
+        p = f"h.{i}."
+        T = B * L
+        W, G = self.W, self.G
+        # ---- feed-forward
+        ds2 = self._new(T, d)
+        ops.layernorm_residual_bwd(dout, c.s2, W(p + "pos_ff.layer_norm.weight"), c.m2, c.r2, ds2,
+                                   G(p + "pos_ff.layer_norm.weight"), G(p + "pos_ff.layer_norm.bias"))
+        ops.gemm(ds2.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=1.0)
+        ops.colsum_acc(ds2, G(p + "pos_ff.CoreNet.2.bias"))
+        dact = self._new(T, dff)
+        ops.gemm(ds2, W(p + "pos_ff.CoreNet.2.weight"), dact)
+        dz = self._new(T, di)
+        ops.ffn_act_bwd(c.z, dact, dz, self.activation_fn)
+        ops.gemm(dz.t(), c.h1, G(p + "pos_ff.CoreNet.0.weight"), beta=1.0)
+        ops.colsum_acc(dz, G(p + "pos_ff.CoreNet.0.bias"))
+        ops.gemm(dz, W(p + "pos_ff.CoreNet.0.weight"), ds2, beta=a)          # dh1 = a*ds2 + dz W1   (in place over ds2)
+        dh1 = ds2
+        # ---- attention
+        ds1 = self._new(T, d)
+        ops.layernorm_residual_bwd(dh1, c.s1, W(p + "dec_attn.layer_norm.weight"), c.m1, c.r1, ds1,
+                                   G(p + "dec_attn.layer_norm.weight"), G(p + "dec_attn.layer_norm.bias"))
+        ops.gemm(ds1.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=1.0)
+        dav = self._new(T, d)
+        ops.gemm(ds1, W(p + "dec_attn.o_net.weight"), dav)
+        dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift)
+        ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=1.0)
+        ops.gemm(dqkv.t(), c.x, G(p + "dec_attn.qkv_net.weight"), beta=1.0)
+        ops.gemm(dqkv, W(p + "dec_attn.qkv_net.weight"), ds1, beta=a)        # dx = a*ds1 + dqkv Wqkv (in place over ds1)
+        return ds1
+
+    # ------------------------------------------------------------------ public API
+    def init_mem(self, batch_size):
+        """transformer_xl.py:470-485"""
+        if self.mem_len > 0:
+            return [torch.zeros(batch_size, self.mem_len, self.n_embed, dtype=self.compute_dtype, device=self.dev)
+                    for _ in range(self.n_layer)]
+        return None
+
+    def forward(self, tasks_input: Sequence, compute_loss: bool = True, mems=None):
+        assert not (compute_loss and mems is not None), "During training, Gato does not use memory mechanism."
+        if self.pre_lnorm:
+            raise NotImplementedError("pre_lnorm=True: the released DB1 runs post-LN (scripts/evaluate/evaluate_rl_1.2B.sh:73); "
+                                      "the HIP path implements that configuration")
+        keep = compute_loss and torch.is_grad_enabled()
+        d = self.d_model
+        embs, labels, masks, ecs, shapes = [], [], [], [], []
+        for t in tasks_input:
+            e, lab, msk, c = self._embed_task(t, compute_loss)
+            embs.append(e); ecs.append(c); shapes.append((e.shape[0], e.shape[1]))
+            if compute_loss:
+                labels.append(lab); masks.append(msk)
+        h = embs[0] if len(embs) == 1 else torch.cat(embs, dim=0)  # concat on the batch dim (:541-545): data movement only
+        B, L, _ = h.shape
+        mlen = mems[0].size(1) if mems is not None else 0
+        klen = L + mlen
+        shift = self._window(L, mlen)
+        if shift < 1 and mlen < 1:
+            raise ValueError("empty attention mask")  # transformer_xl.py:177,205-206
+        R_in = self._sinusoid(klen)
+        x = h.view(B * L, d)
+        hids, lcs = [], []
+        for i in range(self.n_layer):
+            hids.append(x)
+            x, c = self._layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep)
+            lcs.append(c)
+        Wout = self.arena.view(self.arena.work, "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight",
+                               full=True).view(self.vocab_pad, d)
+        T = B * L
+        logits_pad = self._new(T, self.vocab_pad)
+        ops.gemm(x, Wout.t(), logits_pad)
+        V = self.total_vocab_size
+        lm_logits = logits_pad.view(B, L, self.vocab_pad)[:, :, :V]
+        loss = None
+        if compute_loss:
+            lab = (labels[0] if len(labels) == 1 else torch.cat(labels, dim=0)).reshape(-1).contiguous()
+            msk = (masks[0] if len(masks) == 1 else torch.cat(masks, dim=0)).reshape(-1).contiguous()
+            lse = self._new(T, dtype=torch.float32)
+            sums = torch.zeros(2, device=self.dev, dtype=torch.float32)
+            ops.masked_ce_fwd(logits_pad, lab, msk, lse, sums, V)
+            loss = sums[0] / sums[1]
+            if keep:
+                ctx = _Ctx()
+                ctx.ecs, ctx.shapes, ctx.lcs, ctx.R_in, ctx.hfin = ecs, shapes, lcs, R_in, x
+                ctx.logits_pad, ctx.lab, ctx.msk, ctx.lse, ctx.sums = logits_pad, lab, msk, lse, sums
+                ctx.B, ctx.L, ctx.shift = B, L, shift
+                self._ctx = ctx
+        res = (lm_logits, loss)
+        if mems is not None:  # _update_mem (:487-504)
+            end_idx = mlen + max(0, L)
+            beg_idx = max(0, end_idx - self.mem_len)
+            new_mems = [torch.cat([mems[i].to(self.compute_dtype), hids[i].view(B, L, d)], dim=1)[:, beg_idx:end_idx].detach()
+                        for i in range(self.n_layer)]
+            res = res + (new_mems,)
+        return res
+
+    def backward(self, grad_scale: float = 1.0, layer_done_hook=None):
+        """Accumulate d(loss * grad_scale)/d(params) of the last forward into the gradient arena.
+        ``layer_done_hook(name)`` fires as soon as a layer's gradients are final (used by the data-parallel
+        engine to start that layer's bucket all-reduce while earlier layers are still in backward)."""
+        ctx = self._ctx
+        if ctx is None:
+            raise RuntimeError("backward() without a preceding forward(compute_loss=True)")
+        self._ctx = None
+        d, V = self.d_model, self.total_vocab_size
+        B, L = ctx.B, ctx.L
+        T = B * L
+        dlogits = self._new(T, self.vocab_pad) if self.keep_logits else ctx.logits_pad
+        ops.masked_ce_bwd(ctx.logits_pad, ctx.lab, ctx.msk, ctx.lse, ctx.sums, dlogits, V, gscale=grad_scale)
+        wname = "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight"
+        Wout = self.arena.view(self.arena.work, wname, full=True).view(self.vocab_pad, d)
+        gW = self.arena.view(self.arena.grad, wname, full=True).view(self.vocab_pad, d)
+        ops.gemm(dlogits.t(), ctx.hfin, gW, beta=1.0)
+        dh = self._new(T, d)
+        ops.gemm(dlogits, Wout, dh)
+        del dlogits
+        for i in reversed(range(self.n_layer)):
+            dh = self._layer_bwd(i, dh, ctx.lcs[i], ctx.R_in, B, L, ctx.shift)
+            ctx.lcs[i] = None
+            if layer_done_hook is not None:
+                layer_done_hook(f"h.{i}")
+        self._embed_bwd(dh.view(B, L, d), ctx.ecs, ctx.shapes)
+        if layer_done_hook is not None:
+            layer_done_hook("embeddings")
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.arena.grad.zero_()
+
+    # layer -> contiguous [start, end) element range of the gradient arena (bucket boundaries for data parallelism)
+    def grad_buckets(self) -> List[Tuple[str, int, int]]:
+        groups: Dict[str, List[int]] = {}
+        order: List[str] = []
+        for name, (off, shape, alloc) in self.arena.offsets.items():
+            key = ".".join(name.split(".")[:2]) if name.startswith("h.") else "embeddings"
+            if key not in groups:
+                groups[key] = [off, off]
+                order.append(key)
+            groups[key][1] = off + _round_up(alloc, 8)
+        return [(k, groups[k][0], groups[k][1]) for k in order]

@@ -1,0 +1,221 @@
+"""Thin torch-tensor -> C-ABI adapters.  Tensors are containers only: every function passes
+``tensor.data_ptr()`` + sizes to libdb1_hip.so on the current HIP stream.  No arithmetic happens in
+Python or in torch ops here, and nothing falls back to torch when a call fails."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import lib
+from .lib import DB1_BF16, DB1_F32, ACT_CODES
+
+_vp = ctypes.c_void_p
+
+
+def dt_code(t) -> int:
+    dt = t if isinstance(t, torch.dtype) else t.dtype
+    if dt == torch.float32:
+        return DB1_F32
+    if dt == torch.bfloat16:
+        return DB1_BF16
+    raise lib.Db1Error(f"unsupported dtype {dt} (float32 / bfloat16 only)")
+
+
+def P(t: Optional[torch.Tensor]):
+    if t is None:
+        return _vp(0)
+    if not t.is_cuda:
+        raise lib.Db1Error("the DB1 kernels need device tensors (no CPU path)")
+    return _vp(t.data_ptr())
+
+
+def stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _strides2(t: torch.Tensor):
+    assert t.dim() == 2
+    return t.stride(0), t.stride(1)
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias: Optional[torch.Tensor] = None,
+         alpha: float = 1.0, beta: float = 0.0):
+    """out[m,n] = alpha * a[m,k] @ b[k,n] + beta*out + bias[n]; a, b, out are 2-D VIEWS with any strides
+    (pass ``w.t()`` for y = x W^T).  Optional leading batch dims are not handled here (see gemm_batched)."""
+    M, K = a.shape
+    K2, N = b.shape
+    assert K == K2 and out.shape == (M, N), (a.shape, b.shape, out.shape)
+    lib.call("db1_gemm_strided", P(a), P(b), P(out), P(bias), M, N, K, dt_code(a), dt_code(b), dt_code(out),
+             dt_code(bias) if bias is not None else 0, a.stride(0), a.stride(1), b.stride(0), b.stride(1),
+             out.stride(0), out.stride(1), 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, stream())
+    return out
+
+
+def gemm_batched(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, beta: float = 0.0):
+    """4-D views [z0, z1, rows, cols] with arbitrary strides (stride 0 broadcasts)."""
+    Z0, Z1, M, K = a.shape
+    _, _, K2, N = b.shape
+    assert K == K2 and out.shape == (Z0, Z1, M, N) and b.shape[:2] == (Z0, Z1), (a.shape, b.shape, out.shape)
+    lib.call("db1_gemm_strided", P(a), P(b), P(out), _vp(0), M, N, K, dt_code(a), dt_code(b), dt_code(out), 0,
+             a.stride(2), a.stride(3), b.stride(2), b.stride(3), out.stride(2), out.stride(3), Z0, Z1,
+             a.stride(0), a.stride(1), b.stride(0), b.stride(1), out.stride(0), out.stride(1), alpha, beta, stream())
+    return out
+
+
+def layernorm_residual_fwd(x, r, alpha, gamma, beta, y, s_out, mean, rstd, eps):
+    rows, d = x.numel() // x.shape[-1], x.shape[-1]
+    lib.call("db1_layernorm_residual_fwd", P(x), P(r), float(alpha), P(gamma), P(beta), P(y), P(s_out), P(mean), P(rstd),
+             rows, d, float(eps), dt_code(x), dt_code(gamma), stream())
+
+
+def layernorm_residual_bwd(dy, s, gamma, mean, rstd, ds, dgamma_acc, dbeta_acc):
+    rows, d = dy.numel() // dy.shape[-1], dy.shape[-1]
+    lib.call("db1_layernorm_residual_bwd", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dgamma_acc), P(dbeta_acc),
+             rows, d, dt_code(dy), dt_code(gamma), stream())
+
+
+def ffn_act_fwd(z, out, act: str):
+    rows, n = out.numel() // out.shape[-1], out.shape[-1]
+    lib.call("db1_ffn_act_fwd", P(z), P(out), rows, n, ACT_CODES[act], dt_code(z), stream())
+
+
+def ffn_act_bwd(z, dout, dz, act: str):
+    rows, n = dout.numel() // dout.shape[-1], dout.shape[-1]
+    lib.call("db1_ffn_act_bwd", P(z), P(dout), P(dz), rows, n, ACT_CODES[act], dt_code(z), stream())
+
+
+def colsum_acc(x2d, out_acc):
+    rows, cols = x2d.shape
+    assert x2d.stride(1) == 1 and out_acc.dtype == torch.float32
+    lib.call("db1_colsum_acc", P(x2d), P(out_acc), rows, cols, x2d.stride(0), dt_code(x2d), stream())
+
+
+def add(a, b, y):
+    lib.call("db1_add", P(a), P(b), P(y), a.numel(), dt_code(a), stream())
+
+
+def add2d(a2d, b2d, y2d):
+    """y = a + b on 2-D views with unit inner stride (y may alias b)."""
+    rows, cols = y2d.shape
+    assert a2d.stride(1) == 1 and b2d.stride(1) == 1 and y2d.stride(1) == 1 and b2d.dtype == y2d.dtype
+    lib.call("db1_add2d", P(a2d), a2d.stride(0), P(b2d), b2d.stride(0), P(y2d), y2d.stride(0), rows, cols,
+             dt_code(a2d), dt_code(y2d), stream())
+
+
+def cast(x, y):
+    lib.call("db1_cast", P(x), P(y), x.numel(), dt_code(x), dt_code(y), stream())
+
+
+def embed_gather(table, ids, out2d):
+    n, d = out2d.shape
+    assert ids.dtype == torch.int64 and ids.numel() == n and out2d.stride(1) == 1
+    lib.call("db1_embed_gather_fwd", P(table), P(ids), P(out2d), n, d, out2d.stride(0), dt_code(table), dt_code(out2d), stream())
+
+
+def embed_scatter_add(dout2d, ids, dtable_acc):
+    n, d = dout2d.shape
+    assert ids.dtype == torch.int64 and dtable_acc.dtype == torch.float32 and dout2d.stride(1) == 1
+    lib.call("db1_embed_scatter_add_bwd", P(dout2d), P(ids), P(dtable_acc), n, d, dout2d.stride(0), dt_code(dout2d), stream())
+
+
+def rl_assemble_fwd(word_table, pos_table, vis, ids, position_id, labels, out):
+    B, L, d = out.shape
+    nvis = 0 if vis is None else vis.shape[1]
+    lib.call("db1_rl_assemble_fwd", P(word_table), P(pos_table), P(vis), P(ids), P(position_id), P(labels), P(out),
+             B, L, d, nvis, dt_code(word_table), dt_code(out), stream())
+
+
+def rl_assemble_bwd(dout, ids, position_id, dword_acc, dpos_acc, dvis):
+    B, L, d = dout.shape
+    nvis = 0 if dvis is None else dvis.shape[1]
+    lib.call("db1_rl_assemble_bwd", P(dout), P(ids), P(position_id), P(dword_acc), P(dpos_acc), P(dvis), B, L, d, nvis,
+             dt_code(dout), stream())
+
+
+def masked_ce_fwd(logits2d, labels, mask, lse, sums, V):
+    T, ld = logits2d.shape[0], logits2d.stride(0)
+    lib.call("db1_masked_ce_fwd", P(logits2d), P(labels), P(mask), P(lse), P(sums), T, V, ld, dt_code(logits2d), stream())
+
+
+def masked_ce_bwd(logits2d, labels, mask, lse, sums, dlogits2d, V, gscale=1.0):
+    T, ld = logits2d.shape[0], logits2d.stride(0)
+    assert dlogits2d.stride(0) == ld
+    lib.call("db1_masked_ce_bwd", P(logits2d), P(labels), P(mask), P(lse), P(sums), P(dlogits2d), T, V, ld, float(gscale),
+             dt_code(logits2d), stream())
+
+
+def relattn_add_head_bias(qkv, u, vb, qu, qv, B, Lq, Lk, H, D):
+    lib.call("db1_relattn_add_head_bias", P(qkv), P(u), P(vb), P(qu), P(qv), B, Lq, Lk, H, D, dt_code(qkv), dt_code(u), stream())
+
+
+def relattn_softmax_fwd(AC, T, lse, H, B, Lq, Lk, nd, mlen, shift, scale):
+    lib.call("db1_relattn_softmax_fwd", P(AC), P(T), P(lse), H, B, Lq, Lk, nd, mlen, shift, float(scale), stream())
+
+
+def relattn_softmax_bwd(Pm, dP, dT, H, B, Lq, Lk, nd, mlen, shift, scale):
+    lib.call("db1_relattn_softmax_bwd", P(Pm), P(dP), P(dT), H, B, Lq, Lk, nd, mlen, shift, float(scale), stream())
+
+
+def relattn_flash_supported(B, L, H, D, dtype) -> bool:
+    return bool(lib.load().db1_relattn_flash_supported(B, L, H, D, dt_code(dtype)))
+
+
+def relattn_flash_fwd(qkv, R, u, vb, out, lse, B, L, H, D, shift, scale):
+    lib.call("db1_relattn_flash_fwd", P(qkv), P(R), P(u), P(vb), P(out), P(lse), B, L, H, D, shift, float(scale), dt_code(u), stream())
+
+
+def relattn_flash_bwd(qkv, R, u, vb, out, dout, lse, delta, dqkv, dT, B, L, H, D, shift, scale):
+    lib.call("db1_relattn_flash_bwd", P(qkv), P(R), P(u), P(vb), P(out), P(dout), P(lse), P(delta), P(dqkv), P(dT),
+             B, L, H, D, shift, float(scale), dt_code(u), stream())
+
+
+def patch_normalize(pixels, patches, p):
+    n, C, Hh, Ww = pixels.shape
+    lib.call("db1_patch_normalize", P(pixels), P(patches), n, C, Hh, Ww, p, dt_code(pixels), dt_code(patches), stream())
+
+
+def im2col3x3(x, cols, N, C, p):
+    lib.call("db1_im2col3x3", P(x), P(cols), N, C, p, dt_code(x), stream())
+
+
+def col2im3x3(dcols, dx, N, C, p):
+    lib.call("db1_col2im3x3", P(dcols), P(dx), N, C, p, dt_code(dx), stream())
+
+
+def nhwc_to_nchw(x, y, N, C, hw):
+    lib.call("db1_nhwc_to_nchw", P(x), P(y), N, C, hw, dt_code(x), stream())
+
+
+def nchw_to_nhwc(x, y, N, C, hw):
+    lib.call("db1_nchw_to_nhwc", P(x), P(y), N, C, hw, dt_code(x), stream())
+
+
+def groupnorm_gelu_fwd(x, gamma, beta, y, mean, rstd, N, C, hw, groups=32, eps=1e-5):
+    lib.call("db1_groupnorm_gelu_fwd", P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), N, C, hw, groups, float(eps),
+             dt_code(x), dt_code(gamma), stream())
+
+
+def groupnorm_gelu_bwd(dy, x, gamma, beta, mean, rstd, dx, dgamma_acc, dbeta_acc, N, C, hw, groups=32):
+    lib.call("db1_groupnorm_gelu_bwd", P(dy), P(x), P(gamma), P(beta), P(mean), P(rstd), P(dx), P(dgamma_acc), P(dbeta_acc),
+             N, C, hw, groups, dt_code(x), dt_code(gamma), stream())
+
+
+def sumsq_acc(x, acc):
+    lib.call("db1_sumsq_acc", P(x), P(acc), x.numel(), dt_code(x), stream())
+
+
+def adam_step(p32, g, m, v, p_work, lr, beta1, beta2, eps, wd, adamw, step, gscale=1.0, clip=0.0, norm_sq=None):
+    lib.call("db1_adam_step", P(p32), P(g), P(m), P(v), P(p_work), p32.numel(), float(lr), float(beta1), float(beta2), float(eps),
+             float(wd), int(bool(adamw)), int(step), float(gscale), float(clip), P(norm_sq),
+             dt_code(p_work) if p_work is not None else 0, stream())
+
+
+def mulaw_discretize(x, ids, is_action, num_bins=1024, mu=100.0, M=256.0):
+    assert x.dtype == torch.float32 and ids.dtype == torch.int32
+    lib.call("db1_mulaw_discretize", P(x), P(ids), x.numel(), int(bool(is_action)), num_bins, float(mu), float(M), stream())
+
+
+def gemm_force_generic(on: bool):
+    lib.load().db1_gemm_force_generic(1 if on else 0)

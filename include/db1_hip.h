@@ -1,0 +1,194 @@
+/*
+ * db1_hip.h -- C ABI of libdb1_hip.so: the MI355X (gfx950) kernels behind the DB1
+ * hot path (Transformer-XL decoder fwd/bwd, image-patch embedder, masked CE,
+ * fused Adam, mu-law tokenizer).
+ *
+ * The reference (Shanghai-Digital-Brain-Laboratory/BDM-DB1) has NO native boundary
+ * on this path: it is eager PyTorch (src/model/transformer_xl.py) under DeepSpeed.
+ * Each entry point below therefore cites the reference Python lines whose
+ * arithmetic it replaces; bdm_db1_amd/ binds them with ctypes (INTEGRATION.md
+ * shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm tensors are
+ *     only containers); the library never allocates or frees memory;
+ *   - every call is asynchronous on the given hipStream_t (passed as void*);
+ *   - return value: 0 = ok, negative = DB1_ERR_*; db1_last_error() gives a
+ *     thread-local message; no C++ exception crosses the boundary;
+ *   - dtype codes: DB1_F32 / DB1_BF16; "acc" outputs are float32 and are
+ *     ACCUMULATED into (+=), so gradient accumulation and tied parameters are free;
+ *   - one host thread per GPU (one process per rank), no global mutable state.
+ */
+#ifndef DB1_HIP_H
+#define DB1_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DB1_F32 = 0, DB1_BF16 = 1 };
+enum {
+    DB1_OK = 0,
+    DB1_ERR_BAD_SHAPE = -1,
+    DB1_ERR_BAD_ALIGN = -2,
+    DB1_ERR_UNSUPPORTED_DTYPE = -3,
+    DB1_ERR_WORKSPACE_TOO_SMALL = -4,
+    DB1_ERR_HIP = -5,
+    DB1_ERR_UNSUPPORTED = -6
+};
+enum { DB1_ACT_GEGLU = 0, DB1_ACT_GELU = 1, DB1_ACT_RELU = 2 };
+
+int db1_version(void);
+const char* db1_last_error(void);
+/* 1 if the running device is gfx950; product code refuses to run otherwise. */
+int db1_device_is_gfx950(void);
+
+/* ------------------------------------------------------------------ GEMM
+ * C[z][m,n] = alpha * sum_k A[z][m,k] * B[z][k,n] + beta * C[z][m,n] + bias[n]
+ * Fully strided (element (m,k) of A at A + m*a_rs + k*a_cs, etc.), two-level batch
+ * z = z0*batch1 + z1 with per-level strides.  fp32 accumulation always.  Replaces
+ * nn.Linear / torch.einsum (transformer_xl.py:136-141,163-170,220,228,264-268,595).
+ * Dispatch: bf16 operands whose strides form a K-major/M-major pattern with the
+ * alignment the MFMA tile kernels need go to the 128x128x64 bf16 MFMA kernels
+ * (NT / NN / TN); everything else (fp32 parity gate, odd shapes, tiny models) goes to
+ * a strided kernel on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ */
+int db1_gemm_strided(const void* A, const void* B, void* C, const void* bias,
+                     int M, int N, int K, int dtA, int dtB, int dtC, int dtBias,
+                     int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs, int64_t c_cs,
+                     int batch0, int batch1,
+                     int64_t a_bs0, int64_t a_bs1, int64_t b_bs0, int64_t b_bs1, int64_t c_bs0, int64_t c_bs1,
+                     float alpha, float beta, void* stream);
+/* Row-major 2-D conveniences.  nt: C = A[M,K] * B[N,K]^T (y = x W^T);
+ * nn: C = A[M,K] * B[K,N] (dx = dy W);  tn: C = A[K,M]^T * B[K,N] (dW = dy^T x). */
+int db1_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+                int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream);
+int db1_gemm_nn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+                int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream);
+int db1_gemm_tn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+                int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream);
+/* test hook: route every GEMM to the strided fp32-MFMA kernel (cross-checks the tile kernels at full size) */
+void db1_gemm_force_generic(int on);
+/* which kernel db1_gemm_strided would pick: 0 = strided fp32-MFMA, 1 = bf16 MFMA tile kernel */
+int db1_gemm_would_use_fast(int M, int N, int K, int dtA, int dtB, int dtC,
+                            int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs, int64_t c_cs);
+
+/* ------------------------------------------------------------------ residual + LayerNorm
+ * s = alpha * x + r ; y = LayerNorm(s) * gamma + beta   (transformer_xl.py:231-238, 288-290;
+ * alpha = DeepNorm alpha or 1).  r may be NULL (plain LN, pre-LN models).  s_out (may alias r,
+ * may be NULL) receives s for the backward.  mean/rstd: float32 [rows]. */
+int db1_layernorm_residual_fwd(const void* x, const void* r, float alpha, const void* gamma, const void* beta,
+                               void* y, void* s_out, float* mean, float* rstd,
+                               int64_t rows, int d, float eps, int dt, int dtParam, void* stream);
+/* ds = dL/ds (dtype dt); dgamma_acc / dbeta_acc: float32 [d], accumulated. */
+int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
+                               void* ds, float* dgamma_acc, float* dbeta_acc,
+                               int64_t rows, int d, int dt, int dtParam, void* stream);
+
+/* ------------------------------------------------------------------ feed-forward activation
+ * GEGLU: out[r, j] = z[r, j] * gelu_erf(z[r, n + j]) (activations.py:19-32); GELU/RELU: elementwise. */
+int db1_ffn_act_fwd(const void* z, void* out, int64_t rows, int n_out, int act, int dt, void* stream);
+int db1_ffn_act_bwd(const void* z, const void* dout, void* dz, int64_t rows, int n_out, int act, int dt, void* stream);
+
+/* out_acc[c] += sum_r x[r, c]  (bias / u / v gradients). ldx = row stride in elements. */
+int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int cols, int64_t ldx, int dt, void* stream);
+/* y = a + b (elementwise), used by pre-LN residuals and dq = dq_k + dq_r */
+int db1_add(const void* a, const void* b, void* y, int64_t n, int dt, void* stream);
+/* y[r, c] = a[r, c] + b[r, c] with row strides (a may have a different dtype; y may alias b) */
+int db1_add2d(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows, int cols,
+              int dtA, int dt, void* stream);
+/* y[i] = (dtOut) x[i] */
+int db1_cast(const void* x, void* y, int64_t n, int dtIn, int dtOut, void* stream);
+
+/* ------------------------------------------------------------------ embeddings
+ * out[t, :] = table[ids[t], :] (zeros where ids[t] < 0)   (transformer_xl.py:627-629, 665, 677, 686) */
+int db1_embed_gather_fwd(const void* table, const int64_t* ids, void* out, int64_t n_tokens, int d,
+                         int64_t ld_out, int dtTable, int dtOut, void* stream);
+/* dtable_acc[ids[t], :] += dout[t, :] (float32 atomics; ids < 0 skipped) */
+int db1_embed_scatter_add_bwd(const void* dout, const int64_t* ids, float* dtable_acc, int64_t n_tokens, int d,
+                              int64_t ld_dout, int dt, void* stream);
+/* RL sequence assembly (transformer_xl.py:621-660): rows with ids >= 0 take word_table[ids];
+ * the k-th "-1" placeholder of row b takes vis[b, k, :]; then + pos_table[position_id].
+ * labels (may be NULL): label == -1 -> 0 in place (:644-645). */
+int db1_rl_assemble_fwd(const void* word_table, const void* pos_table, const void* vis, const int64_t* ids,
+                        const int64_t* position_id, int64_t* labels, void* out,
+                        int B, int L, int d, int n_vis_per_row, int dtTable, int dt, void* stream);
+int db1_rl_assemble_bwd(const void* dout, const int64_t* ids, const int64_t* position_id,
+                        float* dword_acc, float* dpos_acc, void* dvis,
+                        int B, int L, int d, int n_vis_per_row, int dt, void* stream);
+
+/* ------------------------------------------------------------------ masked cross-entropy on materialised logits
+ * (transformer_xl.py:602-609). logits [T, ld] (columns >= V are padding).  fwd: lse[t], and
+ * sums[0] += sum_t mask*nll, sums[1] += sum_t mask.  bwd: dlogits = mask/sums[1] * gscale * (softmax - onehot)
+ * (zeros in the padding), may be in place. */
+int db1_masked_ce_fwd(const void* logits, const int64_t* labels, const float* mask, float* lse, float* sums,
+                      int64_t T, int V, int64_t ld, int dt, void* stream);
+int db1_masked_ce_bwd(const void* logits, const int64_t* labels, const float* mask, const float* lse, const float* sums,
+                      void* dlogits, int64_t T, int V, int64_t ld, float gscale, int dt, void* stream);
+
+/* ------------------------------------------------------------------ relative-position attention, materialised path
+ * (fp32 parity gate, any head size).  Buffers S,T are float32 in [H][B][Lq][*] layout.
+ * qu = q + u, qv = q + v_bias from the packed qkv activations [B, L, 3, H, D]  (transformer_xl.py:161,167). */
+int db1_relattn_add_head_bias(const void* qkv, const void* u, const void* vb, void* qu, void* qv,
+                              int B, int Lq, int Lk, int H, int D, int dt, int dtParam, void* stream);
+/* P[h,b,i,j] = softmax_j( (AC[h,b,i,j] + T[h,b,i, mlen+i-j]) * scale ) over visible keys
+ * i - shift < j <= i + mlen  (closed form of _rel_shift + mask, transformer_xl.py:98-110,171-209,551-567);
+ * written in place over AC.  lse (nullable) [H,B,Lq]. */
+int db1_relattn_softmax_fwd(float* AC, const float* T, float* lse, int H, int B, int Lq, int Lk, int nd,
+                            int mlen, int shift, float scale, void* stream);
+/* dS = P * (dP - rowsum(P*dP)) * scale, in place over dP; dT[h,b,i,mlen+i-j] = dS[h,b,i,j] (zero elsewhere). */
+int db1_relattn_softmax_bwd(const float* P, float* dP, float* dT, int H, int B, int Lq, int Lk, int nd,
+                            int mlen, int shift, float scale, void* stream);
+
+/* ------------------------------------------------------------------ relative-position flash attention (bf16, D = 128)
+ * Fused QK^T + skewed Q~R^T + online softmax + PV; never materialises (L x L).  qkv [B,L,3,H,D] bf16,
+ * R [L,H,D] bf16 indexed by distance, u, vb [H,D]; out [B,L,H,D] bf16, lse [B,H,L] f32.
+ * Training shape only: Lq == Lk, causal window (shift >= L means plain causal). */
+int db1_relattn_flash_supported(int B, int L, int H, int D, int dt);
+int db1_relattn_flash_fwd(const void* qkv, const void* R, const void* u, const void* vb, void* out, float* lse,
+                          int B, int L, int H, int D, int shift, float scale, int dtParam, void* stream);
+/* dqkv [B,L,3,H,D] bf16 (k and v parts written; q part = dq_k, the (q+u).k branch only);
+ * dT [H,B,L,L] bf16 = dS re-indexed by distance (input of the dq_r / dR GEMMs); delta [B,H,L] f32 scratch. */
+int db1_relattn_flash_bwd(const void* qkv, const void* R, const void* u, const void* vb, const void* out,
+                          const void* dout, const float* lse, float* delta, void* dqkv, void* dT,
+                          int B, int L, int H, int D, int shift, float scale, int dtParam, void* stream);
+
+/* ------------------------------------------------------------------ image-patch embedder pieces
+ * (src/tokenizer/vision_embedding.py:65-86).  pixels [N_img, C, Himg, Wimg] -> normalised patches
+ * [(n h w), C, p, p]: (x-mean)/(1e-6+std_unbiased)/sqrt(p) per (patch, channel). */
+int db1_patch_normalize(const void* pixels, void* patches, int n_img, int C, int Himg, int Wimg, int p,
+                        int dtIn, int dtOut, void* stream);
+/* im2col for 3x3/pad 1 on p x p patches: x [N, C, p, p] -> cols [N*p*p, C*9]; col2im accumulates the reverse. */
+int db1_im2col3x3(const void* x, void* cols, int64_t N, int C, int p, int dt, void* stream);
+int db1_col2im3x3(const void* dcols, void* dx, int64_t N, int C, int p, int dt, void* stream);
+/* layout shuffles between GEMM output [N*p*p, C] ("NHWC") and [N, C, p, p] ("NCHW") */
+int db1_nhwc_to_nchw(const void* x, void* y, int64_t N, int C, int hw, int dt, void* stream);
+int db1_nchw_to_nhwc(const void* x, void* y, int64_t N, int C, int hw, int dt, void* stream);
+/* GroupNorm(groups) + erf-GELU on [N, C, hw]; saves mean/rstd [N*groups]. bwd returns dx and accumulates dgamma/dbeta. */
+int db1_groupnorm_gelu_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                           int64_t N, int C, int hw, int groups, float eps, int dt, int dtParam, void* stream);
+int db1_groupnorm_gelu_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean,
+                           const float* rstd, void* dx, float* dgamma_acc, float* dbeta_acc,
+                           int64_t N, int C, int hw, int groups, int dt, int dtParam, void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * acc[0] += sum(x^2)  (global-norm clipping, train_config.py:211-215) */
+int db1_sumsq_acc(const void* x, float* acc, int64_t n, int dt, void* stream);
+/* One fused Adam/AdamW step over a flat segment (DeepSpeed FusedAdam stand-in; torch.optim semantics).
+ * g: float32 gradients; p32/m/v: float32 state; p_work (nullable): bf16 working copy written alongside.
+ * grad scale = gscale * min(1, clip / (sqrt(*norm_sq) + 1e-6)) when clip > 0 and norm_sq != NULL. */
+int db1_adam_step(float* p32, const float* g, float* m, float* v, void* p_work, int64_t n,
+                  double lr, double beta1, double beta2, double eps, double wd, int adamw, int step,
+                  float gscale, float clip, const float* norm_sq, int dtWork, void* stream);
+
+/* ------------------------------------------------------------------ scalar tokenizer
+ * ContinuousScalarTokenizer.discretize (src/tokenizer/scalar_tokenizer.py:28-45), bit-exact ids. */
+int db1_mulaw_discretize(const float* x, int32_t* ids, int64_t n, int is_action, int num_bins, float mu, float M,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DB1_HIP_H */

@@ -1,0 +1,396 @@
+"""Kernel-level parity: every C-ABI entry point against the CPU oracle on seeded inputs.
+Integer / index results are bit-exact; fp32 results to fp32 round-off; bf16 results are compared
+with the oracle evaluated on the bf16-rounded inputs (tolerance = bf16 output rounding)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import db1_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bdm_db1_amd import ops as _ops, lib
+    assert lib.load().db1_device_is_gfx950() == 1
+    return _ops
+
+
+DEV = "cuda"
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+def bf(a):
+    """round a float array to bf16 (returns float64 values that are exactly representable)"""
+    return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+def close(got, ref, rtol, atol_scale=None, name=""):
+    got = got.detach().to(torch.float64).cpu().numpy() if hasattr(got, "detach") else np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    scale = np.abs(ref).max() + 1e-30
+    err = np.abs(got - ref).max() / scale
+    assert err <= rtol, f"{name}: max err {err:.3e} of scale {scale:.3e} > {rtol}"
+
+
+# ------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("form", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gemm_strided_odd_shapes(ops, form, dtype):
+    rng = np.random.default_rng(1)
+    M, N, K = 70, 130, 37
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N))
+    bias = rng.standard_normal(N)
+    C0 = rng.standard_normal((M, N))
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    if dtype == "bf16":
+        A, B, bias = bf(A), bf(B), bf(bias)
+    a_store = dev(A if form != "tn" else A.T.copy(), td)
+    b_store = dev(B.T.copy() if form == "nt" else B, td)
+    a = a_store if form != "tn" else a_store.t()
+    b = b_store.t() if form == "nt" else b_store
+    out = dev(C0, torch.float32)
+    ops.gemm(a, b, out, bias=dev(bias, td), alpha=0.5, beta=2.0)
+    close(out, 0.5 * A @ B + 2.0 * C0 + bias, 2e-6, name=f"gemm {form} {dtype}")
+
+
+def test_gemm_batched_strided(ops):
+    rng = np.random.default_rng(2)
+    Z0, Z1, M, N, K = 2, 3, 33, 20, 50
+    A = rng.standard_normal((Z0, Z1, M, K))
+    B = rng.standard_normal((Z1, K, N))  # broadcast over z0
+    a = dev(A)
+    b = dev(B).unsqueeze(0).expand(Z0, Z1, K, N)
+    out = torch.zeros(Z0, Z1, M, N, device=DEV)
+    ops.gemm_batched(a, b, out)
+    close(out, np.einsum("xymk,ykn->xymn", A, B), 2e-6, name="gemm batched")
+
+
+@pytest.mark.parametrize("form", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("out_dtype", ["f32", "bf16"])
+def test_gemm_bf16_tile_kernels(ops, form, out_dtype):
+    """the MFMA tile kernels (asymmetric operands; transposes would be caught)"""
+    from bdm_db1_amd import lib
+    rng = np.random.default_rng(3)
+    M, N, K = 256, 384, 192
+    A = bf(rng.standard_normal((M, K)))
+    B = bf(rng.standard_normal((K, N)))
+    bias = bf(rng.standard_normal(N))
+    C0 = bf(rng.standard_normal((M, N)))
+    a_store = dev(A if form != "tn" else A.T.copy(), torch.bfloat16)
+    b_store = dev(B.T.copy() if form == "nt" else B, torch.bfloat16)
+    a = a_store if form != "tn" else a_store.t()
+    b = b_store.t() if form == "nt" else b_store
+    od = torch.float32 if out_dtype == "f32" else torch.bfloat16
+    out = dev(C0, od)
+    assert lib.load().db1_gemm_would_use_fast(M, N, K, 1, 1, 0 if od == torch.float32 else 1, a.stride(0), a.stride(1),
+                                              b.stride(0), b.stride(1), out.stride(0), out.stride(1)) == 1
+    ops.gemm(a, b, out, bias=dev(bias, torch.bfloat16), alpha=0.25, beta=1.0)
+    ref = 0.25 * A @ B + C0 + bias
+    close(out, ref, 2e-6 if out_dtype == "f32" else 6e-3, name=f"tile gemm {form} {out_dtype}")
+    # same call through the strided kernel must agree (accumulation order differs only)
+    out2 = dev(C0, od)
+    ops.gemm_force_generic(True)
+    try:
+        ops.gemm(a, b, out2, bias=dev(bias, torch.bfloat16), alpha=0.25, beta=1.0)
+    finally:
+        ops.gemm_force_generic(False)
+    close(out2, ref, 2e-6 if out_dtype == "f32" else 6e-3, name=f"strided gemm {form} {out_dtype}")
+
+
+def test_gemm_bf16_tile_large_k_and_batch(ops):
+    rng = np.random.default_rng(4)
+    Z, M, N, K = 3, 128, 128, 1024
+    A = bf(rng.standard_normal((Z, M, K)) * 0.1)
+    B = bf(rng.standard_normal((Z, K, N)) * 0.1)
+    a = dev(A, torch.bfloat16).unsqueeze(0)
+    b = dev(B, torch.bfloat16).unsqueeze(0)
+    out = torch.zeros(1, Z, M, N, device=DEV)
+    ops.gemm_batched(a, b, out)
+    close(out, np.einsum("zmk,zkn->zmn", A, B)[None], 3e-6, name="tile gemm batched")
+
+
+# ------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype,d", [("f32", 128), ("f32", 2048), ("bf16", 64), ("bf16", 2048)])
+def test_layernorm_residual(ops, dtype, d):
+    rng = np.random.default_rng(5)
+    rows, alpha, eps = 37, 1.3, 1e-5
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    rnd = (lambda a: a) if dtype == "f32" else bf
+    x, r = rnd(rng.standard_normal((rows, d))), rnd(rng.standard_normal((rows, d)) + 0.5)
+    gamma, beta = rnd(1 + 0.1 * rng.standard_normal(d)), rnd(0.1 * rng.standard_normal(d))
+    dy = rnd(rng.standard_normal((rows, d)))
+    s = rnd(alpha * x + r)
+    y_ref, cache = O.layernorm_fwd(s, gamma, beta, eps)
+    ds_ref, dg_ref, db_ref = O.layernorm_bwd(dy, gamma, cache)
+    X, R, G, Bt = dev(x, td), dev(r, td), dev(gamma, td), dev(beta, td)
+    y, s_out = torch.empty_like(X), torch.empty_like(X)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    ops.layernorm_residual_fwd(X, R, alpha, G, Bt, y, s_out, mean, rstd, eps)
+    tol = 3e-6 if dtype == "f32" else 6e-3
+    close(y, y_ref, tol, name="ln y")
+    close(s_out, s, 1e-6 if dtype == "f32" else 4e-3, name="ln s")
+    close(mean, s_out.to(torch.float64).cpu().numpy().mean(-1), 1e-5, name="ln mean")
+    ds = torch.empty_like(X)
+    dg, db = torch.ones(d, device=DEV), torch.ones(d, device=DEV)  # accumulate on top of ones
+    ops.layernorm_residual_bwd(dev(dy, td), s_out, G, mean, rstd, ds, dg, db)
+    close(ds, ds_ref, 1e-5 if dtype == "f32" else 8e-3, name="ln ds")
+    close(dg, dg_ref + 1, 1e-5 if dtype == "f32" else 3e-3, name="ln dgamma")
+    close(db, db_ref + 1, 1e-5 if dtype == "f32" else 3e-3, name="ln dbeta")
+    # plain LN (r = NULL, no s_out)
+    y2 = torch.empty_like(X)
+    ops.layernorm_residual_fwd(X, None, 1.0, G, Bt, y2, None, mean, rstd, eps)
+    close(y2, O.layernorm_fwd(x, gamma, beta, eps)[0], tol, name="ln plain")
+
+
+@pytest.mark.parametrize("act", ["geglu", "gelu", "relu"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_ffn_activation(ops, act, dtype):
+    rng = np.random.default_rng(6)
+    rows, n = 19, 264
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    rnd = (lambda a: a) if dtype == "f32" else bf
+    z = rnd(rng.standard_normal((rows, 2 * n if act == "geglu" else n)) * 1.5)
+    dout = rnd(rng.standard_normal((rows, n)))
+    if act == "geglu":
+        a, b = z[:, :n], z[:, n:]
+        ref = a * O.gelu(b)
+        dref = np.concatenate([dout * O.gelu(b), dout * a * O.gelu_grad(b)], -1)
+    elif act == "gelu":
+        ref, dref = O.gelu(z), dout * O.gelu_grad(z)
+    else:
+        ref, dref = np.maximum(z, 0), dout * (z > 0)
+    Z = dev(z, td)
+    out = torch.empty(rows, n, device=DEV, dtype=td)
+    ops.ffn_act_fwd(Z, out, act)
+    dz = torch.empty_like(Z)
+    ops.ffn_act_bwd(Z, dev(dout, td), dz, act)
+    tol = 2e-6 if dtype == "f32" else 6e-3
+    close(out, ref, tol, name="act fwd")
+    close(dz, dref, tol, name="act bwd")
+
+
+def test_colsum_add_cast(ops):
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((300, 70))
+    acc = torch.full((70,), 2.0, device=DEV)
+    ops.colsum_acc(dev(x), acc)
+    close(acc, x.sum(0) + 2, 1e-6, name="colsum")
+    xb = dev(bf(x), torch.bfloat16)
+    acc2 = torch.zeros(70, device=DEV)
+    ops.colsum_acc(xb[:, :64], acc2[:64])  # strided rows
+    close(acc2[:64], bf(x)[:, :64].sum(0), 1e-6, name="colsum bf16 strided")
+    a, b = dev(x), dev(x * 2)
+    y = torch.empty_like(a)
+    ops.add(a, b, y)
+    close(y, 3 * x, 1e-7, name="add")
+    c = torch.empty(300, 70, device=DEV, dtype=torch.bfloat16)
+    ops.cast(a, c)
+    assert torch.equal(c, a.to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------- embeddings
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_embedding_gather_scatter(ops, dtype):
+    rng = np.random.default_rng(8)
+    V, d, n = 50, 72, 41
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    table = bf(rng.standard_normal((V, d)))
+    ids = rng.integers(-1, V, n)
+    ids[3] = -1
+    out = torch.full((n, d), 7.0, device=DEV, dtype=td)
+    ops.embed_gather(dev(table, td), torch.from_numpy(ids).to(DEV), out)
+    ref = np.where(ids[:, None] >= 0, table[np.maximum(ids, 0)], 0.0)
+    close(out, ref, 1e-7, name="gather")
+    dout = bf(rng.standard_normal((n, d)))
+    acc = torch.zeros(V, d, device=DEV)
+    ops.embed_scatter_add(dev(dout, td), torch.from_numpy(ids).to(DEV), acc)
+    g = np.zeros((V, d))
+    np.add.at(g, ids[ids >= 0], dout[ids >= 0])
+    close(acc, g, 1e-6, name="scatter")
+
+
+def test_rl_assemble(ops):
+    rng = np.random.default_rng(9)
+    B, L, d, V, nvis = 3, 300, 40, 60, 9
+    ids = rng.integers(0, V, (B, L))
+    for b in range(B):
+        ids[b, rng.choice(L, nvis - b, replace=False)] = -1  # ragged placeholder counts
+    pos = rng.integers(0, 513, (B, L))
+    word, post = rng.standard_normal((V, d)), rng.standard_normal((513, d))
+    vis = rng.standard_normal((B, nvis, d))
+    labels = rng.integers(-1, V, (B, L))
+    out = torch.empty(B, L, d, device=DEV)
+    lab_d = torch.from_numpy(labels).to(DEV)
+    ops.rl_assemble_fwd(dev(word), dev(post), dev(vis), torch.from_numpy(ids).to(DEV), torch.from_numpy(pos).to(DEV), lab_d, out)
+    ref = np.zeros((B, L, d))
+    for b in range(B):
+        k = 0
+        for t in range(L):
+            if ids[b, t] >= 0:
+                ref[b, t] = word[ids[b, t]]
+            else:
+                ref[b, t] = vis[b, k]
+                k += 1
+    ref += post[pos]
+    close(out, ref, 1e-6, name="rl fwd")
+    assert np.array_equal(lab_d.cpu().numpy(), np.where(labels == -1, 0, labels))
+    dout = rng.standard_normal((B, L, d))
+    dw, dp = torch.zeros(V, d, device=DEV), torch.zeros(513, d, device=DEV)
+    dvis = torch.full((B, nvis, d), 5.0, device=DEV)
+    ops.rl_assemble_bwd(dev(dout), torch.from_numpy(ids).to(DEV), torch.from_numpy(pos).to(DEV), dw, dp, dvis)
+    gw, gp, gv = np.zeros((V, d)), np.zeros((513, d)), np.zeros((B, nvis, d))
+    np.add.at(gp, pos.reshape(-1), dout.reshape(-1, d))
+    for b in range(B):
+        k = 0
+        for t in range(L):
+            if ids[b, t] >= 0:
+                gw[ids[b, t]] += dout[b, t]
+            else:
+                gv[b, k] = dout[b, t]
+                k += 1
+    close(dw, gw, 1e-5, name="rl dword")
+    close(dp, gp, 1e-5, name="rl dpos")
+    close(dvis, gv, 1e-6, name="rl dvis")
+
+
+# ------------------------------------------------------------------------------- cross-entropy
+@pytest.mark.parametrize("dtype,V,ld", [("f32", 1325, 1325), ("f32", 1000, 1024), ("bf16", 33025, 33280)])
+def test_masked_ce(ops, dtype, V, ld):
+    rng = np.random.default_rng(10)
+    T = 24
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    rnd = (lambda a: a) if dtype == "f32" else bf
+    lg = rnd(rng.standard_normal((T, V)) * 3)
+    labels = rng.integers(0, V, T)
+    mask = (rng.random(T) > 0.3).astype(np.float32)
+    mask[0] = 1
+    buf = torch.full((T, ld), 9.0, device=DEV, dtype=td)
+    buf[:, :V] = dev(lg, td)
+    lse, sums = torch.empty(T, device=DEV), torch.zeros(2, device=DEV)
+    ops.masked_ce_fwd(buf, torch.from_numpy(labels).to(DEV), dev(mask), lse, sums, V)
+    mx = lg.max(-1)
+    lse_ref = mx + np.log(np.exp(lg - mx[:, None]).sum(-1))
+    nll = lse_ref - lg[np.arange(T), labels]
+    close(lse, lse_ref, 2e-6, name="lse")
+    close(sums, [(nll * mask).sum(), mask.sum()], 2e-6, name="ce sums")
+    dl = torch.empty_like(buf)
+    ops.masked_ce_bwd(buf, torch.from_numpy(labels).to(DEV), dev(mask), lse, sums, dl, V, gscale=1.0)
+    p = np.exp(lg - lse_ref[:, None])
+    p[np.arange(T), labels] -= 1
+    ref = np.zeros((T, ld))
+    ref[:, :V] = p * (mask / mask.sum())[:, None]
+    close(dl, ref, 3e-6 if dtype == "f32" else 6e-3, name="dlogits")
+    assert float(dl[:, V:].abs().max()) == 0.0 if ld > V else True
+
+
+# ------------------------------------------------------------------------------- optimizer
+@pytest.mark.parametrize("adamw", [False, True])
+def test_adam_and_global_norm(ops, adamw):
+    rng = np.random.default_rng(11)
+    n = 4096 + 8
+    p = rng.standard_normal(n).astype(np.float32)
+    P32, M_, V_ = dev(p), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    PW = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    pr, mr, vr = p.astype(np.float64), np.zeros(n), np.zeros(n)
+    for step in range(1, 4):
+        g = (rng.standard_normal(n) * (0.1 if step == 2 else 2.0)).astype(np.float32)
+        G = dev(g)
+        nsq = torch.zeros(1, device=DEV)
+        ops.sumsq_acc(G, nsq)
+        close(nsq, [(g.astype(np.float64) ** 2).sum()], 1e-5, name="sumsq")
+        ops.adam_step(P32, G, M_, V_, PW, 3e-3, 0.9, 0.999, 1e-8, 0.01, adamw, step, gscale=1.0, clip=1.0, norm_sq=nsq)
+        coef = O.clip_coef(np.sqrt((g.astype(np.float64) ** 2).sum()), 1.0)
+        pr, mr, vr = O.adam_step(pr, g.astype(np.float64), mr, vr, step, 3e-3, wd=0.01, adamw=adamw, grad_scale=coef)
+        close(P32, pr, 2e-6, name=f"adam p step {step}")
+        close(M_, mr, 2e-6, name="adam m")
+        close(V_, vr, 2e-6, name="adam v")
+        assert torch.equal(PW, P32.to(torch.bfloat16))
+
+
+def test_adam_matches_torch_golden(ops):
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "adam.npz")))
+    for mode in ("adam", "adamw"):
+        n = 260  # fixture has 257 elements; pad to a multiple of 4
+        pad = lambda a: np.concatenate([a, np.zeros(n - a.size, np.float32)])
+        P32, M_, V_ = dev(pad(gold[f"{mode}/p0"])), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        for i in range(3):
+            G = dev(pad(gold[f"{mode}/g{i}"]))
+            nsq = torch.zeros(1, device=DEV)
+            ops.sumsq_acc(G, nsq)
+            ops.adam_step(P32, G, M_, V_, None, 3e-3, 0.9, 0.999, 1e-8, 0.01, mode == "adamw", i + 1, clip=1.0, norm_sq=nsq)
+            close(P32[:257], gold[f"{mode}/p{i + 1}"], 3e-6, name=f"{mode} p{i + 1}")
+            close(V_[:257], gold[f"{mode}/v{i + 1}"], 3e-6, name=f"{mode} v{i + 1}")
+
+
+# ------------------------------------------------------------------------------- tokenizer (bit-exact)
+def test_mulaw_discretize_bit_exact(ops):
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "scalar_tokenizer.npz")))
+    for key, is_action in (("known_obs", False), ("known_act", True), ("obs", False), ("act", True)):
+        x = torch.from_numpy(gold[key]).to(DEV)
+        ids = torch.empty(x.numel(), device=DEV, dtype=torch.int32)
+        ops.mulaw_discretize(x, ids, is_action)
+        assert np.array_equal(ids.cpu().numpy(), gold[key + "_ids"]), key
+    # large seeded sweep against the oracle (itself pinned to the reference on 24M values)
+    rng = np.random.default_rng(12)
+    x = np.concatenate([rng.standard_normal(500000) * s for s in (1e-3, 0.05, 1.0, 30.0, 500.0)]).astype(np.float32)
+    ids = torch.empty(x.size, device=DEV, dtype=torch.int32)
+    ops.mulaw_discretize(torch.from_numpy(x).to(DEV), ids, False)
+    assert np.array_equal(ids.cpu().numpy(), O.mulaw_discretize(x, False))
+
+
+# ------------------------------------------------------------------------------- patch embedder pieces
+def test_patch_normalize_im2col_groupnorm(ops):
+    rng = np.random.default_rng(13)
+    img = (rng.random((2, 3, 32, 48)) * 255).astype(np.float32)
+    ref = O.patch_normalize(O.patchify(img.astype(np.float64), 16), 16)
+    N = ref.shape[0]
+    out = torch.empty(N, 3, 16, 16, device=DEV)
+    ops.patch_normalize(dev(img), out, 16)
+    close(out, ref, 3e-6, name="patch normalize")
+    x = rng.standard_normal((N, 5, 16, 16))
+    cols = torch.empty(N * 256, 45, device=DEV)
+    ops.im2col3x3(dev(x), cols, N, 5, 16)
+    close(cols, O._im2col3x3(x).reshape(N * 256, 45), 1e-7, name="im2col")
+    dcols = rng.standard_normal((N, 16, 16, 45))
+    dx = torch.empty(N, 5, 16, 16, device=DEV)
+    ops.col2im3x3(dev(dcols.reshape(N * 256, 45)), dx, N, 5, 16)
+    close(dx, O._col2im3x3(dcols, 5), 2e-6, name="col2im")
+    # layout shuffles
+    a = rng.standard_normal((N, 256, 64))
+    y = torch.empty(N, 64, 256, device=DEV)
+    ops.nhwc_to_nchw(dev(a), y, N, 64, 256)
+    close(y, a.transpose(0, 2, 1), 1e-7, name="nhwc->nchw")
+    z = torch.empty(N, 256, 64, device=DEV)
+    ops.nchw_to_nhwc(y, z, N, 64, 256)
+    close(z, a, 1e-7, name="nchw->nhwc")
+    # GroupNorm + GELU
+    xg = rng.standard_normal((N, 64, 16, 16)) * 2 + 0.3
+    gam, bet = 1 + 0.2 * rng.standard_normal(64), 0.2 * rng.standard_normal(64)
+    g_ref, cache = O.groupnorm_fwd(xg, gam, bet)
+    yy = torch.empty(N, 64, 256, device=DEV)
+    mean, rstd = torch.empty(N * 32, device=DEV), torch.empty(N * 32, device=DEV)
+    ops.groupnorm_gelu_fwd(dev(xg), dev(gam), dev(bet), yy, mean, rstd, N, 64, 256)
+    close(yy, O.gelu(g_ref).reshape(N, 64, 256), 3e-6, name="gn+gelu fwd")
+    dy = rng.standard_normal((N, 64, 16, 16))
+    dx_ref, dgam, dbet = O.groupnorm_bwd(dy * O.gelu_grad(g_ref), gam, cache)
+    dxx = torch.empty(N, 64, 256, device=DEV)
+    dga, dbe = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    ops.groupnorm_gelu_bwd(dev(dy), dev(xg), dev(gam), dev(bet), mean, rstd, dxx, dga, dbe, N, 64, 256)
+    close(dxx, dx_ref.reshape(N, 64, 256), 1e-5, name="gn+gelu dx")
+    close(dga, dgam, 1e-5, name="gn dgamma")
+    close(dbe, dbet, 1e-5, name="gn dbeta")
