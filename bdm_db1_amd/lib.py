@@ -57,6 +57,9 @@ def load():
     global _lib, _protos
     if _lib is not None:
         return _lib
+    # torch must be imported first: it loads the HIP runtime (libamdhip64) this process will use for its
+    # tensors and streams, and libdb1_hip.so has to bind to that SAME runtime instance.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise Db1Error(f"{LIB_PATH} is missing: run `python -m bdm_db1_amd.build` (or __graft_entry__.build()). "
                        "There is no CPU fallback for the DB1 hot path.")

@@ -40,6 +40,41 @@ def _strides2(t: torch.Tensor):
     return t.stride(0), t.stride(1)
 
 
+class KernelTimer:
+    """HIP-event timing of the bf16 tile-GEMM launches (bench.py's roofline leg): one event pair per launch,
+    recorded on the stream the kernel is launched on; nothing is synchronised until ``total()``."""
+
+    def __init__(self):
+        self.pairs = []
+        self.flops = 0.0
+        self.launches = 0
+
+    def wrap(self, flops: float, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.pairs.append((e0, e1))
+        self.flops += flops
+        self.launches += 1
+
+    def total_ms(self) -> float:
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in self.pairs))
+
+
+_gemm_timer: Optional[KernelTimer] = None
+
+
+def set_gemm_timer(t: Optional[KernelTimer]):
+    global _gemm_timer
+    _gemm_timer = t
+
+
+def _is_tile_gemm(M, N, K, a, b, out, sa, sb, so) -> bool:
+    return bool(lib.load().db1_gemm_would_use_fast(M, N, K, dt_code(a), dt_code(b), dt_code(out), sa[0], sa[1], sb[0], sb[1], so[0], so[1]))
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias: Optional[torch.Tensor] = None,
          alpha: float = 1.0, beta: float = 0.0):
     """out[m,n] = alpha * a[m,k] @ b[k,n] + beta*out + bias[n]; a, b, out are 2-D VIEWS with any strides
@@ -47,9 +82,16 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias: Optional[tor
     M, K = a.shape
     K2, N = b.shape
     assert K == K2 and out.shape == (M, N), (a.shape, b.shape, out.shape)
-    lib.call("db1_gemm_strided", P(a), P(b), P(out), P(bias), M, N, K, dt_code(a), dt_code(b), dt_code(out),
-             dt_code(bias) if bias is not None else 0, a.stride(0), a.stride(1), b.stride(0), b.stride(1),
-             out.stride(0), out.stride(1), 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, stream())
+
+    def run():
+        lib.call("db1_gemm_strided", P(a), P(b), P(out), P(bias), M, N, K, dt_code(a), dt_code(b), dt_code(out),
+                 dt_code(bias) if bias is not None else 0, a.stride(0), a.stride(1), b.stride(0), b.stride(1),
+                 out.stride(0), out.stride(1), 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, stream())
+
+    if _gemm_timer is not None and _is_tile_gemm(M, N, K, a, b, out, a.stride(), b.stride(), out.stride()):
+        _gemm_timer.wrap(2.0 * M * N * K, run)
+    else:
+        run()
     return out
 
 

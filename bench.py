@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""DB1-1.3B pre-training throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + backward + gradient all-reduce (N > 1) + global-norm clip + fused Adam on one
+micro-batch of B synthetic 1024-token sequences per GPU (weak scaling: per-GPU work is fixed).  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_PER_TOKEN = 6_899_036_160       # fwd+bwd, DB1-1.3B, L=1024, causal-counted attention (SURVEY.md 8d / BASELINE.md 4)
+FLOP_PER_PATCH = 317_227_008         # image-patch embedder fwd+bwd
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def cpu_baseline(max_seconds: float = 45.0):
+    """The CPU oracle (oracle/db1_oracle.py, NumPy + OpenBLAS, fp32) timed on this box's host cores on a bounded
+    sample of the SAME workload: DB1-1.3B geometry, ONE 1024-token sequence, forward + backward through k of the 24
+    decoder layers plus the tied head and loss; tokens/s is extrapolated to 24 layers from the measured per-layer time.
+    Reported baseline only (rank 0, N = 1)."""
+    from oracle import db1_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    d, H, L = 2048, 16, 1024
+    rng = np.random.default_rng(0)
+    times = {}
+    for k in (1, 2):
+        cfg = O.OracleConfig(n_embed=d, n_layer=k, n_head=H, n_position=L, mem_len=L)
+        params = {}
+        f = np.float32
+        params["r_w_bias"], params["r_r_bias"] = (rng.standard_normal((H, d // H)) * 0.02).astype(f), (rng.standard_normal((H, d // H)) * 0.02).astype(f)
+        params["word_embedding.weight"] = (rng.standard_normal((cfg.total_vocab_size, d)) * 0.02).astype(f)
+        for i in range(k):
+            p = f"h.{i}."
+            params[p + "dec_attn.qkv_net.weight"] = (rng.standard_normal((3 * d, d)) * 0.02).astype(f)
+            params[p + "dec_attn.o_net.weight"] = (rng.standard_normal((d, d)) * 0.02).astype(f)
+            params[p + "dec_attn.r_net.weight"] = (rng.standard_normal((d, d)) * 0.02).astype(f)
+            params[p + "pos_ff.CoreNet.0.weight"] = (rng.standard_normal((4 * d, d)) * 0.02).astype(f)
+            params[p + "pos_ff.CoreNet.0.bias"] = np.zeros(4 * d, f)
+            params[p + "pos_ff.CoreNet.2.weight"] = (rng.standard_normal((d, 2 * d)) * 0.02).astype(f)
+            params[p + "pos_ff.CoreNet.2.bias"] = np.zeros(d, f)
+            for ln in ("dec_attn.layer_norm", "pos_ff.layer_norm"):
+                params[p + ln + ".weight"], params[p + ln + ".bias"] = np.ones(d, f), np.zeros(d, f)
+        model = O.OracleModel(cfg, params, dtype=np.float32)
+        ids = rng.integers(0, 32000, (1, L + 1))
+        task = O.TaskBatch(kind="nlp", text_seq=ids[:, :-1], label=ids[:, 1:], loss_mask=np.ones((1, L), np.float32))
+        t0 = time.perf_counter()
+        model.forward([task])
+        model.backward()
+        times[k] = time.perf_counter() - t0
+        if times[k] > max_seconds:
+            break
+    if 2 in times:
+        per_layer = max(times[2] - times[1], 1e-9)
+        fixed = max(times[1] - per_layer, 0.0)
+    else:
+        per_layer, fixed = times[1] * 0.6, times[1] * 0.4
+    full = fixed + 24 * per_layer
+    return {"value": round(L / full, 2), "unit": "tokens/s", "cores": int(threads), "kind": "port",
+            "sample": f"DB1-1.3B geometry, 1 sequence x 1024 tokens, fwd+bwd, fp32 NumPy/OpenBLAS oracle; measured 1 and 2 decoder layers "
+                      f"+ tied head ({times.get(1, 0):.2f}s, {times.get(2, 0):.2f}s), extrapolated to 24 layers ({full:.1f}s/sequence); "
+                      f"{os.cpu_count()} logical CPUs on the box, {threads} BLAS threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DB1_BENCH_BATCH", 16)), help="sequences per GPU per step")
+    ap.add_argument("--layers", type=int, default=24, help="debug only: anything but 24 is not the benchmark config")
+    ap.add_argument("--workload", default="text", choices=["text", "caption", "rl", "mixture"])
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-flash", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from bdm_db1_amd import TransformerXL, initialize, mpu, ops, synth
+    from types import SimpleNamespace
+    if world > 1:
+        mpu.initialize_model_parallel()
+    cfg = synth.db1_config("1.3B", n_layer=args.layers)
+    torch.manual_seed(1234)
+    model = TransformerXL(cfg, device=dev)
+    model.use_flash = not args.no_flash
+    eargs = SimpleNamespace(lr=1e-4, weight_decay=0.01, clip_grad=1.0, optimizer="adam", keep_logits=False)
+    engine, _, _, _ = initialize(eargs, model, mpu=mpu if world > 1 else None)
+    engine.train()
+    B, L = args.batch, cfg.n_position
+    seed = 1234 + rank
+    if args.workload == "text":
+        batch = [synth.text_batch(B, L, seed, dev)]
+    elif args.workload == "caption":
+        batch = [synth.caption_batch(B, L, seed, dev, cfg)]
+    elif args.workload == "rl":
+        batch = [synth.rl_batch(B, L, seed, dev, cfg)]
+    else:
+        batch = synth.mixture_batch(B, L, seed, dev, cfg)
+    model.eval() if args.workload != "text" else None  # deterministic patch position ids; dropout is 0 either way
+    n_patches = 0
+    for t in batch:
+        if getattr(t, "img_seq", None) is not None:
+            n_patches += t.img_seq.shape[0] * (t.img_seq.shape[2] // 16) * (t.img_seq.shape[3] // 16)
+        if getattr(t, "vision_seq", None) is not None:
+            v = t.vision_seq
+            n_patches += v.shape[0] * v.shape[1] * (v.shape[3] // 16) * (v.shape[4] // 16)
+
+    def step():
+        logits, loss = engine(batch)
+        engine.backward(loss)
+        engine.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    timer = None if args.no_kernel_timing else ops.KernelTimer()
+    ops.set_gemm_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.set_gemm_timer(None)
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_v = float(loss)
+
+    tokens = world * B * L * args.steps
+    tok_s = tokens / dt
+    flops_step_all = world * (B * L * FLOP_PER_TOKEN + n_patches * FLOP_PER_PATCH)
+    out = {
+        "metric": "pretrain tokens/sec (whole node) DB1-1.3B seq1024", "value": round(tok_s, 1), "unit": "tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"DB1-1.3B {args.workload} causal LM pre-training step (fwd+bwd+clip+Adam), seq_len 1024, "
+                               f"{B} sequences/GPU/step, random-init weights", "n_layer": args.layers, "n_embed": 2048, "n_head": 16,
+                   "seq_len": L, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "params": int(sum(int(np.prod(s)) for _, s, _ in model.arena.offsets.values()))},
+        "pct_mfma_peak_step": round(100.0 * flops_step_all / (dt / args.steps) / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 2),
+        "final_loss": round(loss_v, 4),
+    }
+    if timer is not None and timer.launches:
+        ms = timer.total_ms()
+        ach = timer.flops / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                           "kernel": "gemm_bf16_tile_kernel (all NT/NN/TN launches of the timed steps, rank 0)",
+                           "launches": timer.launches, "avg_launch_us": round(ms * 1e3 / timer.launches, 2),
+                           "flop_per_launch_avg": round(timer.flops / timer.launches),
+                           "kernel_time_share_of_step": round(ms / (dt * 1e3), 4)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as e:  # the baseline leg must never take the bench line down
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+    if args.layers != 24:
+        out["INVALID"] = "debug run: n_layer != 24 is not the benchmark configuration"
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

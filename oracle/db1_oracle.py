@@ -164,12 +164,16 @@ def relattn_core_fwd(q, k, v, R, u, vb, masked, scale, mlen=0):
 
     score[i,j] = ((q_i+u).k_j + (q_i+vb).R[mlen+i-j]) * scale, masked_fill(-1e30),
     softmax over j, P.v.  This is the closed form of AC + rel_shift(BD)
-    (transformer_xl.py:160-173,98-110), pinned by the golden attention fixture.
+    (transformer_xl.py:160-173,98-110), pinned by the golden model fixtures.
+    Contractions are batched matmuls (BLAS) so the same code also serves as the timed CPU baseline.
     """
     B, Lq, H, D = q.shape
     Lk = k.shape[1]
-    AC = np.einsum("bind,bjnd->bnij", q + u, k)
-    T = np.einsum("bind,rnd->bnir", q + vb, R)  # (B,H,Lq,n_dist)
+    qu = (q + u).transpose(0, 2, 1, 3)             # (B,H,Lq,D)
+    qv = (q + vb).transpose(0, 2, 1, 3)
+    kt = k.transpose(0, 2, 3, 1)                   # (B,H,D,Lk)
+    AC = qu @ kt
+    T = qv @ R.transpose(1, 2, 0)[None]            # (B,H,Lq,n_dist)
     i = np.arange(Lq)[:, None]
     j = np.arange(Lk)[None, :]
     dist = np.clip(mlen + i - j, 0, R.shape[0] - 1)  # entries with dist<0 are always masked
@@ -179,26 +183,31 @@ def relattn_core_fwd(q, k, v, R, u, vb, masked, scale, mlen=0):
     S = S - S.max(-1, keepdims=True)
     P = np.exp(S)
     P = P / P.sum(-1, keepdims=True)
-    out = np.einsum("bnij,bjnd->bind", P, v)
-    return out, (P, dist)
+    out = (P @ v.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3)
+    return out, (P, dist, mlen)
 
 
 def relattn_core_bwd(dout, q, k, v, R, u, vb, scale, cache):
-    P, dist = cache
+    P, dist, mlen = cache
     B, Lq, H, D = q.shape
-    dP = np.einsum("bind,bjnd->bnij", dout, v)
-    dv = np.einsum("bnij,bind->bjnd", P, dout)
+    Lk = k.shape[1]
+    do = dout.transpose(0, 2, 1, 3)                # (B,H,Lq,D)
+    dP = do @ v.transpose(0, 2, 3, 1)
+    dv = (P.transpose(0, 1, 3, 2) @ do).transpose(0, 2, 1, 3)
     dS = P * (dP - (P * dP).sum(-1, keepdims=True)) * scale
-    dqk = np.einsum("bnij,bjnd->bind", dS, k)  # gradient w.r.t. (q+u)
-    dk = np.einsum("bnij,bind->bjnd", dS, q + u)
-    # scatter dS along distances: dT[b,n,i,r] = sum_{j: dist(i,j)=r} dS[b,n,i,j]
+    dqk = (dS @ k.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3)      # gradient w.r.t. (q+u)
+    dk = (dS.transpose(0, 1, 3, 2) @ (q + u).transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3)
+    # re-index dS by distance: dT[b,n,i,r] = dS[b,n,i,j] with j = mlen + i - r (each (i,r) has at most one j;
+    # masked entries of dS are exactly zero, so the clipped distances of the forward contribute nothing)
     nd = R.shape[0]
-    dT = np.zeros((B, H, Lq, nd), dtype=dS.dtype)
-    idx = np.broadcast_to(dist[None, None], dS.shape)
-    np.add.at(dT, (np.arange(B)[:, None, None, None], np.arange(H)[None, :, None, None],
-                   np.arange(Lq)[None, None, :, None], idx), dS)
-    dqr = np.einsum("bnir,rnd->bind", dT, R)  # gradient w.r.t. (q+vb)
-    dR = np.einsum("bnir,bind->rnd", dT, q + vb)
+    i = np.arange(Lq)[:, None]
+    r = np.arange(nd)[None, :]
+    jj = mlen + i - r
+    ok = (jj >= 0) & (jj < Lk)
+    dT = np.take_along_axis(dS, np.broadcast_to(np.clip(jj, 0, Lk - 1)[None, None], (B, H, Lq, nd)), axis=3) * ok[None, None]
+    dqr = (dT @ R.transpose(1, 0, 2)[None]).transpose(0, 2, 1, 3)   # gradient w.r.t. (q+vb)
+    qv = (q + vb).transpose(0, 2, 1, 3)
+    dR = np.einsum("bnri,bnid->rnd", dT.transpose(0, 1, 3, 2), qv, optimize=True)
     dq = dqk + dqr
     du = dqk.sum((0, 1))
     dvb = dqr.sum((0, 1))
