@@ -141,6 +141,7 @@ class TransformerXL(nn.Module):
         self.vocab_pad = _round_up(self.total_vocab_size, 128)
         self.keep_logits = True          # False: the CE backward overwrites the logits buffer (training engines)
         self.use_flash = True            # fused attention when the shape is supported
+        self.use_flash_bwd = False       # fused backward kernels (enabled once built)
         self._ctx: Optional[_Ctx] = None
         self._tables: Dict[Tuple[int, int], torch.Tensor] = {}
 
@@ -493,10 +494,12 @@ class TransformerXL(nn.Module):
         av = self._new(B, Lq, H, D)
         flash = (self.use_flash and mlen == 0 and Lq == Lk and ops.relattn_flash_supported(B, Lq, H, D, self.compute_dtype))
         if flash:
+            qu, qv = self._new(B, Lq, H, D), self._new(B, Lq, H, D)
+            ops.relattn_add_head_bias(qkv, u, vb, qu, qv, B, Lq, Lk, H, D)
             lse = self._new(B, H, Lq, dtype=torch.float32)
-            ops.relattn_flash_fwd(qkv, R, u, vb, av, lse, B, Lq, H, D, shift, 1.0 / math.sqrt(D))
+            ops.relattn_flash_fwd(qu, qv, qkv.view(B, Lk, 3, H, D), R, av, lse, B, Lq, H, D, shift, 1.0 / math.sqrt(D))
             if c is not None:
-                c.lse = lse
+                c.lse, c.qu, c.qv = lse, qu, qv
         else:
             Pm, _, _, _ = self._attn_probs(qkv, R, u, vb, B, Lq, Lk, mlen, shift)
             qkv5 = qkv.view(B, Lk, 3, H, D)
@@ -516,13 +519,11 @@ class TransformerXL(nn.Module):
         dqkv5 = dqkv.view(B, L, 3, H, D)
         qkv5 = qkv.view(B, L, 3, H, D)
         dav4 = dav.view(B, L, H, D)
-        if c.flash:
-            qv = self._new(B, L, H, D)
-            qu = self._new(B, L, H, D)
-            ops.relattn_add_head_bias(qkv, u, vb, qu, qv, B, L, L, H, D)
-            dT = self._new(H, B, L, L)
+        if c.flash and self.use_flash_bwd:
+            qu, qv = c.qu, c.qv
+            dT = torch.zeros(H, B, L, L, device=self.dev, dtype=self.compute_dtype)  # distances never visited stay zero
             delta = self._new(B, H, L, dtype=torch.float32)
-            ops.relattn_flash_bwd(qkv, R, u, vb, c.av, dav, c.lse, delta, dqkv, dT, B, L, H, D, shift, scale)
+            ops.relattn_flash_bwd(qu, qv, qkv5, R, c.av, dav4, c.lse, delta, dqkv5, dT, B, L, H, D, shift, scale)
         else:
             Pm, T, qu, qv = self._attn_probs(qkv, R, u, vb, B, L, L, 0, shift)
             dP = self._new(H, B, L, L, dtype=torch.float32)

@@ -204,13 +204,18 @@ def relattn_flash_supported(B, L, H, D, dtype) -> bool:
     return bool(lib.load().db1_relattn_flash_supported(B, L, H, D, dt_code(dtype)))
 
 
-def relattn_flash_fwd(qkv, R, u, vb, out, lse, B, L, H, D, shift, scale):
-    lib.call("db1_relattn_flash_fwd", P(qkv), P(R), P(u), P(vb), P(out), P(lse), B, L, H, D, shift, float(scale), dt_code(u), stream())
+def relattn_flash_fwd(qu, qv, qkv5, R, out, lse, B, L, H, D, shift, scale):
+    """qkv5: the packed activations viewed [B, L, 3, H, D]; k / v are addressed inside it by stride."""
+    k, v = qkv5[:, :, 1], qkv5[:, :, 2]
+    lib.call("db1_relattn_flash_fwd", P(qu), P(qv), P(k), P(v), k.stride(1), k.stride(0), P(R), P(out), P(lse),
+             B, L, H, D, shift, float(scale), stream())
 
 
-def relattn_flash_bwd(qkv, R, u, vb, out, dout, lse, delta, dqkv, dT, B, L, H, D, shift, scale):
-    lib.call("db1_relattn_flash_bwd", P(qkv), P(R), P(u), P(vb), P(out), P(dout), P(lse), P(delta), P(dqkv), P(dT),
-             B, L, H, D, shift, float(scale), dt_code(u), stream())
+def relattn_flash_bwd(qu, qv, qkv5, R, out, dout, lse, delta, dqkv5, dT, B, L, H, D, shift, scale):
+    k, v = qkv5[:, :, 1], qkv5[:, :, 2]
+    dq, dk, dv = dqkv5[:, :, 0], dqkv5[:, :, 1], dqkv5[:, :, 2]
+    lib.call("db1_relattn_flash_bwd", P(qu), P(qv), P(k), P(v), k.stride(1), k.stride(0), P(R), P(out), P(dout), P(lse), P(delta),
+             P(dq), P(dk), P(dv), dq.stride(1), dq.stride(0), P(dT), B, L, H, D, shift, float(scale), stream())
 
 
 def patch_normalize(pixels, patches, p):

@@ -143,17 +143,22 @@ int db1_relattn_softmax_bwd(const float* P, float* dP, float* dT, int H, int B, 
                             int mlen, int shift, float scale, void* stream);
 
 /* ------------------------------------------------------------------ relative-position flash attention (bf16, D = 128)
- * Fused QK^T + skewed Q~R^T + online softmax + PV; never materialises (L x L).  qkv [B,L,3,H,D] bf16,
- * R [L,H,D] bf16 indexed by distance, u, vb [H,D]; out [B,L,H,D] bf16, lse [B,H,L] f32.
- * Training shape only: Lq == Lk, causal window (shift >= L means plain causal). */
+ * Fused QK^T + skewed Q~R^T + online softmax + PV; never materialises (L x L).
+ * R [L,H,D] bf16 indexed by distance; out [B,L,H,D] bf16, lse [B,H,L] f32.
+ * Training shape only: Lq == Lk, causal window i - shift < j <= i (shift >= L means plain causal). */
 int db1_relattn_flash_supported(int B, int L, int H, int D, int dt);
-int db1_relattn_flash_fwd(const void* qkv, const void* R, const void* u, const void* vb, void* out, float* lse,
-                          int B, int L, int H, int D, int shift, float scale, int dtParam, void* stream);
-/* dqkv [B,L,3,H,D] bf16 (k and v parts written; q part = dq_k, the (q+u).k branch only);
- * dT [H,B,L,L] bf16 = dS re-indexed by distance (input of the dq_r / dR GEMMs); delta [B,H,L] f32 scratch. */
-int db1_relattn_flash_bwd(const void* qkv, const void* R, const void* u, const void* vb, const void* out,
-                          const void* dout, const float* lse, float* delta, void* dqkv, void* dT,
-                          int B, int L, int H, int D, int shift, float scale, int dtParam, void* stream);
+/* qu = q + u, qv = q + v_bias: [B,L,H,D] contiguous (db1_relattn_add_head_bias); k, v: pointers INTO the packed
+ * qkv activations with their row / batch strides in elements. */
+int db1_relattn_flash_fwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
+                          int64_t kv_batch_stride, const void* R, void* out, float* lse,
+                          int B, int L, int H, int D, int shift, float scale, void* stream);
+/* dq (the (q+u).k branch only), dk, dv are written with their own row / batch strides (they live inside dqkv);
+ * dT [H,B,L,L] bf16 = dS re-indexed by distance (input of the dq_r / dR GEMMs, zero where nothing is visible);
+ * delta [B,H,L] f32 scratch. */
+int db1_relattn_flash_bwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
+                          int64_t kv_batch_stride, const void* R, const void* out, const void* dout, const float* lse,
+                          float* delta, void* dq, void* dk, void* dv, int64_t dqkv_row_stride, int64_t dqkv_batch_stride,
+                          void* dT, int B, int L, int H, int D, int shift, float scale, void* stream);
 
 /* ------------------------------------------------------------------ image-patch embedder pieces
  * (src/tokenizer/vision_embedding.py:65-86).  pixels [N_img, C, Himg, Wimg] -> normalised patches

@@ -1,0 +1,151 @@
+"""Relative-position flash attention (bf16, d_head 128) against the CPU oracle and against the materialised HIP path,
+including sliding windows (0 < mem_len < L) and lengths that wrap the 256-row R ring."""
+import math
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import db1_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def bf(a):
+    return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+def dev16(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(torch.bfloat16)
+
+
+def rel_err(got, ref):
+    got = got.detach().to(torch.float64).cpu().numpy() if hasattr(got, "detach") else np.asarray(got, np.float64)
+    return np.abs(got - np.asarray(ref, np.float64)).max() / (np.abs(ref).max() + 1e-30)
+
+
+def make_inputs(B, L, H, D, seed, scale_q=1.0):
+    rng = np.random.default_rng(seed)
+    qkv = bf(rng.standard_normal((B, L, 3, H, D)) * scale_q)
+    R = bf(rng.standard_normal((L, H, D)))
+    u, vb = bf(rng.standard_normal((H, D)) * 0.5), bf(rng.standard_normal((H, D)) * 0.5)
+    return qkv, R, u, vb
+
+
+def masked_for(L, shift):
+    i = np.arange(L)[:, None]
+    j = np.arange(L)[None, :]
+    return (~((j <= i) & (j > i - shift))).astype(np.uint8)
+
+
+@pytest.mark.parametrize("B,L,H,shift", [(2, 256, 2, 256), (1, 512, 2, 512), (1, 512, 1, 130), (1, 384, 3, 33), (1, 1024, 1, 1024)])
+def test_flash_forward_matches_oracle(B, L, H, shift):
+    from bdm_db1_amd import ops
+    D = 128
+    qkv, R, u, vb = make_inputs(B, L, H, D, seed=L + shift)
+    scale = 1.0 / math.sqrt(D)
+    out_ref, (Pm, _, _) = O.relattn_core_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], R, u, vb, masked_for(L, shift), scale)
+    QKV, Rd, U, VB = dev16(qkv), dev16(R), dev16(u), dev16(vb)
+    qu, qv = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16), torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
+    ops.relattn_add_head_bias(QKV, U, VB, qu, qv, B, L, L, H, D)
+    assert ops.relattn_flash_supported(B, L, H, D, torch.bfloat16)
+    out = torch.full((B, L, H, D), 7.0, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, L, device=DEV, dtype=torch.float32)
+    ops.relattn_flash_fwd(qu, qv, QKV, Rd, out, lse, B, L, H, D, shift, scale)
+    torch.cuda.synchronize()
+    # stated tolerance: bf16 rounding of q+u / q+v, of P and of the output
+    e = rel_err(out, out_ref)
+    assert e < 2e-2, f"out rel err {e:.3e}"
+    # lse against the oracle's scores
+    qu_r, qv_r = qkv[:, :, 0] + u, qkv[:, :, 0] + vb
+    AC = np.einsum("bind,bjnd->bnij", qu_r, qkv[:, :, 1])
+    T = np.einsum("bind,rnd->bnir", qv_r, R)
+    i = np.arange(L)[:, None]; j = np.arange(L)[None, :]
+    BD = np.take_along_axis(T, np.broadcast_to(np.clip(i - j, 0, L - 1)[None, None], AC.shape), axis=3)
+    S = np.where(masked_for(L, shift)[None, None].astype(bool), -np.inf, (AC + BD) * scale)
+    mx = S.max(-1)
+    lse_ref = mx + np.log(np.exp(S - mx[..., None]).sum(-1))
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() < 0.15, np.abs(lse.cpu().numpy() - lse_ref).max()
+
+
+def test_flash_forward_matches_materialised_path_full_size():
+    """DB1-1.3B attention geometry (H=16, D=128, L=1024): fused kernel vs the strided-GEMM + softmax path on the same inputs."""
+    from bdm_db1_amd import ops
+    B, L, H, D = 2, 1024, 16, 128
+    qkv, R, u, vb = make_inputs(B, L, H, D, seed=7, scale_q=0.7)
+    scale = 1.0 / math.sqrt(D)
+    QKV, Rd, U, VB = dev16(qkv), dev16(R), dev16(u), dev16(vb)
+    qu, qv = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16), torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
+    ops.relattn_add_head_bias(QKV, U, VB, qu, qv, B, L, L, H, D)
+    out = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, L, device=DEV, dtype=torch.float32)
+    ops.relattn_flash_fwd(qu, qv, QKV, Rd, out, lse, B, L, H, D, L, scale)
+    # materialised path
+    qkv5 = QKV.view(B, L, 3, H, D)
+    AC = torch.empty(H, B, L, L, device=DEV, dtype=torch.float32)
+    ops.gemm_batched(qu.permute(2, 0, 1, 3), qkv5[:, :, 1].permute(2, 0, 3, 1), AC)
+    T = torch.empty(H, B, L, L, device=DEV, dtype=torch.float32)
+    ops.gemm_batched(qv.permute(2, 0, 1, 3), Rd.view(L, H, D).permute(1, 2, 0).unsqueeze(1).expand(H, B, D, L), T)
+    lse2 = torch.empty(H, B, L, device=DEV, dtype=torch.float32)
+    ops.relattn_softmax_fwd(AC, T, lse2, H, B, L, L, L, 0, L, scale)
+    out2 = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_batched(AC, qkv5[:, :, 2].permute(2, 0, 1, 3), out2.permute(2, 0, 1, 3))
+    torch.cuda.synchronize()
+    assert rel_err(out, out2.to(torch.float64).cpu().numpy()) < 2e-2
+    assert float((lse - lse2.permute(1, 0, 2)).abs().max()) < 5e-2
+
+
+def _build_d128_model(compute_dtype, seed=5):
+    from bdm_db1_amd import TransformerXL
+    cfg = dict(n_embed=256, n_position=256, n_layer=2, n_head=2, n_inner=None, pre_lnorm=False, mem_len=256, same_length=True,
+               untie_r=False, text_vocab_size=500, num_discrete_values=64, num_continuous_bin=64, overlap_with_text=True,
+               embd_pdrop=0.0, drop=0.0, dropattn=0.0, activation_fn="geglu", layer_norm_epsilon=1e-5,
+               share_input_output_embedding=True, use_deepnorm=False, fp16=False, vision_patch_size=16,
+               vision_num_input_channels=3, vision_position_vocab_size=128, vision_hidden_dropout_prob=0.0)
+    from golden_util import make_params
+    params = make_params(cfg, seed)
+    model = TransformerXL(SimpleNamespace(**cfg), compute_dtype=compute_dtype)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    params["pos_emb.inv_freq"] = model.pos_emb.inv_freq.cpu().numpy()
+    return cfg, params, model
+
+
+def test_model_bf16_flash_vs_oracle_and_vs_materialised():
+    from bdm_db1_amd.data import NLPTaskInput
+    cfg, params, model = _build_d128_model(torch.bfloat16)
+    rng = np.random.default_rng(3)
+    B, L = 3, 256
+    ids = rng.integers(0, 500, (B, L + 1))
+    mask = (rng.random((B, L)) > 0.2).astype(np.float32)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    mk = lambda: NLPTaskInput(position_id=None, attention_mask=None, loss_mask=T(mask), label=T(ids[:, 1:]), text_seq=T(ids[:, :-1]), text_len=None)
+    oracle = O.OracleModel(O.OracleConfig(**cfg), params)
+    ref_logits, ref_loss, _ = oracle.forward([O.TaskBatch(kind="nlp", text_seq=ids[:, :-1], label=ids[:, 1:], loss_mask=mask)])
+    ref_grads = oracle.backward()
+    results = {}
+    for flash in (True, False):
+        model.use_flash = flash
+        model.zero_grad()
+        logits, loss = model([mk()])
+        model.backward()
+        results[flash] = (logits.float().cpu().numpy().copy(), float(loss), {n: model.G(n).cpu().numpy().copy() for n in ref_grads})
+        assert rel_err(results[flash][0], ref_logits) < 3e-2, flash
+        assert abs(results[flash][1] - ref_loss) < 2e-2, flash
+        for n in ("h.0.dec_attn.qkv_net.weight", "h.1.dec_attn.o_net.weight", "r_w_bias", "r_r_bias", "h.0.dec_attn.r_net.weight", "word_embedding.weight"):
+            assert rel_err(results[flash][2][n], ref_grads[n]) < 6e-2, (flash, n)
+    assert np.abs(results[True][0] - results[False][0]).max() / np.abs(ref_logits).max() < 2e-2
