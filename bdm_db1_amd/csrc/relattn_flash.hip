@@ -1,19 +1,23 @@
 // Relative-position flash attention for gfx950 (bf16, d_head = 128): Transformer-XL scores
 //     s[i,j] = ((q_i+u).k_j + (q_i+v).R[i-j]) / sqrt(d),   visible iff  i - shift < j <= i
 // (closed form of AC + _rel_shift(BD) + mask, transformer_xl.py:98-110,160-209,551-567) with online softmax
-// and P.V fused, never materialising an (L x L) tensor in HBM.
+// and P.V fused, never materialising an (L x L) tensor in HBM in the forward.
 //
-// Forward, per workgroup: 128 queries (4 waves x 32) of one (batch, head); loop over 32-key blocks.
-//   S^T = K.Qu^T              "swapped" MFMA (v_mfma_f32_32x32x16_bf16): lane = query column, the 16 accumulator
-//                             registers = keys -> row statistics are lane-local (+1 half-swap), P^T feeds P.V as the
-//                             B operand straight from registers (no P round trip);
-//   T   = Qv.Rband^T          non-swapped, 64 distances per 32x32 block (band i-j of the block); written to a per-wave
-//                             LDS scratch [32 q][64 dist] and read back SKEWED (element (a, a-b+31)): both the write
-//                             (lanes = consecutive distances) and the read (lane stride 65 words) are bank-conflict free;
-//   O^T += V^T.P^T            V^T fragments by ds_read_b64_tr_b16 from the row-major V tile.
-// K/V tiles and a 256-row ring of R rows (the band slides by 32 distances per key block) are staged with
-// global_load_lds (16 B/lane); 16-B chunks are XOR-swizzled on the SOURCE side (K, R: chunk ^ (row & 15);
-// V: chunk ^ ((row & 3) << 2)) so ds_read_b128 / tr reads are conflict-free.
+// Common machinery (all three kernels; v_mfma_f32_32x32x16_bf16, 4 waves x 32 rows per workgroup, 32-column blocks):
+//   * "swapped" products put the query (fwd, bwd_q) or the key (bwd_kv) on the LANE axis of the accumulator, so
+//     per-row softmax statistics are lane-local and P / dS feed the next MFMA as the B operand straight from registers;
+//   * the relative term T = Qv.Rband^T is computed for the 64 distances a 32x32 block can touch, written to a per-wave
+//     LDS scratch [32 q][64 dist] and read back SKEWED (element (a, a - b + 31)); write (lanes = consecutive distances)
+//     and read (lane stride 65 or -1 words) are both bank-conflict free;
+//   * transposed operands (V^T, K^T, dO^T, Qu^T) come from row-major LDS tiles through ds_read_b64_tr_b16;
+//   * tiles and a 256-row ring of R rows (the band of distances slides by 32 per block) are staged with global_load_lds
+//     (16 B/lane, lane-linear destination); 16-B chunks are XOR-swizzled on the SOURCE side with
+//     swz(row) = ((row & 3) << 2) | ((row >> 2) & 3), which makes BOTH the ds_read_b128 row fragments and the tr reads
+//     conflict-free on the same image.
+// Backward = delta pre-pass + two kernels without atomics (deterministic):
+//   bwd_q : per 128 queries, loop keys  -> dq_k = dS.K (the (q+u).k branch) and dT = dS re-indexed by distance (bf16, HBM);
+//   bwd_kv: per 128 keys,    loop queries -> dV = P^T.dO, dK = dS^T.Qu.
+// dq_r = dT.R and dR = dT^T.Qv are plain batched GEMMs on dT (exact causal FLOPs, no band overhead) run by the caller.
 // Inputs qu = q+u and qv = q+v_bias are materialised once per layer by db1_relattn_add_head_bias.
 #include "db1_common.h"
 
@@ -22,17 +26,13 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 #define FA_D 128
 #define FA_BQ 128
 #define FA_BK 32
 #define FA_RING 256
-#define FA_TW_BYTES 8704                                  // per-wave scratch: T [32][64] f32 (8192) / O staging [32][136] bf16 (8704)
-#define FA_OFF_K 0
-#define FA_OFF_V 8192
-#define FA_OFF_R 16384
-#define FA_OFF_T (16384 + FA_RING * 256)
-#define FA_LDS_BYTES (FA_OFF_T + 4 * FA_TW_BYTES)
+#define FA_TW_BYTES 8704   // per-wave scratch: T [32][64] f32 (8192 B) or a [32][136] bf16 output staging tile (8704 B)
 
 struct FlashArgs {
     const bf16_t* qu; const bf16_t* qv; const bf16_t* k; const bf16_t* v; const bf16_t* R;
@@ -46,11 +46,32 @@ struct FlashArgs {
 };
 
 __device__ __forceinline__ int crow(int r, int hb) { return (r & 3) + 8 * (r >> 2) + 4 * hb; }  // C-layout row of register r
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 // one 1 KiB global_load_lds piece = 4 rows of 256 B; lane -> (row = lane >> 4, chunk position = lane & 15)
-__device__ __forceinline__ void glds_rows4(const bf16_t* row_ptr, int swz, char* lds_piece, int lane) {
-    const int c = (lane & 15) ^ swz;
+__device__ __forceinline__ void glds_row(const bf16_t* row_ptr, int row_for_swz, char* lds_piece, int lane) {
+    const int c = (lane & 15) ^ swz(row_for_swz);
     __builtin_amdgcn_global_load_lds(row_ptr + c * 8, LDS_PTR(void, lds_piece), 16, 0, 0);
+}
+// stage a [32][128] bf16 tile whose global rows are row0 .. row0+31 (stride rs): 8 pieces, 2 per wave
+__device__ __forceinline__ void stage_tile32(const bf16_t* g, int64_t rs, int row0, char* tile, int wave, int lane) {
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int piece = wave * 2 + it;
+        const int r = piece * 4 + (lane >> 4);
+        glds_row(g + (int64_t)(row0 + r) * rs, r, tile + piece * 1024, lane);
+    }
+}
+// ring rows for 32 consecutive distances starting at dist0 (multiple of 4); out-of-range rows are clamped (they are masked)
+__device__ __forceinline__ void stage_ring32(const bf16_t* Rg, int64_t rs, int dist0, int L, char* ring, int wave, int lane) {
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int piece = wave * 2 + it;
+        const int slot0 = (dist0 + piece * 4) & (FA_RING - 1);  // wave-uniform
+        const int dist = dist0 + piece * 4 + (lane >> 4);
+        const int gr = dist < 0 ? 0 : (dist > L - 1 ? L - 1 : dist);
+        glds_row(Rg + (int64_t)gr * rs, slot0 + (lane >> 4), ring + slot0 * 256, lane);
+    }
 }
 
 __device__ __forceinline__ bf16x8_t pack8(const float* p) {
@@ -60,51 +81,91 @@ __device__ __forceinline__ bf16x8_t pack8(const float* p) {
     return o;
 }
 
-// V^T (or any row-major [key][d] tile read as [d][key]) A-fragment for 32x32x16: 16 keys starting at key0, d-block db.
-// slot t of lane (d = lane & 31, hb) <-> key key0 + (t & 3) + 8 * (t >> 2) + 4 * hb, matching the C-layout rows.
-__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int key0, int db, int lane, int swz_shift) {
+// transposed A-fragment from a row-major [row][128] tile: d-block db (32 columns), 16 tile rows starting at row0.
+// slot t of lane (d = lane & 31, hb) <-> tile row row0 + (t & 3) + 8 * (t >> 2) + 4 * hb == the C-layout row order.
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int row0, int db, int lane) {
     const int g4 = lane >> 4, t = lane & 15, hb = g4 >> 1;
     const int gran = ((32 * db + 16 * (g4 & 1)) >> 2) + (t & 3);  // 8-byte granule inside the 256-B row
     bf16x8_t out;
 #pragma unroll
     for (int h2 = 0; h2 < 2; h2++) {
-        const int row = key0 + 4 * hb + 8 * h2 + (t >> 2);
-        const int chunk = (gran >> 1) ^ ((row & 3) << swz_shift);
-        const int off = row * 256 + chunk * 16 + (gran & 1) * 8;
+        const int row = row0 + 4 * hb + 8 * h2 + (t >> 2);
+        const int off = row * 256 + (((gran >> 1) ^ swz(row)) << 4) + (gran & 1) * 8;
         bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4_t, const_cast<char*>(tile) + off));
         out[h2 * 4 + 0] = v[0]; out[h2 * 4 + 1] = v[1]; out[h2 * 4 + 2] = v[2]; out[h2 * 4 + 3] = v[3];
     }
     return out;
 }
-
-// row-major [row][128] tile with chunk ^ (row & 15) swizzle: fragment "row (lane & 31), k = ks*16 + (lane>>5)*8 .. +8"
+// fragment "tile row `row`, k = ks*16 + (lane>>5)*8 .. +8" (A or B operand image) from a swizzled row-major tile
 __device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row, int ks, int lane) {
-    const int chunk = (ks * 2 + (lane >> 5)) ^ (row & 15);
-    return *reinterpret_cast<const bf16x8_t*>(tile + row * 256 + chunk * 16);
+    return *reinterpret_cast<const bf16x8_t*>(tile + row * 256 + (((ks * 2 + (lane >> 5)) ^ swz(row)) << 4));
 }
+__device__ __forceinline__ void zero16(f32x16& x) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = 0.f;
+}
+// acc^T [4 d-blocks](rows = d, col = lane) -> bf16 rows [32][128] at dst (row stride rs), staged through the wave scratch
+__device__ __forceinline__ void store_acc_t(const f32x16* acc, float mul, bf16_t* Ow, bf16_t* dst, int64_t rs, int lane) {
+    const int a = lane & 31, hb = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 4; db++)
+#pragma unroll
+        for (int rq = 0; rq < 4; rq++) {
+            uint2 o;
+            o.x = (unsigned)f2bf(acc[db][rq * 4 + 0] * mul) | ((unsigned)f2bf(acc[db][rq * 4 + 1] * mul) << 16);
+            o.y = (unsigned)f2bf(acc[db][rq * 4 + 2] * mul) | ((unsigned)f2bf(acc[db][rq * 4 + 3] * mul) << 16);
+            *reinterpret_cast<uint2*>(Ow + a * 136 + 32 * db + 8 * rq + 4 * hb) = o;
+        }
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int row = it * 4 + (lane >> 4), ch = lane & 15;
+        const uint4 v = *reinterpret_cast<const uint4*>(Ow + row * 136 + ch * 8);
+        *reinterpret_cast<uint4*>(dst + (int64_t)row * rs + ch * 8) = v;
+    }
+}
+// T = Arows . Rband^T for the 64 distances starting at dist_lo, written to the wave scratch Tw[32][64]
+__device__ __forceinline__ void rel_band_to_lds(const bf16x8_t* fa_regs, const char* a_tile, bool a_from_regs, const char* ring, int dist_lo,
+                                                float* Tw, int lane) {
+    const int a = lane & 31, hb = lane >> 5;
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++) {
+        f32x16 acc_t;
+        zero16(acc_t);
+        const int slot = (dist_lo + 32 * blk + a) & (FA_RING - 1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++)
+            acc_t = MFMA32(a_from_regs ? fa_regs[ks] : row_frag(a_tile, a, ks, lane), row_frag(ring, slot, ks, lane), acc_t);
+#pragma unroll
+        for (int r = 0; r < 16; r++) Tw[crow(r, hb) * 64 + 32 * blk + a] = acc_t[r];
+    }
+}
+
+// ======================================================================================= forward
+#define FWD_OFF_K 0
+#define FWD_OFF_V 8192
+#define FWD_OFF_R 16384
+#define FWD_OFF_T (16384 + FA_RING * 256)
+#define FWD_LDS_BYTES (FWD_OFF_T + 4 * FA_TW_BYTES)
 
 __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nqt = p.L / FA_BQ;
-    const int qt = nqt - 1 - (int)blockIdx.x;  // heavy (late) query tiles first
+    const int qt = p.L / FA_BQ - 1 - (int)blockIdx.x;  // heavy (late) query tiles first
     const int h = blockIdx.y, b = blockIdx.z;
     const int H = p.H, L = p.L, HD = H * FA_D;
     const int i0 = qt * FA_BQ, iw = i0 + 32 * wave;
     const int a = lane & 31, hb = lane >> 5;
-    char* Ks = smem + FA_OFF_K;
-    char* Vs = smem + FA_OFF_V;
-    char* Rr = smem + FA_OFF_R;
-    float* Tw = reinterpret_cast<float*>(smem + FA_OFF_T + wave * FA_TW_BYTES);
-
+    char* Ks = smem + FWD_OFF_K;
+    char* Vs = smem + FWD_OFF_V;
+    char* Rr = smem + FWD_OFF_R;
+    float* Tw = reinterpret_cast<float*>(smem + FWD_OFF_T + wave * FA_TW_BYTES);
     const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
     const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
     const bf16_t* kg = p.k + (int64_t)b * p.kv_bs + h * FA_D;
     const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * FA_D;
     const bf16_t* Rg = p.R + h * FA_D;
 
-    // Q fragments (A and B operands share the register image): row iw + a, k = ks*16 + hb*8
-    bf16x8_t fqu[8], fqv[8];
+    bf16x8_t fqu[8], fqv[8];  // row iw + a, k = ks*16 + hb*8 (A and B operand images coincide)
 #pragma unroll
     for (int ks = 0; ks < 8; ks++) {
         fqu[ks] = *reinterpret_cast<const bf16x8_t*>(qu + (int64_t)(iw + a) * HD + ks * 16 + hb * 8);
@@ -113,70 +174,31 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
     int jlo = i0 - p.shift + 1;
     if (jlo < 0) jlo = 0;
     const int jb_lo = jlo / FA_BK, jb_hi = (i0 + FA_BQ - 1) / FA_BK;
-    // prologue: ring rows for distances [i0 - j0lo, i0 - j0lo + 128)
-    {
-        const int dbase = i0 - jb_lo * FA_BK;
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int piece = wave * 8 + it;                 // 32 pieces x 4 rows
-            const int slot0 = (dbase + piece * 4) & (FA_RING - 1);   // wave-uniform, multiple of 4
-            const int dist = dbase + piece * 4 + (lane >> 4);
-            const int slot = slot0 + (lane >> 4);
-            int gr = dist < 0 ? 0 : (dist > L - 1 ? L - 1 : dist);
-            glds_rows4(Rg + (int64_t)gr * HD, slot & 15, Rr + slot0 * 256, lane);
-        }
-    }
+    for (int c4 = 0; c4 < 4; c4++) stage_ring32(Rg, HD, i0 - jb_lo * FA_BK + 32 * c4, L, Rr, wave, lane);  // distances [i0-j0lo, +128)
     f32x16 acc_o[4];
 #pragma unroll
-    for (int db = 0; db < 4; db++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc_o[db][r] = 0.f;
+    for (int db = 0; db < 4; db++) zero16(acc_o[db]);
     float m_i = -1.0e30f, l_i = 0.f;
 
     for (int jb = jb_lo; jb <= jb_hi; jb++) {
         const int j0 = jb * FA_BK;
-        __syncthreads();  // every wave is done with the previous K/V tiles and the ring rows about to be replaced
-        {
-#pragma unroll
-            for (int it = 0; it < 2; it++) {
-                const int piece = wave * 2 + it;             // 8 pieces x 4 rows = 32 rows
-                const int r = piece * 4 + (lane >> 4);
-                glds_rows4(kg + (int64_t)(j0 + r) * p.kv_rs, r & 15, Ks + piece * 1024, lane);
-                glds_rows4(vg + (int64_t)(j0 + r) * p.kv_rs, (r & 3) << 2, Vs + piece * 1024, lane);
-                const int slot0 = (i0 - j0 - 32 + piece * 4) & (FA_RING - 1);
-                const int dist = i0 - j0 - 32 + r;
-                const int slot = slot0 + (lane >> 4);
-                int gr = dist < 0 ? 0 : (dist > L - 1 ? L - 1 : dist);
-                glds_rows4(Rg + (int64_t)gr * HD, slot & 15, Rr + slot0 * 256, lane);
-            }
-        }
+        __syncthreads();  // every wave is done with the previous K/V tiles and with the ring rows about to be replaced
+        stage_tile32(kg, p.kv_rs, j0, Ks, wave, lane);
+        stage_tile32(vg, p.kv_rs, j0, Vs, wave, lane);
+        stage_ring32(Rg, HD, i0 - j0 - 32, L, Rr, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // wave-uniform skip of blocks that are entirely outside this wave's visibility window
-        if (j0 > iw + 31 || j0 + 31 <= iw - p.shift) continue;
+        if (j0 > iw + 31 || j0 + 31 <= iw - p.shift) continue;  // wave-uniform: block entirely outside this wave's window
 
         f32x16 acc_s;
+        zero16(acc_s);
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc_s[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, a, ks, lane), fqu[ks], acc_s, 0, 0, 0);
-        // T = Qv . Rband^T for distances iw - j0 - 31 + [0, 64)
-#pragma unroll
-        for (int blk = 0; blk < 2; blk++) {
-            f32x16 acc_t;
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc_t[r] = 0.f;
-            const int slot = (iw - j0 - 31 + 32 * blk + a) & (FA_RING - 1);
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) acc_t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fqv[ks], row_frag(Rr, slot, ks, lane), acc_t, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; r++) Tw[crow(r, hb) * 64 + 32 * blk + a] = acc_t[r];
-        }
-        // skewed read-back + scale + mask (this lane: query iw + a; register r: key j0 + crow(r, hb))
+        for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(row_frag(Ks, a, ks, lane), fqu[ks], acc_s);  // S^T[key][query]
+        rel_band_to_lds(fqv, nullptr, true, Rr, iw - j0 - 31, Tw, lane);
         float s[16];
         float mblk = -1.0e30f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int r = 0; r < 16; r++) {  // this lane: query iw + a; register r: key j0 + crow(r, hb)
             const int bk = crow(r, hb);
             const float bd = Tw[a * 64 + a - bk + 31];
             const int i = iw + a, j = j0 + bk;
@@ -199,33 +221,216 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
             for (int r = 0; r < 16; r++) acc_o[db][r] *= alpha;
         const bf16x8_t pb0 = pack8(s), pb1 = pack8(s + 8);
 #pragma unroll
-        for (int db = 0; db < 4; db++) {
-            acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vs, 0, db, lane, 2), pb0, acc_o[db], 0, 0, 0);
-            acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vs, 16, db, lane, 2), pb1, acc_o[db], 0, 0, 0);
+        for (int db = 0; db < 4; db++) {  // O^T[d][query] += V^T . P^T
+            acc_o[db] = MFMA32(tr_frag(Vs, 0, db, lane), pb0, acc_o[db]);
+            acc_o[db] = MFMA32(tr_frag(Vs, 16, db, lane), pb1, acc_o[db]);
         }
     }
-    // epilogue: O[q][d] = acc_o^T / l, staged through the wave's scratch so that global stores are whole 256-B rows
-    const float inv = 1.f / l_i;
-    bf16_t* Ow = reinterpret_cast<bf16_t*>(Tw);  // [32][136] bf16 (row stride 272 B)
-#pragma unroll
-    for (int db = 0; db < 4; db++)
-#pragma unroll
-        for (int rq = 0; rq < 4; rq++) {
-            uint2 o;
-            o.x = (unsigned)f2bf(acc_o[db][rq * 4 + 0] * inv) | ((unsigned)f2bf(acc_o[db][rq * 4 + 1] * inv) << 16);
-            o.y = (unsigned)f2bf(acc_o[db][rq * 4 + 2] * inv) | ((unsigned)f2bf(acc_o[db][rq * 4 + 3] * inv) << 16);
-            *reinterpret_cast<uint2*>(Ow + a * 136 + 32 * db + 8 * rq + 4 * hb) = o;
-        }
-    bf16_t* og = p.o + ((int64_t)b * L + iw) * HD + h * FA_D;
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const int row = it * 4 + (lane >> 4), ch = lane & 15;
-        const uint4 v = *reinterpret_cast<const uint4*>(Ow + row * 136 + ch * 8);
-        *reinterpret_cast<uint4*>(og + (int64_t)row * HD + ch * 8) = v;
-    }
+    store_acc_t(acc_o, 1.f / l_i, reinterpret_cast<bf16_t*>(Tw), p.o + ((int64_t)b * L + iw) * HD + h * FA_D, HD, lane);
     if (hb == 0) p.lse_out[((int64_t)b * H + h) * L + iw + a] = m_i + logf(l_i);
 }
 
+// ======================================================================================= backward: delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void relattn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta,
+                                                            int64_t n_rows, int L, int H) {
+    // one wave per (b, i, h) row of 128 elements (2 per lane)
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned x = reinterpret_cast<const unsigned*>(o + row * FA_D)[lane];
+    const unsigned y = reinterpret_cast<const unsigned*>(dout + row * FA_D)[lane];
+    float s = __uint_as_float(x << 16) * __uint_as_float(y << 16) + __uint_as_float(x & 0xffff0000u) * __uint_as_float(y & 0xffff0000u);
+    s = wave_sum(s);
+    if (lane == 0) {
+        const int64_t bi = row / H;
+        const int hh = (int)(row % H);
+        const int64_t bb = bi / L, i = bi % L;
+        delta[(bb * H + hh) * L + i] = s;
+    }
+}
+
+// ======================================================================================= backward w.r.t. queries (+ dT)
+__global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qt = p.L / FA_BQ - 1 - (int)blockIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int H = p.H, L = p.L, HD = H * FA_D;
+    const int i0 = qt * FA_BQ, iw = i0 + 32 * wave;
+    const int a = lane & 31, hb = lane >> 5;
+    char* Ks = smem + FWD_OFF_K;
+    char* Vs = smem + FWD_OFF_V;
+    char* Rr = smem + FWD_OFF_R;
+    float* Tw = reinterpret_cast<float*>(smem + FWD_OFF_T + wave * FA_TW_BYTES);
+    const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* dog = p.dout + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* kg = p.k + (int64_t)b * p.kv_bs + h * FA_D;
+    const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * FA_D;
+    const bf16_t* Rg = p.R + h * FA_D;
+    bf16_t* dTg = p.dT + (((int64_t)h * p.B + b) * L) * L;
+
+    bf16x8_t fqu[8], fqv[8], fdo[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+        fqu[ks] = *reinterpret_cast<const bf16x8_t*>(qu + (int64_t)(iw + a) * HD + ks * 16 + hb * 8);
+        fqv[ks] = *reinterpret_cast<const bf16x8_t*>(qv + (int64_t)(iw + a) * HD + ks * 16 + hb * 8);
+        fdo[ks] = *reinterpret_cast<const bf16x8_t*>(dog + (int64_t)(iw + a) * HD + ks * 16 + hb * 8);
+    }
+    const float lse_a = p.lse[((int64_t)b * H + h) * L + iw + a];
+    const float delta_a = p.delta[((int64_t)b * H + h) * L + iw + a];
+    int jlo = i0 - p.shift + 1;
+    if (jlo < 0) jlo = 0;
+    const int jb_lo = jlo / FA_BK, jb_hi = (i0 + FA_BQ - 1) / FA_BK;
+    for (int c4 = 0; c4 < 4; c4++) stage_ring32(Rg, HD, i0 - jb_lo * FA_BK + 32 * c4, L, Rr, wave, lane);
+    f32x16 acc_dq[4];
+#pragma unroll
+    for (int db = 0; db < 4; db++) zero16(acc_dq[db]);
+
+    for (int jb = jb_lo; jb <= jb_hi; jb++) {
+        const int j0 = jb * FA_BK;
+        __syncthreads();
+        stage_tile32(kg, p.kv_rs, j0, Ks, wave, lane);
+        stage_tile32(vg, p.kv_rs, j0, Vs, wave, lane);
+        stage_ring32(Rg, HD, i0 - j0 - 32, L, Rr, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (j0 > iw + 31 || j0 + 31 <= iw - p.shift) continue;
+
+        f32x16 acc_s, acc_dp;
+        zero16(acc_s);
+        zero16(acc_dp);
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(row_frag(Ks, a, ks, lane), fqu[ks], acc_s);    // S^T[key][query]
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc_dp = MFMA32(row_frag(Vs, a, ks, lane), fdo[ks], acc_dp);  // dP^T[key][query]
+        rel_band_to_lds(fqv, nullptr, true, Rr, iw - j0 - 31, Tw, lane);
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int bk = crow(r, hb);
+            const float bd = Tw[a * 64 + a - bk + 31];
+            const int i = iw + a, j = j0 + bk;
+            const bool vis = (j <= i) && (j > i - p.shift);
+            const float pr = vis ? __expf((acc_s[r] + bd) * p.scale - lse_a) : 0.f;
+            ds[r] = pr * (acc_dp[r] - delta_a) * p.scale;
+        }
+        // dS re-indexed by distance: write into the scratch at (a, a - b + 31), then rows go out as 32 contiguous bf16
+#pragma unroll
+        for (int r = 0; r < 16; r++) Tw[a * 64 + a - crow(r, hb) + 31] = ds[r];
+        const bf16x8_t db0 = pack8(ds), db1 = pack8(ds + 8);
+#pragma unroll
+        for (int db = 0; db < 4; db++) {  // dq^T[d][query] += K^T . dS^T
+            acc_dq[db] = MFMA32(tr_frag(Ks, 0, db, lane), db0, acc_dq[db]);
+            acc_dq[db] = MFMA32(tr_frag(Ks, 16, db, lane), db1, acc_dq[db]);
+        }
+        {
+            const int t = lane & 31;
+#pragma unroll
+            for (int it = 0; it < 16; it++) {
+                const int row = it * 2 + (lane >> 5);
+                const int dist = iw + row - j0 - 31 + t;  // = i - j with j = j0 + 31 - t
+                if (dist >= 0) dTg[(int64_t)(iw + row) * L + dist] = f2bf(Tw[row * 64 + row + t]);
+            }
+        }
+    }
+    store_acc_t(acc_dq, 1.f, reinterpret_cast<bf16_t*>(Tw), p.dq + (int64_t)b * p.dq_bs + (int64_t)iw * p.dq_rs + h * FA_D, p.dq_rs, lane);
+}
+
+// ======================================================================================= backward w.r.t. keys / values
+#define KV_OFF_QU 0
+#define KV_OFF_QV 8192
+#define KV_OFF_DO 16384
+#define KV_OFF_ST 24576                      // lse[32], delta[32] floats
+#define KV_OFF_R 24832
+#define KV_OFF_T (KV_OFF_R + FA_RING * 256)
+#define KV_LDS_BYTES (KV_OFF_T + 4 * FA_TW_BYTES)
+
+__global__ __launch_bounds__(256, 1) void relattn_flash_bwd_kv_kernel(FlashArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kt = blockIdx.x;  // early key tiles see the most queries and are dispatched first
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int H = p.H, L = p.L, HD = H * FA_D;
+    const int j0 = kt * FA_BQ, kw = j0 + 32 * wave;
+    const int a = lane & 31, hb = lane >> 5;   // a = key column of this lane
+    char* Qus = smem + KV_OFF_QU;
+    char* Qvs = smem + KV_OFF_QV;
+    char* dOs = smem + KV_OFF_DO;
+    float* stat = reinterpret_cast<float*>(smem + KV_OFF_ST);
+    char* Rr = smem + KV_OFF_R;
+    float* Tw = reinterpret_cast<float*>(smem + KV_OFF_T + wave * FA_TW_BYTES);
+    const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* dog = p.dout + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* kg = p.k + (int64_t)b * p.kv_bs + h * FA_D;
+    const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * FA_D;
+    const bf16_t* Rg = p.R + h * FA_D;
+    const float* lseg = p.lse + ((int64_t)b * H + h) * L;
+    const float* delg = p.delta + ((int64_t)b * H + h) * L;
+
+    bf16x8_t fk[8], fv[8];  // B-operand images: column = key kw + a
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+        fk[ks] = *reinterpret_cast<const bf16x8_t*>(kg + (int64_t)(kw + a) * p.kv_rs + ks * 16 + hb * 8);
+        fv[ks] = *reinterpret_cast<const bf16x8_t*>(vg + (int64_t)(kw + a) * p.kv_rs + ks * 16 + hb * 8);
+    }
+    const int ib_lo = j0 / FA_BK;
+    int ihi = j0 + FA_BQ - 1 + p.shift - 1;  // last query that can see the last key of the tile
+    if (ihi > L - 1) ihi = L - 1;
+    const int ib_hi = ihi / FA_BK;
+    // ring: distances [i0q - j0 - 128, i0q - j0) before the first block; every block adds [i0q - j0, i0q - j0 + 32)
+    for (int c4 = 0; c4 < 4; c4++) stage_ring32(Rg, HD, ib_lo * FA_BK - j0 - 128 + 32 * c4, L, Rr, wave, lane);
+    f32x16 acc_dk[4], acc_dv[4];
+#pragma unroll
+    for (int db = 0; db < 4; db++) { zero16(acc_dk[db]); zero16(acc_dv[db]); }
+
+    for (int ib = ib_lo; ib <= ib_hi; ib++) {
+        const int i0q = ib * FA_BK;
+        __syncthreads();
+        stage_tile32(qu, HD, i0q, Qus, wave, lane);
+        stage_tile32(qv, HD, i0q, Qvs, wave, lane);
+        stage_tile32(dog, HD, i0q, dOs, wave, lane);
+        stage_ring32(Rg, HD, i0q - j0, L, Rr, wave, lane);
+        if (tid < 32) stat[tid] = lseg[i0q + tid];
+        else if (tid < 64) stat[tid] = delg[i0q + tid - 32];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (i0q + 31 < kw || i0q >= kw + 31 + p.shift) continue;  // no (i, j) of this block pair is visible
+
+        f32x16 acc_s, acc_dp;
+        zero16(acc_s);
+        zero16(acc_dp);
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(row_frag(Qus, a, ks, lane), fk[ks], acc_s);    // S[query][key]
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc_dp = MFMA32(row_frag(dOs, a, ks, lane), fv[ks], acc_dp);  // dP[query][key]
+        rel_band_to_lds(nullptr, Qvs, false, Rr, i0q - kw - 31, Tw, lane);
+        float pr[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {  // this lane: key kw + a; register r: query i0q + crow(r, hb)
+            const int aq = crow(r, hb);
+            const float bd = Tw[aq * 64 + aq - a + 31];
+            const int i = i0q + aq, j = kw + a;
+            const bool vis = (j <= i) && (j > i - p.shift);
+            pr[r] = vis ? __expf((acc_s[r] + bd) * p.scale - stat[aq]) : 0.f;
+            ds[r] = pr[r] * (acc_dp[r] - stat[32 + aq]) * p.scale;
+        }
+        const bf16x8_t pb0 = pack8(pr), pb1 = pack8(pr + 8), sb0 = pack8(ds), sb1 = pack8(ds + 8);
+#pragma unroll
+        for (int db = 0; db < 4; db++) {
+            acc_dv[db] = MFMA32(tr_frag(dOs, 0, db, lane), pb0, acc_dv[db]);   // dV^T[d][key] += dO^T . P
+            acc_dv[db] = MFMA32(tr_frag(dOs, 16, db, lane), pb1, acc_dv[db]);
+            acc_dk[db] = MFMA32(tr_frag(Qus, 0, db, lane), sb0, acc_dk[db]);   // dK^T[d][key] += Qu^T . dS
+            acc_dk[db] = MFMA32(tr_frag(Qus, 16, db, lane), sb1, acc_dk[db]);
+        }
+    }
+    bf16_t* Ow = reinterpret_cast<bf16_t*>(Tw);
+    store_acc_t(acc_dk, 1.f, Ow, p.dk + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
+    store_acc_t(acc_dv, 1.f, Ow, p.dv + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
+}
+
+// ======================================================================================= host side
 extern "C" int db1_relattn_flash_supported(int B, int L, int H, int D, int dt) {
     return (dt == DB1_BF16 && D == FA_D && B > 0 && H > 0 && L >= FA_BQ && (L % FA_BQ) == 0 && B <= 65535 && H <= 65535) ? 1 : 0;
 }
@@ -250,9 +455,9 @@ extern "C" int db1_relattn_flash_fwd(const void* qu, const void* qv, const void*
     if (st) return st;
     if (!db1_aligned16(out)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_flash_fwd: out alignment");
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)relattn_flash_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_BYTES); attr = true; }
+    if (!attr) { hipFuncSetAttribute((const void*)relattn_flash_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES); attr = true; }
     dim3 grid((unsigned)(L / FA_BQ), (unsigned)H, (unsigned)B);
-    relattn_flash_fwd_kernel<<<grid, 256, FA_LDS_BYTES, (hipStream_t)stream>>>(a);
+    relattn_flash_fwd_kernel<<<grid, 256, FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_fwd");
     return DB1_OK;
 }
@@ -261,8 +466,31 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
                                      int64_t kv_batch_stride, const void* R, const void* out, const void* dout, const float* lse,
                                      float* delta, void* dq, void* dk, void* dv, int64_t dqkv_row_stride, int64_t dqkv_batch_stride,
                                      void* dT, int B, int L, int H, int D, int shift, float scale, void* stream) {
-    (void)qu; (void)qv; (void)k; (void)v; (void)kv_row_stride; (void)kv_batch_stride; (void)R; (void)out; (void)dout; (void)lse; (void)delta;
-    (void)dq; (void)dk; (void)dv; (void)dqkv_row_stride; (void)dqkv_batch_stride; (void)dT; (void)B; (void)L; (void)H; (void)D; (void)shift;
-    (void)scale; (void)stream;
-    DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_flash_bwd: not built yet");
+    FlashArgs a = {};
+    a.qu = (const bf16_t*)qu; a.qv = (const bf16_t*)qv; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.R = (const bf16_t*)R;
+    a.out = (const bf16_t*)out; a.dout = (const bf16_t*)dout; a.lse = lse; a.delta = delta;
+    a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dT = (bf16_t*)dT;
+    a.kv_rs = kv_row_stride; a.kv_bs = kv_batch_stride; a.dq_rs = dqkv_row_stride; a.dq_bs = dqkv_batch_stride;
+    a.B = B; a.L = L; a.H = H; a.shift = shift; a.scale = scale;
+    int st = flash_check(a, D, "relattn_flash_bwd");
+    if (st) return st;
+    if ((a.dq_rs % 8) || (a.dq_bs % 8) || !db1_aligned16(dq) || !db1_aligned16(dk) || !db1_aligned16(dv) || !db1_aligned16(out) || !db1_aligned16(dout))
+        DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_flash_bwd: alignment");
+    if (!delta || !dT || !lse) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_flash_bwd: null buffer");
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)relattn_flash_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES);
+        hipFuncSetAttribute((const void*)relattn_flash_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV_LDS_BYTES);
+        attr = true;
+    }
+    const int64_t n_rows = (int64_t)B * L * H;
+    relattn_delta_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, s>>>(a.out, a.dout, delta, n_rows, L, H);
+    DB1_CHECK_LAUNCH("relattn_delta");
+    dim3 grid((unsigned)(L / FA_BQ), (unsigned)H, (unsigned)B);
+    relattn_flash_bwd_q_kernel<<<grid, 256, FWD_LDS_BYTES, s>>>(a);
+    DB1_CHECK_LAUNCH("relattn_flash_bwd_q");
+    relattn_flash_bwd_kv_kernel<<<grid, 256, KV_LDS_BYTES, s>>>(a);
+    DB1_CHECK_LAUNCH("relattn_flash_bwd_kv");
+    return DB1_OK;
 }

@@ -141,7 +141,7 @@ class TransformerXL(nn.Module):
         self.vocab_pad = _round_up(self.total_vocab_size, 128)
         self.keep_logits = True          # False: the CE backward overwrites the logits buffer (training engines)
         self.use_flash = True            # fused attention when the shape is supported
-        self.use_flash_bwd = False       # fused backward kernels (enabled once built)
+        self.use_flash_bwd = True        # fused backward kernels (False: recompute through the materialised path)
         self._ctx: Optional[_Ctx] = None
         self._tables: Dict[Tuple[int, int], torch.Tensor] = {}
 

@@ -110,6 +110,41 @@ def test_flash_forward_matches_materialised_path_full_size():
     assert float((lse - lse2.permute(1, 0, 2)).abs().max()) < 5e-2
 
 
+@pytest.mark.parametrize("B,L,H,shift", [(2, 256, 2, 256), (1, 512, 2, 130), (1, 384, 1, 384)])
+def test_flash_backward_matches_oracle(B, L, H, shift):
+    from bdm_db1_amd import ops
+    D = 128
+    qkv, R, u, vb = make_inputs(B, L, H, D, seed=11 + L + shift, scale_q=0.8)
+    rng = np.random.default_rng(99)
+    dout = bf(rng.standard_normal((B, L, H, D)))
+    scale = 1.0 / math.sqrt(D)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    out_ref, cache = O.relattn_core_fwd(q, k, v, R, u, vb, masked_for(L, shift), scale)
+    dq_ref, dk_ref, dv_ref, dR_ref, du_ref, dvb_ref = O.relattn_core_bwd(dout, q, k, v, R, u, vb, scale, cache)
+    QKV, Rd, U, VB = dev16(qkv), dev16(R), dev16(u), dev16(vb)
+    qu, qv = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16), torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
+    ops.relattn_add_head_bias(QKV, U, VB, qu, qv, B, L, L, H, D)
+    out = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, L, device=DEV, dtype=torch.float32)
+    ops.relattn_flash_fwd(qu, qv, QKV, Rd, out, lse, B, L, H, D, shift, scale)
+    dqkv = torch.full((B, L, 3, H, D), 3.0, device=DEV, dtype=torch.bfloat16)
+    dT = torch.zeros(H, B, L, L, device=DEV, dtype=torch.bfloat16)
+    delta = torch.empty(B, H, L, device=DEV, dtype=torch.float32)
+    ops.relattn_flash_bwd(qu, qv, QKV, Rd, out, dev16(dout), lse, delta, dqkv, dT, B, L, H, D, shift, scale)
+    torch.cuda.synchronize()
+    g = dqkv.to(torch.float64).cpu().numpy()
+    dTn = dT.to(torch.float64).cpu().numpy()
+    assert rel_err(g[:, :, 2], dv_ref) < 3e-2, "dv"
+    assert rel_err(g[:, :, 1], dk_ref) < 3e-2, "dk"
+    dqr = np.einsum("nbir,rnd->bind", dTn, R)
+    assert rel_err(g[:, :, 0] + dqr, dq_ref) < 3e-2, "dq"
+    dR = np.einsum("nbir,bind->rnd", dTn, qv.to(torch.float64).cpu().numpy())
+    assert rel_err(dR, dR_ref) < 3e-2, "dR"
+    assert rel_err(g[:, :, 0].sum((0, 1)), du_ref) < 3e-2, "du"
+    assert rel_err(dqr.sum((0, 1)), dvb_ref) < 3e-2, "dv_bias"
+    assert np.abs(delta.cpu().numpy() - np.einsum("bind,bind->bni", out.to(torch.float64).cpu().numpy(), dout)).max() < 5e-2
+
+
 def _build_d128_model(compute_dtype, seed=5):
     from bdm_db1_amd import TransformerXL
     cfg = dict(n_embed=256, n_position=256, n_layer=2, n_head=2, n_inner=None, pre_lnorm=False, mem_len=256, same_length=True,
