@@ -15,80 +15,11 @@
 // so that each lane ends up with 4 CONSECUTIVE n of one row m: the epilogue stores 8-byte (bf16) or
 // 16-byte (fp32) vectors.  Workgroup = 256 threads = 2x2 waves, wave tile 64x64 = 4x4 fragments.
 // Workgroup ids are remapped so that each XCD (private L2) owns a contiguous band of output tiles.
-#include "db1_common.h"
+#include "gemm_tile.h"
 #include "gemm_args.h"
-
-typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#include <stdlib.h>
 
 int db1_gemm_strided_generic(const GemmStridedArgs& a, int dtA, int dtB, int dtC, int dtBias, int batch, hipStream_t st);
-
-#define TBM 128
-#define TBN 128
-#define TBK 64
-#define TILE_BYTES (128 * 64 * 2)  // 16 KiB per operand per stage
-
-struct GemmTileArgs {
-    const bf16_t* A; const bf16_t* B; void* C; const void* bias;
-    int M, N, K;
-    int64_t lda, ldb, ldc;  // leading dimensions in elements
-    int batch1;
-    int64_t a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
-    float alpha, beta;
-    int tiles_m, tiles_n;
-};
-
-// ---- staging: one 16 KiB operand tile, 16 wave-instructions of 1 KiB, 4 per wave
-template <bool KMAJOR>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, int row0, int k0, char* lds, int wave, int lane) {
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int q = wave * 4 + it;  // which 1 KiB piece
-        const bf16_t* src;
-        if (KMAJOR) {
-            // piece q = rows [8q, 8q+8), 128 B per row: lane -> (r = lane/8, cp = lane%8); holds global chunk cp ^ (r & 7)
-            const int r = q * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (r & 7);
-            src = g + (int64_t)(row0 + r) * ld + k0 + c * 8;
-        } else {
-            // piece q = k-rows [4q, 4q+4), 256 B per k-row: lane -> (kr = lane/16, cp = lane%16); holds chunk cp ^ f(kr)
-            const int kr = q * 4 + (lane >> 4);
-            const int f = ((kr & 3) << 1) | (kr & 8);
-            const int c = (lane & 15) ^ f;
-            src = g + (int64_t)(k0 + kr) * ld + row0 + c * 8;
-        }
-        __builtin_amdgcn_global_load_lds(src, LDS_PTR(void, lds + q * 1024), 16, 0, 0);
-    }
-}
-
-// ---- fragment: 8 consecutive k (k = ks*32 + g*8 + 0..7) for tile row (rbase + lane&15)
-template <bool KMAJOR>
-__device__ __forceinline__ bf16x8_t load_frag(const char* lds, int rbase, int ks, int lane) {
-    const int i = lane & 15, g = lane >> 4;
-    if (KMAJOR) {
-        const int row = rbase + i;
-        const int chunk = (ks * 4 + g) ^ (row & 7);
-        return *reinterpret_cast<const bf16x8_t*>(lds + row * 128 + chunk * 16);
-    } else {
-        // tr16_b64: lane t of a 16-lane group passes the address of (k-row kb + t/4, 4 rows-elements at rbase + (t%4)*4)
-        // and receives k-rows kb..kb+3 of tile row rbase + t.
-        const int kb = ks * 32 + g * 8;
-        const int q = (rbase >> 2) + (i & 3);  // 8-byte granule index inside the k-row
-        bf16x8_t out;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int kr = kb + h * 4 + (i >> 2);
-            const int f = ((kr & 3) << 1) | (kr & 8);
-            const int off = kr * 256 + ((((q >> 1) ^ f)) << 4) + (q & 1) * 8;
-            bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4_t, const_cast<char*>(lds) + off));
-            out[h * 4 + 0] = v[0]; out[h * 4 + 1] = v[1]; out[h * 4 + 2] = v[2]; out[h * 4 + 3] = v[3];
-        }
-        return out;
-    }
-}
 
 template <bool A_KMAJOR, bool B_KMAJOR, typename TC, typename TBIAS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_tile_kernel(GemmTileArgs p) {
@@ -120,8 +51,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tile_kernel(GemmTileArgs p) 
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nt = p.K / TBK;
-    stage_tile<A_KMAJOR>(A, p.lda, m0, 0, smem, wave, lane);
-    stage_tile<B_KMAJOR>(B, p.ldb, n0, 0, smem + TILE_BYTES, wave, lane);
+    stage_tile<A_KMAJOR, 4>(A, p.lda, m0, 0, smem, wave, lane);
+    stage_tile<B_KMAJOR, 4>(B, p.ldb, n0, 0, smem + TILE_BYTES, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
@@ -130,8 +61,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tile_kernel(GemmTileArgs p) 
         char* sb = sa + TILE_BYTES;
         if (t + 1 < nt) {
             char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile<A_KMAJOR>(A, p.lda, m0, (t + 1) * TBK, na, wave, lane);
-            stage_tile<B_KMAJOR>(B, p.ldb, n0, (t + 1) * TBK, na + TILE_BYTES, wave, lane);
+            stage_tile<A_KMAJOR, 4>(A, p.lda, m0, (t + 1) * TBK, na, wave, lane);
+            stage_tile<B_KMAJOR, 4>(B, p.ldb, n0, (t + 1) * TBK, na + TILE_BYTES, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
@@ -251,6 +182,12 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
         t.M = M; t.N = N; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = c_rs;
         t.batch1 = batch1; t.a_bs0 = a_bs0; t.a_bs1 = a_bs1; t.b_bs0 = b_bs0; t.b_bs1 = b_bs1; t.c_bs0 = c_bs0; t.c_bs1 = c_bs1;
         t.alpha = alpha; t.beta = beta; t.tiles_m = M / TBM; t.tiles_n = N / TBN;
+        // measured on MI355X at the DB1-1.3B shapes (tools/bench_kernels.py gemm): the 3-stage 256x128 kernel wins for the
+        // transposed-operand forms (NN +3..17 %, TN +4..8 %), the 2-stage 128x128 kernel for NT.  DB1_GEMM_TILE=128|256 pins one.
+        static int tile_pref = -1;
+        if (tile_pref < 0) { const char* e = getenv("DB1_GEMM_TILE"); tile_pref = e ? atoi(e) : 0; }
+        const bool want256 = tile_pref == 256 || (tile_pref != 128 && fb == 1);
+        if (want256 && (M % 256) == 0) return db1_gemm_tile256_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
         dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch);
         static bool attr_set = false;
         if (!attr_set) {

@@ -1,0 +1,118 @@
+// Shared pieces of the bf16 MFMA tile GEMMs (gemm.hip: 128x128 tile / 4 waves; gemm256.hip: 256x128 tile / 8 waves).
+#pragma once
+#include "db1_common.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+#define TBM 128
+#define TBN 128
+#define TBK 64
+#define TILE_BYTES (128 * 64 * 2)  // 16 KiB: one 128-row operand (sub-)tile per stage
+
+struct GemmTileArgs {
+    const bf16_t* A; const bf16_t* B; void* C; const void* bias;
+    int M, N, K;
+    int64_t lda, ldb, ldc;  // leading dimensions in elements
+    int batch1;
+    int64_t a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
+    float alpha, beta;
+    int tiles_m, tiles_n;
+};
+
+// ---- staging of one 16 KiB operand (sub-)tile = 16 wave-instructions of 1 KiB, PIECES per wave (wave w takes w*PIECES ..)
+//   K-major : memory [row][k]   -> LDS image [128 rows][128 B];  piece q = rows [8q, 8q+8):   lane -> (r = lane/8,  cp = lane%8),  holds chunk cp ^ (r & 7)
+//   M-major : memory [k][row]   -> LDS image [64 k][256 B];      piece q = k-rows [4q, 4q+4): lane -> (kr = lane/16, cp = lane%16), holds chunk cp ^ f(kr)
+template <bool KMAJOR, int PIECES>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, int row0, int k0, char* lds, int wave, int lane) {
+#pragma unroll
+    for (int it = 0; it < PIECES; it++) {
+        const int q = wave * PIECES + it;
+        const bf16_t* src;
+        if (KMAJOR) {
+            const int r = q * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            src = g + (int64_t)(row0 + r) * ld + k0 + c * 8;
+        } else {
+            const int kr = q * 4 + (lane >> 4);
+            const int f = ((kr & 3) << 1) | (kr & 8);
+            const int c = (lane & 15) ^ f;
+            src = g + (int64_t)(k0 + kr) * ld + row0 + c * 8;
+        }
+        __builtin_amdgcn_global_load_lds(src, LDS_PTR(void, lds + q * 1024), 16, 0, 0);
+    }
+}
+
+// ---- fragment: 8 consecutive k (k = ks*32 + g*8 + 0..7) for tile row (rbase + lane&15); 16x16x32 A/B operand image
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8_t load_frag(const char* lds, int rbase, int ks, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    if (KMAJOR) {
+        const int row = rbase + i;
+        const int chunk = (ks * 4 + g) ^ (row & 7);
+        return *reinterpret_cast<const bf16x8_t*>(lds + row * 128 + chunk * 16);
+    } else {
+        // tr16_b64: lane t of a 16-lane group passes the address of (k-row kb + t/4, 4 row-elements at rbase + (t%4)*4)
+        // and receives k-rows kb..kb+3 of tile row rbase + t  (lane map verified in profiles/r01_probe_gfx950_layouts.txt)
+        const int kb = ks * 32 + g * 8;
+        const int q = (rbase >> 2) + (i & 3);  // 8-byte granule index inside the k-row
+        bf16x8_t out;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int kr = kb + h * 4 + (i >> 2);
+            const int f = ((kr & 3) << 1) | (kr & 8);
+            const int off = kr * 256 + ((((q >> 1) ^ f)) << 4) + (q & 1) * 8;
+            bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4_t, const_cast<char*>(lds) + off));
+            out[h * 4 + 0] = v[0]; out[h * 4 + 1] = v[1]; out[h * 4 + 2] = v[2]; out[h * 4 + 3] = v[3];
+        }
+        return out;
+    }
+}
+
+// ---- epilogue for the swapped-operand accumulators: lane holds m = lane & 15, n = (lane >> 4) * 4 + r of each 16x16 fragment
+template <typename TC, typename TBIAS>
+__device__ __forceinline__ void store_frag(const f32x4& acc, TC* C, int64_t ldc, int m, int n, float alpha, float beta, const void* bias) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = alpha * acc[r];
+    if (bias) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] += ldf((const TBIAS*)bias + n + r);
+    }
+    TC* c = C + (int64_t)m * ldc + n;
+    if (sizeof(TC) == 4) {
+        if (beta != 0.f) {
+            float4 o = *reinterpret_cast<const float4*>(c);
+            v[0] += beta * o.x; v[1] += beta * o.y; v[2] += beta * o.z; v[3] += beta * o.w;
+        }
+        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        if (beta != 0.f) {
+            uint2 o = *reinterpret_cast<const uint2*>(c);
+            v[0] += beta * __uint_as_float(o.x << 16); v[1] += beta * __uint_as_float(o.x & 0xffff0000u);
+            v[2] += beta * __uint_as_float(o.y << 16); v[3] += beta * __uint_as_float(o.y & 0xffff0000u);
+        }
+        uint2 o;
+        o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(c) = o;
+    }
+}
+
+// XCD-aware tile walk: hardware block ids round-robin over the 8 XCDs (private L2s); give each XCD a contiguous span of
+// tiles, walked column-major inside bands of `band` tile-rows so neighbouring workgroups share A and B panels in L2.
+__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int band, int& tm, int& tn) {
+    const int nblk = tiles_m * tiles_n;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tiles_per_band = band * tiles_n;
+    const int b0 = bid / tiles_per_band, rem = bid % tiles_per_band;
+    const int band_rows = (tiles_m - b0 * band) < band ? (tiles_m - b0 * band) : band;
+    tm = b0 * band + rem % band_rows;
+    tn = rem / band_rows;
+}
+
+int db1_gemm_tile256_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);

@@ -20,6 +20,7 @@
 // dq_r = dT.R and dR = dT^T.Qv are plain batched GEMMs on dT (exact causal FLOPs, no band overhead) run by the caller.
 // Inputs qu = q+u and qv = q+v_bias are materialised once per layer by db1_relattn_add_head_bias.
 #include "db1_common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
@@ -74,11 +75,18 @@ __device__ __forceinline__ void stage_ring32(const bf16_t* Rg, int64_t rs, int d
     }
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+    f32x2_t v = {lo, hi};
+    bf16x2_hw r = __builtin_convertvector(v, bf16x2_hw);
+    return *reinterpret_cast<unsigned*>(&r);
+}
 __device__ __forceinline__ bf16x8_t pack8(const float* p) {
-    bf16x8_t o;
+    union { unsigned u[4]; bf16x8_t v; } o;
 #pragma unroll
-    for (int t = 0; t < 8; t++) o[t] = (short)f2bf(p[t]);
-    return o;
+    for (int t = 0; t < 4; t++) o.u[t] = pk_bf16(p[2 * t], p[2 * t + 1]);
+    return o.v;
 }
 
 // transposed A-fragment from a row-major [row][128] tile: d-block db (32 columns), 16 tile rows starting at row0.
@@ -112,8 +120,8 @@ __device__ __forceinline__ void store_acc_t(const f32x16* acc, float mul, bf16_t
 #pragma unroll
         for (int rq = 0; rq < 4; rq++) {
             uint2 o;
-            o.x = (unsigned)f2bf(acc[db][rq * 4 + 0] * mul) | ((unsigned)f2bf(acc[db][rq * 4 + 1] * mul) << 16);
-            o.y = (unsigned)f2bf(acc[db][rq * 4 + 2] * mul) | ((unsigned)f2bf(acc[db][rq * 4 + 3] * mul) << 16);
+            o.x = pk_bf16(acc[db][rq * 4 + 0] * mul, acc[db][rq * 4 + 1] * mul);
+            o.y = pk_bf16(acc[db][rq * 4 + 2] * mul, acc[db][rq * 4 + 3] * mul);
             *reinterpret_cast<uint2*>(Ow + a * 136 + 32 * db + 8 * rq + 4 * hb) = o;
         }
 #pragma unroll
@@ -123,28 +131,65 @@ __device__ __forceinline__ void store_acc_t(const f32x16* acc, float mul, bf16_t
         *reinterpret_cast<uint4*>(dst + (int64_t)row * rs + ch * 8) = v;
     }
 }
-// T = Arows . Rband^T for the 64 distances starting at dist_lo, written to the wave scratch Tw[32][64]
-__device__ __forceinline__ void rel_band_to_lds(const bf16x8_t* fa_regs, const char* a_tile, bool a_from_regs, const char* ring, int dist_lo,
+// lane-constant LDS byte offsets (computed once per kernel: the loops then issue LDS reads with almost no address VALU)
+struct LaneOffs {
+    int row[8];    // row_frag of tile row (lane & 31):   a*256 + (((ks*2 + hb) ^ swz(a)) << 4)
+    int ring[8];   // chunk part of a ring row_frag:      ((ks*2 + hb) ^ swz((a + 1) & 15)) << 4   (slot & 15 never changes)
+    int tr[4][2];  // tr_frag(tile, row0 = 0, db) halves: add 4096 for row0 = 16
+};
+__device__ __forceinline__ void make_offs(LaneOffs& o, int lane) {
+    const int a = lane & 31, hb = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+        o.row[ks] = a * 256 + (((ks * 2 + hb) ^ swz(a)) << 4);
+        o.ring[ks] = ((ks * 2 + hb) ^ swz((a + 1) & 15)) << 4;
+    }
+    const int g4 = lane >> 4, t = lane & 15, hb4 = g4 >> 1;
+#pragma unroll
+    for (int db = 0; db < 4; db++)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+            const int gran = ((32 * db + 16 * (g4 & 1)) >> 2) + (t & 3);
+            const int row = 4 * hb4 + 8 * h2 + (t >> 2);
+            o.tr[db][h2] = row * 256 + (((gran >> 1) ^ swz(row)) << 4) + (gran & 1) * 8;
+        }
+}
+__device__ __forceinline__ bf16x8_t rowf(const char* tile, const LaneOffs& o, int ks) { return *reinterpret_cast<const bf16x8_t*>(tile + o.row[ks]); }
+__device__ __forceinline__ bf16x8_t trf(const char* tile, const LaneOffs& o, int row0, int db) {
+    bf16x8_t out;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+        bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4_t, const_cast<char*>(tile) + o.tr[db][h2] + row0 * 256));
+        out[h2 * 4 + 0] = v[0]; out[h2 * 4 + 1] = v[1]; out[h2 * 4 + 2] = v[2]; out[h2 * 4 + 3] = v[3];
+    }
+    return out;
+}
+// T = Arows . Rband^T for the 64 distances starting at dist_lo (dist_lo + a == 1 mod 16 by construction), into Tw[32][64]
+template <bool A_REGS>
+__device__ __forceinline__ void rel_band_to_lds(const bf16x8_t* fa_regs, const char* a_tile, const LaneOffs& o, const char* ring, int dist_lo,
                                                 float* Tw, int lane) {
     const int a = lane & 31, hb = lane >> 5;
+    const int rr0 = ((dist_lo + a) & (FA_RING - 1)) << 8;
+    float* tw = Tw + hb * 256 + a;
 #pragma unroll
     for (int blk = 0; blk < 2; blk++) {
         f32x16 acc_t;
         zero16(acc_t);
-        const int slot = (dist_lo + 32 * blk + a) & (FA_RING - 1);
+        const char* rrow = ring + ((rr0 + blk * 8192) & (FA_RING * 256 - 1));
 #pragma unroll
         for (int ks = 0; ks < 8; ks++)
-            acc_t = MFMA32(a_from_regs ? fa_regs[ks] : row_frag(a_tile, a, ks, lane), row_frag(ring, slot, ks, lane), acc_t);
+            acc_t = MFMA32(A_REGS ? fa_regs[ks] : rowf(a_tile, o, ks), *reinterpret_cast<const bf16x8_t*>(rrow + o.ring[ks]), acc_t);
 #pragma unroll
-        for (int r = 0; r < 16; r++) Tw[crow(r, hb) * 64 + 32 * blk + a] = acc_t[r];
+        for (int r = 0; r < 16; r++) tw[((r & 3) + 8 * (r >> 2)) * 64 + 32 * blk] = acc_t[r];
     }
 }
+#define LOG2E 1.4426950408889634f
 
 // ======================================================================================= forward
-#define FWD_OFF_K 0
-#define FWD_OFF_V 8192
-#define FWD_OFF_R 16384
-#define FWD_OFF_T (16384 + FA_RING * 256)
+#define FWD_OFF_K 0          // two stages of 8 KiB
+#define FWD_OFF_V 16384      // two stages of 8 KiB
+#define FWD_OFF_R 32768
+#define FWD_OFF_T (32768 + FA_RING * 256)
 #define FWD_LDS_BYTES (FWD_OFF_T + 4 * FA_TW_BYTES)
 
 __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) {
@@ -155,15 +200,18 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
     const int H = p.H, L = p.L, HD = H * FA_D;
     const int i0 = qt * FA_BQ, iw = i0 + 32 * wave;
     const int a = lane & 31, hb = lane >> 5;
-    char* Ks = smem + FWD_OFF_K;
-    char* Vs = smem + FWD_OFF_V;
+    char* Ks0 = smem + FWD_OFF_K;
+    char* Vs0 = smem + FWD_OFF_V;
     char* Rr = smem + FWD_OFF_R;
     float* Tw = reinterpret_cast<float*>(smem + FWD_OFF_T + wave * FA_TW_BYTES);
+    const float* twr = Tw + a * 65 + 31 - 4 * hb;  // skewed read base: element (a, a - crow(r,hb) + 31)
     const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
     const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
     const bf16_t* kg = p.k + (int64_t)b * p.kv_bs + h * FA_D;
     const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * FA_D;
     const bf16_t* Rg = p.R + h * FA_D;
+    LaneOffs offs;
+    make_offs(offs, lane);
 
     bf16x8_t fqu[8], fqv[8];  // row iw + a, k = ks*16 + hb*8 (A and B operand images coincide)
 #pragma unroll
@@ -174,60 +222,80 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
     int jlo = i0 - p.shift + 1;
     if (jlo < 0) jlo = 0;
     const int jb_lo = jlo / FA_BK, jb_hi = (i0 + FA_BQ - 1) / FA_BK;
-    for (int c4 = 0; c4 < 4; c4++) stage_ring32(Rg, HD, i0 - jb_lo * FA_BK + 32 * c4, L, Rr, wave, lane);  // distances [i0-j0lo, +128)
+    // prologue: ring rows for distances [i0-j0lo-32, i0-j0lo+128) and the first K/V tiles
+    for (int c4 = -1; c4 < 4; c4++) stage_ring32(Rg, HD, i0 - jb_lo * FA_BK + 32 * c4, L, Rr, wave, lane);
+    stage_tile32(kg, p.kv_rs, jb_lo * FA_BK, Ks0, wave, lane);
+    stage_tile32(vg, p.kv_rs, jb_lo * FA_BK, Vs0, wave, lane);
     f32x16 acc_o[4];
 #pragma unroll
     for (int db = 0; db < 4; db++) zero16(acc_o[db]);
-    float m_i = -1.0e30f, l_i = 0.f;
+    const float c2 = p.scale * LOG2E;
+    float m_i = -1.0e30f, l_i = 0.f;  // m_i in RAW score units (before the 1/sqrt(d) scale)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
-    for (int jb = jb_lo; jb <= jb_hi; jb++) {
+    auto block = [&](auto CUR, int jb) {
+        constexpr int cur = decltype(CUR)::value;
         const int j0 = jb * FA_BK;
-        __syncthreads();  // every wave is done with the previous K/V tiles and with the ring rows about to be replaced
-        stage_tile32(kg, p.kv_rs, j0, Ks, wave, lane);
-        stage_tile32(vg, p.kv_rs, j0, Vs, wave, lane);
-        stage_ring32(Rg, HD, i0 - j0 - 32, L, Rr, wave, lane);
+        const char* Ks = Ks0 + cur * 8192;
+        const char* Vs = Vs0 + cur * 8192;
+        if (jb < jb_hi) {  // prefetch the next block's tiles and ring rows; they land while this block is computed
+            stage_tile32(kg, p.kv_rs, j0 + FA_BK, Ks0 + (cur ^ 1) * 8192, wave, lane);
+            stage_tile32(vg, p.kv_rs, j0 + FA_BK, Vs0 + (cur ^ 1) * 8192, wave, lane);
+            stage_ring32(Rg, HD, i0 - j0 - 64, L, Rr, wave, lane);
+        }
+        if (!(j0 > iw + 31 || j0 + 31 <= iw - p.shift)) {  // wave-uniform: skip blocks entirely outside this wave's window
+            f32x16 acc_s;
+            zero16(acc_s);
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(rowf(Ks, offs, ks), fqu[ks], acc_s);  // S^T[key][query]
+            rel_band_to_lds<true>(fqv, nullptr, offs, Rr, iw - j0 - 31, Tw, lane);
+            float s[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) s[r] = acc_s[r] + twr[-((r & 3) + 8 * (r >> 2))];  // this lane: query iw+a; register r: key j0+crow(r,hb)
+            if (j0 + 31 > iw || j0 <= iw + 31 - p.shift) {  // only diagonal / window-edge blocks need the element mask
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int i = iw + a, j = j0 + crow(r, hb);
+                    s[r] = ((j <= i) && (j > i - p.shift)) ? s[r] : -1.0e30f;
+                }
+            }
+            float mblk = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) mblk = fmaxf(mblk, s[r]);
+            mblk = fmaxf(mblk, __shfl_xor(mblk, 32, 64));
+            const float m_new = fmaxf(m_i, mblk);
+            if (!__all(m_new == m_i)) {  // the running maxima rarely move after the first blocks: skip the O-wide rescale then
+                const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c2);
+                l_i *= alpha;
+#pragma unroll
+                for (int db = 0; db < 4; db++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc_o[db][r] *= alpha;
+                m_i = m_new;
+            }
+            const float mc = -m_i * c2;
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, mc)); rs += s[r]; }
+            rs += __shfl_xor(rs, 32, 64);
+            l_i += rs;
+            const bf16x8_t pb0 = pack8(s), pb1 = pack8(s + 8);
+#pragma unroll
+            for (int db = 0; db < 4; db++) {  // O^T[d][query] += V^T . P^T
+                acc_o[db] = MFMA32(trf(Vs, offs, 0, db), pb0, acc_o[db]);
+                acc_o[db] = MFMA32(trf(Vs, offs, 16, db), pb1, acc_o[db]);
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (j0 > iw + 31 || j0 + 31 <= iw - p.shift) continue;  // wave-uniform: block entirely outside this wave's window
-
-        f32x16 acc_s;
-        zero16(acc_s);
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(row_frag(Ks, a, ks, lane), fqu[ks], acc_s);  // S^T[key][query]
-        rel_band_to_lds(fqv, nullptr, true, Rr, iw - j0 - 31, Tw, lane);
-        float s[16];
-        float mblk = -1.0e30f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {  // this lane: query iw + a; register r: key j0 + crow(r, hb)
-            const int bk = crow(r, hb);
-            const float bd = Tw[a * 64 + a - bk + 31];
-            const int i = iw + a, j = j0 + bk;
-            const bool vis = (j <= i) && (j > i - p.shift);
-            s[r] = vis ? (acc_s[r] + bd) * p.scale : -1.0e30f;
-            mblk = fmaxf(mblk, s[r]);
-        }
-        mblk = fmaxf(mblk, __shfl_xor(mblk, 32, 64));
-        const float m_new = fmaxf(m_i, mblk);
-        const float alpha = __expf(m_i - m_new);
-        float rs = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) { s[r] = __expf(s[r] - m_new); rs += s[r]; }
-        rs += __shfl_xor(rs, 32, 64);
-        l_i = l_i * alpha + rs;
-        m_i = m_new;
-#pragma unroll
-        for (int db = 0; db < 4; db++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc_o[db][r] *= alpha;
-        const bf16x8_t pb0 = pack8(s), pb1 = pack8(s + 8);
-#pragma unroll
-        for (int db = 0; db < 4; db++) {  // O^T[d][query] += V^T . P^T
-            acc_o[db] = MFMA32(tr_frag(Vs, 0, db, lane), pb0, acc_o[db]);
-            acc_o[db] = MFMA32(tr_frag(Vs, 16, db, lane), pb1, acc_o[db]);
-        }
+        __syncthreads();  // next tiles have landed; every wave is done reading the current ones
+    };
+    for (int jb = jb_lo; jb <= jb_hi; jb += 2) {
+        block(std::integral_constant<int, 0>{}, jb);
+        if (jb + 1 <= jb_hi) block(std::integral_constant<int, 1>{}, jb + 1);
     }
     store_acc_t(acc_o, 1.f / l_i, reinterpret_cast<bf16_t*>(Tw), p.o + ((int64_t)b * L + iw) * HD + h * FA_D, HD, lane);
-    if (hb == 0) p.lse_out[((int64_t)b * H + h) * L + iw + a] = m_i + logf(l_i);
+    if (hb == 0) p.lse_out[((int64_t)b * H + h) * L + iw + a] = m_i * p.scale + logf(l_i);
 }
 
 // ======================================================================================= backward: delta = rowsum(dO * O)
@@ -258,10 +326,11 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
     const int H = p.H, L = p.L, HD = H * FA_D;
     const int i0 = qt * FA_BQ, iw = i0 + 32 * wave;
     const int a = lane & 31, hb = lane >> 5;
-    char* Ks = smem + FWD_OFF_K;
-    char* Vs = smem + FWD_OFF_V;
+    char* Ks0 = smem + FWD_OFF_K;
+    char* Vs0 = smem + FWD_OFF_V;
     char* Rr = smem + FWD_OFF_R;
     float* Tw = reinterpret_cast<float*>(smem + FWD_OFF_T + wave * FA_TW_BYTES);
+    float* twr = Tw + a * 65 + 31 - 4 * hb;
     const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
     const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
     const bf16_t* dog = p.dout + ((int64_t)b * L) * HD + h * FA_D;
@@ -269,6 +338,8 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
     const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * FA_D;
     const bf16_t* Rg = p.R + h * FA_D;
     bf16_t* dTg = p.dT + (((int64_t)h * p.B + b) * L) * L;
+    LaneOffs offs;
+    make_offs(offs, lane);
 
     bf16x8_t fqu[8], fqv[8], fdo[8];
 #pragma unroll
@@ -277,72 +348,88 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
         fqv[ks] = *reinterpret_cast<const bf16x8_t*>(qv + (int64_t)(iw + a) * HD + ks * 16 + hb * 8);
         fdo[ks] = *reinterpret_cast<const bf16x8_t*>(dog + (int64_t)(iw + a) * HD + ks * 16 + hb * 8);
     }
-    const float lse_a = p.lse[((int64_t)b * H + h) * L + iw + a];
+    const float c2 = p.scale * LOG2E;
+    const float nlse2 = -p.lse[((int64_t)b * H + h) * L + iw + a] * LOG2E;
     const float delta_a = p.delta[((int64_t)b * H + h) * L + iw + a];
     int jlo = i0 - p.shift + 1;
     if (jlo < 0) jlo = 0;
     const int jb_lo = jlo / FA_BK, jb_hi = (i0 + FA_BQ - 1) / FA_BK;
-    for (int c4 = 0; c4 < 4; c4++) stage_ring32(Rg, HD, i0 - jb_lo * FA_BK + 32 * c4, L, Rr, wave, lane);
+    for (int c4 = -1; c4 < 4; c4++) stage_ring32(Rg, HD, i0 - jb_lo * FA_BK + 32 * c4, L, Rr, wave, lane);
+    stage_tile32(kg, p.kv_rs, jb_lo * FA_BK, Ks0, wave, lane);
+    stage_tile32(vg, p.kv_rs, jb_lo * FA_BK, Vs0, wave, lane);
     f32x16 acc_dq[4];
 #pragma unroll
     for (int db = 0; db < 4; db++) zero16(acc_dq[db]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
-    for (int jb = jb_lo; jb <= jb_hi; jb++) {
+    auto block = [&](auto CUR, int jb) {
+        constexpr int cur = decltype(CUR)::value;
         const int j0 = jb * FA_BK;
-        __syncthreads();
-        stage_tile32(kg, p.kv_rs, j0, Ks, wave, lane);
-        stage_tile32(vg, p.kv_rs, j0, Vs, wave, lane);
-        stage_ring32(Rg, HD, i0 - j0 - 32, L, Rr, wave, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (j0 > iw + 31 || j0 + 31 <= iw - p.shift) continue;
-
-        f32x16 acc_s, acc_dp;
-        zero16(acc_s);
-        zero16(acc_dp);
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(row_frag(Ks, a, ks, lane), fqu[ks], acc_s);    // S^T[key][query]
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc_dp = MFMA32(row_frag(Vs, a, ks, lane), fdo[ks], acc_dp);  // dP^T[key][query]
-        rel_band_to_lds(fqv, nullptr, true, Rr, iw - j0 - 31, Tw, lane);
-        float ds[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int bk = crow(r, hb);
-            const float bd = Tw[a * 64 + a - bk + 31];
-            const int i = iw + a, j = j0 + bk;
-            const bool vis = (j <= i) && (j > i - p.shift);
-            const float pr = vis ? __expf((acc_s[r] + bd) * p.scale - lse_a) : 0.f;
-            ds[r] = pr * (acc_dp[r] - delta_a) * p.scale;
+        const char* Ks = Ks0 + cur * 8192;
+        const char* Vs = Vs0 + cur * 8192;
+        if (jb < jb_hi) {
+            stage_tile32(kg, p.kv_rs, j0 + FA_BK, Ks0 + (cur ^ 1) * 8192, wave, lane);
+            stage_tile32(vg, p.kv_rs, j0 + FA_BK, Vs0 + (cur ^ 1) * 8192, wave, lane);
+            stage_ring32(Rg, HD, i0 - j0 - 64, L, Rr, wave, lane);
         }
-        // dS re-indexed by distance: write into the scratch at (a, a - b + 31), then rows go out as 32 contiguous bf16
+        if (!(j0 > iw + 31 || j0 + 31 <= iw - p.shift)) {
+            f32x16 acc_s, acc_dp;
+            zero16(acc_s);
+            zero16(acc_dp);
 #pragma unroll
-        for (int r = 0; r < 16; r++) Tw[a * 64 + a - crow(r, hb) + 31] = ds[r];
-        const bf16x8_t db0 = pack8(ds), db1 = pack8(ds + 8);
+            for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(rowf(Ks, offs, ks), fqu[ks], acc_s);    // S^T[key][query]
 #pragma unroll
-        for (int db = 0; db < 4; db++) {  // dq^T[d][query] += K^T . dS^T
-            acc_dq[db] = MFMA32(tr_frag(Ks, 0, db, lane), db0, acc_dq[db]);
-            acc_dq[db] = MFMA32(tr_frag(Ks, 16, db, lane), db1, acc_dq[db]);
-        }
-        {
-            const int t = lane & 31;
+            for (int ks = 0; ks < 8; ks++) acc_dp = MFMA32(rowf(Vs, offs, ks), fdo[ks], acc_dp);  // dP^T[key][query]
+            rel_band_to_lds<true>(fqv, nullptr, offs, Rr, iw - j0 - 31, Tw, lane);
+            float ds[16];
 #pragma unroll
-            for (int it = 0; it < 16; it++) {
-                const int row = it * 2 + (lane >> 5);
-                const int dist = iw + row - j0 - 31 + t;  // = i - j with j = j0 + 31 - t
-                if (dist >= 0) dTg[(int64_t)(iw + row) * L + dist] = f2bf(Tw[row * 64 + row + t]);
+            for (int r = 0; r < 16; r++) ds[r] = __builtin_amdgcn_exp2f(fmaf(acc_s[r] + twr[-((r & 3) + 8 * (r >> 2))], c2, nlse2));
+            if (j0 + 31 > iw || j0 <= iw + 31 - p.shift) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int i = iw + a, j = j0 + crow(r, hb);
+                    ds[r] = ((j <= i) && (j > i - p.shift)) ? ds[r] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) ds[r] = ds[r] * (acc_dp[r] - delta_a) * p.scale;
+            // dS re-indexed by distance: write into the scratch at (a, a - b + 31), then rows go out as 32 contiguous bf16
+#pragma unroll
+            for (int r = 0; r < 16; r++) twr[-((r & 3) + 8 * (r >> 2))] = ds[r];
+            const bf16x8_t db0 = pack8(ds), db1 = pack8(ds + 8);
+#pragma unroll
+            for (int db = 0; db < 4; db++) {  // dq^T[d][query] += K^T . dS^T
+                acc_dq[db] = MFMA32(trf(Ks, offs, 0, db), db0, acc_dq[db]);
+                acc_dq[db] = MFMA32(trf(Ks, offs, 16, db), db1, acc_dq[db]);
+            }
+            {
+                const int t = lane & 31;
+                bf16_t* drow = dTg + (int64_t)(iw + hb) * L + (iw + hb - j0 - 31 + t);  // row = 2*it + hb, dist = i - j with j = j0 + 31 - t
+                const float* trow = Tw + hb * 65 + t;
+#pragma unroll
+                for (int it = 0; it < 16; it++) {
+                    const int dist = iw + 2 * it + hb - j0 - 31 + t;
+                    if (dist >= 0) drow[(int64_t)(2 * it) * (L + 1)] = f2bf(trow[2 * it * 65]);
+                }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    for (int jb = jb_lo; jb <= jb_hi; jb += 2) {
+        block(std::integral_constant<int, 0>{}, jb);
+        if (jb + 1 <= jb_hi) block(std::integral_constant<int, 1>{}, jb + 1);
     }
     store_acc_t(acc_dq, 1.f, reinterpret_cast<bf16_t*>(Tw), p.dq + (int64_t)b * p.dq_bs + (int64_t)iw * p.dq_rs + h * FA_D, p.dq_rs, lane);
 }
 
 // ======================================================================================= backward w.r.t. keys / values
-#define KV_OFF_QU 0
-#define KV_OFF_QV 8192
-#define KV_OFF_DO 16384
-#define KV_OFF_ST 24576                      // lse[32], delta[32] floats
-#define KV_OFF_R 24832
+#define KV_OFF_QU 0                          // two stages of 8 KiB each for Qu, Qv, dO
+#define KV_OFF_QV 16384
+#define KV_OFF_DO 32768
+#define KV_OFF_ST 49152                      // two stages of {lse[32], delta[32]} floats
+#define KV_OFF_R 49664
 #define KV_OFF_T (KV_OFF_R + FA_RING * 256)
 #define KV_LDS_BYTES (KV_OFF_T + 4 * FA_TW_BYTES)
 
@@ -354,12 +441,13 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_kv_kernel(FlashArgs 
     const int H = p.H, L = p.L, HD = H * FA_D;
     const int j0 = kt * FA_BQ, kw = j0 + 32 * wave;
     const int a = lane & 31, hb = lane >> 5;   // a = key column of this lane
-    char* Qus = smem + KV_OFF_QU;
-    char* Qvs = smem + KV_OFF_QV;
-    char* dOs = smem + KV_OFF_DO;
-    float* stat = reinterpret_cast<float*>(smem + KV_OFF_ST);
+    char* Qus0 = smem + KV_OFF_QU;
+    char* Qvs0 = smem + KV_OFF_QV;
+    char* dOs0 = smem + KV_OFF_DO;
+    float* stat0 = reinterpret_cast<float*>(smem + KV_OFF_ST);
     char* Rr = smem + KV_OFF_R;
     float* Tw = reinterpret_cast<float*>(smem + KV_OFF_T + wave * FA_TW_BYTES);
+    const float* twr = Tw + 4 * hb * 65 + 31 - a;  // element (aq, aq - a + 31) with aq = crow(r, hb)
     const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
     const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
     const bf16_t* dog = p.dout + ((int64_t)b * L) * HD + h * FA_D;
@@ -368,6 +456,8 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_kv_kernel(FlashArgs 
     const bf16_t* Rg = p.R + h * FA_D;
     const float* lseg = p.lse + ((int64_t)b * H + h) * L;
     const float* delg = p.delta + ((int64_t)b * H + h) * L;
+    LaneOffs offs;
+    make_offs(offs, lane);
 
     bf16x8_t fk[8], fv[8];  // B-operand images: column = key kw + a
 #pragma unroll
@@ -375,60 +465,86 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_kv_kernel(FlashArgs 
         fk[ks] = *reinterpret_cast<const bf16x8_t*>(kg + (int64_t)(kw + a) * p.kv_rs + ks * 16 + hb * 8);
         fv[ks] = *reinterpret_cast<const bf16x8_t*>(vg + (int64_t)(kw + a) * p.kv_rs + ks * 16 + hb * 8);
     }
+    const float c2 = p.scale * LOG2E;
     const int ib_lo = j0 / FA_BK;
     int ihi = j0 + FA_BQ - 1 + p.shift - 1;  // last query that can see the last key of the tile
     if (ihi > L - 1) ihi = L - 1;
     const int ib_hi = ihi / FA_BK;
-    // ring: distances [i0q - j0 - 128, i0q - j0) before the first block; every block adds [i0q - j0, i0q - j0 + 32)
-    for (int c4 = 0; c4 < 4; c4++) stage_ring32(Rg, HD, ib_lo * FA_BK - j0 - 128 + 32 * c4, L, Rr, wave, lane);
+    // ring: distances [i0q - j0 - 128, i0q - j0 + 32) for the first block; every block prefetches the next 32
+    for (int c4 = 0; c4 < 5; c4++) stage_ring32(Rg, HD, ib_lo * FA_BK - j0 - 128 + 32 * c4, L, Rr, wave, lane);
+    stage_tile32(qu, HD, ib_lo * FA_BK, Qus0, wave, lane);
+    stage_tile32(qv, HD, ib_lo * FA_BK, Qvs0, wave, lane);
+    stage_tile32(dog, HD, ib_lo * FA_BK, dOs0, wave, lane);
+    if (tid < 32) stat0[tid] = -lseg[ib_lo * FA_BK + tid] * LOG2E;
+    else if (tid < 64) stat0[tid] = delg[ib_lo * FA_BK + tid - 32];
     f32x16 acc_dk[4], acc_dv[4];
 #pragma unroll
     for (int db = 0; db < 4; db++) { zero16(acc_dk[db]); zero16(acc_dv[db]); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
-    for (int ib = ib_lo; ib <= ib_hi; ib++) {
+    auto block = [&](auto CUR, int ib) {
+        constexpr int cur = decltype(CUR)::value;
         const int i0q = ib * FA_BK;
-        __syncthreads();
-        stage_tile32(qu, HD, i0q, Qus, wave, lane);
-        stage_tile32(qv, HD, i0q, Qvs, wave, lane);
-        stage_tile32(dog, HD, i0q, dOs, wave, lane);
-        stage_ring32(Rg, HD, i0q - j0, L, Rr, wave, lane);
-        if (tid < 32) stat[tid] = lseg[i0q + tid];
-        else if (tid < 64) stat[tid] = delg[i0q + tid - 32];
+        const char* Qus = Qus0 + cur * 8192;
+        const char* Qvs = Qvs0 + cur * 8192;
+        const char* dOs = dOs0 + cur * 8192;
+        const float* stat = stat0 + cur * 64 + 4 * hb;
+        if (ib < ib_hi) {  // prefetch the next query block
+            const int nx = i0q + FA_BK;
+            stage_tile32(qu, HD, nx, Qus0 + (cur ^ 1) * 8192, wave, lane);
+            stage_tile32(qv, HD, nx, Qvs0 + (cur ^ 1) * 8192, wave, lane);
+            stage_tile32(dog, HD, nx, dOs0 + (cur ^ 1) * 8192, wave, lane);
+            stage_ring32(Rg, HD, nx - j0, L, Rr, wave, lane);
+            float* sn = stat0 + (cur ^ 1) * 64;
+            if (tid < 32) sn[tid] = -lseg[nx + tid] * LOG2E;
+            else if (tid < 64) sn[tid] = delg[nx + tid - 32];
+        }
+        if (!(i0q + 31 < kw || i0q >= kw + 31 + p.shift)) {  // some (i, j) of this block pair is visible
+            f32x16 acc_s, acc_dp;
+            zero16(acc_s);
+            zero16(acc_dp);
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(rowf(Qus, offs, ks), fk[ks], acc_s);    // S[query][key]
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) acc_dp = MFMA32(rowf(dOs, offs, ks), fv[ks], acc_dp);  // dP[query][key]
+            rel_band_to_lds<false>(nullptr, Qvs, offs, Rr, i0q - kw - 31, Tw, lane);
+            float pr[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {  // this lane: key kw + a; register r: query i0q + crow(r, hb)
+                const int q8 = (r & 3) + 8 * (r >> 2);
+                pr[r] = __builtin_amdgcn_exp2f(fmaf(acc_s[r] + twr[q8 * 65], c2, stat[q8]));
+            }
+            if (i0q < kw + 31 || i0q + 31 >= kw + p.shift) {  // diagonal / window-edge block pairs need the element mask
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int i = i0q + crow(r, hb), j = kw + a;
+                    pr[r] = ((j <= i) && (j > i - p.shift)) ? pr[r] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) ds[r] = pr[r] * (acc_dp[r] - stat[32 + (r & 3) + 8 * (r >> 2)]) * p.scale;
+            const bf16x8_t pb0 = pack8(pr), pb1 = pack8(pr + 8), sb0 = pack8(ds), sb1 = pack8(ds + 8);
+#pragma unroll
+            for (int db = 0; db < 4; db++) {
+                acc_dv[db] = MFMA32(trf(dOs, offs, 0, db), pb0, acc_dv[db]);   // dV^T[d][key] += dO^T . P
+                acc_dv[db] = MFMA32(trf(dOs, offs, 16, db), pb1, acc_dv[db]);
+                acc_dk[db] = MFMA32(trf(Qus, offs, 0, db), sb0, acc_dk[db]);   // dK^T[d][key] += Qu^T . dS
+                acc_dk[db] = MFMA32(trf(Qus, offs, 16, db), sb1, acc_dk[db]);
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (i0q + 31 < kw || i0q >= kw + 31 + p.shift) continue;  // no (i, j) of this block pair is visible
-
-        f32x16 acc_s, acc_dp;
-        zero16(acc_s);
-        zero16(acc_dp);
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(row_frag(Qus, a, ks, lane), fk[ks], acc_s);    // S[query][key]
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc_dp = MFMA32(row_frag(dOs, a, ks, lane), fv[ks], acc_dp);  // dP[query][key]
-        rel_band_to_lds(nullptr, Qvs, false, Rr, i0q - kw - 31, Tw, lane);
-        float pr[16], ds[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {  // this lane: key kw + a; register r: query i0q + crow(r, hb)
-            const int aq = crow(r, hb);
-            const float bd = Tw[aq * 64 + aq - a + 31];
-            const int i = i0q + aq, j = kw + a;
-            const bool vis = (j <= i) && (j > i - p.shift);
-            pr[r] = vis ? __expf((acc_s[r] + bd) * p.scale - stat[aq]) : 0.f;
-            ds[r] = pr[r] * (acc_dp[r] - stat[32 + aq]) * p.scale;
-        }
-        const bf16x8_t pb0 = pack8(pr), pb1 = pack8(pr + 8), sb0 = pack8(ds), sb1 = pack8(ds + 8);
-#pragma unroll
-        for (int db = 0; db < 4; db++) {
-            acc_dv[db] = MFMA32(tr_frag(dOs, 0, db, lane), pb0, acc_dv[db]);   // dV^T[d][key] += dO^T . P
-            acc_dv[db] = MFMA32(tr_frag(dOs, 16, db, lane), pb1, acc_dv[db]);
-            acc_dk[db] = MFMA32(tr_frag(Qus, 0, db, lane), sb0, acc_dk[db]);   // dK^T[d][key] += Qu^T . dS
-            acc_dk[db] = MFMA32(tr_frag(Qus, 16, db, lane), sb1, acc_dk[db]);
-        }
+    };
+    for (int ib = ib_lo; ib <= ib_hi; ib += 2) {
+        block(std::integral_constant<int, 0>{}, ib);
+        if (ib + 1 <= ib_hi) block(std::integral_constant<int, 1>{}, ib + 1);
     }
     bf16_t* Ow = reinterpret_cast<bf16_t*>(Tw);
     store_acc_t(acc_dk, 1.f, Ow, p.dk + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
     store_acc_t(acc_dv, 1.f, Ow, p.dv + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
 }
+
 
 // ======================================================================================= host side
 extern "C" int db1_relattn_flash_supported(int B, int L, int H, int D, int dt) {

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the hot kernels at DB1-1.3B sizes (HIP-event timing, random data).
+    python tools/bench_kernels.py flash [B]     relative-position flash attention fwd / bwd
+    python tools/bench_kernels.py gemm  [B]     the bf16 tile GEMM on the model's NT / NN / TN shapes
+Used under rocprofv3 (--kernel-trace --stats, or --pmc ...) to attribute time and counters per kernel."""
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from bdm_db1_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def flash(B=16, L=1024, H=16, D=128):
+    torch.manual_seed(0)
+    qkv = (torch.randn(B, L, 3, H, D, device=DEV) * 0.7).to(torch.bfloat16)
+    R = torch.randn(L, H, D, device=DEV).to(torch.bfloat16)
+    u = (torch.randn(H, D, device=DEV) * 0.3).to(torch.bfloat16)
+    vb = (torch.randn(H, D, device=DEV) * 0.3).to(torch.bfloat16)
+    qu, qv = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16), torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
+    ops.relattn_add_head_bias(qkv, u, vb, qu, qv, B, L, L, H, D)
+    out = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, L, device=DEV, dtype=torch.float32)
+    dout = torch.randn(B, L, H, D, device=DEV).to(torch.bfloat16)
+    dqkv = torch.empty(B, L, 3, H, D, device=DEV, dtype=torch.bfloat16)
+    dT = torch.zeros(H, B, L, L, device=DEV, dtype=torch.bfloat16)
+    delta = torch.empty(B, H, L, device=DEV, dtype=torch.float32)
+    scale = 1.0 / math.sqrt(D)
+    unit = 2.0 * B * H * (L * (L + 1) / 2) * D  # one causal-counted L x L x D contraction
+    t = timeit(lambda: ops.relattn_flash_fwd(qu, qv, qkv, R, out, lse, B, L, H, D, L, scale))
+    print(f"flash fwd  B={B}: {t * 1e3:8.1f} us   {3 * unit / t / 1e9:7.1f} TFLOP/s algorithmic (3 contractions)")
+    t = timeit(lambda: ops.relattn_flash_bwd(qu, qv, qkv, R, out, dout, lse, delta, dqkv, dT, B, L, H, D, L, scale))
+    print(f"flash bwd  B={B}: {t * 1e3:8.1f} us   {6 * unit / t / 1e9:7.1f} TFLOP/s algorithmic (6 contractions, excl. dq_r/dR GEMMs)")
+
+
+def gemm(B=16, L=1024):
+    T, d = B * L, 2048
+    torch.manual_seed(0)
+    shapes = [("qkv  NT", T, 3 * d, d), ("ff1  NT", T, 4 * d, d), ("ff2  NT", T, d, 2 * d), ("head NT", T, 33280, d)]
+    for name, M, N, K in shapes:
+        x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=DEV) * 0.02).to(torch.bfloat16)
+        y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        t = timeit(lambda: ops.gemm(x, w.t(), y))
+        print(f"{name} M={M} N={N} K={K}: {t * 1e3:8.1f} us  {2.0 * M * N * K / t / 1e9:7.1f} TFLOP/s")
+        dy = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+        dx = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
+        t = timeit(lambda: ops.gemm(dy, w, dx))
+        print(f"  dx NN M={M} N={K} K={N}: {t * 1e3:8.1f} us  {2.0 * M * N * K / t / 1e9:7.1f} TFLOP/s")
+        dw = torch.zeros(N, K, device=DEV, dtype=torch.float32)
+        t = timeit(lambda: ops.gemm(dy.t(), x, dw, beta=1.0))
+        print(f"  dW TN M={N} N={K} K={M}: {t * 1e3:8.1f} us  {2.0 * M * N * K / t / 1e9:7.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "flash"
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    {"flash": flash, "gemm": gemm}[which](B)
