@@ -177,8 +177,18 @@ def main():
     if timer is not None and timer.launches:
         ms = timer.total_ms()
         ach = timer.flops / (ms * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        try:  # HBM-side bytes per tile-GEMM launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")))
+            if cands and B == 16 and args.workload == "text":
+                traffic = json.load(open(cands[-1]))["tile_gemm_avg_bytes_per_launch"]
+                traffic_src = os.path.relpath(cands[-1], ROOT)
+        except Exception:
+            traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
+                           "traffic_source": traffic_src,
                            "kernel": "gemm_bf16_tile_kernel (all NT/NN/TN launches of the timed steps, rank 0)",
                            "launches": timer.launches, "avg_launch_us": round(ms * 1e3 / timer.launches, 2),
                            "flop_per_launch_avg": round(timer.flops / timer.launches),
