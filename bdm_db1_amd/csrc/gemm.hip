@@ -50,9 +50,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tile_kernel(GemmTileArgs p) 
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = p.K / TBK;
-    stage_tile<A_KMAJOR, 4>(A, p.lda, m0, 0, smem, wave, lane);
-    stage_tile<B_KMAJOR, 4>(B, p.ldb, n0, 0, smem + TILE_BYTES, wave, lane);
+    const int nt = p.K / TBK / p.ksplit;          // k-tiles of this split
+    const int kt0 = (int)blockIdx.z * nt;          // first k-tile
+    const int mv = p.M - m0 < TBM ? p.M - m0 : TBM, nv = p.N - n0 < TBN ? p.N - n0 : TBN;  // valid rows / columns of this tile
+    stage_tile<A_KMAJOR, 4>(A, p.lda, m0, kt0 * TBK, smem, wave, lane, mv);
+    stage_tile<B_KMAJOR, 4>(B, p.ldb, n0, kt0 * TBK, smem + TILE_BYTES, wave, lane, nv);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
@@ -61,8 +63,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tile_kernel(GemmTileArgs p) 
         char* sb = sa + TILE_BYTES;
         if (t + 1 < nt) {
             char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile<A_KMAJOR, 4>(A, p.lda, m0, (t + 1) * TBK, na, wave, lane);
-            stage_tile<B_KMAJOR, 4>(B, p.ldb, n0, (t + 1) * TBK, na + TILE_BYTES, wave, lane);
+            stage_tile<A_KMAJOR, 4>(A, p.lda, m0, (kt0 + t + 1) * TBK, na, wave, lane, mv);
+            stage_tile<B_KMAJOR, 4>(B, p.ldb, n0, (kt0 + t + 1) * TBK, na + TILE_BYTES, wave, lane, nv);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
@@ -89,15 +91,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tile_kernel(GemmTileArgs p) 
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (m >= p.M || n >= p.N) continue;  // tail tile
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = p.alpha * acc[i][j][r];
-            if (p.bias) {
+            if (p.bias && blockIdx.z == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] += ldf((const TBIAS*)p.bias + n + r);
             }
             TC* c = C + (int64_t)m * p.ldc + n;
-            if (sizeof(TC) == 4) {
+            if (sizeof(TC) == 4 && p.ksplit > 1) {  // split-K: C already holds beta*C (beta == 1); partial sums are added atomically
+#pragma unroll
+                for (int r = 0; r < 4; r++) atomicAdd(reinterpret_cast<float*>(c) + r, v[r]);
+            } else if (sizeof(TC) == 4) {
                 if (p.beta != 0.f) {
                     float4 o = *reinterpret_cast<const float4*>(c);
                     v[0] += p.beta * o.x; v[1] += p.beta * o.y; v[2] += p.beta * o.z; v[3] += p.beta * o.w;
@@ -128,11 +134,12 @@ static int operand_form(int64_t row_stride, int64_t k_stride, int64_t* ld) {
 static bool fast_ok(int M, int N, int K, int dtA, int dtB, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs,
                     int64_t c_cs, int* fa, int* fb, int64_t* lda, int64_t* ldb) {
     if (dtA != DB1_BF16 || dtB != DB1_BF16) return false;
-    if (M % TBM || N % TBN || K % TBK || M <= 0 || N <= 0 || K <= 0) return false;
+    if (K % TBK || M < 8 || N < 8 || (N % 8) || K <= 0) return false;  // M / N tails are handled by clamped loads + masked stores
     if (c_cs != 1 || (c_rs % 4)) return false;
     *fa = operand_form(a_rs, a_cs, lda);  // A: rows = m, k stride = a_cs
     *fb = operand_form(b_cs, b_rs, ldb);  // B: rows = n (stride b_cs), k stride = b_rs
     if (*fa < 0 || *fb < 0) return false;
+    if (*fa == 1 && (M % 8)) return false;  // an M-major A tile is loaded in 8-row chunks
     if (*fa == 1 && *fb == 0) return false;  // "TT" never occurs on the path
     if ((*lda % 8) || (*ldb % 8)) return false;
     return true;
@@ -181,14 +188,23 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
         t.A = (const bf16_t*)A; t.B = (const bf16_t*)B; t.C = C; t.bias = bias;
         t.M = M; t.N = N; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = c_rs;
         t.batch1 = batch1; t.a_bs0 = a_bs0; t.a_bs1 = a_bs1; t.b_bs0 = b_bs0; t.b_bs1 = b_bs1; t.c_bs0 = c_bs0; t.c_bs1 = c_bs1;
-        t.alpha = alpha; t.beta = beta; t.tiles_m = M / TBM; t.tiles_n = N / TBN;
+        t.alpha = alpha; t.beta = beta; t.tiles_m = (M + TBM - 1) / TBM; t.tiles_n = (N + TBN - 1) / TBN;
         // measured on MI355X at the DB1-1.3B shapes (tools/bench_kernels.py gemm): the 3-stage 256x128 kernel wins for the
         // transposed-operand forms (NN +3..17 %, TN +4..8 %), the 2-stage 128x128 kernel for NT.  DB1_GEMM_TILE=128|256 pins one.
         static int tile_pref = -1;
         if (tile_pref < 0) { const char* e = getenv("DB1_GEMM_TILE"); tile_pref = e ? atoi(e) : 0; }
         const bool want256 = tile_pref == 256 || (tile_pref != 128 && fb == 1);
-        if (want256 && (M % 256) == 0) return db1_gemm_tile256_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
-        dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch);
+        if (want256 && (M % 256) == 0 && (N % TBN) == 0) return db1_gemm_tile256_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
+        // split-K for small outputs with a very long contraction (weight gradients of the 64-channel patch convolutions:
+        // 64 x 576 outputs over 1.9 M rows would otherwise occupy 5 of 256 CUs)
+        t.ksplit = 1;
+        const int ntiles = t.tiles_m * t.tiles_n * (int)batch;
+        if (dtC == DB1_F32 && beta == 1.0f && ntiles < 128 && K >= 64 * TBK) {
+            int ks = 512 / ntiles;
+            while (ks > 1 && ((K / TBK) % ks || (K / TBK) / ks < 8)) ks--;
+            t.ksplit = ks;
+        }
+        dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch, (unsigned)t.ksplit);
         static bool attr_set = false;
         if (!attr_set) {
             // 64 KiB of dynamic LDS needs the opt-in attribute on every instantiation

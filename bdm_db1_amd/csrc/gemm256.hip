@@ -143,6 +143,7 @@ int db1_gemm_tile256_launch(const GemmTileArgs& t_in, int fa, int fb, int dtC, i
     GemmTileArgs t = t_in;
     t.tiles_m = t.M / 256;
     t.tiles_n = t.N / TBN;
+    t.ksplit = 1;
     static bool attr_set = false;
     if (!attr_set) {
 #define SET_ATTR(AK, BK_, TC, TB) hipFuncSetAttribute((const void*)gemm_bf16_tile256_kernel<AK, BK_, TC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS_BYTES)

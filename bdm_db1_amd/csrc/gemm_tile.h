@@ -21,13 +21,17 @@ struct GemmTileArgs {
     int64_t a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
     float alpha, beta;
     int tiles_m, tiles_n;
+    int ksplit;  // > 1: blockIdx.z owns K / ksplit of the contraction and accumulates into fp32 C with atomics (beta must be 1)
 };
 
 // ---- staging of one 16 KiB operand (sub-)tile = 16 wave-instructions of 1 KiB, PIECES per wave (wave w takes w*PIECES ..)
 //   K-major : memory [row][k]   -> LDS image [128 rows][128 B];  piece q = rows [8q, 8q+8):   lane -> (r = lane/8,  cp = lane%8),  holds chunk cp ^ (r & 7)
 //   M-major : memory [k][row]   -> LDS image [64 k][256 B];      piece q = k-rows [4q, 4q+4): lane -> (kr = lane/16, cp = lane%16), holds chunk cp ^ f(kr)
+// rows_valid (< 128 only in a tail tile): rows beyond it are loaded from the last valid row / 8-row chunk instead (their
+// products land in accumulator rows / columns that the masked epilogue never stores).
 template <bool KMAJOR, int PIECES>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, int row0, int k0, char* lds, int wave, int lane) {
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, int row0, int k0, char* lds, int wave, int lane,
+                                           int rows_valid = 128) {
 #pragma unroll
     for (int it = 0; it < PIECES; it++) {
         const int q = wave * PIECES + it;
@@ -35,11 +39,13 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t
         if (KMAJOR) {
             const int r = q * 8 + (lane >> 3);
             const int c = (lane & 7) ^ (r & 7);
-            src = g + (int64_t)(row0 + r) * ld + k0 + c * 8;
+            const int re = r < rows_valid ? r : rows_valid - 1;
+            src = g + (int64_t)(row0 + re) * ld + k0 + c * 8;
         } else {
             const int kr = q * 4 + (lane >> 4);
             const int f = ((kr & 3) << 1) | (kr & 8);
-            const int c = (lane & 15) ^ f;
+            int c = (lane & 15) ^ f;
+            if (c * 8 + 8 > rows_valid) c = (rows_valid >> 3) - 1;
             src = g + (int64_t)(k0 + kr) * ld + row0 + c * 8;
         }
         __builtin_amdgcn_global_load_lds(src, LDS_PTR(void, lds + q * 1024), 16, 0, 0);

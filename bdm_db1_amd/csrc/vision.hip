@@ -48,11 +48,12 @@ extern "C" int db1_patch_normalize(const void* pixels, void* patches, int n_img,
 
 // ---- im2col 3x3 pad 1: x [N, C, p, p] -> cols [N*p*p, C*9], column index = c*9 + ky*3 + kx (matches weight.reshape(Cout, C*9))
 template <typename T>
-__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T* __restrict__ cols, int64_t total, int C, int p) {
-    const int K = C * 9;
+__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T* __restrict__ cols, int64_t total, int C, int p, int K) {
+    // K = row stride of cols (>= C*9; the padding columns are written as zeros)
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int col = (int)(idx % K);
         const int64_t pix = idx / K;
+        if (col >= C * 9) { cols[idx] = 0; continue; }
         const int c = col / 9, ky = (col % 9) / 3, kx = col % 3;
         const int xw = (int)(pix % p), yh = (int)((pix / p) % p);
         const int64_t n = pix / (p * p);
@@ -62,21 +63,20 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T*
         cols[idx] = v;
     }
 }
-extern "C" int db1_im2col3x3(const void* x, void* cols, int64_t N, int C, int p, int dt, void* stream) {
+extern "C" int db1_im2col3x3(const void* x, void* cols, int64_t N, int C, int p, int kpad, int dt, void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "im2col: dtype");
-    if (N <= 0 || C <= 0 || p <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "im2col: shape");
-    const int64_t total = N * p * p * C * 9;
+    if (N <= 0 || C <= 0 || p <= 0 || kpad < C * 9) DB1_FAIL(DB1_ERR_BAD_SHAPE, "im2col: shape");
+    const int64_t total = N * p * p * kpad;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    DB1_DISPATCH_DT(dt, T, (im2col_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)cols, total, C, p)));
+    DB1_DISPATCH_DT(dt, T, (im2col_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)cols, total, C, p, kpad)));
     DB1_CHECK_LAUNCH("im2col");
     return DB1_OK;
 }
 
 // ---- col2im: dx[n,c,y,x] = sum over the (<= 9) column entries that read it (gather form, no atomics)
 template <typename T>
-__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcols, T* __restrict__ dx, int64_t total, int C, int p) {
-    const int K = C * 9;
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcols, T* __restrict__ dx, int64_t total, int C, int p, int K) {
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int xw = (int)(idx % p), yh = (int)((idx / p) % p);
         const int c = (int)((idx / (p * p)) % C);
@@ -92,13 +92,13 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcols
         stf(dx + idx, a);
     }
 }
-extern "C" int db1_col2im3x3(const void* dcols, void* dx, int64_t N, int C, int p, int dt, void* stream) {
+extern "C" int db1_col2im3x3(const void* dcols, void* dx, int64_t N, int C, int p, int kpad, int dt, void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "col2im: dtype");
-    if (N <= 0 || C <= 0 || p <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "col2im: shape");
+    if (N <= 0 || C <= 0 || p <= 0 || kpad < C * 9) DB1_FAIL(DB1_ERR_BAD_SHAPE, "col2im: shape");
     const int64_t total = N * C * p * p;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    DB1_DISPATCH_DT(dt, T, (col2im_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const T*)dcols, (T*)dx, total, C, p)));
+    DB1_DISPATCH_DT(dt, T, (col2im_kernel<T><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const T*)dcols, (T*)dx, total, C, p, kpad)));
     DB1_CHECK_LAUNCH("col2im");
     return DB1_OK;
 }

@@ -308,11 +308,22 @@ class TransformerXL(nn.Module):
     def _conv3x3_fwd(self, x_nchw, wname, bname, N, Cin):
         """per-patch 3x3 conv as im2col + GEMM; returns NHWC output [N*256, 64] and the column matrix"""
         hw = self.patch_size * self.patch_size
-        cols = self._new(N * hw, Cin * 9)
+        K = Cin * 9
+        Kp = _round_up(K, 8)  # conv1: 27 -> 32 zero-padded columns so its weight gradient can use the MFMA tile kernel (split-K)
+        cols = self._new(N * hw, Kp)
         ops.im2col3x3(x_nchw, cols, N, Cin, self.patch_size)
         out = self._new(N * hw, 64)
-        ops.gemm(cols, self.W(wname).view(64, Cin * 9).t(), out, bias=self.W(bname))
+        ops.gemm(cols, self._conv_weight(wname, K, Kp).t(), out, bias=self.W(bname))
         return out, cols
+
+    def _conv_weight(self, wname, K, Kp):
+        """[64, Kp] view of a 3x3 conv weight in the compute dtype (zero-padded copy when Cin*9 is not a multiple of 8)"""
+        w = self.W(wname).view(64, K)
+        if Kp == K:
+            return w
+        wp = torch.zeros(64, Kp, device=self.dev, dtype=self.compute_dtype)
+        ops.add2d(w, wp[:, :K], wp[:, :K])
+        return wp
 
     def _vision_fwd(self, pixels: torch.Tensor, row_ids=None, col_ids=None):
         pixels = pixels.to(device=self.dev, dtype=torch.float32).contiguous()
@@ -356,12 +367,19 @@ class TransformerXL(nn.Module):
         return emb.view(n_img, h0 * w0, d), c
 
     def _conv3x3_bwd(self, dy_nhwc, cols, wname, bname, N, Cin, need_dx):
-        ops.gemm(dy_nhwc.t(), cols, self.G(wname).view(64, Cin * 9), beta=1.0)
+        K, Kp = Cin * 9, cols.shape[1]
+        if Kp == K:
+            ops.gemm(dy_nhwc.t(), cols, self.G(wname).view(64, K), beta=1.0)
+        else:  # padded columns: reduce into a [64, Kp] float32 scratch, then add its first K columns to the gradient
+            gp = torch.zeros(64, Kp, device=self.dev, dtype=torch.float32)
+            ops.gemm(dy_nhwc.t(), cols, gp, beta=1.0)
+            g = self.G(wname).view(64, K)
+            ops.add2d(gp[:, :K], g, g)
         ops.colsum_acc(dy_nhwc, self.G(bname))
         if not need_dx:
             return None
-        dcols = self._new(cols.shape[0], cols.shape[1])
-        ops.gemm(dy_nhwc, self.W(wname).view(64, Cin * 9), dcols)
+        dcols = self._new(cols.shape[0], Kp)
+        ops.gemm(dy_nhwc, self._conv_weight(wname, K, Kp), dcols)
         dx = self._new(N, Cin, self.patch_size * self.patch_size)
         ops.col2im3x3(dcols, dx, N, Cin, self.patch_size)
         return dx

@@ -224,11 +224,11 @@ def patch_normalize(pixels, patches, p):
 
 
 def im2col3x3(x, cols, N, C, p):
-    lib.call("db1_im2col3x3", P(x), P(cols), N, C, p, dt_code(x), stream())
+    lib.call("db1_im2col3x3", P(x), P(cols), N, C, p, cols.shape[-1], dt_code(x), stream())
 
 
 def col2im3x3(dcols, dx, N, C, p):
-    lib.call("db1_col2im3x3", P(dcols), P(dx), N, C, p, dt_code(dx), stream())
+    lib.call("db1_col2im3x3", P(dcols), P(dx), N, C, p, dcols.shape[-1], dt_code(dx), stream())
 
 
 def nhwc_to_nchw(x, y, N, C, hw):

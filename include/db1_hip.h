@@ -165,9 +165,10 @@ int db1_relattn_flash_bwd(const void* qu, const void* qv, const void* k, const v
  * [(n h w), C, p, p]: (x-mean)/(1e-6+std_unbiased)/sqrt(p) per (patch, channel). */
 int db1_patch_normalize(const void* pixels, void* patches, int n_img, int C, int Himg, int Wimg, int p,
                         int dtIn, int dtOut, void* stream);
-/* im2col for 3x3/pad 1 on p x p patches: x [N, C, p, p] -> cols [N*p*p, C*9]; col2im accumulates the reverse. */
-int db1_im2col3x3(const void* x, void* cols, int64_t N, int C, int p, int dt, void* stream);
-int db1_col2im3x3(const void* dcols, void* dx, int64_t N, int C, int p, int dt, void* stream);
+/* im2col for 3x3/pad 1 on p x p patches: x [N, C, p, p] -> cols [N*p*p, kpad] (kpad >= C*9 is the row stride; padding
+ * columns are zero-filled so that K is a multiple of 8 for the MFMA tile GEMM); col2im gathers the reverse. */
+int db1_im2col3x3(const void* x, void* cols, int64_t N, int C, int p, int kpad, int dt, void* stream);
+int db1_col2im3x3(const void* dcols, void* dx, int64_t N, int C, int p, int kpad, int dt, void* stream);
 /* layout shuffles between GEMM output [N*p*p, C] ("NHWC") and [N, C, p, p] ("NCHW") */
 int db1_nhwc_to_nchw(const void* x, void* y, int64_t N, int C, int hw, int dt, void* stream);
 int db1_nchw_to_nhwc(const void* x, void* y, int64_t N, int C, int hw, int dt, void* stream);

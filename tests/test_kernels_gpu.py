@@ -112,6 +112,45 @@ def test_gemm_bf16_tile_kernels(ops, form, out_dtype):
     close(out2, ref, 2e-6 if out_dtype == "f32" else 6e-3, name=f"strided gemm {form} {out_dtype}")
 
 
+@pytest.mark.parametrize("form,M,N,K", [("nt", 200, 72, 128), ("nn", 328, 576, 64), ("tn", 72, 200, 192), ("nt", 1568, 2048, 256), ("tn", 576, 64, 512)])
+def test_gemm_bf16_tile_tails(ops, form, M, N, K):
+    """ragged M / N (image-patch counts, 64-channel convolutions) stay on the MFMA tile kernel: clamped loads, masked stores"""
+    from bdm_db1_amd import lib
+    rng = np.random.default_rng(M + N + K)
+    A = bf(rng.standard_normal((M, K)))
+    B = bf(rng.standard_normal((K, N)))
+    a_store = dev(A if form != "tn" else A.T.copy(), torch.bfloat16)
+    b_store = dev(B.T.copy() if form == "nt" else B, torch.bfloat16)
+    a = a_store if form != "tn" else a_store.t()
+    b = b_store.t() if form == "nt" else b_store
+    canvas = torch.full((M + 3, N + 8), 5.0, device=DEV, dtype=torch.float32)  # guard band around the output
+    out = canvas[:M, :N]
+    assert lib.load().db1_gemm_would_use_fast(M, N, K, 1, 1, 0, a.stride(0), a.stride(1), b.stride(0), b.stride(1), out.stride(0), out.stride(1)) == 1
+    ops.gemm(a, b, out)
+    close(out, A @ B, 3e-6, name=f"tail gemm {form}")
+    assert float(canvas[M:].min()) == 5.0 and float(canvas[:, N:].min()) == 5.0  # nothing written outside [M, N]
+
+
+def test_gemm_bf16_split_k_weight_gradient(ops):
+    """64 x 576 output over a 32 768-row contraction (patch-conv weight gradient): split-K with fp32 atomics, beta = 1"""
+    rng = np.random.default_rng(21)
+    M, N, K = 64, 576, 32768
+    A = bf(rng.standard_normal((M, K)) * 0.1)
+    B = bf(rng.standard_normal((K, N)) * 0.1)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    a = dev(A.T.copy(), torch.bfloat16).t()
+    out = dev(C0)
+    ops.gemm(a, dev(B, torch.bfloat16), out, beta=1.0)
+    close(out, A @ B + C0, 2e-5, name="split-K TN")
+    # padded im2col columns (27 -> 32) are zero
+    x = rng.standard_normal((3, 3, 16, 16))
+    cols = torch.full((3 * 256, 32), 9.0, device=DEV)
+    ops.im2col3x3(dev(x), cols, 3, 3, 16)
+    ref = np.zeros((3 * 256, 32))
+    ref[:, :27] = O._im2col3x3(x).reshape(3 * 256, 27)
+    close(cols, ref, 1e-7, name="padded im2col")
+
+
 def test_gemm_bf16_tile_large_k_and_batch(ops):
     rng = np.random.default_rng(4)
     Z, M, N, K = 3, 128, 128, 1024
