@@ -1,4 +1,5 @@
-// bf16 MFMA GEMM, 256x128x64 workgroup tile, 8 waves (4 along M x 2 along N, 64x64 each), 3-stage LDS ring.
+// bf16 MFMA GEMM, 256x128x64 workgroup tile, 3-stage LDS ring, two wave layouts:
+//   NWM x NWN = 4 x 2 (8 waves, 64x64 wave tiles, 2 waves/SIMD)  or  2 x 2 (4 waves, 128x64 wave tiles, 1 wave/SIMD).
 //
 // Why this shape on gfx950: one k-step of the 128x128 kernel is ~0.25 us of MFMA work per workgroup while a
 // global_load_lds round trip is 1-2 us, so with a 2-stage buffer every k-step ends in a vmcnt(0) drain.  Here the
@@ -8,9 +9,12 @@
 // put `s_waitcnt vmcnt(0)` in front of every fragment read (measured: that made this kernel slower than the 2-stage
 // one), so the fragment reads are issued through inline asm with hand-counted lgkmcnt waits + sched_barrier
 // (cdna_hip_programming.md 5.7): reads of k-substep 1 are in flight under the MFMAs of k-substep 0.
-// One barrier per k-step.  The larger tile also cuts L2->LDS traffic per FLOP by 25 %.  Operand forms, swizzles and the
-// swapped-operand epilogue are those of gemm.hip (gemm_tile.h); an A tile is staged as two independent 128-row sub-tiles.
+// One barrier per k-step.  The 64x64 wave tile needs 1 KiB of fragment reads per 16 MFMAs (LDS read bandwidth ~= MFMA time);
+// the 128x64 wave tile needs 25 % less and leaves the whole register file to one wave per SIMD.
+// Operand forms, swizzles and the swapped-operand epilogue are those of gemm.hip (gemm_tile.h); an A tile is staged as two
+// independent 128-row sub-tiles.
 #include "gemm_tile.h"
+#include <stdlib.h>
 
 #define T256_STAGE_BYTES (3 * TILE_BYTES)   // A0 | A1 | B
 #define T256_LDS_BYTES (3 * T256_STAGE_BYTES)
@@ -47,11 +51,12 @@ template <> struct Frag<false> {
     __device__ __forceinline__ bf16x8_t get() const { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, typename TC, typename TBIAS>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_tile256_kernel(GemmTileArgs p) {
+template <bool A_KMAJOR, bool B_KMAJOR, typename TC, typename TBIAS, int NWM, int NWN, bool STAGGER>
+__global__ __launch_bounds__(NWM * NWN * 64, 1) void gemm_bf16_tile256_kernel(GemmTileArgs p) {
+    constexpr int NW = NWM * NWN, NI = 256 / NWM / 16, NJ = 128 / NWN / 16, PIECES = 16 / NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;      // wave tile: rows wm*64 .. +64 of 256, columns wn*64 .. +64 of 128
+    const int wm = wave / NWN, wn = wave % NWN;
     int tm, tn;
     tile_coords(blockIdx.x, p.tiles_m, p.tiles_n, 4, tm, tn);
     const int z = blockIdx.y, z0 = z / p.batch1, z1 = z % p.batch1;
@@ -60,83 +65,146 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tile256_kernel(GemmTileArgs 
     const int m0 = tm * 256, n0 = tn * TBN;
     const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
 
-    // lane-constant fragment offsets inside a stage: [ks][frag][half]
-    unsigned aoff[2][4][2], boff[2][4][2];
+    // lane-constant fragment addresses inside stage 0: [ks][frag][half]
+    unsigned aoff[2][NI][2], boff[2][NJ][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++)
+    for (int ks = 0; ks < 2; ks++) {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NI; i++) {
+            const int row = wm * (256 / NWM) + i * 16;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                aoff[ks][i][h] = lds0 + (wm >> 1) * TILE_BYTES + frag_off<A_KMAJOR>((wm & 1) * 64 + i * 16, ks, lane, h);
-                boff[ks][i][h] = lds0 + 2 * TILE_BYTES + frag_off<B_KMAJOR>(wn * 64 + i * 16, ks, lane, h);
-            }
+            for (int h = 0; h < 2; h++) aoff[ks][i][h] = lds0 + (row >> 7) * TILE_BYTES + frag_off<A_KMAJOR>(row & 127, ks, lane, h);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) boff[ks][j][h] = lds0 + 2 * TILE_BYTES + frag_off<B_KMAJOR>(wn * (128 / NWN) + j * 16, ks, lane, h);
+    }
 
-    f32x4 acc[4][4];
+    f32x4 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto stage = [&](int t, int buf) {  // 6 global_load_lds per wave
+    auto stage = [&](int t, int buf) {  // 3 * PIECES global_load_lds per wave
         char* s = smem + buf * T256_STAGE_BYTES;
-        stage_tile<A_KMAJOR, 2>(A, p.lda, m0, t * TBK, s, wave, lane);
-        stage_tile<A_KMAJOR, 2>(A, p.lda, m0 + 128, t * TBK, s + TILE_BYTES, wave, lane);
-        stage_tile<B_KMAJOR, 2>(B, p.ldb, n0, t * TBK, s + 2 * TILE_BYTES, wave, lane);
+        stage_tile<A_KMAJOR, PIECES>(A, p.lda, m0, t * TBK, s, wave, lane);
+        stage_tile<A_KMAJOR, PIECES>(A, p.lda, m0 + 128, t * TBK, s + TILE_BYTES, wave, lane);
+        stage_tile<B_KMAJOR, PIECES>(B, p.ldb, n0, t * TBK, s + 2 * TILE_BYTES, wave, lane);
     };
     const int nt = p.K / TBK;
     stage(0, 0);
     if (nt > 1) stage(1, 1);
-    int buf = 0;
-    for (int t = 0; t < nt; t++) {
-        // tile t has landed once at most the 6 loads of tile t+1 are still outstanding
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto reads = [&](int ks, Frag<A_KMAJOR>* af, Frag<B_KMAJOR>* bf, unsigned sb) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) af[i].read(aoff[ks][i][0] + sb, aoff[ks][i][1] + sb);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) bf[j].read(boff[ks][j][0] + sb, boff[ks][j][1] + sb);
+    };
+    auto mfmas = [&](const Frag<A_KMAJOR>* af, const Frag<B_KMAJOR>* bf) {
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j].get(), af[i].get(), acc[i][j], 0, 0, 0);  // swapped: D[n][m]
+    };
+    auto tile_ready = [&](int t) {  // tile t has landed once at most the loads of tile t+1 are still outstanding
+        if (t + 1 < nt) {
+            if (PIECES == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();  // everyone's pieces of tile t are in LDS; everyone is done reading tile t-1
-        if (t + 2 < nt) stage(t + 2, buf == 0 ? 2 : buf - 1);  // overwrites the stage read during iteration t-1
-        const unsigned sb = buf * T256_STAGE_BYTES;
-        Frag<A_KMAJOR> af0[4], af1[4];
-        Frag<B_KMAJOR> bf0[4], bf1[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) af0[i].read(aoff[0][i][0] + sb, aoff[0][i][1] + sb);
-#pragma unroll
-        for (int j = 0; j < 4; j++) bf0[j].read(boff[0][j][0] + sb, boff[0][j][1] + sb);
+    };
+    int buf = 0;
+    if (!STAGGER || wave < NW / 2) {
+        // waves 0 .. NW/2-1: [fragment reads of both k-substeps | 2 MFMA batches]
+        for (int t = 0; t < nt; t++) {
+            tile_ready(t);
+            if (t + 2 < nt) stage(t + 2, buf == 0 ? 2 : buf - 1);  // overwrites the stage read during iteration t-1
+            const unsigned sb = buf * T256_STAGE_BYTES;
+            Frag<A_KMAJOR> af0[NI], af1[NI];
+            Frag<B_KMAJOR> bf0[NJ], bf1[NJ];
+            reads(0, af0, bf0, sb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            reads(1, af1, bf1, sb);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(af0, bf0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(af1, bf1);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    } else {
+        // waves NW/2 .. NW-1 share their SIMDs with the first half (wave w and w + 4 sit on one SIMD): they run the SAME number of
+        // barriers but defer the second MFMA batch of every k-step to just after the next barrier, so that the matrix pipe has
+        // work while the partner wave is in its fragment-read phase.  The deferred operands live in alternating register sets.
+        Frag<A_KMAJOR> afx[NI], afy[NI];
+        Frag<B_KMAJOR> bfx[NJ], bfy[NJ];
+        auto half = [&](int t, Frag<A_KMAJOR>* afc, Frag<B_KMAJOR>* bfc, const Frag<A_KMAJOR>* afp, const Frag<B_KMAJOR>* bfp) {
+            tile_ready(t);
+            if (t + 2 < nt) stage(t + 2, buf == 0 ? 2 : buf - 1);
+            const unsigned sb = buf * T256_STAGE_BYTES;
+            Frag<A_KMAJOR> af0[NI];
+            Frag<B_KMAJOR> bf0[NJ];
+            if (t > 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(afp, bfp);  // second batch of k-step t-1
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            reads(0, af0, bf0, sb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            reads(1, afc, bfc, sb);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            buf = buf == 2 ? 0 : buf + 1;
+        };
+        for (int t = 0; t < nt; t += 2) {
+            half(t, afx, bfx, afy, bfy);
+            if (t + 1 < nt) half(t + 1, afy, bfy, afx, bfx);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; i++) af1[i].read(aoff[1][i][0] + sb, aoff[1][i][1] + sb);
-#pragma unroll
-        for (int j = 0; j < 4; j++) bf1[j].read(boff[1][j][0] + sb, boff[1][j][1] + sb);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j].get(), af0[i].get(), acc[i][j], 0, 0, 0);  // swapped: D[n][m]
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j].get(), af1[i].get(), acc[i][j], 0, 0, 0);
-        buf = buf == 2 ? 0 : buf + 1;
+        if (nt & 1) mfmas(afx, bfx); else mfmas(afy, bfy);
     }
     TC* C = (TC*)p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            store_frag<TC, TBIAS>(acc[i][j], C, p.ldc, m0 + wm * 64 + i * 16 + (lane & 15), n0 + wn * 64 + j * 16 + (lane >> 4) * 4, p.alpha, p.beta, p.bias);
+        for (int j = 0; j < NJ; j++)
+            store_frag<TC, TBIAS>(acc[i][j], C, p.ldc, m0 + wm * (256 / NWM) + i * 16 + (lane & 15), n0 + wn * (128 / NWN) + j * 16 + (lane >> 4) * 4,
+                                  p.alpha, p.beta, p.bias);
 }
 
-template <bool AK, bool BK_>
+template <bool AK, bool BK_, int NWM, int NWN, bool SG>
 static void launch256(const GemmTileArgs& t, int dtC, int dtBias, dim3 grid, hipStream_t st) {
-    if (dtC == DB1_F32) {
-        if (dtBias == DB1_BF16) gemm_bf16_tile256_kernel<AK, BK_, float, bf16_t><<<grid, 512, T256_LDS_BYTES, st>>>(t);
-        else gemm_bf16_tile256_kernel<AK, BK_, float, float><<<grid, 512, T256_LDS_BYTES, st>>>(t);
-    } else {
-        if (dtBias == DB1_BF16) gemm_bf16_tile256_kernel<AK, BK_, bf16_t, bf16_t><<<grid, 512, T256_LDS_BYTES, st>>>(t);
-        else gemm_bf16_tile256_kernel<AK, BK_, bf16_t, float><<<grid, 512, T256_LDS_BYTES, st>>>(t);
+    constexpr int TH = NWM * NWN * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+#define SET_ATTR(TC, TB) hipFuncSetAttribute((const void*)gemm_bf16_tile256_kernel<AK, BK_, TC, TB, NWM, NWN, SG>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS_BYTES)
+        SET_ATTR(float, float); SET_ATTR(float, bf16_t); SET_ATTR(bf16_t, float); SET_ATTR(bf16_t, bf16_t);
+#undef SET_ATTR
+        attr_set = true;
     }
+    if (dtC == DB1_F32) {
+        if (dtBias == DB1_BF16) gemm_bf16_tile256_kernel<AK, BK_, float, bf16_t, NWM, NWN, SG><<<grid, TH, T256_LDS_BYTES, st>>>(t);
+        else gemm_bf16_tile256_kernel<AK, BK_, float, float, NWM, NWN, SG><<<grid, TH, T256_LDS_BYTES, st>>>(t);
+    } else {
+        if (dtBias == DB1_BF16) gemm_bf16_tile256_kernel<AK, BK_, bf16_t, bf16_t, NWM, NWN, SG><<<grid, TH, T256_LDS_BYTES, st>>>(t);
+        else gemm_bf16_tile256_kernel<AK, BK_, bf16_t, float, NWM, NWN, SG><<<grid, TH, T256_LDS_BYTES, st>>>(t);
+    }
+}
+
+template <int NWM, int NWN, bool SG>
+static void launch256_form(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, dim3 grid, hipStream_t st) {
+    if (fa == 0 && fb == 0) launch256<true, true, NWM, NWN, SG>(t, dtC, dtBias, grid, st);
+    else if (fa == 0 && fb == 1) launch256<true, false, NWM, NWN, SG>(t, dtC, dtBias, grid, st);
+    else launch256<false, false, NWM, NWN, SG>(t, dtC, dtBias, grid, st);
 }
 
 int db1_gemm_tile256_launch(const GemmTileArgs& t_in, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st) {
@@ -144,19 +212,14 @@ int db1_gemm_tile256_launch(const GemmTileArgs& t_in, int fa, int fb, int dtC, i
     t.tiles_m = t.M / 256;
     t.tiles_n = t.N / TBN;
     t.ksplit = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-#define SET_ATTR(AK, BK_, TC, TB) hipFuncSetAttribute((const void*)gemm_bf16_tile256_kernel<AK, BK_, TC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS_BYTES)
-#define SET_ALL(AK, BK_) SET_ATTR(AK, BK_, float, float); SET_ATTR(AK, BK_, float, bf16_t); SET_ATTR(AK, BK_, bf16_t, float); SET_ATTR(AK, BK_, bf16_t, bf16_t)
-        SET_ALL(true, true); SET_ALL(true, false); SET_ALL(false, false);
-#undef SET_ALL
-#undef SET_ATTR
-        attr_set = true;
-    }
+    static int waves = -1;  // DB1_GEMM256_WAVES=4|8 pins a wave layout (A/B measurements)
+    if (waves < 0) { const char* e = getenv("DB1_GEMM256_WAVES"); waves = e ? atoi(e) : 8; }
     dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch);
-    if (fa == 0 && fb == 0) launch256<true, true>(t, dtC, dtBias, grid, st);
-    else if (fa == 0 && fb == 1) launch256<true, false>(t, dtC, dtBias, grid, st);
-    else launch256<false, false>(t, dtC, dtBias, grid, st);
+    static int stagger = -1;  // DB1_GEMM256_STAGGER=0 runs both wave halves in lockstep (A/B measurements)
+    if (stagger < 0) { const char* e = getenv("DB1_GEMM256_STAGGER"); stagger = e ? atoi(e) : 0; }
+    if (waves == 8 && stagger) launch256_form<4, 2, true>(t, fa, fb, dtC, dtBias, grid, st);
+    else if (waves == 8) launch256_form<4, 2, false>(t, fa, fb, dtC, dtBias, grid, st);
+    else launch256_form<2, 2, false>(t, fa, fb, dtC, dtBias, grid, st);
     DB1_CHECK_LAUNCH("gemm_bf16_tile256");
     return DB1_OK;
 }
