@@ -539,7 +539,17 @@ class TransformerXL(nn.Module):
         dav4 = dav.view(B, L, H, D)
         if c.flash and self.use_flash_bwd:
             qu, qv = c.qu, c.qv
-            dT = torch.zeros(H, B, L, L, device=self.dev, dtype=self.compute_dtype)  # distances never visited stay zero
+            # dT[h,b,i,dist]: entries with dist > i are never written and must read as zero.  With the plain causal window every
+            # entry dist <= i is rewritten by each call, so ONE zero-initialised buffer is reused by all layers and steps; a sliding
+            # window leaves unvisited entries below the diagonal, so it gets a fresh zeroed buffer per call.
+            if shift >= L:
+                key = (H, B, L)
+                if getattr(self, "_dT_key", None) != key:
+                    self._dT_buf = torch.zeros(H, B, L, L, device=self.dev, dtype=self.compute_dtype)
+                    self._dT_key = key
+                dT = self._dT_buf
+            else:
+                dT = torch.zeros(H, B, L, L, device=self.dev, dtype=self.compute_dtype)
             delta = self._new(B, H, L, dtype=torch.float32)
             ops.relattn_flash_bwd(qu, qv, qkv5, R, c.av, dav4, c.lse, delta, dqkv5, dT, B, L, H, D, shift, scale)
         else:

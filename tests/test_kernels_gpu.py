@@ -233,6 +233,11 @@ def test_colsum_add_cast(ops):
     acc2 = torch.zeros(70, device=DEV)
     ops.colsum_acc(xb[:, :64], acc2[:64])  # strided rows
     close(acc2[:64], bf(x)[:, :64].sum(0), 1e-6, name="colsum bf16 strided")
+    xv = rng.standard_normal((1000, 264))  # 16-byte column groups: the vectorised kernel
+    for td, ref in ((torch.float32, xv), (torch.bfloat16, bf(xv))):
+        accv = torch.full((264,), -1.0, device=DEV)
+        ops.colsum_acc(dev(ref, td), accv)
+        close(accv, ref.sum(0) - 1, 2e-6, name=f"colsum vec {td}")
     a, b = dev(x), dev(x * 2)
     y = torch.empty_like(a)
     ops.add(a, b, y)
