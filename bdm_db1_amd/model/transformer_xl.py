@@ -612,6 +612,80 @@ class TransformerXL(nn.Module):
             c.h1, c.z, c.act, c.s2, c.m2, c.r2 = h1, z, act, f, m2, r2
         return out, c
 
+    # ---- pre-LN ordering of the same kernels (config default `--pre-lnorm True`; transformer_xl.py:126-137,231-233,277-282)
+    def _layer_fwd_prelnorm(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool):
+        d, di, dff = self.d_model, self.d_inner, self.d_ff
+        p = f"h.{i}."
+        c = _Ctx() if keep else None
+        T = B * L
+        if mem is not None:
+            cat = torch.cat([mem.to(self.compute_dtype), x.view(B, L, d)], dim=1).contiguous()
+            Lk = cat.shape[1]
+            xin = cat.view(B * Lk, d)
+        else:
+            Lk, xin = L, x
+        hin = self._new(B * Lk, d)
+        m1, r1 = self._new(B * Lk, dtype=torch.float32), self._new(B * Lk, dtype=torch.float32)
+        ops.layernorm_residual_fwd(xin, None, 1.0, self.W(p + "dec_attn.layer_norm.weight"), self.W(p + "dec_attn.layer_norm.bias"),
+                                   hin, None, m1, r1, self.layer_norm_epsilon)
+        qkv = self._new(B * Lk, 3 * d)
+        ops.gemm(hin, self.W(p + "dec_attn.qkv_net.weight").t(), qkv)
+        R = self._new(R_in.shape[0], d)
+        ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
+        av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c)
+        o = self._new(T, d)
+        ops.gemm(av.view(T, d), self.W(p + "dec_attn.o_net.weight").t(), o)
+        h1 = self._new(T, d)
+        ops.add(x, o, h1)                                                      # residual (:233)
+        fin = self._new(T, d)
+        m2, r2 = self._new(T, dtype=torch.float32), self._new(T, dtype=torch.float32)
+        ops.layernorm_residual_fwd(h1, None, 1.0, self.W(p + "pos_ff.layer_norm.weight"), self.W(p + "pos_ff.layer_norm.bias"),
+                                   fin, None, m2, r2, self.layer_norm_epsilon)
+        z = self._new(T, di)
+        ops.gemm(fin, self.W(p + "pos_ff.CoreNet.0.weight").t(), z, bias=self.W(p + "pos_ff.CoreNet.0.bias"))
+        act = self._new(T, dff)
+        ops.ffn_act_fwd(z, act, self.activation_fn)
+        out = self._new(T, d)
+        ops.gemm(act, self.W(p + "pos_ff.CoreNet.2.weight").t(), out, bias=self.W(p + "pos_ff.CoreNet.2.bias"))
+        ops.add(out, h1, out)                                                  # residual (:282)
+        if keep:
+            c.x, c.hin, c.qkv, c.R, c.av, c.m1, c.r1 = x, hin, qkv, R, av, m1, r1
+            c.h1, c.fin, c.z, c.act, c.m2, c.r2 = h1, fin, z, act, m2, r2
+        return out, c
+
+    def _layer_bwd_prelnorm(self, i, dout, c: _Ctx, R_in, B, L, shift):
+        d, di, dff = self.d_model, self.d_inner, self.d_ff
+        p = f"h.{i}."
+        T = B * L
+        W, G = self.W, self.G
+        ops.gemm(dout.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=1.0)
+        ops.colsum_acc(dout, G(p + "pos_ff.CoreNet.2.bias"))
+        dact = self._new(T, dff)
+        ops.gemm(dout, W(p + "pos_ff.CoreNet.2.weight"), dact)
+        dz = self._new(T, di)
+        ops.ffn_act_bwd(c.z, dact, dz, self.activation_fn)
+        ops.gemm(dz.t(), c.fin, G(p + "pos_ff.CoreNet.0.weight"), beta=1.0)
+        ops.colsum_acc(dz, G(p + "pos_ff.CoreNet.0.bias"))
+        dfin = self._new(T, d)
+        ops.gemm(dz, W(p + "pos_ff.CoreNet.0.weight"), dfin)
+        dh1 = self._new(T, d)
+        ops.layernorm_residual_bwd(dfin, c.h1, W(p + "pos_ff.layer_norm.weight"), c.m2, c.r2, dh1,
+                                   G(p + "pos_ff.layer_norm.weight"), G(p + "pos_ff.layer_norm.bias"))
+        ops.add(dh1, dout, dh1)                                                # + the residual branch
+        ops.gemm(dh1.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=1.0)
+        dav = self._new(T, d)
+        ops.gemm(dh1, W(p + "dec_attn.o_net.weight"), dav)
+        dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift)
+        ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=1.0)
+        ops.gemm(dqkv.t(), c.hin, G(p + "dec_attn.qkv_net.weight"), beta=1.0)
+        dhin = self._new(T, d)
+        ops.gemm(dqkv, W(p + "dec_attn.qkv_net.weight"), dhin)
+        dx = self._new(T, d)
+        ops.layernorm_residual_bwd(dhin, c.x, W(p + "dec_attn.layer_norm.weight"), c.m1, c.r1, dx,
+                                   G(p + "dec_attn.layer_norm.weight"), G(p + "dec_attn.layer_norm.bias"))
+        ops.add(dx, dh1, dx)
+        return dx
+
     def _layer_bwd(self, i, dout, c: _Ctx, R_in, B, L, shift):
         d, di, dff = self.d_model, self.d_inner, self.d_ff
         a = 1.0 if self.deepnorm_alpha is None else self.deepnorm_alpha
@@ -655,9 +729,6 @@ class TransformerXL(nn.Module):
 
     def forward(self, tasks_input: Sequence, compute_loss: bool = True, mems=None):
         assert not (compute_loss and mems is not None), "During training, Gato does not use memory mechanism."
-        if self.pre_lnorm:
-            raise NotImplementedError("pre_lnorm=True: the released DB1 runs post-LN (scripts/evaluate/evaluate_rl_1.2B.sh:73); "
-                                      "the HIP path implements that configuration")
         keep = compute_loss and torch.is_grad_enabled()
         d = self.d_model
         embs, labels, masks, ecs, shapes = [], [], [], [], []
@@ -678,7 +749,8 @@ class TransformerXL(nn.Module):
         hids, lcs = [], []
         for i in range(self.n_layer):
             hids.append(x)
-            x, c = self._layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep)
+            layer_fwd = self._layer_fwd_prelnorm if self.pre_lnorm else self._layer_fwd
+            x, c = layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep)
             lcs.append(c)
         Wout = self.arena.view(self.arena.work, "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight",
                                full=True).view(self.vocab_pad, d)
@@ -731,7 +803,7 @@ class TransformerXL(nn.Module):
         ops.gemm(dlogits, Wout, dh)
         del dlogits
         for i in reversed(range(self.n_layer)):
-            dh = self._layer_bwd(i, dh, ctx.lcs[i], ctx.R_in, B, L, ctx.shift)
+            dh = (self._layer_bwd_prelnorm if self.pre_lnorm else self._layer_bwd)(i, dh, ctx.lcs[i], ctx.R_in, B, L, ctx.shift)
             ctx.lcs[i] = None
             if layer_done_hook is not None:
                 layer_done_hook(f"h.{i}")

@@ -66,7 +66,7 @@ def rel_err(got, ref):
     return np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
 
 
-TRAIN_CASES = [n for n in CASES if n not in ("small_mems", "small_prelnorm")]
+TRAIN_CASES = [n for n in CASES if n != "small_mems"]
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
