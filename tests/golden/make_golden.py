@@ -218,7 +218,47 @@ def gen_rl_packing():
     return out
 
 
+SAMPLER_CASES = [  # (total, consumed, micro_batch, rank, world)
+    (100, 0, 4, 0, 2), (100, 0, 4, 1, 2), (64, 16, 2, 3, 4), (37, 0, 5, 0, 1), (1000, 256, 8, 5, 8), (96, 192, 4, 1, 2),
+]
+
+
+def gen_samplers():
+    from src.data.data_samplers import SequentialPretrainingSampler, RandomPretrainingSampler, my_collate_fn
+    from src.data.input_specs import NLPTaskInput, RLTaskInput
+    out = {"cases": np.array(SAMPLER_CASES)}
+    for i, (tot, cons, mb, rank, world) in enumerate(SAMPLER_CASES):
+        if cons < tot:
+            s = SequentialPretrainingSampler(tot, cons, mb, rank, world)
+            out[f"seq{i}"] = np.array([b for b in s], dtype=np.int64).reshape(-1, mb)
+            s2 = SequentialPretrainingSampler(tot, cons, mb, rank, world, drop_last=False)
+            bl = [b for b in s2]
+            out[f"seq_last{i}"] = np.array(bl[-1], dtype=np.int64)
+        for sharding in (True, False):
+            r = RandomPretrainingSampler(list(range(tot)), tot, cons, mb, rank, world, sharding)
+            out[f"rand{int(sharding)}_{i}"] = np.array([b for b in r], dtype=np.int64).reshape(-1, mb)
+            out[f"rand{int(sharding)}_{i}_consumed"] = np.int64(r.consumed_samples)
+    # collate: 2 NLP + 1 RL + 1 NLP samples -> [NLP(3 rows), RL(1 row)]
+    mk = lambda v: torch.full((1, 6), v, dtype=torch.int64)
+    tasks = [NLPTaskInput(position_id=None, attention_mask=None, loss_mask=mk(1).float(), label=mk(10), text_seq=mk(11), text_len=None),
+             NLPTaskInput(position_id=None, attention_mask=None, loss_mask=mk(2).float(), label=mk(20), text_seq=mk(21), text_len=None),
+             RLTaskInput(position_id=mk(3), attention_mask=None, loss_mask=mk(3).float(), label=mk(30), text_seq=None,
+                         vision_seq=torch.full((1, 2, 3, 16, 16), 3.0), tensor_seq=mk(31)),
+             NLPTaskInput(position_id=None, attention_mask=None, loss_mask=mk(4).float(), label=mk(40), text_seq=mk(41), text_len=None)]
+    merged = my_collate_fn(tasks)
+    out["collate_types"] = np.array([type(m).__name__ for m in merged])
+    out["collate_nlp_label"] = merged[0].label.numpy()
+    out["collate_nlp_text"] = merged[0].text_seq.numpy()
+    out["collate_rl_vision_shape"] = np.array(merged[1].vision_seq.shape)
+    out["collate_rl_tensor"] = merged[1].tensor_seq.numpy()
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "samplers":
+        np.savez_compressed(os.path.join(HERE, "samplers.npz"), **gen_samplers())
+        print("wrote samplers")
+        return
     torch.manual_seed(0)
     for i, name in enumerate(CASES):
         d = gen_model_case(name, seed=100 + i)

@@ -198,3 +198,32 @@ def test_input_spec_classes_have_reference_field_names():
     x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=torch.ones(2, 3), label=torch.zeros(2, 3), text_seq=torch.zeros(2, 3), text_len=None)
     x.to(dtype=torch.float64)
     assert x.loss_mask.dtype == torch.float64
+
+
+def test_samplers_and_collate_match_reference_golden():
+    from bdm_db1_amd.data import NLPTaskInput, RLTaskInput
+    from bdm_db1_amd.data.samplers import RandomPretrainingSampler, SequentialPretrainingSampler, my_collate_fn
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "samplers.npz")))
+    for i, (tot, cons, mb, rank, world) in enumerate(gold["cases"].tolist()):
+        if cons < tot:
+            got = np.array(list(SequentialPretrainingSampler(tot, cons, mb, rank, world)), dtype=np.int64).reshape(-1, mb)
+            assert np.array_equal(got, gold[f"seq{i}"]), ("seq", i)
+            last = list(SequentialPretrainingSampler(tot, cons, mb, rank, world, drop_last=False))[-1]
+            assert np.array_equal(np.array(last, dtype=np.int64), gold[f"seq_last{i}"]), ("seq_last", i)
+        for sharding in (True, False):
+            s = RandomPretrainingSampler(list(range(tot)), tot, cons, mb, rank, world, sharding)
+            got = np.array(list(s), dtype=np.int64).reshape(-1, mb)
+            assert np.array_equal(got, gold[f"rand{int(sharding)}_{i}"]), ("rand", sharding, i)
+            assert s.consumed_samples == int(gold[f"rand{int(sharding)}_{i}_consumed"])
+    mk = lambda v: torch.full((1, 6), v, dtype=torch.int64)
+    tasks = [NLPTaskInput(position_id=None, attention_mask=None, loss_mask=mk(1).float(), label=mk(10), text_seq=mk(11), text_len=None),
+             NLPTaskInput(position_id=None, attention_mask=None, loss_mask=mk(2).float(), label=mk(20), text_seq=mk(21), text_len=None),
+             RLTaskInput(position_id=mk(3), attention_mask=None, loss_mask=mk(3).float(), label=mk(30), text_seq=None,
+                         vision_seq=torch.full((1, 2, 3, 16, 16), 3.0), tensor_seq=mk(31)),
+             NLPTaskInput(position_id=None, attention_mask=None, loss_mask=mk(4).float(), label=mk(40), text_seq=mk(41), text_len=None)]
+    merged = my_collate_fn(tasks)
+    assert [type(m).__name__ for m in merged] == gold["collate_types"].tolist()
+    assert np.array_equal(merged[0].label.numpy(), gold["collate_nlp_label"])
+    assert np.array_equal(merged[0].text_seq.numpy(), gold["collate_nlp_text"])
+    assert list(merged[1].vision_seq.shape) == gold["collate_rl_vision_shape"].tolist()
+    assert np.array_equal(merged[1].tensor_seq.numpy(), gold["collate_rl_tensor"])
