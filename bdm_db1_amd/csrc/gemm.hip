@@ -167,6 +167,8 @@ static void launch_tile(const GemmTileArgs& t, int dtC, int dtBias, dim3 grid, h
 
 static int g_force_generic = 0;
 extern "C" void db1_gemm_force_generic(int on) { g_force_generic = on; }
+static int g_tile_pref = -1;  // -1: read DB1_GEMM_TILE on first use; 0: measured heuristics; 128 / 256 / 512: pin that tile kernel
+extern "C" void db1_gemm_tile_override(int tile) { g_tile_pref = tile; }
 
 extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int dtA, int dtB,
                                 int dtC, int dtBias, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs,
@@ -189,10 +191,15 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
         t.M = M; t.N = N; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = c_rs;
         t.batch1 = batch1; t.a_bs0 = a_bs0; t.a_bs1 = a_bs1; t.b_bs0 = b_bs0; t.b_bs1 = b_bs1; t.c_bs0 = c_bs0; t.c_bs1 = c_bs1;
         t.alpha = alpha; t.beta = beta; t.tiles_m = (M + TBM - 1) / TBM; t.tiles_n = (N + TBN - 1) / TBN;
-        // measured on MI355X at the DB1-1.3B shapes (tools/bench_kernels.py gemm): the 3-stage 256x128 kernel wins for the
-        // transposed-operand forms (NN +3..17 %, TN +4..8 %), the 2-stage 128x128 kernel for NT.  DB1_GEMM_TILE=128|256 pins one.
-        static int tile_pref = -1;
-        if (tile_pref < 0) { const char* e = getenv("DB1_GEMM_TILE"); tile_pref = e ? atoi(e) : 0; }
+        // measured on MI355X at the DB1-1.3B shapes (tools/bench_kernels.py gemm; table in DESIGN.md): the 256x256 ping-pong
+        // kernel wins by 15-35 % wherever it has >= ~160 output tiles to spread over the 256 CUs; below that the 3-stage
+        // 256x128 kernel wins for the transposed-operand forms and the 2-stage 128x128 kernel for NT / small outputs.
+        // DB1_GEMM_TILE=128|256|512 pins one.
+        if (g_tile_pref < 0) { const char* e = getenv("DB1_GEMM_TILE"); g_tile_pref = e ? atoi(e) : 0; }
+        const int tile_pref = g_tile_pref;
+        if ((M % 256) == 0 && (N % 256) == 0 &&
+            (tile_pref == 512 || (tile_pref == 0 && (int64_t)(M / 256) * (N / 256) * batch >= 160)))
+            return db1_gemm_pp_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
         const bool want256 = tile_pref == 256 || (tile_pref != 128 && fb == 1);
         if (want256 && (M % 256) == 0 && (N % TBN) == 0) return db1_gemm_tile256_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
         // split-K for small outputs with a very long contraction (weight gradients of the 64-channel patch convolutions:

@@ -266,3 +266,8 @@ def mulaw_discretize(x, ids, is_action, num_bins=1024, mu=100.0, M=256.0):
 
 def gemm_force_generic(on: bool):
     lib.load().db1_gemm_force_generic(1 if on else 0)
+
+
+def gemm_tile_override(tile: int):
+    """0 = measured heuristics; 128 / 256 / 512 pin one bf16 tile kernel (tests, tuning)."""
+    lib.load().db1_gemm_tile_override(int(tile))

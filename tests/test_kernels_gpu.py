@@ -112,6 +112,31 @@ def test_gemm_bf16_tile_kernels(ops, form, out_dtype):
     close(out2, ref, 2e-6 if out_dtype == "f32" else 6e-3, name=f"strided gemm {form} {out_dtype}")
 
 
+@pytest.mark.parametrize("form", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("tile", [256, 512])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 320), (768, 512, 1024)])
+def test_gemm_bf16_large_tile_kernels(ops, form, tile, M, N, K):
+    """the 256x128 3-stage and 256x256 ping-pong kernels, pinned through the ABI hook: 1, odd and even k-tile counts"""
+    rng = np.random.default_rng(7)
+    A = bf(rng.standard_normal((M, K)))
+    B = bf(rng.standard_normal((K, N)))
+    a_store = dev(A if form != "tn" else A.T.copy(), torch.bfloat16)
+    b_store = dev(B.T.copy() if form == "nt" else B, torch.bfloat16)
+    a = a_store if form != "tn" else a_store.t()
+    b = b_store.t() if form == "nt" else b_store
+    bias = bf(rng.standard_normal(N))
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    ops.gemm_tile_override(tile)
+    try:
+        for od, tol in ((torch.float32, 2e-6), (torch.bfloat16, 6e-3)):
+            c0 = bf(C0) if od == torch.bfloat16 else C0
+            out = dev(c0, od)
+            ops.gemm(a, b, out, bias=dev(bias, torch.bfloat16), alpha=0.5, beta=1.0)
+            close(out, 0.5 * A @ B + c0 + bias, tol, name=f"tile{tile} gemm {form} {od}")
+    finally:
+        ops.gemm_tile_override(0)
+
+
 @pytest.mark.parametrize("form,M,N,K", [("nt", 200, 72, 128), ("nn", 328, 576, 64), ("tn", 72, 200, 192), ("nt", 1568, 2048, 256), ("tn", 576, 64, 512)])
 def test_gemm_bf16_tile_tails(ops, form, M, N, K):
     """ragged M / N (image-patch counts, 64-channel convolutions) stay on the MFMA tile kernel: clamped loads, masked stores"""
