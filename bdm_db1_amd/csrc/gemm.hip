@@ -200,7 +200,9 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
         if ((M % 256) == 0 && (N % 256) == 0 &&
             (tile_pref == 512 || (tile_pref == 0 && (int64_t)(M / 256) * (N / 256) * batch >= 160)))
             return db1_gemm_pp_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
-        const bool want256 = tile_pref == 256 || (tile_pref != 128 && fb == 1);
+        // (measured: routing the under-filled transposed-operand cases -- o_net dW on 128 workgroups, the per-head dR on 64 --
+        // to the 128x128 kernel for more workgroups made them 15-20 % slower, so form alone decides)
+        const bool want256 = tile_pref == 256 || (tile_pref == 0 && fb == 1);
         if (want256 && (M % 256) == 0 && (N % TBN) == 0) return db1_gemm_tile256_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
         // split-K for small outputs with a very long contraction (weight gradients of the 64-channel patch convolutions:
         // 64 x 576 outputs over 1.9 M rows would otherwise occupy 5 of 256 CUs)

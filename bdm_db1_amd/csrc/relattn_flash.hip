@@ -50,9 +50,25 @@ __device__ __forceinline__ int crow(int r, int hb) { return (r & 3) + 8 * (r >> 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 // one 1 KiB global_load_lds piece = 4 rows of 256 B; lane -> (row = lane >> 4, chunk position = lane & 15)
+// The LDS-DMA is issued from inline asm on purpose: with the builtin, hipcc knows an LDS write is pending on vmcnt and puts
+// `s_waitcnt vmcnt(0)` in front of the first LDS access it cannot disambiguate (the tr reads of V / K, the scratch writes
+// of the backward kernels), i.e. the prefetch of the NEXT block was drained in the middle of (bwd_kv: at the start of) the
+// current one.  The kernels wait for their own prefetch explicitly (vmcnt(0) + barrier at the end of every block).
 __device__ __forceinline__ void glds_row(const bf16_t* row_ptr, int row_for_swz, char* lds_piece, int lane) {
     const int c = (lane & 15) ^ swz(row_for_swz);
-    __builtin_amdgcn_global_load_lds(row_ptr + c * 8, LDS_PTR(void, lds_piece), 16, 0, 0);
+    const bf16_t* src = row_ptr + c * 8;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(char, lds_piece));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+// {lse[i0 .. i0+32), delta[i0 .. i0+32)} -> 64 floats in LDS, one 4-byte LDS-DMA per lane of ONE wave
+__device__ __forceinline__ void glds_stat(const float* lse, const float* delta, int i0, float* dst_lds, int lane) {
+    const float* src = (lane < 32 ? lse : delta - 32) + i0 + lane;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(float, dst_lds));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 // stage a [32][128] bf16 tile whose global rows are row0 .. row0+31 (stride rs): 8 pieces, 2 per wave
 __device__ __forceinline__ void stage_tile32(const bf16_t* g, int64_t rs, int row0, char* tile, int wave, int lane) {
@@ -231,6 +247,7 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
     for (int db = 0; db < 4; db++) zero16(acc_o[db]);
     const float c2 = p.scale * LOG2E;
     float m_i = -1.0e30f, l_i = 0.f;  // m_i in RAW score units (before the 1/sqrt(d) scale)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as a builtin so that hipcc's own bookkeeping sees the fragment loads retired
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -360,6 +377,7 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
     f32x16 acc_dq[4];
 #pragma unroll
     for (int db = 0; db < 4; db++) zero16(acc_dq[db]);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as a builtin so that hipcc's own bookkeeping sees the fragment loads retired
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -428,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
 #define KV_OFF_QU 0                          // two stages of 8 KiB each for Qu, Qv, dO
 #define KV_OFF_QV 16384
 #define KV_OFF_DO 32768
-#define KV_OFF_ST 49152                      // two stages of {lse[32], delta[32]} floats
+#define KV_OFF_ST 49152                      // two stages of {lse[32], delta[32]} floats (raw, via LDS-DMA)
 #define KV_OFF_R 49664
 #define KV_OFF_T (KV_OFF_R + FA_RING * 256)
 #define KV_LDS_BYTES (KV_OFF_T + 4 * FA_TW_BYTES)
@@ -475,11 +493,11 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_kv_kernel(FlashArgs 
     stage_tile32(qu, HD, ib_lo * FA_BK, Qus0, wave, lane);
     stage_tile32(qv, HD, ib_lo * FA_BK, Qvs0, wave, lane);
     stage_tile32(dog, HD, ib_lo * FA_BK, dOs0, wave, lane);
-    if (tid < 32) stat0[tid] = -lseg[ib_lo * FA_BK + tid] * LOG2E;
-    else if (tid < 64) stat0[tid] = delg[ib_lo * FA_BK + tid - 32];
+    if (wave == 0) glds_stat(lseg, delg, ib_lo * FA_BK, stat0, lane);
     f32x16 acc_dk[4], acc_dv[4];
 #pragma unroll
     for (int db = 0; db < 4; db++) { zero16(acc_dk[db]); zero16(acc_dv[db]); }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as a builtin so that hipcc's own bookkeeping sees the fragment loads retired
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -496,9 +514,7 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_kv_kernel(FlashArgs 
             stage_tile32(qv, HD, nx, Qvs0 + (cur ^ 1) * 8192, wave, lane);
             stage_tile32(dog, HD, nx, dOs0 + (cur ^ 1) * 8192, wave, lane);
             stage_ring32(Rg, HD, nx - j0, L, Rr, wave, lane);
-            float* sn = stat0 + (cur ^ 1) * 64;
-            if (tid < 32) sn[tid] = -lseg[nx + tid] * LOG2E;
-            else if (tid < 64) sn[tid] = delg[nx + tid - 32];
+            if (wave == 0) glds_stat(lseg, delg, nx, stat0 + (cur ^ 1) * 64, lane);
         }
         if (!(i0q + 31 < kw || i0q >= kw + 31 + p.shift)) {  // some (i, j) of this block pair is visible
             f32x16 acc_s, acc_dp;
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_kv_kernel(FlashArgs 
 #pragma unroll
             for (int r = 0; r < 16; r++) {  // this lane: key kw + a; register r: query i0q + crow(r, hb)
                 const int q8 = (r & 3) + 8 * (r >> 2);
-                pr[r] = __builtin_amdgcn_exp2f(fmaf(acc_s[r] + twr[q8 * 65], c2, stat[q8]));
+                pr[r] = __builtin_amdgcn_exp2f(fmaf(acc_s[r] + twr[q8 * 65], c2, -LOG2E * stat[q8]));
             }
             if (i0q < kw + 31 || i0q + 31 >= kw + p.shift) {  // diagonal / window-edge block pairs need the element mask
 #pragma unroll

@@ -138,7 +138,7 @@ class TransformerXL(nn.Module):
             compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[compute_dtype]
         assert compute_dtype in (torch.float32, torch.bfloat16)
         self.compute_dtype = compute_dtype
-        self.vocab_pad = _round_up(self.total_vocab_size, 128)
+        self.vocab_pad = _round_up(self.total_vocab_size, 256)  # whole 256x256 GEMM tiles for the tied head
         self.keep_logits = True          # False: the CE backward overwrites the logits buffer (training engines)
         self.use_flash = True            # fused attention when the shape is supported
         self.use_flash_bwd = True        # fused backward kernels (False: recompute through the materialised path)
