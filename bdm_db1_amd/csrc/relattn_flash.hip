@@ -199,6 +199,26 @@ __device__ __forceinline__ void rel_band_to_lds(const bf16x8_t* fa_regs, const c
         for (int r = 0; r < 16; r++) tw[((r & 3) + 8 * (r >> 2)) * 64 + 32 * blk] = acc_t[r];
     }
 }
+// Workgroup id -> (tile rank, head, batch).  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin and a free
+// CU takes the next id, so the id order is the schedule:
+//   * all tiles of one (batch, head) are given ids of ONE XCD, so its K / V / Q rows are shared in that XCD's L2;
+//   * inside a chunk of 4 (batch, head) pairs per XCD (= 256 workgroups chip-wide at L = 1024) the ids go heaviest tile first
+//     (rank 0 = the tile with the longest loop), so the light tiles fill the tail instead of one 32-block tile ending alone.
+// returns false for the padding ids of a ragged last chunk
+__device__ __forceinline__ bool flash_wg_coords(int ntile, int H, int B, int& rank, int& h, int& b) {
+    const int i = blockIdx.x, xcd = i & 7, j = i >> 3;
+    const int per_chunk = 4 * ntile, chunk = j / per_chunk, jl = j % per_chunk;
+    rank = jl >> 2;
+    const int bh = (chunk * 4 + (jl & 3)) * 8 + xcd;
+    if (bh >= B * H) return false;
+    h = bh % H;
+    b = bh / H;
+    return true;
+}
+static unsigned flash_grid(int ntile, int H, int B) {
+    const int per_xcd = (B * H + 7) / 8, chunks = (per_xcd + 3) / 4;
+    return (unsigned)(8 * chunks * 4 * ntile);
+}
 #define LOG2E 1.4426950408889634f
 
 // ======================================================================================= forward
@@ -211,8 +231,9 @@ __device__ __forceinline__ void rel_band_to_lds(const bf16x8_t* fa_regs, const c
 __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qt = p.L / FA_BQ - 1 - (int)blockIdx.x;  // heavy (late) query tiles first
-    const int h = blockIdx.y, b = blockIdx.z;
+    int rank, h, b;
+    if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, rank, h, b)) return;
+    const int qt = p.L / FA_BQ - 1 - rank;  // late query tiles have the longest key loops
     const int H = p.H, L = p.L, HD = H * FA_D;
     const int i0 = qt * FA_BQ, iw = i0 + 32 * wave;
     const int a = lane & 31, hb = lane >> 5;
@@ -262,11 +283,48 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
             stage_ring32(Rg, HD, i0 - j0 - 64, L, Rr, wave, lane);
         }
         if (!(j0 > iw + 31 || j0 + 31 <= iw - p.shift)) {  // wave-uniform: skip blocks entirely outside this wave's window
-            f32x16 acc_s;
-            zero16(acc_s);
+            // ONE wave per SIMD: nothing but this wave's own instruction order hides an LDS round trip or a dependent-MFMA
+            // bubble, and hipcc re-serialises plain LDS reads (3 in flight).  The fragment reads are therefore inline asm in a
+            // fixed order with counted lgkmcnt waits: K and low-band R fragments up front, the high-band R fragments into the K
+            // registers as those are consumed, the V^T fragments into the low-band registers during the last (dependent) chain.
+            const unsigned k_base = (unsigned)(size_t)LDS_PTR(char, const_cast<char*>(Ks));
+            const unsigned v_base = (unsigned)(size_t)LDS_PTR(char, const_cast<char*>(Vs));
+            const unsigned r_base = (unsigned)(size_t)LDS_PTR(char, Rr);
+            const unsigned rr0 = (unsigned)(((iw - j0 - 31 + a) & (FA_RING - 1)) << 8);
+            const unsigned rrow0 = r_base + rr0, rrow1 = r_base + ((rr0 + 8192) & (FA_RING * 256 - 1));
+            bf16x8_t kf[8], rf[8];
 #pragma unroll
-            for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(rowf(Ks, offs, ks), fqu[ks], acc_s);  // S^T[key][query]
-            rel_band_to_lds<true>(fqv, nullptr, offs, Rr, iw - j0 - 31, Tw, lane);
+            for (int ks = 0; ks < 8; ks++) {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(kf[ks]) : "v"(k_base + offs.row[ks]));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(rf[ks]) : "v"(rrow0 + offs.ring[ks]));
+            }
+            f32x16 acc_s, acc_t0, acc_t1;
+            zero16(acc_s);
+            zero16(acc_t0);
+            zero16(acc_t1);
+#define FA_WAIT_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define FA_STEP1(ks, n)                                                                                              \
+    FA_WAIT_LGKM(n);                                                                                                 \
+    acc_s = MFMA32(kf[ks], fqu[ks], acc_s);     /* S^T[key][query] */                                                \
+    acc_t0 = MFMA32(fqv[ks], rf[ks], acc_t0);   /* T[query][dist], distances 0..31 of the band */                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(kf[ks]) : "v"(rrow1 + offs.ring[ks]));  /* high band -> K registers */
+            // outstanding before step ks: 16 - 2 ks of the first batch + ks of the second; the pair (kf[ks], rf[ks]) is the oldest
+            FA_STEP1(0, 14) FA_STEP1(1, 13) FA_STEP1(2, 12) FA_STEP1(3, 11) FA_STEP1(4, 10) FA_STEP1(5, 9) FA_STEP1(6, 8) FA_STEP1(7, 7)
+#define FA_STEP2(ks, n)                                                                                              \
+    FA_WAIT_LGKM(n);                                                                                                 \
+    acc_t1 = MFMA32(fqv[ks], kf[ks], acc_t1);   /* distances 32..63 */                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=v"(vlo[ks]), "=v"(vhi[ks])           \
+                 : "v"(v_base + offs.tr[ks >> 1][0] + (ks & 1) * 4096), "v"(v_base + offs.tr[ks >> 1][1] + (ks & 1) * 4096));
+            bf16x4_t vlo[8], vhi[8];  // V^T fragments: index 2 * db + (rows 16..31 ? 1 : 0)
+            // outstanding before step ks: (8 - ks) high-band reads + 2 ks tr reads; kf[ks] is the oldest
+            FA_STEP2(0, 7) FA_STEP2(1, 8) FA_STEP2(2, 9) FA_STEP2(3, 10) FA_STEP2(4, 11) FA_STEP2(5, 12) FA_STEP2(6, 13) FA_STEP2(7, 14)
+            {
+                float* tw = Tw + hb * 256 + a;
+#pragma unroll
+                for (int r = 0; r < 16; r++) { tw[((r & 3) + 8 * (r >> 2)) * 64] = acc_t0[r]; tw[((r & 3) + 8 * (r >> 2)) * 64 + 32] = acc_t1[r]; }
+            }
             float s[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) s[r] = acc_s[r] + twr[-((r & 3) + 8 * (r >> 2))];  // this lane: query iw+a; register r: key j0+crow(r,hb)
@@ -299,9 +357,11 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
             l_i += rs;
             const bf16x8_t pb0 = pack8(s), pb1 = pack8(s + 8);
 #pragma unroll
+            FA_WAIT_LGKM(0);  // the V^T fragments (requested before the skew round trip and the softmax)
+#pragma unroll
             for (int db = 0; db < 4; db++) {  // O^T[d][query] += V^T . P^T
-                acc_o[db] = MFMA32(trf(Vs, offs, 0, db), pb0, acc_o[db]);
-                acc_o[db] = MFMA32(trf(Vs, offs, 16, db), pb1, acc_o[db]);
+                acc_o[db] = MFMA32(__builtin_shufflevector(vlo[2 * db], vhi[2 * db], 0, 1, 2, 3, 4, 5, 6, 7), pb0, acc_o[db]);
+                acc_o[db] = MFMA32(__builtin_shufflevector(vlo[2 * db + 1], vhi[2 * db + 1], 0, 1, 2, 3, 4, 5, 6, 7), pb1, acc_o[db]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -338,8 +398,9 @@ __global__ __launch_bounds__(256) void relattn_delta_kernel(const bf16_t* __rest
 __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qt = p.L / FA_BQ - 1 - (int)blockIdx.x;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int rank, h, b;
+    if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, rank, h, b)) return;
+    const int qt = p.L / FA_BQ - 1 - rank;
     const int H = p.H, L = p.L, HD = H * FA_D;
     const int i0 = qt * FA_BQ, iw = i0 + 32 * wave;
     const int a = lane & 31, hb = lane >> 5;
@@ -454,8 +515,8 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
 __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_kv_kernel(FlashArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kt = blockIdx.x;  // early key tiles see the most queries and are dispatched first
-    const int h = blockIdx.y, b = blockIdx.z;
+    int kt, h, b;  // early key tiles see the most queries: rank == tile index
+    if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, kt, h, b)) return;
     const int H = p.H, L = p.L, HD = H * FA_D;
     const int j0 = kt * FA_BQ, kw = j0 + 32 * wave;
     const int a = lane & 31, hb = lane >> 5;   // a = key column of this lane
@@ -588,7 +649,7 @@ extern "C" int db1_relattn_flash_fwd(const void* qu, const void* qv, const void*
     if (!db1_aligned16(out)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_flash_fwd: out alignment");
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)relattn_flash_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES); attr = true; }
-    dim3 grid((unsigned)(L / FA_BQ), (unsigned)H, (unsigned)B);
+    dim3 grid(flash_grid(L / FA_BQ, H, B));
     relattn_flash_fwd_kernel<<<grid, 256, FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_fwd");
     return DB1_OK;
@@ -619,7 +680,7 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
     const int64_t n_rows = (int64_t)B * L * H;
     relattn_delta_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, s>>>(a.out, a.dout, delta, n_rows, L, H);
     DB1_CHECK_LAUNCH("relattn_delta");
-    dim3 grid((unsigned)(L / FA_BQ), (unsigned)H, (unsigned)B);
+    dim3 grid(flash_grid(L / FA_BQ, H, B));
     relattn_flash_bwd_q_kernel<<<grid, 256, FWD_LDS_BYTES, s>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_bwd_q");
     relattn_flash_bwd_kv_kernel<<<grid, 256, KV_LDS_BYTES, s>>>(a);
