@@ -283,48 +283,11 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
             stage_ring32(Rg, HD, i0 - j0 - 64, L, Rr, wave, lane);
         }
         if (!(j0 > iw + 31 || j0 + 31 <= iw - p.shift)) {  // wave-uniform: skip blocks entirely outside this wave's window
-            // ONE wave per SIMD: nothing but this wave's own instruction order hides an LDS round trip or a dependent-MFMA
-            // bubble, and hipcc re-serialises plain LDS reads (3 in flight).  The fragment reads are therefore inline asm in a
-            // fixed order with counted lgkmcnt waits: K and low-band R fragments up front, the high-band R fragments into the K
-            // registers as those are consumed, the V^T fragments into the low-band registers during the last (dependent) chain.
-            const unsigned k_base = (unsigned)(size_t)LDS_PTR(char, const_cast<char*>(Ks));
-            const unsigned v_base = (unsigned)(size_t)LDS_PTR(char, const_cast<char*>(Vs));
-            const unsigned r_base = (unsigned)(size_t)LDS_PTR(char, Rr);
-            const unsigned rr0 = (unsigned)(((iw - j0 - 31 + a) & (FA_RING - 1)) << 8);
-            const unsigned rrow0 = r_base + rr0, rrow1 = r_base + ((rr0 + 8192) & (FA_RING * 256 - 1));
-            bf16x8_t kf[8], rf[8];
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) {
-                asm volatile("ds_read_b128 %0, %1" : "=v"(kf[ks]) : "v"(k_base + offs.row[ks]));
-                asm volatile("ds_read_b128 %0, %1" : "=v"(rf[ks]) : "v"(rrow0 + offs.ring[ks]));
-            }
-            f32x16 acc_s, acc_t0, acc_t1;
+            f32x16 acc_s;
             zero16(acc_s);
-            zero16(acc_t0);
-            zero16(acc_t1);
-#define FA_WAIT_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define FA_STEP1(ks, n)                                                                                              \
-    FA_WAIT_LGKM(n);                                                                                                 \
-    acc_s = MFMA32(kf[ks], fqu[ks], acc_s);     /* S^T[key][query] */                                                \
-    acc_t0 = MFMA32(fqv[ks], rf[ks], acc_t0);   /* T[query][dist], distances 0..31 of the band */                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                               \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(kf[ks]) : "v"(rrow1 + offs.ring[ks]));  /* high band -> K registers */
-            // outstanding before step ks: 16 - 2 ks of the first batch + ks of the second; the pair (kf[ks], rf[ks]) is the oldest
-            FA_STEP1(0, 14) FA_STEP1(1, 13) FA_STEP1(2, 12) FA_STEP1(3, 11) FA_STEP1(4, 10) FA_STEP1(5, 9) FA_STEP1(6, 8) FA_STEP1(7, 7)
-#define FA_STEP2(ks, n)                                                                                              \
-    FA_WAIT_LGKM(n);                                                                                                 \
-    acc_t1 = MFMA32(fqv[ks], kf[ks], acc_t1);   /* distances 32..63 */                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                               \
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=v"(vlo[ks]), "=v"(vhi[ks])           \
-                 : "v"(v_base + offs.tr[ks >> 1][0] + (ks & 1) * 4096), "v"(v_base + offs.tr[ks >> 1][1] + (ks & 1) * 4096));
-            bf16x4_t vlo[8], vhi[8];  // V^T fragments: index 2 * db + (rows 16..31 ? 1 : 0)
-            // outstanding before step ks: (8 - ks) high-band reads + 2 ks tr reads; kf[ks] is the oldest
-            FA_STEP2(0, 7) FA_STEP2(1, 8) FA_STEP2(2, 9) FA_STEP2(3, 10) FA_STEP2(4, 11) FA_STEP2(5, 12) FA_STEP2(6, 13) FA_STEP2(7, 14)
-            {
-                float* tw = Tw + hb * 256 + a;
 #pragma unroll
-                for (int r = 0; r < 16; r++) { tw[((r & 3) + 8 * (r >> 2)) * 64] = acc_t0[r]; tw[((r & 3) + 8 * (r >> 2)) * 64 + 32] = acc_t1[r]; }
-            }
+            for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(rowf(Ks, offs, ks), fqu[ks], acc_s);  // S^T[key][query]
+            rel_band_to_lds<true>(fqv, nullptr, offs, Rr, iw - j0 - 31, Tw, lane);
             float s[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) s[r] = acc_s[r] + twr[-((r & 3) + 8 * (r >> 2))];  // this lane: query iw+a; register r: key j0+crow(r,hb)
@@ -357,11 +320,9 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
             l_i += rs;
             const bf16x8_t pb0 = pack8(s), pb1 = pack8(s + 8);
 #pragma unroll
-            FA_WAIT_LGKM(0);  // the V^T fragments (requested before the skew round trip and the softmax)
-#pragma unroll
             for (int db = 0; db < 4; db++) {  // O^T[d][query] += V^T . P^T
-                acc_o[db] = MFMA32(__builtin_shufflevector(vlo[2 * db], vhi[2 * db], 0, 1, 2, 3, 4, 5, 6, 7), pb0, acc_o[db]);
-                acc_o[db] = MFMA32(__builtin_shufflevector(vlo[2 * db + 1], vhi[2 * db + 1], 0, 1, 2, 3, 4, 5, 6, 7), pb1, acc_o[db]);
+                acc_o[db] = MFMA32(trf(Vs, offs, 0, db), pb0, acc_o[db]);
+                acc_o[db] = MFMA32(trf(Vs, offs, 16, db), pb1, acc_o[db]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
