@@ -124,6 +124,59 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tile_kernel(GemmTileArgs p) 
     }
 }
 
+// ---- deterministic split-K for outputs too small to fill the chip (o_net / ff2 weight gradients, the per-head dR of the
+// relative-position attention): the contraction is cut into S slices that run as an extra batch dimension of the SAME tile
+// kernels (operand base pointers advance by K/S per slice, no kernel change), each writing an fp32 partial into a workspace;
+// splitk_reduce_kernel then adds the partials in a fixed order, so results do not depend on scheduling (no atomics).
+template <typename TC, typename TBIAS>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, TC* __restrict__ C, const TBIAS* __restrict__ bias, int M, int N,
+                                                            int S, int64_t ldc, int64_t c_bs0, float beta) {
+    const int nq = N >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * nq) return;
+    const int m = (int)(idx / nq), n = (int)(idx % nq) * 4;
+    const int b0 = blockIdx.y;
+    const float* w = ws + ((int64_t)b0 * S * M + m) * N + n;
+    float4 acc = *reinterpret_cast<const float4*>(w);
+    for (int z = 1; z < S; z++) {
+        const float4 v = *reinterpret_cast<const float4*>(w + (int64_t)z * M * N);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (bias) { acc.x += ldf(bias + n); acc.y += ldf(bias + n + 1); acc.z += ldf(bias + n + 2); acc.w += ldf(bias + n + 3); }
+    TC* c = C + (int64_t)b0 * c_bs0 + (int64_t)m * ldc + n;
+    if (sizeof(TC) == 4) {
+        if (beta != 0.f) {
+            const float4 o = *reinterpret_cast<const float4*>(c);
+            acc.x += beta * o.x; acc.y += beta * o.y; acc.z += beta * o.z; acc.w += beta * o.w;
+        }
+        *reinterpret_cast<float4*>(c) = acc;
+    } else {
+        if (beta != 0.f) {
+            const uint2 o = *reinterpret_cast<const uint2*>(c);
+            acc.x += beta * __uint_as_float(o.x << 16); acc.y += beta * __uint_as_float(o.x & 0xffff0000u);
+            acc.z += beta * __uint_as_float(o.y << 16); acc.w += beta * __uint_as_float(o.y & 0xffff0000u);
+        }
+        uint2 o;
+        o.x = (unsigned)f2bf(acc.x) | ((unsigned)f2bf(acc.y) << 16);
+        o.y = (unsigned)f2bf(acc.z) | ((unsigned)f2bf(acc.w) << 16);
+        *reinterpret_cast<uint2*>(c) = o;
+    }
+}
+// grow-only partial-sum workspace.  One per process: the library serialises its GEMMs on the caller's stream (the model
+// and the engine use a single compute stream), which is what makes reuse across calls safe.
+static float* g_splitk_ws = nullptr;
+static size_t g_splitk_ws_bytes = 0;
+static float* splitk_workspace(size_t bytes) {
+    if (bytes > g_splitk_ws_bytes) {
+        if (g_splitk_ws) { hipDeviceSynchronize(); hipFree(g_splitk_ws); }
+        g_splitk_ws = nullptr;
+        g_splitk_ws_bytes = 0;
+        if (hipMalloc((void**)&g_splitk_ws, bytes) != hipSuccess) return nullptr;
+        g_splitk_ws_bytes = bytes;
+    }
+    return g_splitk_ws;
+}
+
 // storage form of an operand from its strides: returns 0 = K-major, 1 = M-major, -1 = neither
 static int operand_form(int64_t row_stride, int64_t k_stride, int64_t* ld) {
     if (k_stride == 1 && row_stride >= 1) { *ld = row_stride; return 0; }
@@ -167,6 +220,7 @@ static void launch_tile(const GemmTileArgs& t, int dtC, int dtBias, dim3 grid, h
 
 static int g_force_generic = 0;
 extern "C" void db1_gemm_force_generic(int on) { g_force_generic = on; }
+static int g_splitk = 1;      // DB1_GEMM_SPLITK=0 disables the workspace split-K (A/B measurements)
 static int g_tile_pref = -1;  // -1: read DB1_GEMM_TILE on first use; 0: measured heuristics; 128 / 256 / 512: pin that tile kernel
 extern "C" void db1_gemm_tile_override(int tile) { g_tile_pref = tile; }
 
@@ -195,15 +249,44 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
         // kernel wins by 15-35 % wherever it has >= ~160 output tiles to spread over the 256 CUs; below that the 3-stage
         // 256x128 kernel wins for the transposed-operand forms and the 2-stage 128x128 kernel for NT / small outputs.
         // DB1_GEMM_TILE=128|256|512 pins one.
-        if (g_tile_pref < 0) { const char* e = getenv("DB1_GEMM_TILE"); g_tile_pref = e ? atoi(e) : 0; }
+        if (g_tile_pref < 0) {
+            const char* e = getenv("DB1_GEMM_TILE"); g_tile_pref = e ? atoi(e) : 0;
+            const char* k = getenv("DB1_GEMM_SPLITK"); if (k) g_splitk = atoi(k);
+        }
         const int tile_pref = g_tile_pref;
-        if ((M % 256) == 0 && (N % 256) == 0 &&
-            (tile_pref == 512 || (tile_pref == 0 && (int64_t)(M / 256) * (N / 256) * batch >= 160)))
+        const bool pp_shape = (M % 256) == 0 && (N % 256) == 0, t256_shape = (M % 256) == 0 && (N % TBN) == 0;
+        // deterministic split-K (see splitk_reduce_kernel): only when the big-tile kernels would leave most CUs idle
+        if (tile_pref == 0 && g_splitk && batch1 == 1 && (pp_shape || (t256_shape && fb == 1)) && c_cs == 1) {
+            const int64_t wg = pp_shape ? (int64_t)(M / 256) * (N / 256) * batch : (int64_t)(M / 256) * (N / TBN) * batch;
+            int S = 0;
+            for (int cand = 8; cand >= 2; cand >>= 1)
+                if (wg * cand <= 288 && (K / TBK) % cand == 0 && (K / TBK) / cand >= 32) { S = cand; break; }
+            if (S && wg <= 96 && (!pp_shape || wg * S >= 160)) {  // measured: 128 tiles x 2 slices (ff2 dW) gains nothing
+                float* ws = splitk_workspace((size_t)batch * S * M * N * sizeof(float));
+                if (!ws) DB1_FAIL(DB1_ERR_HIP, "gemm: cannot allocate %zu bytes of split-K workspace", (size_t)batch * S * M * N * sizeof(float));
+                GemmTileArgs u = t;
+                const int64_t kc = K / S;
+                u.K = (int)kc; u.C = ws; u.bias = nullptr; u.beta = 0.f; u.ldc = N;
+                u.batch1 = S; u.a_bs1 = fa == 0 ? kc : kc * lda; u.b_bs1 = fb == 0 ? kc : kc * ldb;
+                u.c_bs0 = (int64_t)S * M * N; u.c_bs1 = (int64_t)M * N;
+                int rc = pp_shape ? db1_gemm_pp_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st)
+                                  : db1_gemm_tile256_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st);
+                if (rc) return rc;
+                dim3 rg((unsigned)(((int64_t)M * (N / 4) + 255) / 256), (unsigned)batch);
+#define RED(TC, TB) splitk_reduce_kernel<TC, TB><<<rg, 256, 0, st>>>(ws, (TC*)C, (const TB*)bias, M, N, S, c_rs, c_bs0, beta)
+                if (dtC == DB1_F32) { if (dtBias == DB1_BF16) RED(float, bf16_t); else RED(float, float); }
+                else { if (dtBias == DB1_BF16) RED(bf16_t, bf16_t); else RED(bf16_t, float); }
+#undef RED
+                DB1_CHECK_LAUNCH("splitk_reduce");
+                return DB1_OK;
+            }
+        }
+        if (pp_shape && (tile_pref == 512 || (tile_pref == 0 && (int64_t)(M / 256) * (N / 256) * batch >= 160)))
             return db1_gemm_pp_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
         // (measured: routing the under-filled transposed-operand cases -- o_net dW on 128 workgroups, the per-head dR on 64 --
         // to the 128x128 kernel for more workgroups made them 15-20 % slower, so form alone decides)
         const bool want256 = tile_pref == 256 || (tile_pref == 0 && fb == 1);
-        if (want256 && (M % 256) == 0 && (N % TBN) == 0) return db1_gemm_tile256_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
+        if (want256 && t256_shape) return db1_gemm_tile256_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
         // split-K for small outputs with a very long contraction (weight gradients of the 64-channel patch convolutions:
         // 64 x 576 outputs over 1.9 M rows would otherwise occupy 5 of 256 CUs)
         t.ksplit = 1;

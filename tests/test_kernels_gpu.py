@@ -137,6 +137,40 @@ def test_gemm_bf16_large_tile_kernels(ops, form, tile, M, N, K):
         ops.gemm_tile_override(0)
 
 
+@pytest.mark.parametrize("case", ["weight_grad", "per_head_batched"])
+def test_gemm_bf16_workspace_split_k(ops, case):
+    """small outputs over a long contraction take the deterministic workspace split-K (partials + fixed-order reduce):
+    a 2048x2048 weight gradient over K = 8192 (fp32, accumulating; 256x256 ping-pong kernel, 4 slices) and a batched 1024x128
+    bf16 output (256x128 kernel, 4 slices);
+    two runs must agree bit for bit"""
+    rng = np.random.default_rng(11)
+    if case == "weight_grad":
+        M, N, K, nb = 2048, 2048, 8192, 1
+    else:
+        M, N, K, nb = 1024, 128, 8192, 2
+    A = bf(rng.standard_normal((nb, M, K)) * 0.5)
+    B = bf(rng.standard_normal((nb, K, N)) * 0.5)
+    a_store = dev(np.ascontiguousarray(A.transpose(0, 2, 1)), torch.bfloat16)   # [nb, K, M]: M-major A
+    b_store = dev(B, torch.bfloat16)                                             # [nb, K, N]: M-major B
+    a, b = a_store.transpose(1, 2).unsqueeze(1), b_store.unsqueeze(1)
+    if case == "weight_grad":
+        C0 = rng.standard_normal((nb, M, N)).astype(np.float32)
+        outs = []
+        for _ in range(2):
+            out = dev(C0, torch.float32)
+            ops.gemm(a[0, 0], b[0, 0], out[0], beta=1.0)
+            outs.append(out)
+        close(outs[0], np.einsum("bmk,bkn->bmn", A, B) + C0, 3e-6, name="split-K dW")
+    else:
+        outs = []
+        for _ in range(2):
+            out = torch.empty(nb, 1, M, N, device=DEV, dtype=torch.bfloat16)
+            ops.gemm_batched(a, b, out)
+            outs.append(out)
+        close(outs[0][:, 0], np.einsum("bmk,bkn->bmn", A, B), 6e-3, name="split-K batched")
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("form,M,N,K", [("nt", 200, 72, 128), ("nn", 328, 576, 64), ("tn", 72, 200, 192), ("nt", 1568, 2048, 256), ("tn", 576, 64, 512)])
 def test_gemm_bf16_tile_tails(ops, form, M, N, K):
     """ragged M / N (image-patch counts, 64-channel convolutions) stay on the MFMA tile kernel: clamped loads, masked stores"""

@@ -69,7 +69,25 @@ def gemm(B=16, L=1024):
         print(f"  dW TN M={N} N={K} K={M}: {t * 1e3:8.1f} us  {2.0 * M * N * K / t / 1e9:7.1f} TFLOP/s")
 
 
+def small_out(B=16, L=1024):
+    """the under-filled transposed-operand GEMMs of a layer's backward (split-K candidates)"""
+    T, d, H, D = B * L, 2048, 16, 128
+    torch.manual_seed(0)
+    for name, M, N in [("o_net dW", d, d), ("ff2 dW", d, 2 * d), ("qkv dW", 3 * d, d)]:
+        dy = torch.randn(T, M, device=DEV).to(torch.bfloat16)
+        x = torch.randn(T, N, device=DEV).to(torch.bfloat16)
+        dw = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+        t = timeit(lambda: ops.gemm(dy.t(), x, dw, beta=1.0))
+        print(f"{name} TN M={M} N={N} K={T}: {t * 1e3:8.1f} us  {2.0 * M * N * T / t / 1e9:7.1f} TFLOP/s")
+    dT = torch.randn(H, B, L, L, device=DEV).to(torch.bfloat16)
+    qv = torch.randn(B, L, H, D, device=DEV).to(torch.bfloat16)
+    dR = torch.empty(L, H * D, device=DEV, dtype=torch.bfloat16)
+    t = timeit(lambda: ops.gemm_batched(dT.view(H, B * L, L).transpose(1, 2).unsqueeze(1), qv.view(B * L, H, D).permute(1, 0, 2).unsqueeze(1),
+                                        dR.view(L, H, D).permute(1, 0, 2).unsqueeze(1)))
+    print(f"dR per head M={L} N={D} K={T} x{H}: {t * 1e3:8.1f} us  {dT.numel() * 2 / t / 1e6:7.1f} GB/s of dT")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "flash"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-    {"flash": flash, "gemm": gemm}[which](B)
+    {"flash": flash, "gemm": gemm, "small_out": small_out}[which](B)
