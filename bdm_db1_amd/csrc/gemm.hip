@@ -269,7 +269,8 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
                 u.K = (int)kc; u.C = ws; u.bias = nullptr; u.beta = 0.f; u.ldc = N;
                 u.batch1 = S; u.a_bs1 = fa == 0 ? kc : kc * lda; u.b_bs1 = fb == 0 ? kc : kc * ldb;
                 u.c_bs0 = (int64_t)S * M * N; u.c_bs1 = (int64_t)M * N;
-                int rc = pp_shape ? db1_gemm_pp_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st)
+                int rc = pp_shape ? (fb == 1 ? db1_gemm_pp32_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st)
+                                             : db1_gemm_pp_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st))
                                   : db1_gemm_tile256_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st);
                 if (rc) return rc;
                 dim3 rg((unsigned)(((int64_t)M * (N / 4) + 255) / 256), (unsigned)batch);
@@ -281,8 +282,13 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
                 return DB1_OK;
             }
         }
-        if (pp_shape && (tile_pref == 512 || (tile_pref == 0 && (int64_t)(M / 256) * (N / 256) * batch >= 160)))
+        if (pp_shape && tile_pref == 1024) return db1_gemm_pp32_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
+        if (pp_shape && (tile_pref == 512 || (tile_pref == 0 && (int64_t)(M / 256) * (N / 256) * batch >= 160))) {
+            // measured: the 4-stage k32 ring is 3-9 % faster when B is M-major (NN, TN); with both operands K-major
+            // (NT) its 64-byte rows fetch half cache lines and the 2-stage k64 kernel is 4-9 % faster
+            if (tile_pref == 0 && fb == 1) return db1_gemm_pp32_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
             return db1_gemm_pp_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
+        }
         // (measured: routing the under-filled transposed-operand cases -- o_net dW on 128 workgroups, the per-head dR on 64 --
         // to the 128x128 kernel for more workgroups made them 15-20 % slower, so form alone decides)
         const bool want256 = tile_pref == 256 || (tile_pref == 0 && fb == 1);

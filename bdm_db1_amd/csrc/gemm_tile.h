@@ -123,3 +123,4 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
 
 int db1_gemm_tile256_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);
 int db1_gemm_pp_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);
+int db1_gemm_pp32_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);

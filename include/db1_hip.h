@@ -72,7 +72,7 @@ int db1_gemm_tn(const void* A, const void* B, void* C, const void* bias, int M, 
 /* test hook: route every GEMM to the strided fp32-MFMA kernel (cross-checks the tile kernels at full size) */
 void db1_gemm_force_generic(int on);
 /* test / tuning hook: pin one bf16 tile kernel where its shape constraints hold (128 = 128x128, 256 = 256x128 3-stage,
-   512 = 256x256 ping-pong; 0 = the measured heuristics, the default unless DB1_GEMM_TILE is set in the environment) */
+   512 = 256x256 ping-pong with 2 stages of k64, 1024 = the same with a 4-stage ring of k32; 0 = the measured heuristics, the default unless DB1_GEMM_TILE is set in the environment) */
 void db1_gemm_tile_override(int tile);
 /* which kernel db1_gemm_strided would pick: 0 = strided fp32-MFMA, 1 = bf16 MFMA tile kernel */
 int db1_gemm_would_use_fast(int M, int N, int K, int dtA, int dtB, int dtC,

@@ -1,6 +1,6 @@
 """Developer check of the 256x256 ping-pong GEMM (DB1_GEMM_TILE=512): all three operand forms, odd/even k-tile counts."""
 import os, sys
-os.environ["DB1_GEMM_TILE"] = "512"
+os.environ.setdefault("DB1_GEMM_TILE", "512")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bdm_db1_amd import ops
