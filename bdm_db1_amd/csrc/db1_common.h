@@ -96,6 +96,35 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * __expf(-0.5f * x * x) * 0.39894228040143267794f;
 }
 
+// bf16 storage path: Phi(x) = 0.5 (1 + erf(x / sqrt 2)) and e = exp(-x^2 / 2) from ONE v_exp and one v_rcp (Abramowitz-Stegun
+// 7.1.26, |error| <= 1.5e-7 absolute: three orders below the bf16 rounding of the result).  libm's erff costs ~3x the VALU work
+// and made the activation kernels VALU-bound (act_bwd: ~100 us of VALU for 124 us).  The fp32 path keeps erff (parity gate).
+__device__ __forceinline__ void gelu_phi_fast(float x, float& phi, float& e) {
+    const float t = fabsf(x) * 0.70710678118654752440f;
+    e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);  // exp(-x^2/2) = 2^(-x^2/2 * log2 e)
+    const float k = __builtin_amdgcn_rcpf(fmaf(0.3275911f, t, 1.0f));
+    float poly = fmaf(1.061405429f, k, -1.453152027f);
+    poly = fmaf(poly, k, 1.421413741f);
+    poly = fmaf(poly, k, -0.284496736f);
+    poly = fmaf(poly, k, 0.254829592f);
+    const float erf_abs = fmaf(-poly * k, e, 1.0f);
+    phi = 0.5f + copysignf(0.5f * erf_abs, x);
+}
+template <typename T> __device__ __forceinline__ float gelu_fwd_t(float x) {
+    if (sizeof(T) == 4) return gelu_erf(x);
+    float phi, e;
+    gelu_phi_fast(x, phi, e);
+    return x * phi;
+}
+// gelu(x) and d gelu / dx together (they share erf and the exponential)
+template <typename T> __device__ __forceinline__ void gelu_both_t(float x, float& y, float& dy) {
+    if (sizeof(T) == 4) { y = gelu_erf(x); dy = gelu_erf_grad(x); return; }
+    float phi, e;
+    gelu_phi_fast(x, phi, e);
+    y = x * phi;
+    dy = fmaf(x * 0.39894228040143267794f, e, phi);
+}
+
 // dtype dispatch helpers (host)
 #define DB1_DISPATCH_DT(dt, T, ...)                          \
     do {                                                     \

@@ -125,6 +125,155 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const T* __restrict__
     atomicAdd(dbeta + c, ab);
 }
 
+// ---- register-resident variants for d == 64 * V * NV (d = 2048 in bf16: NV = 4): the row lives in registers, so the forward
+// is ONE pass over x / r (the kernels above re-read the row from L2 three times) and the backward produces ds and the
+// dgamma / dbeta partial sums of its rows from the same registers (the separate parameter pass re-read dy and s from HBM).
+// Partials go to a workspace [block][2][d] and are added in block order by ln_param_reduce_kernel: no atomics, deterministic.
+template <typename T, typename TP, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const T* __restrict__ x, const T* __restrict__ r, float alpha,
+                                                         const TP* __restrict__ gamma, const TP* __restrict__ beta,
+                                                         T* __restrict__ y, T* s_out, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int64_t rows, int d, float eps) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int V = Vec16<T>::N;
+    Vec16<T> a[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) a[k].load(x + row * d + (k * 64 + lane) * V);
+    if (r) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            Vec16<T> b;
+            b.load(r + row * d + (k * 64 + lane) * V);
+#pragma unroll
+            for (int j = 0; j < V; j++) a[k].v[j] = alpha * a[k].v[j] + b.v[j];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+#pragma unroll
+            for (int j = 0; j < V; j++) a[k].v[j] = alpha * a[k].v[j];
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            if (sizeof(T) == 2) a[k].v[j] = bf2f(f2bf(a[k].v[j]));  // s is a tensor of dtype T in the reference
+            sum += a[k].v[j];
+        }
+    const float mu = wave_sum(sum) / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+#pragma unroll
+        for (int j = 0; j < V; j++) { const float c = a[k].v[j] - mu; sq += c * c; }
+    const float rs = rsqrtf(wave_sum(sq) / (float)d + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int i = (k * 64 + lane) * V;
+        if (s_out) a[k].store(s_out + row * d + i);
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < V; j++) o.v[j] = (a[k].v[j] - mu) * rs * ldf(gamma + i + j) + ldf(beta + i + j);
+        o.store(y + row * d + i);
+    }
+}
+
+template <typename T, typename TP, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ s, const TP* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ ds,
+                                                           float* __restrict__ part, int64_t rows, int d, int rows_per_block) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float red[2 * 64 * V * NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gam[NV][V], ag[NV][V], ab[NV][V];
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+#pragma unroll
+        for (int j = 0; j < V; j++) { gam[k][j] = ldf(gamma + (k * 64 + lane) * V + j); ag[k][j] = 0.f; ab[k][j] = 0.f; }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (int64_t row = r0 + wave; row < r1; row += 4) {
+        Vec16<T> a[NV], b[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) { a[k].load(dy + row * d + (k * 64 + lane) * V); b[k].load(s + row * d + (k * 64 + lane) * V); }
+        const float mu = mean[row], rs = rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                const float xh = (b[k].v[j] - mu) * rs, g = a[k].v[j] * gam[k][j];
+                b[k].v[j] = xh;
+                c1 += g;
+                c2 += g * xh;
+                ag[k][j] += a[k].v[j] * xh;
+                ab[k][j] += a[k].v[j];
+            }
+        c1 = wave_sum(c1) / (float)d;
+        c2 = wave_sum(c2) / (float)d;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            Vec16<T> o;
+#pragma unroll
+            for (int j = 0; j < V; j++) o.v[j] = rs * (a[k].v[j] * gam[k][j] - c1 - b[k].v[j] * c2);
+            o.store(ds + row * d + (k * 64 + lane) * V);
+        }
+    }
+    if (!part) return;
+    // the four waves add their column partials in wave order (fixed order: deterministic), then one row of the workspace is written
+    for (int w = 0; w < 4; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int k = 0; k < NV; k++)
+#pragma unroll
+                for (int j = 0; j < V; j++) {
+                    const int c = (k * 64 + lane) * V + j;
+                    if (w == 0) { red[c] = ag[k][j]; red[d + c] = ab[k][j]; }
+                    else { red[c] += ag[k][j]; red[d + c] += ab[k][j]; }
+                }
+        }
+        __syncthreads();
+    }
+    float* dst = part + (int64_t)blockIdx.x * 2 * d;
+    for (int c = threadIdx.x; c < 2 * d; c += 256) dst[c] = red[c];
+}
+// 64 columns per workgroup; wave w adds the partial rows w, w+4, ... in order, then the four wave sums are added in wave order
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, float* dgamma, float* dbeta, int nblocks, int d) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;  // < 2 * d (d is a multiple of 64 here)
+    float acc = 0.f;
+#pragma unroll 8
+    for (int b = wave; b < nblocks; b += 4) acc += part[(int64_t)b * 2 * d + c];
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        if (c < d) dgamma[c] += t; else dbeta[c - d] += t;
+    }
+}
+static float* g_ln_ws = nullptr;  // grow-only partial-sum workspace (single compute stream, like the split-K workspace in gemm.hip)
+static size_t g_ln_ws_bytes = 0;
+static float* ln_workspace(size_t bytes) {
+    if (bytes > g_ln_ws_bytes) {
+        if (g_ln_ws) { hipDeviceSynchronize(); hipFree(g_ln_ws); }
+        g_ln_ws = nullptr;
+        g_ln_ws_bytes = 0;
+        if (hipMalloc((void**)&g_ln_ws, bytes) != hipSuccess) return nullptr;
+        g_ln_ws_bytes = bytes;
+    }
+    return g_ln_ws;
+}
+template <typename T> static int ln_reg_nv(int d) {  // NV such that d == 64 * V * NV, or 0
+    const int V = Vec16<T>::N;
+    for (int nv = 1; nv <= 4; nv <<= 1) if (d == 64 * V * nv) return nv;
+    return 0;
+}
+
 extern "C" int db1_layernorm_residual_fwd(const void* x, const void* r, float alpha, const void* gamma, const void* beta,
                                           void* y, void* s_out, float* mean, float* rstd, int64_t rows, int d, float eps,
                                           int dt, int dtParam, void* stream) {
@@ -135,6 +284,16 @@ extern "C" int db1_layernorm_residual_fwd(const void* x, const void* r, float al
         DB1_FAIL(DB1_ERR_BAD_ALIGN, "layernorm fwd: pointers must be 16-byte aligned");
     dim3 grid((unsigned)((rows + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
+    if (dt == DB1_BF16 && ln_reg_nv<bf16_t>(d)) {  // register-resident one-pass kernel
+        const int nv = ln_reg_nv<bf16_t>(d);
+#define LN_FWD_REG(TP, NV) ln_fwd_reg_kernel<bf16_t, TP, NV><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)r, alpha, (const TP*)gamma, (const TP*)beta, (bf16_t*)y, (bf16_t*)s_out, mean, rstd, rows, d, eps)
+#define LN_FWD_NV(TP) do { if (nv == 1) LN_FWD_REG(TP, 1); else if (nv == 2) LN_FWD_REG(TP, 2); else LN_FWD_REG(TP, 4); } while (0)
+        if (dtParam == DB1_BF16) LN_FWD_NV(bf16_t); else LN_FWD_NV(float);
+#undef LN_FWD_NV
+#undef LN_FWD_REG
+        DB1_CHECK_LAUNCH("layernorm fwd (registers)");
+        return DB1_OK;
+    }
 #define LN_FWD(T, TP) ln_fwd_kernel<T, TP><<<grid, 256, 0, st>>>((const T*)x, (const T*)r, alpha, (const TP*)gamma, (const TP*)beta, (T*)y, (T*)s_out, mean, rstd, rows, d, eps)
     if (dt == DB1_F32 && dtParam == DB1_F32) LN_FWD(float, float);
     else if (dt == DB1_BF16 && dtParam == DB1_BF16) LN_FWD(bf16_t, bf16_t);
@@ -153,6 +312,27 @@ extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const v
     if (rows <= 0 || d <= 0 || d % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd: d=%d must be a multiple of %d", d, V);
     if (!db1_aligned16(dy) || !db1_aligned16(s) || !db1_aligned16(ds)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "layernorm bwd: alignment");
     hipStream_t st = (hipStream_t)stream;
+    if (dt == DB1_BF16 && ln_reg_nv<bf16_t>(d)) {  // fused one-pass backward (ds + parameter partials)
+        const int nv = ln_reg_nv<bf16_t>(d), rpb = 32;
+        const int nblocks = (int)((rows + rpb - 1) / rpb);
+        const bool params = dgamma_acc && dbeta_acc;
+        float* ws = nullptr;
+        if (params) {
+            ws = ln_workspace((size_t)nblocks * 2 * d * sizeof(float));
+            if (!ws) DB1_FAIL(DB1_ERR_HIP, "layernorm bwd: cannot allocate the partial-sum workspace");
+        }
+#define LN_BWD_F(TP, NV) ln_bwd_fused_kernel<bf16_t, TP, NV><<<nblocks, 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)s, (const TP*)gamma, mean, rstd, (bf16_t*)ds, ws, rows, d, rpb)
+#define LN_BWD_NV(TP) do { if (nv == 1) LN_BWD_F(TP, 1); else if (nv == 2) LN_BWD_F(TP, 2); else LN_BWD_F(TP, 4); } while (0)
+        if (dtParam == DB1_BF16) LN_BWD_NV(bf16_t); else LN_BWD_NV(float);
+#undef LN_BWD_NV
+#undef LN_BWD_F
+        DB1_CHECK_LAUNCH("layernorm bwd (fused)");
+        if (params) {
+            ln_param_reduce_kernel<<<2 * d / 64, 256, 0, st>>>(ws, dgamma_acc, dbeta_acc, nblocks, d);
+            DB1_CHECK_LAUNCH("layernorm bwd param reduce");
+        }
+        return DB1_OK;
+    }
     dim3 grid((unsigned)((rows + 3) / 4));
 #define LN_BWD(T, TP) ln_bwd_ds_kernel<T, TP><<<grid, 256, 0, st>>>((const T*)dy, (const T*)s, (const TP*)gamma, mean, rstd, (T*)ds, rows, d)
     if (dt == DB1_F32 && dtParam == DB1_F32) LN_BWD(float, float);
@@ -188,10 +368,10 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const T* __restrict__ z, T
             Vec16<T> b;
             b.load(z + r * ld + n + c);
 #pragma unroll
-            for (int j = 0; j < V; j++) o.v[j] = a.v[j] * gelu_erf(b.v[j]);
+            for (int j = 0; j < V; j++) o.v[j] = a.v[j] * gelu_fwd_t<T>(b.v[j]);
         } else if (ACT == DB1_ACT_GELU) {
 #pragma unroll
-            for (int j = 0; j < V; j++) o.v[j] = gelu_erf(a.v[j]);
+            for (int j = 0; j < V; j++) o.v[j] = gelu_fwd_t<T>(a.v[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < V; j++) o.v[j] = fmaxf(a.v[j], 0.f);
@@ -216,13 +396,13 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ z, c
             Vec16<T> b, o2;
             b.load(z + r * ld + n + c);
 #pragma unroll
-            for (int j = 0; j < V; j++) { o.v[j] = g.v[j] * gelu_erf(b.v[j]); o2.v[j] = g.v[j] * a.v[j] * gelu_erf_grad(b.v[j]); }
+            for (int j = 0; j < V; j++) { float y, dy; gelu_both_t<T>(b.v[j], y, dy); o.v[j] = g.v[j] * y; o2.v[j] = g.v[j] * a.v[j] * dy; }
             o.store(dz + r * ld + c);
             o2.store(dz + r * ld + n + c);
         } else {
             if (ACT == DB1_ACT_GELU) {
 #pragma unroll
-                for (int j = 0; j < V; j++) o.v[j] = g.v[j] * gelu_erf_grad(a.v[j]);
+                for (int j = 0; j < V; j++) { float y, dy; gelu_both_t<T>(a.v[j], y, dy); o.v[j] = g.v[j] * dy; }
             } else {
 #pragma unroll
                 for (int j = 0; j < V; j++) o.v[j] = a.v[j] > 0.f ? g.v[j] : 0.f;
@@ -230,6 +410,74 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ z, c
             o.store(dz + r * ld + c);
         }
     }
+}
+
+// Activation backward that also produces the column sums of dz (the gradient of the first feed-forward bias) from the values
+// it stores: thread = one 16-byte column vector (both GEGLU halves), block = 256 vectors x a chunk of rows; per-chunk partial
+// sums go to a workspace [chunk][ld] and are added in chunk order by colsum_part_reduce_kernel (deterministic, no atomics).
+// This removes a separate full read of dz (the widest activation of the layer: 8192 columns at d = 2048).
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void act_bwd_bias_kernel(const T* __restrict__ z, const T* __restrict__ dout, T* __restrict__ dz,
+                                                           float* __restrict__ part, int64_t rows, int n, int rows_per_chunk) {
+    constexpr int V = Vec16<T>::N;
+    const int ld = ACT == DB1_ACT_GEGLU ? 2 * n : n;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (c >= n) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+    float s1[V], s2[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int64_t r = r0; r < r1; r++) {
+        Vec16<T> a, g, o;
+        a.load(z + r * ld + c);
+        g.load(dout + r * n + c);
+        if (ACT == DB1_ACT_GEGLU) {
+            Vec16<T> b, o2;
+            b.load(z + r * ld + n + c);
+#pragma unroll
+            for (int j = 0; j < V; j++) { float y, dy; gelu_both_t<T>(b.v[j], y, dy); o.v[j] = g.v[j] * y; o2.v[j] = g.v[j] * a.v[j] * dy; }
+            o.store(dz + r * ld + c);
+            o2.store(dz + r * ld + n + c);
+#pragma unroll
+            for (int j = 0; j < V; j++) {  // sum what was stored (dz is a tensor of dtype T in the reference)
+                s1[j] += sizeof(T) == 2 ? bf2f(f2bf(o.v[j])) : o.v[j];
+                s2[j] += sizeof(T) == 2 ? bf2f(f2bf(o2.v[j])) : o2.v[j];
+            }
+        } else {
+            if (ACT == DB1_ACT_GELU) {
+#pragma unroll
+                for (int j = 0; j < V; j++) { float y, dy; gelu_both_t<T>(a.v[j], y, dy); o.v[j] = g.v[j] * dy; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < V; j++) o.v[j] = a.v[j] > 0.f ? g.v[j] : 0.f;
+            }
+            o.store(dz + r * ld + c);
+#pragma unroll
+            for (int j = 0; j < V; j++) s1[j] += sizeof(T) == 2 ? bf2f(f2bf(o.v[j])) : o.v[j];
+        }
+    }
+    float* dst = part + (int64_t)blockIdx.y * ld + c;
+#pragma unroll
+    for (int j = 0; j < V; j += 4) *reinterpret_cast<float4*>(dst + j) = make_float4(s1[j], s1[j + 1], s1[j + 2], s1[j + 3]);
+    if (ACT == DB1_ACT_GEGLU) {
+#pragma unroll
+        for (int j = 0; j < V; j += 4) *reinterpret_cast<float4*>(dst + n + j) = make_float4(s2[j], s2[j + 1], s2[j + 2], s2[j + 3]);
+    }
+}
+// out[c] += sum over chunks of part[chunk][c]; 64 columns per workgroup, wave w takes chunks w, w+4, ... in order
+__global__ __launch_bounds__(256) void colsum_part_reduce_kernel(const float* __restrict__ part, float* out, int nchunks, int cols) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    if (c < cols) {
+#pragma unroll 8
+        for (int b = wave; b < nchunks; b += 4) acc += part[(int64_t)b * cols + c];
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < cols) out[c] += ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 static inline unsigned grid_for(int64_t work_items) {
@@ -264,6 +512,28 @@ extern "C" int db1_ffn_act_bwd(const void* z, const void* dout, void* dz, int64_
     DB1_DISPATCH_DT(dt, T, { if (act == 0) L(T, 0); else if (act == 1) L(T, 1); else L(T, 2); });
 #undef L
     DB1_CHECK_LAUNCH("ffn_act_bwd");
+    return DB1_OK;
+}
+
+extern "C" int db1_ffn_act_bwd_bias(const void* z, const void* dout, void* dz, float* dbias_acc, int64_t rows, int n, int act, int dt,
+                                    void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "ffn_act_bwd_bias: dtype");
+    const int V = dt == DB1_F32 ? 4 : 8;
+    if (rows <= 0 || n <= 0 || n % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "ffn_act_bwd_bias: n=%d must be a multiple of %d", n, V);
+    if (act < 0 || act > 2) DB1_FAIL(DB1_ERR_UNSUPPORTED, "ffn_act_bwd_bias: act %d", act);
+    if (!dbias_acc) DB1_FAIL(DB1_ERR_BAD_SHAPE, "ffn_act_bwd_bias: null accumulator");
+    hipStream_t st = (hipStream_t)stream;
+    const int ld = act == DB1_ACT_GEGLU ? 2 * n : n;
+    const int rpc = 32, nchunks = (int)((rows + rpc - 1) / rpc);
+    float* ws = ln_workspace((size_t)nchunks * ld * sizeof(float));
+    if (!ws) DB1_FAIL(DB1_ERR_HIP, "ffn_act_bwd_bias: cannot allocate the partial-sum workspace");
+    dim3 g((unsigned)((n / V + 255) / 256), (unsigned)nchunks);
+#define L(T, A) act_bwd_bias_kernel<T, A><<<g, 256, 0, st>>>((const T*)z, (const T*)dout, (T*)dz, ws, rows, n, rpc)
+    DB1_DISPATCH_DT(dt, T, { if (act == 0) L(T, 0); else if (act == 1) L(T, 1); else L(T, 2); });
+#undef L
+    DB1_CHECK_LAUNCH("ffn_act_bwd_bias");
+    colsum_part_reduce_kernel<<<(ld + 63) / 64, 256, 0, st>>>(ws, dbias_acc, nchunks, ld);
+    DB1_CHECK_LAUNCH("ffn_act_bwd_bias reduce");
     return DB1_OK;
 }
 

@@ -663,9 +663,8 @@ class TransformerXL(nn.Module):
         dact = self._new(T, dff)
         ops.gemm(dout, W(p + "pos_ff.CoreNet.2.weight"), dact)
         dz = self._new(T, di)
-        ops.ffn_act_bwd(c.z, dact, dz, self.activation_fn)
+        ops.ffn_act_bwd_bias(c.z, dact, dz, G(p + "pos_ff.CoreNet.0.bias"), self.activation_fn)
         ops.gemm(dz.t(), c.fin, G(p + "pos_ff.CoreNet.0.weight"), beta=1.0)
-        ops.colsum_acc(dz, G(p + "pos_ff.CoreNet.0.bias"))
         dfin = self._new(T, d)
         ops.gemm(dz, W(p + "pos_ff.CoreNet.0.weight"), dfin)
         dh1 = self._new(T, d)
@@ -701,9 +700,8 @@ class TransformerXL(nn.Module):
         dact = self._new(T, dff)
         ops.gemm(ds2, W(p + "pos_ff.CoreNet.2.weight"), dact)
         dz = self._new(T, di)
-        ops.ffn_act_bwd(c.z, dact, dz, self.activation_fn)
+        ops.ffn_act_bwd_bias(c.z, dact, dz, G(p + "pos_ff.CoreNet.0.bias"), self.activation_fn)
         ops.gemm(dz.t(), c.h1, G(p + "pos_ff.CoreNet.0.weight"), beta=1.0)
-        ops.colsum_acc(dz, G(p + "pos_ff.CoreNet.0.bias"))
         ops.gemm(dz, W(p + "pos_ff.CoreNet.0.weight"), ds2, beta=a)          # dh1 = a*ds2 + dz W1   (in place over ds2)
         dh1 = ds2
         # ---- attention

@@ -128,6 +128,13 @@ def ffn_act_bwd(z, dout, dz, act: str):
     lib.call("db1_ffn_act_bwd", P(z), P(dout), P(dz), rows, n, ACT_CODES[act], dt_code(z), stream())
 
 
+def ffn_act_bwd_bias(z, dout, dz, dbias_acc, act: str):
+    """activation backward + dbias_acc += column sums of dz, one pass"""
+    rows, n = dout.numel() // dout.shape[-1], dout.shape[-1]
+    assert dbias_acc.dtype == torch.float32 and dbias_acc.numel() == dz.shape[-1]
+    lib.call("db1_ffn_act_bwd_bias", P(z), P(dout), P(dz), P(dbias_acc), rows, n, ACT_CODES[act], dt_code(z), stream())
+
+
 def colsum_acc(x2d, out_acc):
     rows, cols = x2d.shape
     assert x2d.stride(1) == 1 and out_acc.dtype == torch.float32

@@ -94,6 +94,10 @@ int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma,
  * GEGLU: out[r, j] = z[r, j] * gelu_erf(z[r, n + j]) (activations.py:19-32); GELU/RELU: elementwise. */
 int db1_ffn_act_fwd(const void* z, void* out, int64_t rows, int n_out, int act, int dt, void* stream);
 int db1_ffn_act_bwd(const void* z, const void* dout, void* dz, int64_t rows, int n_out, int act, int dt, void* stream);
+/* same, and dbias_acc[c] += sum_r dz[r, c] over all columns of dz (float32 [2*n_out] for GEGLU, [n_out] otherwise): the
+ * gradient of the first feed-forward bias (transformer_xl.py:264) from the same pass; fixed summation order. */
+int db1_ffn_act_bwd_bias(const void* z, const void* dout, void* dz, float* dbias_acc, int64_t rows, int n_out, int act, int dt,
+                         void* stream);
 
 /* out_acc[c] += sum_r x[r, c]  (bias / u / v gradients). ldx = row stride in elements. */
 int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int cols, int64_t ldx, int dt, void* stream);

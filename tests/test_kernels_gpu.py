@@ -280,6 +280,12 @@ def test_ffn_activation(ops, act, dtype):
     tol = 2e-6 if dtype == "f32" else 6e-3
     close(out, ref, tol, name="act fwd")
     close(dz, dref, tol, name="act bwd")
+    # fused variant: same dz, plus the column sums of what it stored, accumulated into an existing vector
+    dz2 = torch.empty_like(Z)
+    acc = torch.full((dz2.shape[-1],), 0.5, device=DEV, dtype=torch.float32)
+    ops.ffn_act_bwd_bias(Z, dev(dout, td), dz2, acc, act)
+    close(dz2, dref, tol, name="act bwd (fused)")
+    close(acc, dz2.double().sum(0).cpu().numpy() + 0.5, 1e-5, name="act bwd bias sums")
 
 
 def test_colsum_add_cast(ops):
