@@ -581,11 +581,52 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x
     }
 }
 
+// deterministic variant: per-chunk partial sums (4 waves added in wave order) -> workspace [chunk][cols] -> colsum_part_reduce_kernel
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_chunk_kernel(const T* __restrict__ x, float* __restrict__ part, int64_t rows, int cols, int64_t ldx, int rpc) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float red[4][64 * 8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + lane) * V;
+    const int64_t r0 = (int64_t)blockIdx.y * rpc;
+    const int64_t r1 = r0 + rpc < rows ? r0 + rpc : rows;
+    float a[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) a[j] = 0.f;
+    if (c0 < cols) {
+#pragma unroll 8
+        for (int64_t r = r0 + w; r < r1; r += 4) {
+            Vec16<T> v;
+            v.load(x + r * ldx + c0);
+#pragma unroll
+            for (int j = 0; j < V; j++) a[j] += v.v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; j++) red[w][lane * V + j] = a[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * V; i += 256) {
+        const int c = blockIdx.x * 64 * V + i;
+        if (c < cols) part[(int64_t)blockIdx.y * cols + c] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    }
+}
+
 extern "C" int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int cols, int64_t ldx, int dt, void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "colsum: dtype");
     if (rows <= 0 || cols <= 0 || ldx < cols) DB1_FAIL(DB1_ERR_BAD_SHAPE, "colsum: shape");
     const int V = dt == DB1_F32 ? 4 : 8;
     if (cols % V == 0 && ldx % V == 0 && db1_aligned16(x)) {
+        if (rows >= 1024) {  // long inputs: chunk partials + ordered reduce (deterministic, ~16 resident waves per CU)
+            const int rpc = 32, nchunks = (int)((rows + rpc - 1) / rpc);
+            float* ws = ln_workspace((size_t)nchunks * cols * sizeof(float));
+            if (!ws) DB1_FAIL(DB1_ERR_HIP, "colsum: cannot allocate the partial-sum workspace");
+            dim3 gc((unsigned)((cols / V + 63) / 64), (unsigned)nchunks);
+            DB1_DISPATCH_DT(dt, T, (colsum_chunk_kernel<T><<<gc, 256, 0, (hipStream_t)stream>>>((const T*)x, ws, rows, cols, ldx, rpc)));
+            DB1_CHECK_LAUNCH("colsum_chunk");
+            colsum_part_reduce_kernel<<<(cols + 63) / 64, 256, 0, (hipStream_t)stream>>>(ws, out_acc, nchunks, cols);
+            DB1_CHECK_LAUNCH("colsum reduce");
+            return DB1_OK;
+        }
         const int rpbv = 256;
         dim3 gv((unsigned)((cols / V + 63) / 64), (unsigned)((rows + rpbv - 1) / rpbv));
         DB1_DISPATCH_DT(dt, T, (colsum_vec_kernel<T><<<gv, 256, 0, (hipStream_t)stream>>>((const T*)x, out_acc, rows, cols, ldx, rpbv)));
@@ -621,11 +662,34 @@ __global__ __launch_bounds__(256) void add2d_kernel(const TA* __restrict__ a, in
         stf(y + r * ldy + c, ldf(a + r * lda + c) + ldf(b + r * ldb + c));
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void add2d_vec_kernel(const T* __restrict__ a, int64_t lda, const T* b, int64_t ldb, T* y, int64_t ldy,
+                                                        int64_t rows, int cols) {
+    constexpr int V = Vec16<T>::N;
+    const int vpr = cols / V;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * vpr; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / vpr;
+        const int c = (int)(i - r * vpr) * V;
+        Vec16<T> p, q, o;
+        p.load(a + r * lda + c);
+        q.load(b + r * ldb + c);
+#pragma unroll
+        for (int j = 0; j < V; j++) o.v[j] = p.v[j] + q.v[j];
+        o.store(y + r * ldy + c);
+    }
+}
 extern "C" int db1_add2d(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows, int cols, int dtA,
                          int dt, void* stream) {
     if (!db1_dt_ok(dt) || !db1_dt_ok(dtA)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "add2d: dtype");
     if (rows <= 0 || cols <= 0 || lda < cols || ldb < cols || ldy < cols) DB1_FAIL(DB1_ERR_BAD_SHAPE, "add2d: shape");
     hipStream_t st = (hipStream_t)stream;
+    const int Vv = dt == DB1_F32 ? 4 : 8;
+    if (dtA == dt && cols % Vv == 0 && lda % Vv == 0 && ldb % Vv == 0 && ldy % Vv == 0 && db1_aligned16(a) && db1_aligned16(b) && db1_aligned16(y)) {
+        unsigned gv = grid_for(rows * (cols / Vv));
+        DB1_DISPATCH_DT(dt, T, (add2d_vec_kernel<T><<<gv, 256, 0, st>>>((const T*)a, lda, (const T*)b, ldb, (T*)y, ldy, rows, cols)));
+        DB1_CHECK_LAUNCH("add2d (vec)");
+        return DB1_OK;
+    }
     unsigned g = grid_for(rows * cols);
 #define L_(TA, T) add2d_kernel<TA, T><<<g, 256, 0, st>>>((const TA*)a, lda, (const T*)b, ldb, (T*)y, ldy, rows, cols)
     if (dtA == DB1_F32 && dt == DB1_F32) L_(float, float);

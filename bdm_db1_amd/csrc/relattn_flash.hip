@@ -339,18 +339,23 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
 // ======================================================================================= backward: delta = rowsum(dO * O)
 __global__ __launch_bounds__(256) void relattn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta,
                                                             int64_t n_rows, int L, int H) {
-    // one wave per (b, i, h) row of 128 elements (2 per lane)
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // 16 lanes per (b, i, h) row of 128 elements (16 B per lane), 16 rows per 256-thread block
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (row >= n_rows) return;
-    const int lane = threadIdx.x & 63;
-    const unsigned x = reinterpret_cast<const unsigned*>(o + row * FA_D)[lane];
-    const unsigned y = reinterpret_cast<const unsigned*>(dout + row * FA_D)[lane];
-    float s = __uint_as_float(x << 16) * __uint_as_float(y << 16) + __uint_as_float(x & 0xffff0000u) * __uint_as_float(y & 0xffff0000u);
-    s = wave_sum(s);
-    if (lane == 0) {
+    const int sub = threadIdx.x & 15;
+    const uint4 x = *reinterpret_cast<const uint4*>(o + row * FA_D + sub * 8);
+    const uint4 y = *reinterpret_cast<const uint4*>(dout + row * FA_D + sub * 8);
+    const unsigned xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        s += __uint_as_float(xs[t] << 16) * __uint_as_float(ys[t] << 16) + __uint_as_float(xs[t] & 0xffff0000u) * __uint_as_float(ys[t] & 0xffff0000u);
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (sub == 0) {
         const int64_t bi = row / H;
-        const int hh = (int)(row % H);
-        const int64_t bb = bi / L, i = bi % L;
+        const int hh = (int)(row - bi * H);
+        const int64_t bb = bi / L, i = bi - bb * L;
         delta[(bb * H + hh) * L + i] = s;
     }
 }
@@ -639,7 +644,7 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
         attr = true;
     }
     const int64_t n_rows = (int64_t)B * L * H;
-    relattn_delta_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, s>>>(a.out, a.dout, delta, n_rows, L, H);
+    relattn_delta_kernel<<<(unsigned)((n_rows + 15) / 16), 256, 0, s>>>(a.out, a.dout, delta, n_rows, L, H);
     DB1_CHECK_LAUNCH("relattn_delta");
     dim3 grid(flash_grid(L / FA_BQ, H, B));
     relattn_flash_bwd_q_kernel<<<grid, 256, FWD_LDS_BYTES, s>>>(a);

@@ -22,6 +22,25 @@ __global__ __launch_bounds__(256) void add_head_bias_kernel(const T* __restrict_
     }
 }
 
+// 16-byte vectors (HD % V == 0): thread = V consecutive channels of one query token
+template <typename T, typename TP>
+__global__ __launch_bounds__(256) void add_head_bias_vec_kernel(const T* __restrict__ qkv, const TP* __restrict__ u, const TP* __restrict__ vb,
+                                                                T* __restrict__ qu, T* __restrict__ qv, int64_t n_tok_q, int Lq, int Lk, int HD) {
+    constexpr int V = Vec16<T>::N;
+    const int vpr = HD / V;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n_tok_q * vpr; idx += (int64_t)gridDim.x * 256) {
+        const int64_t t = idx / vpr;
+        const int c = (int)(idx - t * vpr) * V;
+        const int64_t b = t / Lq, i = t - b * Lq;
+        Vec16<T> q, a, o;
+        q.load(qkv + ((b * Lk + (Lk - Lq) + i) * 3) * HD + c);
+#pragma unroll
+        for (int j = 0; j < V; j++) { a.v[j] = q.v[j] + ldf(u + c + j); o.v[j] = q.v[j] + ldf(vb + c + j); }
+        a.store(qu + t * HD + c);
+        o.store(qv + t * HD + c);
+    }
+}
+
 extern "C" int db1_relattn_add_head_bias(const void* qkv, const void* u, const void* vb, void* qu, void* qv, int B, int Lq, int Lk,
                                          int H, int D, int dt, int dtParam, void* stream) {
     if (!db1_dt_ok(dt) || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "add_head_bias: dtype");
@@ -30,6 +49,19 @@ extern "C" int db1_relattn_add_head_bias(const void* qkv, const void* u, const v
     int64_t blocks = (n * H * D + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
+    const int Vv = dt == DB1_F32 ? 4 : 8;
+    if ((H * D) % Vv == 0 && db1_aligned16(qkv) && db1_aligned16(qu) && db1_aligned16(qv)) {
+        int64_t vb_ = (n * (H * D / Vv) + 255) / 256;
+        if (vb_ > 256 * 32) vb_ = 256 * 32;
+#define LV_(T, TP) add_head_bias_vec_kernel<T, TP><<<(unsigned)vb_, 256, 0, st>>>((const T*)qkv, (const TP*)u, (const TP*)vb, (T*)qu, (T*)qv, n, Lq, Lk, H * D)
+        if (dt == DB1_F32 && dtParam == DB1_F32) LV_(float, float);
+        else if (dt == DB1_BF16 && dtParam == DB1_BF16) LV_(bf16_t, bf16_t);
+        else if (dt == DB1_BF16) LV_(bf16_t, float);
+        else LV_(float, bf16_t);
+#undef LV_
+        DB1_CHECK_LAUNCH("add_head_bias (vec)");
+        return DB1_OK;
+    }
 #define L_(T, TP) add_head_bias_kernel<T, TP><<<(unsigned)blocks, 256, 0, st>>>((const T*)qkv, (const TP*)u, (const TP*)vb, (T*)qu, (T*)qv, n, Lq, Lk, H * D)
     if (dt == DB1_F32 && dtParam == DB1_F32) L_(float, float);
     else if (dt == DB1_BF16 && dtParam == DB1_BF16) L_(bf16_t, bf16_t);
