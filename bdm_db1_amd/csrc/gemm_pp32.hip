@@ -9,6 +9,9 @@
 //                      (conflict-free for ds_read_b128's 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...)
 //   M-major sub-tile : [32 k][256 B], the image of gemm_tile.h restricted to 32 k-rows.
 #include "gemm_tile.h"
+#ifndef DB1_KROT
+#define DB1_KROT 1
+#endif
 #include <stdlib.h>
 
 #define P32_SUB_BYTES 8192             // one 128-row operand sub-tile of a 32-wide k-tile
@@ -89,10 +92,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp32_kernel(GemmTileArgs p) 
     const char* Bbase = (const char*)(B_KMAJOR ? B + (int64_t)n0 * p.ldb : B + n0);
     const int64_t a_kstep = (A_KMAJOR ? (int64_t)32 : (int64_t)32 * p.lda) * 2, a_half = (A_KMAJOR ? 128 * p.lda : (int64_t)128) * 2;
     const int64_t b_kstep = (B_KMAJOR ? (int64_t)32 : (int64_t)32 * p.ldb) * 2, b_half = (B_KMAJOR ? 128 * p.ldb : (int64_t)128) * 2;
+    const int nt_ = p.K / 32;  // k-tile rotation per workgroup against memory-channel camping (see gemm_pp.hip)
+    const int rot = 0;  // measured: rotation only helps NT (gemm_pp.hip); NN -1 %, TN -3..-9 %
+    auto krot = [&](int t) __attribute__((always_inline)) { const int k = t + rot; return k >= nt_ ? k - nt_ : k; };
     auto stage = [&](int t) __attribute__((always_inline)) {  // this wave's piece of each of the four sub-tiles of k-tile t
         char* s = smem + (t % NS) * P32_STAGE_BYTES + wave * 1024;
-        const char* a0 = Abase + t * a_kstep;
-        const char* b0 = Bbase + t * b_kstep;
+        const int kt = krot(t);
+        const char* a0 = Abase + kt * a_kstep;
+        const char* b0 = Bbase + kt * b_kstep;
         __builtin_amdgcn_global_load_lds(a0 + voffA, LDS_PTR(void, s), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(a0 + a_half + voffA, LDS_PTR(void, s + P32_SUB_BYTES), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(b0 + voffB, LDS_PTR(void, s + 2 * P32_SUB_BYTES), 16, 0, 0);
