@@ -100,9 +100,17 @@ def gemm_batched(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: flo
     Z0, Z1, M, K = a.shape
     _, _, K2, N = b.shape
     assert K == K2 and out.shape == (Z0, Z1, M, N) and b.shape[:2] == (Z0, Z1), (a.shape, b.shape, out.shape)
-    lib.call("db1_gemm_strided", P(a), P(b), P(out), _vp(0), M, N, K, dt_code(a), dt_code(b), dt_code(out), 0,
-             a.stride(2), a.stride(3), b.stride(2), b.stride(3), out.stride(2), out.stride(3), Z0, Z1,
-             a.stride(0), a.stride(1), b.stride(0), b.stride(1), out.stride(0), out.stride(1), alpha, beta, stream())
+
+    def run():
+        lib.call("db1_gemm_strided", P(a), P(b), P(out), _vp(0), M, N, K, dt_code(a), dt_code(b), dt_code(out), 0,
+                 a.stride(2), a.stride(3), b.stride(2), b.stride(3), out.stride(2), out.stride(3), Z0, Z1,
+                 a.stride(0), a.stride(1), b.stride(0), b.stride(1), out.stride(0), out.stride(1), alpha, beta, stream())
+
+    # the batched contractions of the attention backward (dq_r, dR) run on the same tile kernels: timed with the dense 2MNK they execute
+    if _gemm_timer is not None and _is_tile_gemm(M, N, K, a, b, out, a.stride()[2:], b.stride()[2:], out.stride()[2:]):
+        _gemm_timer.wrap(2.0 * M * N * K * Z0 * Z1, run)
+    else:
+        run()
     return out
 
 
