@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DB1_BENCH_BATCH", 16)), help="sequences per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DB1_BENCH_BATCH", 64)), help="sequences per GPU per step")
     ap.add_argument("--layers", type=int, default=24, help="debug only: anything but 24 is not the benchmark config")
     ap.add_argument("--workload", default="text", choices=["text", "caption", "rl", "mixture"])
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -181,9 +181,11 @@ def main():
         try:  # HBM-side bytes per tile-GEMM launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")))
-            if cands and B == 16 and args.workload == "text":
-                traffic = json.load(open(cands[-1]))["tile_gemm_avg_bytes_per_launch"]
-                traffic_src = os.path.relpath(cands[-1], ROOT)
+            if cands and args.workload == "text":
+                rec = json.load(open(cands[-1]))
+                if rec.get("batch_per_gpu", 16) == B:  # bytes per launch scale with the batch: only the matching recording applies
+                    traffic = rec["tile_gemm_avg_bytes_per_launch"]
+                    traffic_src = os.path.relpath(cands[-1], ROOT)
         except Exception:
             traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

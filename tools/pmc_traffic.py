@@ -46,11 +46,12 @@ gemm = [(k, v) for k, v in kernels.items() if k.startswith("gemm_bf16_")]
 tot_l = sum(v["launches"] for _, v in gemm)
 res = {
     "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
-              "--no-kernel-timing` (B=16); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request; "
+              "--no-kernel-timing` (default batch, recorded in batch_per_gpu); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request; "
               "calibrated on adam_kernel: 16 B/param read, 14 B/param written, and on ce_fwd: T x vocab_pad x 2 B read)",
     "kernels": kernels,
     "tile_gemm_avg_bytes_per_launch": round(sum(v["hbm_side_bytes_per_launch"] * v["launches"] for _, v in gemm) / tot_l) if tot_l else None,
     "tile_gemm_launches": tot_l,
+    "batch_per_gpu": int(os.environ.get("DB1_BENCH_BATCH", 64)),
 }
 json.dump(res, open(os.path.join(out_dir, "hbm_traffic_pmc.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "kernels"})[:600])
