@@ -238,6 +238,10 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
     const int64_t batch = (int64_t)batch0 * batch1;
     const bool aligned = db1_aligned16(A) && db1_aligned16(B) && db1_aligned16(C) && !(a_bs0 % 8) && !(a_bs1 % 8) && !(b_bs0 % 8) &&
                          !(b_bs1 % 8) && !(c_bs0 % 4) && !(c_bs1 % 4);
+    // few rows (inference with memory: 1 .. ~50 new tokens): stream W once, see gemm_skinny.hip
+    if (!g_force_generic && aligned && batch == 1 && dtA == DB1_BF16 && dtB == DB1_BF16 && M <= 64 && a_cs == 1 && b_rs == 1 && c_cs == 1 &&
+        (N % 16) == 0 && (K % 64) == 0 && (a_rs % 8) == 0 && (b_cs % 8) == 0 && (c_rs % 4) == 0 && (g_tile_pref <= 0))
+        return db1_gemm_skinny_launch((const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, a_rs, b_cs, c_rs, alpha, beta, dtC, dtBias, st);
     if (!g_force_generic && aligned && batch <= 65535 &&
         fast_ok(M, N, K, dtA, dtB, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, &fa, &fb, &lda, &ldb)) {
         GemmTileArgs t;

@@ -137,6 +137,22 @@ def test_gemm_bf16_large_tile_kernels(ops, form, tile, M, N, K):
         ops.gemm_tile_override(0)
 
 
+@pytest.mark.parametrize("M", [1, 5, 16, 22, 33, 64])
+@pytest.mark.parametrize("N,K,od", [(2048, 2048, "bf16"), (8192, 2048, "bf16"), (2048, 4096, "f32"), (33280, 2048, "bf16")])
+def test_gemm_skinny_few_rows(ops, M, N, K, od):
+    """y = x W^T (+ bias, accumulate) with 1..64 rows: the W-streaming kernel used by inference with memory"""
+    rng = np.random.default_rng(M * 7 + N)
+    x = bf(rng.standard_normal((M, K)))
+    w = bf(rng.standard_normal((N, K)) * 0.05)
+    bias = bf(rng.standard_normal(N))
+    td = torch.float32 if od == "f32" else torch.bfloat16
+    c0 = rng.standard_normal((M, N)).astype(np.float32)
+    c0 = c0 if od == "f32" else bf(c0)
+    out = dev(c0, td)
+    ops.gemm(dev(x, torch.bfloat16), dev(w, torch.bfloat16).t(), out, bias=dev(bias, torch.bfloat16), alpha=0.5, beta=1.0)
+    close(out, 0.5 * x @ w.T + c0 + bias, 2e-6 if od == "f32" else 6e-3, name=f"skinny gemm M={M}")
+
+
 @pytest.mark.parametrize("case", ["weight_grad", "per_head_batched"])
 def test_gemm_bf16_workspace_split_k(ops, case):
     """small outputs over a long contraction take the deterministic workspace split-K (partials + fixed-order reduce):
