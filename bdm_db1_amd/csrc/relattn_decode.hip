@@ -1,0 +1,216 @@
+// Relative-position attention for inference with Transformer-XL memory (evaluate_rl.py:157-266; transformer_xl.py:124-133,
+// 160-225): 1 .. 64 new queries against klen = mlen + q cached keys / values (bf16, d_head = 128).
+//     s[i,j] = ((q_i+u).k_j + (q_i+v).R[mlen+i-j]) / sqrt(d),   visible iff  i - shift < j <= i + mlen,   j in [0, klen)
+// The materialised path ran two batched GEMMs, a softmax and another batched GEMM per layer on the generic strided kernel
+// (135 us for P.V alone at q = 1); here one launch covers them, split over the keys ("flash decoding"):
+//   grid = (key chunks of 128, heads, batch); the 4 waves of a workgroup are the 4 possible 16-query tiles (a wave whose tile
+//   is empty exits); every wave is self-contained (own LDS: a 32-key V tile for the transposed reads + the skew scratch).
+//   Per 32-key step and wave: S^T = K.Qu^T (2 x 4 v_mfma_f32_16x16x32_bf16, K fragments straight from global), the relative
+//   term for the 47 distances the 16 x 32 block touches (3 x 4 MFMA against R rows) written to LDS [48 dist][16 q] and read
+//   back skewed (element (a, a - b + 31)), online softmax (statistics lane-local + two cross-group shuffles), O^T += V^T.P^T
+//   (8 MFMA; V^T via ds_read_b64_tr_b16 from the staged rows, with the key permutation that makes the S registers directly
+//   the B operand: slots 0-3 = keys 4g..4g+3 of the first 16-key block, slots 4-7 = the same keys of the second).
+//   Partials (m, l, O) per chunk go to a workspace; relattn_decode_merge_kernel combines them in chunk order.
+#include "db1_common.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+#define DEC_D 128
+#define DEC_KC 128                       // keys per workgroup
+#define DEC_WAVE_LDS (32 * 256 + 48 * 16 * 4)  // V tile [32][128] bf16 + T scratch [48][16] f32
+
+struct DecodeArgs {
+    const bf16_t* qu; const bf16_t* qv; const bf16_t* k; const bf16_t* v; const bf16_t* R;
+    float* part;   // [B][H][nchunk][64 queries][D + 2]: O (unnormalised), m, l
+    bf16_t* out;
+    int64_t kv_rs, kv_bs;
+    int B, q, klen, mlen, H, shift, nd, nchunk;
+    float scale;
+};
+
+typedef __attribute__((ext_vector_type(2))) float dec_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 dec_bf16x2;
+__device__ __forceinline__ unsigned dec_pk(float lo, float hi) {
+    dec_f32x2 v = {lo, hi};
+    dec_bf16x2 r = __builtin_convertvector(v, dec_bf16x2);
+    return *reinterpret_cast<unsigned*>(&r);
+}
+
+__global__ __launch_bounds__(256) void relattn_decode_kernel(DecodeArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = wave * 16;
+    if (i0 >= p.q) return;  // waves are independent: no workgroup barrier below
+    const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int a = lane & 15, g = lane >> 4;
+    const int HD = p.H * DEC_D;
+    char* Vs = smem + wave * DEC_WAVE_LDS;
+    float* Tw = reinterpret_cast<float*>(Vs + 32 * 256);
+    const int qi = i0 + a < p.q ? i0 + a : p.q - 1;  // rows beyond q repeat the last query (never stored)
+    const bf16_t* qu = p.qu + ((int64_t)b * p.q + qi) * HD + h * DEC_D + g * 8;
+    const bf16_t* qv = p.qv + ((int64_t)b * p.q + qi) * HD + h * DEC_D + g * 8;
+    bf16x8_t fqu[4], fqv[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        fqu[ks] = *reinterpret_cast<const bf16x8_t*>(qu + ks * 32);
+        fqv[ks] = *reinterpret_cast<const bf16x8_t*>(qv + ks * 32);
+    }
+    const bf16_t* kg = p.k + (int64_t)b * p.kv_bs + h * DEC_D;
+    const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * DEC_D;
+    const bf16_t* Rg = p.R + h * DEC_D;
+    f32x4 acc_o[8];
+#pragma unroll
+    for (int db = 0; db < 8; db++) acc_o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_i = -1.0e30f, l_i = 0.f;
+    const int i = i0 + a;  // this lane's query
+    const int jc0 = chunk * DEC_KC;
+    for (int st = 0; st < DEC_KC / 32; st++) {
+        const int j0 = jc0 + st * 32;
+        if (j0 >= p.klen) break;
+        // whole step outside the window of every query of the tile?  (wave-uniform)
+        if (j0 > i0 + 15 + p.mlen || j0 + 31 <= i0 - p.shift) continue;
+        // ---- stage V rows j0 .. j0+31 (rows past klen are clamped: their probabilities are exactly zero)
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int row = it * 4 + (lane >> 4), ch = lane & 15;
+            const int jr = j0 + row < p.klen ? j0 + row : p.klen - 1;
+            const uint4 val = *reinterpret_cast<const uint4*>(vg + (int64_t)jr * p.kv_rs + ch * 8);
+            *reinterpret_cast<uint4*>(Vs + row * 256 + ch * 16) = val;
+        }
+        // ---- S^T[key][query] for the two 16-key blocks
+        f32x4 acc_s[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++) {
+            acc_s[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int jr = j0 + 16 * blk + a < p.klen ? j0 + 16 * blk + a : p.klen - 1;
+            const bf16_t* kr = kg + (int64_t)jr * p.kv_rs + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+                acc_s[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(kr + ks * 32), fqu[ks], acc_s[blk], 0, 0, 0);
+        }
+        // ---- relative term: distances d_lo .. d_lo+47 with d_lo = mlen + i0 - j0 - 31  ->  Tw[dist][query]
+        const int d_lo = p.mlen + i0 - j0 - 31;
+#pragma unroll
+        for (int tb = 0; tb < 3; tb++) {
+            int dr = d_lo + 16 * tb + a;
+            dr = dr < 0 ? 0 : (dr > p.nd - 1 ? p.nd - 1 : dr);  // out-of-range distances belong to masked pairs
+            const bf16_t* rr = Rg + (int64_t)dr * HD + g * 8;
+            f32x4 acc_t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+                acc_t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(rr + ks * 32), fqv[ks], acc_t, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) Tw[(16 * tb + 4 * g + r) * 16 + a] = acc_t[r];
+        }
+        // (same wave wrote and reads the scratch; LDS operations of a wave complete in order)
+        float s[8];
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int bcol = 16 * blk + 4 * g + r;  // key j0 + bcol
+                const int j = j0 + bcol;
+                const float v = (acc_s[blk][r] + Tw[(a - bcol + 31) * 16 + a]) * p.scale;
+                const bool vis = (j < p.klen) && (j <= i + p.mlen) && (j > i - p.shift) && (i < p.q);
+                s[blk * 4 + r] = vis ? v : -1.0e30f;
+            }
+        float mb = s[0];
+#pragma unroll
+        for (int t = 1; t < 8; t++) mb = fmaxf(mb, s[t]);
+        mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        const float m_new = fmaxf(m_i, mb);
+        const float alpha = __expf(m_i - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; t++) { s[t] = s[t] > -1.0e29f ? __expf(s[t] - m_new) : 0.f; rs += s[t]; }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_i = l_i * alpha + rs;
+        m_i = m_new;
+        union { unsigned u[4]; bf16x8_t v; } pb;
+#pragma unroll
+        for (int t = 0; t < 4; t++) pb.u[t] = dec_pk(s[2 * t], s[2 * t + 1]);
+        // ---- O^T[d][query] += V^T . P^T over the 32 keys (key permutation as described in the header)
+#pragma unroll
+        for (int db = 0; db < 8; db++) {
+            const int t16 = lane & 15;
+            const char* base = Vs + (t16 >> 2) * 256 + (db * 16 + (t16 & 3) * 4) * 2;
+            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4_t, const_cast<char*>(base) + (4 * g) * 256));
+            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4_t, const_cast<char*>(base) + (16 + 4 * g) * 256));
+            const bf16x8_t vt = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc_o[db][r] *= alpha;
+            acc_o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb.v, acc_o[db], 0, 0, 0);
+        }
+    }
+    // ---- partial results of this chunk: lane holds query a, d = db*16 + 4g + r
+    if (i < p.q) {
+        float* dst = p.part + ((((int64_t)b * p.H + h) * p.nchunk + chunk) * 64 + i) * (DEC_D + 2);
+#pragma unroll
+        for (int db = 0; db < 8; db++)
+            *reinterpret_cast<float2*>(dst + db * 16 + 4 * g) = make_float2(acc_o[db][0], acc_o[db][1]),
+            *reinterpret_cast<float2*>(dst + db * 16 + 4 * g + 2) = make_float2(acc_o[db][2], acc_o[db][3]);
+        if (g == 0) { dst[DEC_D] = m_i; dst[DEC_D + 1] = l_i; }
+    }
+}
+
+// one 128-thread block per (query, head, batch): combine the chunk partials in chunk order
+__global__ __launch_bounds__(128) void relattn_decode_merge_kernel(DecodeArgs p) {
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
+    const float* src = p.part + ((((int64_t)b * p.H + h) * p.nchunk) * 64 + i) * (DEC_D + 2);
+    const int64_t cs = (int64_t)64 * (DEC_D + 2);
+    float m = -1.0e30f;
+    for (int c = 0; c < p.nchunk; c++) m = fmaxf(m, src[c * cs + DEC_D]);
+    float l = 0.f, o = 0.f;
+    for (int c = 0; c < p.nchunk; c++) {
+        const float lc = src[c * cs + DEC_D + 1];
+        if (lc > 0.f) {
+            const float w = __expf(src[c * cs + DEC_D] - m);
+            l += lc * w;
+            o += src[c * cs + d] * w;
+        }
+    }
+    p.out[((int64_t)b * p.q + i) * p.H * DEC_D + h * DEC_D + d] = f2bf(l > 0.f ? o / l : 0.f);
+}
+
+static float* g_dec_ws = nullptr;  // grow-only workspace (single compute stream, like the others)
+static size_t g_dec_ws_bytes = 0;
+
+extern "C" int db1_relattn_decode_supported(int B, int q, int klen, int H, int D, int dt) {
+    return (dt == DB1_BF16 && D == DEC_D && B > 0 && H > 0 && q >= 1 && q <= 64 && klen >= q && B <= 65535 && H <= 65535) ? 1 : 0;
+}
+
+extern "C" int db1_relattn_decode_fwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
+                                      int64_t kv_batch_stride, const void* R, int nd, void* out, int B, int q, int klen, int mlen, int H,
+                                      int D, int shift, float scale, void* stream) {
+    if (!db1_relattn_decode_supported(B, q, klen, H, D, DB1_BF16))
+        DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_decode: needs bf16, d_head = 128, 1 <= q <= 64 (got q=%d klen=%d D=%d)", q, klen, D);
+    if (mlen != klen - q) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_decode: klen (%d) must be mlen (%d) + q (%d)", klen, mlen, q);
+    if (nd < 1 || !R) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_decode: R rows");
+    if ((kv_row_stride % 8) || (kv_batch_stride % 8) || !db1_aligned16(qu) || !db1_aligned16(qv) || !db1_aligned16(k) || !db1_aligned16(v) ||
+        !db1_aligned16(R) || !db1_aligned16(out))
+        DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_decode: operands must be 16-byte aligned, strides multiples of 8 elements");
+    DecodeArgs a;
+    a.qu = (const bf16_t*)qu; a.qv = (const bf16_t*)qv; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.R = (const bf16_t*)R;
+    a.out = (bf16_t*)out; a.kv_rs = kv_row_stride; a.kv_bs = kv_batch_stride;
+    a.B = B; a.q = q; a.klen = klen; a.mlen = mlen; a.H = H; a.shift = shift; a.nd = nd; a.scale = scale;
+    a.nchunk = (klen + DEC_KC - 1) / DEC_KC;
+    const size_t need = (size_t)B * H * a.nchunk * 64 * (DEC_D + 2) * sizeof(float);
+    if (need > g_dec_ws_bytes) {
+        if (g_dec_ws) { hipDeviceSynchronize(); hipFree(g_dec_ws); }
+        g_dec_ws = nullptr; g_dec_ws_bytes = 0;
+        if (hipMalloc((void**)&g_dec_ws, need) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "relattn_decode: cannot allocate %zu bytes of workspace", need);
+        g_dec_ws_bytes = need;
+    }
+    a.part = g_dec_ws;
+    hipStream_t st = (hipStream_t)stream;
+    relattn_decode_kernel<<<dim3((unsigned)a.nchunk, (unsigned)H, (unsigned)B), 256, 4 * DEC_WAVE_LDS, st>>>(a);
+    DB1_CHECK_LAUNCH("relattn_decode");
+    relattn_decode_merge_kernel<<<dim3((unsigned)q, (unsigned)H, (unsigned)B), 128, 0, st>>>(a);
+    DB1_CHECK_LAUNCH("relattn_decode_merge");
+    return DB1_OK;
+}

@@ -151,6 +151,7 @@ class DB1Engine:
                       grp["lr"], self.beta1, self.beta2, self.eps, grp["weight_decay"], self.adamw, self.global_steps,
                       gscale=gscale, clip=self.clip, norm_sq=self._norm_sq if self.clip > 0 else None)
         ar.grad.zero_()
+        self.module.mark_weights_changed()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step(1)
 

@@ -19,6 +19,7 @@ There is no CPU or torch-op fallback: without libdb1_hip.so or without a gfx950 
 from __future__ import annotations
 
 import math
+from types import SimpleNamespace
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -142,6 +143,10 @@ class TransformerXL(nn.Module):
         self.keep_logits = True          # False: the CE backward overwrites the logits buffer (training engines)
         self.use_flash = True            # fused attention when the shape is supported
         self.use_flash_bwd = True        # fused backward kernels (False: recompute through the materialised path)
+        self.use_decode = True           # inference with memory: K/V-cached path + fused decode attention when the shape allows
+        self._wversion = 0               # bumped whenever the weights change (invalidates the inference caches)
+        self._dec_state = None           # K/V cache of the memory returned by the last forward (see _decode_begin)
+        self._dec_R = None               # (version, [R_i = r_net_i(sinusoid(dist)) for dist < mem_len + 64])
         self._ctx: Optional[_Ctx] = None
         self._tables: Dict[Tuple[int, int], torch.Tensor] = {}
 
@@ -238,11 +243,18 @@ class TransformerXL(nn.Module):
         sd = dict(state_dict)
         res = super().load_state_dict(sd, strict=strict, **kw)
         self.arena.sync_work()
+        self.mark_weights_changed()
         return res
+
+    def mark_weights_changed(self):
+        """called after every parameter update (load_state_dict, optimizer step): drops the inference caches"""
+        self._wversion += 1
+        self._dec_state, self._dec_R = None, None
 
     def sync_work_params(self):
         """Refresh the bf16 working copy after the float32 master parameters were edited by hand."""
         self.arena.sync_work()
+        self.mark_weights_changed()
 
     def W(self, name: str) -> torch.Tensor:
         """parameter in the compute dtype"""
@@ -526,6 +538,62 @@ class TransformerXL(nn.Module):
             c.flash = flash
         return av
 
+    # ---- inference with memory (evaluate_rl.py:157-266): K/V cache + fused decode attention.  The caller-visible contract is the
+    # reference's: ``mems`` are per-layer hidden states (init_mem / _update_mem, :470-504) passed back opaquely.  Beside them the
+    # model keeps the projected keys / values of exactly those tensors; if the caller hands in anything else (identity check) the
+    # cache is rebuilt from the hidden states, so results never depend on it.
+    def _decode_R(self):
+        """R_i[dist] = r_net_i(sinusoid(dist)) for dist < mem_len + 64: depends on the weights only, computed once per weight version"""
+        if self._dec_R is None or self._dec_R[0] != self._wversion:
+            R_in = self._sinusoid(self.mem_len + 64)
+            Rs = []
+            for i in range(self.n_layer):
+                R = torch.empty(R_in.shape[0], self.d_model, device=self.dev, dtype=self.compute_dtype)
+                ops.gemm(R_in, self.W(f"h.{i}.dec_attn.r_net.weight").t(), R)
+                Rs.append(R)
+            self._dec_R = (self._wversion, Rs)
+        return self._dec_R[1]
+
+    def _decode_begin(self, mems, B, L, mlen):
+        """decode context for this call, or None when the fused path does not apply (then the materialised path runs)"""
+        if not (self.use_decode and self.compute_dtype == torch.bfloat16 and mlen + L <= self.mem_len + 64 and
+                ops.relattn_decode_supported(B, L, mlen + L, self.n_head, self.d_head, self.compute_dtype)):
+            return None
+        st = self._dec_state
+        H, D, d = self.n_head, self.d_head, self.d_model
+        valid = (st is not None and st.version == self._wversion and len(st.mems) == len(mems) and
+                 all(a is b for a, b in zip(st.mems, mems)) and st.kv[0].shape[0] == B and st.kv[0].shape[1] >= mlen)
+        if valid:
+            kv = st.kv
+        else:  # rebuild from the hidden states (first call after init_mem, or a caller that edited the memory)
+            kv = []
+            for i in range(self.n_layer):
+                p = f"h.{i}."
+                m = mems[i].to(self.compute_dtype).contiguous().view(B * mlen, d)
+                if self.pre_lnorm:
+                    hin = self._new(B * mlen, d)
+                    m1, r1 = self._new(B * mlen, dtype=torch.float32), self._new(B * mlen, dtype=torch.float32)
+                    ops.layernorm_residual_fwd(m, None, 1.0, self.W(p + "dec_attn.layer_norm.weight"), self.W(p + "dec_attn.layer_norm.bias"),
+                                               hin, None, m1, r1, self.layer_norm_epsilon)
+                    m = hin
+                qkv = self._new(B * mlen, 3 * d)
+                ops.gemm(m, self.W(p + "dec_attn.qkv_net.weight").t(), qkv)
+                kv.append(qkv.view(B, mlen, 3, H, D)[:, :, 1:3].contiguous())
+        return SimpleNamespace(kv=kv, R=self._decode_R(), new_kv=[])
+
+    def _attention_decode(self, qkv, i, B, L, mlen, shift, dec):
+        H, D = self.n_head, self.d_head
+        u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
+        qu, qv = self._new(B, L, H, D), self._new(B, L, H, D)
+        ops.relattn_add_head_bias(qkv, u, vb, qu, qv, B, L, L, H, D)
+        old = dec.kv[i]
+        kv_all = torch.cat([old[:, old.shape[1] - mlen:], qkv.view(B, L, 3, H, D)[:, :, 1:3]], dim=1)  # [B, klen, 2, H, D]
+        klen = mlen + L
+        av = self._new(B, L, H, D)
+        ops.relattn_decode_fwd(qu, qv, kv_all[:, :, 0], kv_all[:, :, 1], dec.R[i], av, B, L, klen, mlen, H, D, shift, 1.0 / math.sqrt(D))
+        dec.new_kv.append(kv_all[:, max(0, klen - self.mem_len):])
+        return av
+
     def _attention_bwd(self, dav, c: _Ctx, i, B, L, shift):
         """returns dqkv [B*L, 3d] and dR [L, d]; accumulates du / dv_bias"""
         H, D, d = self.n_head, self.d_head, self.d_model
@@ -574,23 +642,28 @@ class TransformerXL(nn.Module):
         return dqkv, dR
 
     # ------------------------------------------------------------------ one decoder layer (post-LN; transformer_xl.py:112-353)
-    def _layer_fwd(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool):
+    def _layer_fwd(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool, dec=None):
         d, di, dff = self.d_model, self.d_inner, self.d_ff
         a = 1.0 if self.deepnorm_alpha is None else self.deepnorm_alpha
         p = f"h.{i}."
         c = _Ctx() if keep else None
         T = B * L
-        if mem is not None:
-            cat = torch.cat([mem.to(self.compute_dtype), x.view(B, L, d)], dim=1).contiguous()  # data movement only (:125)
-            Lk = cat.shape[1]
-            xin = cat.view(B * Lk, d)
+        if dec is not None:  # K/V-cached inference: only the new tokens are projected (identical maths: qkv_net has no bias)
+            qkv = self._new(T, 3 * d)
+            ops.gemm(x, self.W(p + "dec_attn.qkv_net.weight").t(), qkv)
+            av = self._attention_decode(qkv, i, B, L, mlen, shift, dec)
         else:
-            Lk, xin = L, x
-        qkv = self._new(B * Lk, 3 * d)
-        ops.gemm(xin, self.W(p + "dec_attn.qkv_net.weight").t(), qkv)
-        R = self._new(R_in.shape[0], d)
-        ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
-        av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c)
+            if mem is not None:
+                cat = torch.cat([mem.to(self.compute_dtype), x.view(B, L, d)], dim=1).contiguous()  # data movement only (:125)
+                Lk = cat.shape[1]
+                xin = cat.view(B * Lk, d)
+            else:
+                Lk, xin = L, x
+            qkv = self._new(B * Lk, 3 * d)
+            ops.gemm(xin, self.W(p + "dec_attn.qkv_net.weight").t(), qkv)
+            R = self._new(R_in.shape[0], d)
+            ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
+            av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c)
         o = self._new(T, d)
         ops.gemm(av.view(T, d), self.W(p + "dec_attn.o_net.weight").t(), o)
         h1 = self._new(T, d)
@@ -613,12 +686,12 @@ class TransformerXL(nn.Module):
         return out, c
 
     # ---- pre-LN ordering of the same kernels (config default `--pre-lnorm True`; transformer_xl.py:126-137,231-233,277-282)
-    def _layer_fwd_prelnorm(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool):
+    def _layer_fwd_prelnorm(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool, dec=None):
         d, di, dff = self.d_model, self.d_inner, self.d_ff
         p = f"h.{i}."
         c = _Ctx() if keep else None
         T = B * L
-        if mem is not None:
+        if mem is not None and dec is None:
             cat = torch.cat([mem.to(self.compute_dtype), x.view(B, L, d)], dim=1).contiguous()
             Lk = cat.shape[1]
             xin = cat.view(B * Lk, d)
@@ -630,9 +703,12 @@ class TransformerXL(nn.Module):
                                    hin, None, m1, r1, self.layer_norm_epsilon)
         qkv = self._new(B * Lk, 3 * d)
         ops.gemm(hin, self.W(p + "dec_attn.qkv_net.weight").t(), qkv)
-        R = self._new(R_in.shape[0], d)
-        ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
-        av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c)
+        if dec is not None:  # K/V-cached inference (the cache holds W_kv . LN(mem): LayerNorm is per token)
+            av = self._attention_decode(qkv, i, B, L, mlen, shift, dec)
+        else:
+            R = self._new(R_in.shape[0], d)
+            ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
+            av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c)
         o = self._new(T, d)
         ops.gemm(av.view(T, d), self.W(p + "dec_attn.o_net.weight").t(), o)
         h1 = self._new(T, d)
@@ -742,13 +818,14 @@ class TransformerXL(nn.Module):
         shift = self._window(L, mlen)
         if shift < 1 and mlen < 1:
             raise ValueError("empty attention mask")  # transformer_xl.py:177,205-206
-        R_in = self._sinusoid(klen)
+        dec = self._decode_begin(mems, B, L, mlen) if (mems is not None and mlen > 0) else None
+        R_in = self._sinusoid(klen) if dec is None else None
         x = h.view(B * L, d)
         hids, lcs = [], []
         for i in range(self.n_layer):
             hids.append(x)
             layer_fwd = self._layer_fwd_prelnorm if self.pre_lnorm else self._layer_fwd
-            x, c = layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep)
+            x, c = layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep, dec)
             lcs.append(c)
         Wout = self.arena.view(self.arena.work, "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight",
                                full=True).view(self.vocab_pad, d)
@@ -777,6 +854,8 @@ class TransformerXL(nn.Module):
             beg_idx = max(0, end_idx - self.mem_len)
             new_mems = [torch.cat([mems[i].to(self.compute_dtype), hids[i].view(B, L, d)], dim=1)[:, beg_idx:end_idx].detach()
                         for i in range(self.n_layer)]
+            # the K/V cache belongs to exactly these tensors (checked by identity on the next call)
+            self._dec_state = None if dec is None else SimpleNamespace(mems=new_mems, kv=dec.new_kv, version=self._wversion)
             res = res + (new_mems,)
         return res
 

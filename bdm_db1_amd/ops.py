@@ -215,6 +215,17 @@ def relattn_softmax_bwd(Pm, dP, dT, H, B, Lq, Lk, nd, mlen, shift, scale):
     lib.call("db1_relattn_softmax_bwd", P(Pm), P(dP), P(dT), H, B, Lq, Lk, nd, mlen, shift, float(scale), stream())
 
 
+def relattn_decode_supported(B, q, klen, H, D, dtype) -> bool:
+    return bool(lib.load().db1_relattn_decode_supported(B, q, klen, H, D, dt_code(dtype)))
+
+
+def relattn_decode_fwd(qu, qv, k, v, R, out, B, q, klen, mlen, H, D, shift, scale):
+    """k, v: views [B, klen, H, D] (any row / batch stride, unit stride inside a head row)"""
+    assert k.stride(3) == 1 and k.stride(2) == D and v.stride() == k.stride()
+    lib.call("db1_relattn_decode_fwd", P(qu), P(qv), P(k), P(v), k.stride(1), k.stride(0), P(R), R.shape[0], P(out),
+             B, q, klen, mlen, H, D, shift, float(scale), stream())
+
+
 def relattn_flash_supported(B, L, H, D, dtype) -> bool:
     return bool(lib.load().db1_relattn_flash_supported(B, L, H, D, dt_code(dtype)))
 

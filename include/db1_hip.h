@@ -135,6 +135,16 @@ int db1_masked_ce_fwd(const void* logits, const int64_t* labels, const float* ma
 int db1_masked_ce_bwd(const void* logits, const int64_t* labels, const float* mask, const float* lse, const float* sums,
                       void* dlogits, int64_t T, int V, int64_t ld, float gscale, int dt, void* stream);
 
+/* ------------------------------------------------------------------ relative-position attention for inference with memory
+ * (evaluate_rl.py:157-266; transformer_xl.py:124-133,160-225).  q = 1..64 new queries per sequence against klen = mlen + q cached
+ * keys / values (bf16, d_head 128).  qu, qv: [B, q, H, D]; k, v: row j of sequence b at k + b*kv_batch_stride + j*kv_row_stride
+ * (+ h*D); R: [nd, H*D] rows indexed by distance mlen + i - j; out: [B, q, H, D].  Same visibility predicate as the
+ * materialised path: i - shift < j <= i + mlen. */
+int db1_relattn_decode_supported(int B, int q, int klen, int H, int D, int dt);
+int db1_relattn_decode_fwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
+                           int64_t kv_batch_stride, const void* R, int nd, void* out, int B, int q, int klen, int mlen, int H,
+                           int D, int shift, float scale, void* stream);
+
 /* ------------------------------------------------------------------ relative-position attention, materialised path
  * (fp32 parity gate, any head size).  Buffers S,T are float32 in [H][B][Lq][*] layout.
  * qu = q + u, qv = q + v_bias from the packed qkv activations [B, L, 3, H, D]  (transformer_xl.py:161,167). */

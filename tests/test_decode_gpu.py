@@ -1,0 +1,99 @@
+"""Inference with Transformer-XL memory: the fused decode attention kernel (1..64 queries against mlen + q cached keys) against a
+NumPy statement of the closed form, and the model's K/V-cached memory path against the reference's golden logits."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def bf(a):
+    return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+def dev16(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("B,q,mlen,H,shift", [(1, 1, 1024, 16, 1024), (2, 5, 100, 2, 105), (1, 22, 1024, 3, 1024), (1, 40, 300, 2, 64),
+                                               (2, 64, 64, 1, 128), (1, 1, 0, 2, 1), (1, 17, 7, 2, 5)])
+def test_decode_attention_matches_closed_form(B, q, mlen, H, shift):
+    """score[i,j] = ((q_i+u).k_j + (q_i+v).R[mlen+i-j]) / sqrt(d), visible iff i - shift < j <= i + mlen (transformer_xl.py:160-209)"""
+    from bdm_db1_amd import ops
+    D, klen = 128, mlen + q
+    rng = np.random.default_rng(q * 1000 + mlen)
+    qu, qv = bf(rng.standard_normal((B, q, H, D))), bf(rng.standard_normal((B, q, H, D)))
+    kv = bf(rng.standard_normal((B, klen, 2, H, D)))
+    R = bf(rng.standard_normal((klen, H, D)))
+    scale = 1.0 / math.sqrt(D)
+    i = np.arange(q)[:, None]; j = np.arange(klen)[None, :]
+    AC = np.einsum("bihd,bjhd->bhij", qu, kv[:, :, 0])
+    T = np.einsum("bihd,rhd->bhir", qv, R)
+    BD = np.take_along_axis(T, np.broadcast_to(np.clip(mlen + i - j, 0, klen - 1)[None, None], AC.shape), axis=3)
+    vis = (j <= i + mlen) & (j > i - shift)
+    S = np.where(vis[None, None], (AC + BD) * scale, -np.inf)
+    Pm = np.exp(S - S.max(-1, keepdims=True))
+    Pm /= Pm.sum(-1, keepdims=True)
+    ref = np.einsum("bhij,bjhd->bihd", Pm, kv[:, :, 1])
+    KV = dev16(kv)
+    out = torch.full((B, q, H, D), 7.0, device=DEV, dtype=torch.bfloat16)
+    assert ops.relattn_decode_supported(B, q, klen, H, D, torch.bfloat16)
+    ops.relattn_decode_fwd(dev16(qu), dev16(qv), KV[:, :, 0], KV[:, :, 1], dev16(R).view(klen, H * D), out, B, q, klen, mlen, H, D, shift, scale)
+    torch.cuda.synchronize()
+    err = np.abs(out.double().cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < 2e-2, f"decode attention rel err {err:.3e}"  # bf16 rounding of P and of the output
+
+
+@pytest.mark.parametrize("pre_lnorm", [False, True])
+def test_model_kv_cached_memory_inference_matches_rereojection(pre_lnorm):
+    """the K/V-cached path (new tokens projected once, fused decode attention) against the reference-shaped path that
+    re-projects cat([mem, w]) every call (transformer_xl.py:124-133), over a call sequence like evaluate_rl's: a multi-token
+    observation, then single tokens; memory first zero (init_mem), then filling, then sliding.  Also: a caller that hands in
+    copies of the memory (cache miss -> rebuilt from the hidden states) gets the same logits."""
+    from bdm_db1_amd import TransformerXL, synth
+    from bdm_db1_amd.data import NLPTaskInput
+    cfg = synth.db1_config("tiny", n_embed=256, n_head=2, n_layer=2, n_position=64, mem_len=40, pre_lnorm=pre_lnorm, fp16=True)
+    torch.manual_seed(3)
+    model = TransformerXL(cfg, device=torch.device(DEV), compute_dtype=torch.bfloat16)
+    model.eval()
+    assert model.d_head == 128
+    rng = np.random.default_rng(0)
+    calls = [rng.integers(0, 32000, (2, q)) for q in (7, 1, 1, 22, 1, 30, 1, 1)]
+
+    def run(use_decode, copy_mems):
+        model.use_decode = use_decode
+        model._dec_state = None
+        mems = model.init_mem(2)
+        outs = []
+        with torch.no_grad():
+            for ids in calls:
+                x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None,
+                                 text_seq=torch.from_numpy(ids).to(DEV), text_len=None)
+                logits, _, mems = model([x], compute_loss=False, mems=mems)
+                outs.append(logits.float().cpu().numpy())
+                if copy_mems:
+                    mems = [m.clone() for m in mems]
+        return outs
+
+    ref = run(False, False)
+    for copy_mems in (False, True):
+        got = run(True, copy_mems)
+        for step, (a, b) in enumerate(zip(got, ref)):
+            err = np.abs(a - b).max() / np.abs(b).max()
+            assert err < 3e-2, f"step {step} (copy_mems={copy_mems}): rel err {err:.3e}"  # two bf16 pipelines, different rounding points
+    assert model._dec_state is not None  # the fused path really ran
