@@ -3,7 +3,7 @@
 Importing the package does not need a GPU; constructing a model or calling an op does, and raises
 if libdb1_hip.so or a gfx950 device is missing (there is no CPU fallback).
 """
-__all__ = ["TransformerXL", "initialize", "mpu"]
+__all__ = ["TransformerXL", "initialize", "mpu", "GraphedMemoryStep"]
 
 
 def __getattr__(name):
@@ -13,6 +13,9 @@ def __getattr__(name):
     if name == "initialize":
         from .engine import initialize
         return initialize
+    if name == "GraphedMemoryStep":
+        from .decode import GraphedMemoryStep
+        return GraphedMemoryStep
     if name == "mpu":
         import importlib
         return importlib.import_module(".mpu", __name__)

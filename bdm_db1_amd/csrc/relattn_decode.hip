@@ -3,7 +3,7 @@
 //     s[i,j] = ((q_i+u).k_j + (q_i+v).R[mlen+i-j]) / sqrt(d),   visible iff  i - shift < j <= i + mlen,   j in [0, klen)
 // The materialised path ran two batched GEMMs, a softmax and another batched GEMM per layer on the generic strided kernel
 // (135 us for P.V alone at q = 1); here one launch covers them, split over the keys ("flash decoding"):
-//   grid = (key chunks of 128, heads, batch); the 4 waves of a workgroup are the 4 possible 16-query tiles (a wave whose tile
+//   grid = (key chunks of 64, heads, batch); the 4 waves of a workgroup are the 4 possible 16-query tiles (a wave whose tile
 //   is empty exits); every wave is self-contained (own LDS: a 32-key V tile for the transposed reads + the skew scratch).
 //   Per 32-key step and wave: S^T = K.Qu^T (2 x 4 v_mfma_f32_16x16x32_bf16, K fragments straight from global), the relative
 //   term for the 47 distances the 16 x 32 block touches (3 x 4 MFMA against R rows) written to LDS [48 dist][16 q] and read
@@ -19,7 +19,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 #define DEC_D 128
-#define DEC_KC 128                       // keys per workgroup
+#define DEC_KC 64                        // keys per workgroup (two 32-key steps: the chunks, not the loop, provide the parallelism)
 #define DEC_WAVE_LDS (32 * 256 + 48 * 16 * 4)  // V tile [32][128] bf16 + T scratch [48][16] f32
 
 struct DecodeArgs {

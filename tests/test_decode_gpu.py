@@ -97,3 +97,29 @@ def test_model_kv_cached_memory_inference_matches_rereojection(pre_lnorm):
             err = np.abs(a - b).max() / np.abs(b).max()
             assert err < 3e-2, f"step {step} (copy_mems={copy_mems}): rel err {err:.3e}"  # two bf16 pipelines, different rounding points
     assert model._dec_state is not None  # the fused path really ran
+
+
+def test_graphed_memory_step_matches_eager_calls():
+    """one hipGraph replay per call (static buffers) reproduces the eager K/V-cached calls on the same token stream"""
+    from bdm_db1_amd import TransformerXL, GraphedMemoryStep, synth
+    from bdm_db1_amd.data import NLPTaskInput
+    cfg = synth.db1_config("tiny", n_embed=256, n_head=2, n_layer=2, n_position=64, mem_len=40, fp16=True)
+    torch.manual_seed(5)
+    model = TransformerXL(cfg, device=torch.device(DEV), compute_dtype=torch.bfloat16)
+    model.eval()
+    rng = np.random.default_rng(1)
+    stream = [torch.from_numpy(rng.integers(0, 32000, (1, 3))).to(DEV) for _ in range(12)]
+    mems, eager = model.init_mem(1), []
+    with torch.no_grad():
+        for ids in stream:
+            x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
+            logits, _, mems = model([x], compute_loss=False, mems=mems)
+            eager.append(logits.float().cpu().numpy())
+    step = GraphedMemoryStep(model, batch_size=1, n_new=3)
+    for rep in range(2):  # second pass after reset_memory(): a new episode starts from the zero memory again
+        for t, ids in enumerate(stream):
+            logits, _ = step(ids)
+            got = logits.float().cpu().numpy()
+            err = np.abs(got - eager[t]).max() / np.abs(eager[t]).max()
+            assert err < 1e-6, f"pass {rep} call {t}: graph vs eager rel err {err:.3e}"
+        step.reset_memory()

@@ -45,6 +45,21 @@ def timed(q, n, mems):
     return e0.elapsed_time(e1) / n, wall, mems
 
 
+for q in (q_first, 1):  # same calls as ONE hipGraph replay each (bdm_db1_amd/decode.py)
+    from bdm_db1_amd import GraphedMemoryStep
+    step = GraphedMemoryStep(model, batch_size=1, n_new=q)
+    ids = torch.randint(0, 32000, (1, q), device=dev)
+    for _ in range(3):
+        step(ids)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(ids)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    print(f"graphed q={q:3d} mem={step.mems[0].shape[1]}: {ms:8.3f} ms/call (wall)  {q / ms * 1e3:9.1f} tokens/s")
+    del step
+
 mems = model.init_mem(1)
 for q in (q_first, 1):
     ms, wall, mems = timed(q, steps, mems)
