@@ -186,3 +186,52 @@ def test_bf16_forward_backward_close_to_oracle():
     for n in ("h.0.dec_attn.qkv_net.weight", "h.1.pos_ff.CoreNet.0.weight", "word_embedding.weight", "r_w_bias", "r_r_bias",
               "h.0.dec_attn.r_net.weight", "h.1.pos_ff.layer_norm.weight"):
         assert rel_err(model.G(n), ref_grads[n]) < 6e-2, n
+
+
+def test_checkpoint_round_trip_deepspeed_layout(tmp_path):
+    """save_checkpoint / load_checkpoint (checkpointing.py:17-22, evaluate_rl.py:510): <dir>/<tag>/mp_rank_00_model_states.pt with the
+    weights under "module" in the reference's parameter names, `latest` tag file, optimizer moments restored; a file written the way
+    DeepSpeed writes it (only "module" + client keys) loads too."""
+    from bdm_db1_amd import initialize
+    name = "small_window"
+    cfg, params, gold, model, oracle, seed = build(name)
+    args = SimpleNamespace(lr=2e-3, weight_decay=0.0, clip_grad=1.0, optimizer="adam", keep_logits=True)
+    engine, _, _, _ = initialize(args, model)
+    tasks = make_batch(name, cfg, seed)
+    engine.train()
+    for _ in range(2):
+        logits, loss = engine(to_inputs(tasks))
+        engine.backward(loss)
+        engine.step()
+    engine.save_checkpoint(str(tmp_path), tag="latest_model", client_state={"iteration": 2, "args": {"n_layer": cfg["n_layer"]}})
+    assert (tmp_path / "latest").read_text().strip() == "latest_model"
+    blob = torch.load(tmp_path / "latest_model" / "mp_rank_00_model_states.pt", map_location="cpu", weights_only=False)
+    assert set(params.keys()) <= set(blob["module"].keys()) and blob["iteration"] == 2
+    sd_before = {k: v.clone() for k, v in model.state_dict().items()}
+    m_before = model.arena.exp_avg.clone()
+    # a fresh model + engine restores weights, moments and the step counter, and produces the same next step
+    cfg2, _, _, model2, _, _ = build(name)
+    engine2, _, _, _ = initialize(args, model2)
+    path, client = engine2.load_checkpoint(str(tmp_path), None)
+    assert path.endswith("mp_rank_00_model_states.pt") and client["iteration"] == 2
+    for k, v in sd_before.items():
+        assert torch.equal(model2.state_dict()[k].cpu(), v.cpu()), k
+    assert torch.equal(model2.arena.exp_avg, m_before) and engine2.global_steps == 2
+    engine2.train()
+    for e in (engine, engine2):
+        lg, ls = e(to_inputs(tasks))
+        e.backward(ls)
+        e.step()
+    for k in sd_before:  # (the embedding scatter-add uses fp32 atomics: not bit-reproducible between two runs, hence a tolerance)
+        assert rel_err(model2.state_dict()[k], model.state_dict()[k].double().cpu().numpy()) < 1e-6, k
+    # DeepSpeed-shaped file: weights only
+    ds_dir = tmp_path / "ds" / "db1_870task_checkpoint"
+    ds_dir.mkdir(parents=True)
+    torch.save({"module": {k: torch.from_numpy(np.asarray(v)) for k, v in params.items()}, "iteration": 7},
+               ds_dir / "mp_rank_00_model_states.pt")
+    cfg3, _, _, model3, _, _ = build(name)
+    engine3, _, _, _ = initialize(args, model3)
+    _, client3 = engine3.load_checkpoint(str(tmp_path / "ds"), "db1_870task_checkpoint")
+    assert client3["iteration"] == 7
+    for k, v in params.items():
+        assert rel_err(model3.state_dict()[k], v) < 1e-7, k
