@@ -69,5 +69,22 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+DATA_SRC = os.path.join(HERE, "csrc_host", "db1_data.cpp")
+DATA_LIB = os.path.join(HERE, "libdb1_data.so")
+
+
+def build_data_lib(force: bool = False) -> str:
+    """libdb1_data.so: the host-side data ingest (include/db1_data.h) -- plain C++17, g++."""
+    hdr = os.path.join(os.path.dirname(HERE), "include", "db1_data.h")
+    newest = max(os.path.getmtime(DATA_SRC), os.path.getmtime(hdr))
+    if not force and os.path.exists(DATA_LIB) and os.path.getmtime(DATA_LIB) >= newest:
+        return DATA_LIB
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", DATA_LIB, DATA_SRC], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed on db1_data.cpp:\n{r.stderr[-4000:]}")
+    return DATA_LIB
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_data_lib(force="--force" in sys.argv))

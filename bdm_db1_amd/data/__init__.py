@@ -1,3 +1,11 @@
 from .input_specs import GatoInputBase, RLTaskInput, NLPTaskInput, ICTaskInput, VQATaskInput  # noqa: F401
 from .samplers import (my_collate_fn, SequentialPretrainingSampler, RandomPretrainingSampler, RandomSeedDataset,  # noqa: F401
                        build_pretraining_data_loader)
+
+
+def __getattr__(name):  # the token store / index builders need libdb1_data.so: imported on first use
+    if name in ("MMapIndexedDataset", "build_sample_idx", "build_rl_sample_idx", "build_blending_indices", "indexed"):
+        import importlib
+        mod = importlib.import_module(".indexed", __name__)
+        return mod if name == "indexed" else getattr(mod, name)
+    raise AttributeError(name)

@@ -254,7 +254,63 @@ def gen_samplers():
     return out
 
 
+def gen_data_ingest():
+    """Golden vectors for libdb1_data.so, produced by the reference itself:
+    * a token store written by the reference's MMapIndexedDatasetBuilder (src/data/indexed_dataset.py:566-598) -> data_fixture.idx/.bin
+      (data files) plus the items / sizes / doc_idx it reads back;
+    * the reference's native index builders (src/data/helpers.cpp compiled by oracle/Makefile into oracle/_ref/)."""
+    if not hasattr(np, "float"):
+        np.float = np.float64  # the reference's dtype table still uses the alias numpy removed (indexed_dataset.py:109)
+    from src.data import indexed_dataset as ref_idx
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref"))
+    import helpers as ref_helpers
+    rng = np.random.default_rng(21)
+    out = {}
+    prefix = os.path.join(HERE, "data_fixture")
+    b = ref_idx.MMapIndexedDatasetBuilder(prefix + ".bin", dtype=np.uint16)
+    lens = [5, 1, 17, 64, 3, 9, 33, 2, 40, 7, 12]
+    items = [rng.integers(0, 50000, n).astype(np.uint16) for n in lens]
+    for i, it in enumerate(items):
+        b.add_item(torch.from_numpy(it.astype(np.int64)))
+        if i in (1, 3, 4, 8, 10):
+            b.end_document()
+    b.finalize(prefix + ".idx")
+    ds = ref_idx.MMapIndexedDataset(prefix, skip_warmup=True)
+    out["store_sizes"], out["store_doc_idx"] = np.array(ds.sizes), np.array(ds.doc_idx)
+    out["store_flat"] = np.concatenate([np.array(ds[i]) for i in range(len(ds))])
+    out["store_get_3_10_20"] = np.array(ds.get(3, 10, 20))
+    out["store_get_8_5"] = np.array(ds.get(8, 5))
+    sl = ds[2:6]
+    out["store_slice_2_6_lens"] = np.array([len(x) for x in sl])
+    out["store_slice_2_6_flat"] = np.concatenate([np.array(x) for x in sl])
+    del ds
+    # sample index: documents = the store's items shuffled over 3 epochs, as gpt_dataset.py:262-292 calls it
+    sizes = np.array(lens, dtype=np.int32)
+    for k, (seq, epochs) in enumerate([(16, 3), (7, 2), (50, 4), (2, 1)]):
+        doc_idx = np.concatenate([rng.permutation(len(lens)) for _ in range(epochs)]).astype(np.int32)
+        tpe = int(sizes.sum())
+        out[f"sample_args{k}"] = np.array([seq, epochs, tpe])
+        out[f"sample_doc_idx{k}"] = doc_idx
+        out[f"sample_idx{k}"] = np.array(ref_helpers.build_sample_idx(sizes, doc_idx, seq, epochs, tpe))
+    out["sample_sizes"] = sizes
+    pl = rng.integers(2, 40, 23).astype(np.int32)
+    out["rl_path_lengths"] = pl
+    for tn in (1, 5, 47):
+        out[f"rl_idx_tn{tn}"] = np.array(ref_helpers.build_rl_sample_idx(pl, tn))
+    w = np.array([0.5, 0.25, 0.15, 0.1])
+    for size in (1, 10, 1000):
+        di, dsi = np.zeros(size, np.uint8), np.zeros(size, np.int64)
+        ref_helpers.build_blending_indices(di, dsi, w, len(w), size, False)
+        out[f"blend_index_{size}"], out[f"blend_sample_{size}"] = di, dsi
+    out["blend_weights"] = w
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "data":
+        np.savez_compressed(os.path.join(HERE, "data_ingest.npz"), **gen_data_ingest())
+        print("wrote data_ingest + data_fixture.idx/.bin")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "samplers":
         np.savez_compressed(os.path.join(HERE, "samplers.npz"), **gen_samplers())
         print("wrote samplers")

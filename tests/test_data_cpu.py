@@ -1,0 +1,114 @@
+"""libdb1_data.so (include/db1_data.h): the memory-mapped token store and the index builders against golden vectors produced by
+the reference itself (its MMapIndexedDatasetBuilder / MMapIndexedDataset and its native helpers.cpp: tests/golden/make_golden.py data),
+and, when oracle/_ref is present (build container), directly against the reference's compiled helpers on random inputs."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def D():
+    from bdm_db1_amd.build import build_data_lib
+    build_data_lib()
+    from bdm_db1_amd.data import indexed
+    return indexed
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(os.path.join(G, "data_ingest.npz")))
+
+
+def test_library_exports_every_declared_symbol(D):
+    hdr = open(os.path.join(ROOT, "include", "db1_data.h")).read()
+    names = sorted(set(re.findall(r"\b(db1_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 15
+    lib = ctypes.CDLL(os.path.join(ROOT, "bdm_db1_amd", "libdb1_data.so"))
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_token_store_reads_what_the_reference_wrote(D, gold):
+    ds = D.MMapIndexedDataset(os.path.join(G, "data_fixture"))
+    assert len(ds) == len(gold["store_sizes"]) and ds.dtype == np.uint16
+    assert np.array_equal(ds.sizes, gold["store_sizes"]) and np.array_equal(ds.doc_idx, gold["store_doc_idx"])
+    assert np.array_equal(np.concatenate([ds[i] for i in range(len(ds))]), gold["store_flat"])
+    assert np.array_equal(ds.get(3, 10, 20), gold["store_get_3_10_20"])
+    assert np.array_equal(ds.get(8, 5), gold["store_get_8_5"])
+    sl = ds[2:6]
+    assert [len(x) for x in sl] == list(gold["store_slice_2_6_lens"])
+    assert np.array_equal(np.concatenate(sl), gold["store_slice_2_6_flat"])
+    assert ds[2:2] == [] and D.MMapIndexedDataset.exists(os.path.join(G, "data_fixture"))
+    with pytest.raises(D.Db1DataError):
+        ds.get(len(ds))
+    with pytest.raises(D.Db1DataError):
+        ds.get(0, 3, 100)
+    with pytest.raises(ValueError):
+        ds[0:4:2]
+    with pytest.raises(D.Db1DataError):
+        D.MMapIndexedDataset(os.path.join(G, "no_such_prefix"))
+
+
+def test_rejects_a_corrupt_index(D, tmp_path):
+    raw = open(os.path.join(G, "data_fixture.idx"), "rb").read()
+    for name, blob in (("magic", b"XXIDIDX\x00\x00" + raw[9:]), ("short", raw[:40]), ("dtype", raw[:17] + b"\x63" + raw[18:])):
+        p = tmp_path / name
+        (tmp_path / (name + ".idx")).write_bytes(blob)
+        (tmp_path / (name + ".bin")).write_bytes(open(os.path.join(G, "data_fixture.bin"), "rb").read())
+        with pytest.raises(D.Db1DataError):
+            D.MMapIndexedDataset(str(p))
+
+
+def test_index_builders_match_reference_golden(D, gold):
+    for k in range(4):
+        seq, epochs, tpe = (int(v) for v in gold[f"sample_args{k}"])
+        got = D.build_sample_idx(gold["sample_sizes"], gold[f"sample_doc_idx{k}"], seq, epochs, tpe)
+        assert got.dtype == np.int32 and np.array_equal(got, gold[f"sample_idx{k}"]), k
+    for tn in (1, 5, 47):
+        assert np.array_equal(D.build_rl_sample_idx(gold["rl_path_lengths"], tn), gold[f"rl_idx_tn{tn}"])
+    for size in (1, 10, 1000):
+        di, dsi = np.zeros(size, np.uint8), np.zeros(size, np.int64)
+        D.build_blending_indices(di, dsi, gold["blend_weights"], len(gold["blend_weights"]), size)
+        assert np.array_equal(di, gold[f"blend_index_{size}"]) and np.array_equal(dsi, gold[f"blend_sample_{size}"])
+    with pytest.raises(D.Db1DataError):
+        D.build_sample_idx(gold["sample_sizes"], gold["sample_doc_idx0"], 1, 1, 100)  # seq_length must exceed 1
+
+
+def test_index_builders_against_compiled_reference_helpers(D):
+    """the reference's own helpers.cpp, compiled by oracle/Makefile (present in the build container only)"""
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.isdir(ref_dir) or not any(f.startswith("helpers") for f in os.listdir(ref_dir)):
+        pytest.skip("oracle/_ref/helpers*.so not built (needs /root/reference)")
+    sys.path.insert(0, ref_dir)
+    import helpers as ref
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        ndoc = int(rng.integers(1, 60))
+        sizes = rng.integers(1, 300, ndoc).astype(np.int32)
+        epochs = int(rng.integers(1, 4))
+        doc_idx = np.concatenate([rng.permutation(ndoc) for _ in range(epochs)]).astype(np.int32)
+        seq = int(rng.integers(2, 128))
+        tpe = int(sizes.sum())
+        if tpe <= 1:
+            continue
+        assert np.array_equal(D.build_sample_idx(sizes, doc_idx, seq, epochs, tpe), np.array(ref.build_sample_idx(sizes, doc_idx, seq, epochs, tpe)))
+        pl = rng.integers(2, 100, int(rng.integers(1, 50))).astype(np.int32)
+        tn = int(rng.integers(1, 60))
+        assert np.array_equal(D.build_rl_sample_idx(pl, tn), np.array(ref.build_rl_sample_idx(pl, tn)))
+        nd = int(rng.integers(1, 9))
+        w = rng.random(nd)
+        w /= w.sum()
+        size = int(rng.integers(1, 5000))
+        a, b = np.zeros(size, np.uint8), np.zeros(size, np.int64)
+        c, e = np.zeros(size, np.uint8), np.zeros(size, np.int64)
+        D.build_blending_indices(a, b, w, nd, size)
+        ref.build_blending_indices(c, e, w, nd, size, False)
+        assert np.array_equal(a, c) and np.array_equal(b, e)
