@@ -1,6 +1,7 @@
 from .input_specs import GatoInputBase, RLTaskInput, NLPTaskInput, ICTaskInput, VQATaskInput  # noqa: F401
 from .samplers import (my_collate_fn, SequentialPretrainingSampler, RandomPretrainingSampler, RandomSeedDataset,  # noqa: F401
                        build_pretraining_data_loader)
+from .packers import _get_action_flag_and_position_id, _truncate_or_pad_to_match_seq_len  # noqa: F401
 
 
 def __getattr__(name):  # the token store / index builders need libdb1_data.so: imported on first use

@@ -227,3 +227,18 @@ def test_samplers_and_collate_match_reference_golden():
     assert np.array_equal(merged[0].text_seq.numpy(), gold["collate_nlp_text"])
     assert list(merged[1].vision_seq.shape) == gold["collate_rl_vision_shape"].tolist()
     assert np.array_equal(merged[1].tensor_seq.numpy(), gold["collate_rl_tensor"])
+
+
+def test_rl_packers_match_reference_golden():
+    """bdm_db1_amd.data._get_action_flag_and_position_id / _truncate_or_pad_to_match_seq_len (rl_dataset.py:44-71,865-872)"""
+    from bdm_db1_amd.data import _get_action_flag_and_position_id, _truncate_or_pad_to_match_seq_len
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "rl_packing.npz")))
+    i = 0
+    while f"args{i}" in gold:
+        f, p = _get_action_flag_and_position_id(*[int(x) for x in gold[f"args{i}"]])
+        assert f.dtype == np.int64 and (f == gold[f"flag{i}"]).all() and (p == gold[f"pos{i}"]).all(), i
+        i += 1
+    assert i >= 5
+    assert (_truncate_or_pad_to_match_seq_len(gold["pad_in"], 8) == gold["pad8"]).all()
+    assert (_truncate_or_pad_to_match_seq_len(gold["pad_in"], 3) == gold["pad3"]).all()
+    assert _truncate_or_pad_to_match_seq_len(gold["pad_in"], 5) is gold["pad_in"]
