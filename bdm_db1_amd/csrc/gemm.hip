@@ -218,6 +218,7 @@ static void launch_tile(const GemmTileArgs& t, int dtC, int dtBias, dim3 grid, h
     }
 }
 
+static thread_local int g_tri_mode = 0, g_tri_period = 0;  // structural-zero hint of the current call (db1_gemm_strided_tri)
 static int g_force_generic = 0;
 extern "C" void db1_gemm_force_generic(int on) { g_force_generic = on; }
 static int g_splitk = 1;      // DB1_GEMM_SPLITK=0 disables the workspace split-K (A/B measurements)
@@ -249,6 +250,8 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
         t.M = M; t.N = N; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = c_rs;
         t.batch1 = batch1; t.a_bs0 = a_bs0; t.a_bs1 = a_bs1; t.b_bs0 = b_bs0; t.b_bs1 = b_bs1; t.c_bs0 = c_bs0; t.c_bs1 = c_bs1;
         t.alpha = alpha; t.beta = beta; t.tiles_m = (M + TBM - 1) / TBM; t.tiles_n = (N + TBN - 1) / TBN;
+        t.tri_mode = g_tri_mode; t.tri_period = g_tri_period;
+        if (t.tri_mode == 2 && (t.tri_period <= 0 || (t.tri_period % TBK) || (K % t.tri_period))) t.tri_mode = 0;
         // measured on MI355X at the DB1-1.3B shapes (tools/bench_kernels.py gemm; table in DESIGN.md): the 256x256 ping-pong
         // kernel wins by 15-35 % wherever it has >= ~160 output tiles to spread over the 256 CUs; below that the 3-stage
         // 256x128 kernel wins for the transposed-operand forms and the 2-stage 128x128 kernel for NT / small outputs.
@@ -271,6 +274,7 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
                 GemmTileArgs u = t;
                 const int64_t kc = K / S;
                 u.K = (int)kc; u.C = ws; u.bias = nullptr; u.beta = 0.f; u.ldc = N;
+                if (u.tri_mode == 1 || (u.tri_mode == 2 && (kc % u.tri_period))) u.tri_mode = 0;  // a slice of k no longer starts at k = 0 / on a period
                 u.batch1 = S; u.a_bs1 = fa == 0 ? kc : kc * lda; u.b_bs1 = fb == 0 ? kc : kc * ldb;
                 u.c_bs0 = (int64_t)S * M * N; u.c_bs1 = (int64_t)M * N;
                 int rc = pp_shape ? (fb == 1 ? db1_gemm_pp32_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st)
@@ -329,6 +333,21 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
     a.batch1 = batch1; a.a_bs0 = a_bs0; a.a_bs1 = a_bs1; a.b_bs0 = b_bs0; a.b_bs1 = b_bs1; a.c_bs0 = c_bs0; a.c_bs1 = c_bs1;
     a.alpha = alpha; a.beta = beta;
     return db1_gemm_strided_generic(a, dtA, dtB, dtC, dtBias, (int)batch, st);
+}
+
+extern "C" int db1_gemm_strided_tri(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int dtA, int dtB,
+                                    int dtC, int dtBias, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs,
+                                    int64_t c_cs, int batch0, int batch1, int64_t a_bs0, int64_t a_bs1, int64_t b_bs0,
+                                    int64_t b_bs1, int64_t c_bs0, int64_t c_bs1, float alpha, float beta, int tri_mode, int tri_period,
+                                    void* stream) {
+    if (tri_mode < 0 || tri_mode > 2) DB1_FAIL(DB1_ERR_UNSUPPORTED, "gemm_strided_tri: mode %d", tri_mode);
+    g_tri_mode = tri_mode;
+    g_tri_period = tri_period;
+    const int rc = db1_gemm_strided(A, B, C, bias, M, N, K, dtA, dtB, dtC, dtBias, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, batch0, batch1, a_bs0,
+                                    a_bs1, b_bs0, b_bs1, c_bs0, c_bs1, alpha, beta, stream);
+    g_tri_mode = 0;
+    g_tri_period = 0;
+    return rc;
 }
 
 extern "C" int db1_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,

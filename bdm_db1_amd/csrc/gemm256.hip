@@ -87,14 +87,26 @@ __global__ __launch_bounds__(NWM * NWN * 64, 1) void gemm_bf16_tile256_kernel(Ge
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // k-tiles that can hold non-zeros of A (structural-zero hint, gemm_tile.h): t -> k-tile index
+    int nt = p.K / TBK, tri_lo = 0, tri_cnt = 1, tri_per = 1;
+    if (p.tri_mode == 1) {
+        const int lim = m0 / TBK + 256 / TBK;
+        nt = nt < lim ? nt : lim;
+    } else if (p.tri_mode == 2) {
+        tri_per = p.tri_period / TBK;
+        tri_lo = m0 / TBK < tri_per ? m0 / TBK : tri_per;
+        tri_cnt = tri_per - tri_lo;
+        nt = (nt / tri_per) * tri_cnt;
+    }
+    auto ktile = [&](int t) { return p.tri_mode == 2 ? (t / tri_cnt) * tri_per + tri_lo + t % tri_cnt : t; };
     auto stage = [&](int t, int buf) {  // 3 * PIECES global_load_lds per wave
         char* s = smem + buf * T256_STAGE_BYTES;
-        stage_tile<A_KMAJOR, PIECES>(A, p.lda, m0, t * TBK, s, wave, lane);
-        stage_tile<A_KMAJOR, PIECES>(A, p.lda, m0 + 128, t * TBK, s + TILE_BYTES, wave, lane);
-        stage_tile<B_KMAJOR, PIECES>(B, p.ldb, n0, t * TBK, s + 2 * TILE_BYTES, wave, lane);
+        const int k0 = ktile(t) * TBK;
+        stage_tile<A_KMAJOR, PIECES>(A, p.lda, m0, k0, s, wave, lane);
+        stage_tile<A_KMAJOR, PIECES>(A, p.lda, m0 + 128, k0, s + TILE_BYTES, wave, lane);
+        stage_tile<B_KMAJOR, PIECES>(B, p.ldb, n0, k0, s + 2 * TILE_BYTES, wave, lane);
     };
-    const int nt = p.K / TBK;
-    stage(0, 0);
+    if (nt > 0) stage(0, 0);
     if (nt > 1) stage(1, 1);
     auto reads = [&](int ks, Frag<A_KMAJOR>* af, Frag<B_KMAJOR>* bf, unsigned sb) {
 #pragma unroll

@@ -22,6 +22,10 @@ struct GemmTileArgs {
     float alpha, beta;
     int tiles_m, tiles_n;
     int ksplit;  // > 1: blockIdx.z owns K / ksplit of the contraction and accumulates into fp32 C with atomics (beta must be 1)
+    // structural-zero hint for A (256x128 kernel only; elsewhere ignored, the zeros are simply multiplied):
+    //   1: A[m, k] == 0 for k > m                      -> k-tiles beyond the tile's last row are skipped (dq_r = dT . R)
+    //   2: A[m, k] == 0 for (k mod tri_period) < m     -> per period only the k-tiles from the tile's first row on (dR = dT^T . qv)
+    int tri_mode, tri_period;
 };
 
 // ---- staging of one 16 KiB operand (sub-)tile = 16 wave-instructions of 1 KiB, PIECES per wave (wave w takes w*PIECES ..)

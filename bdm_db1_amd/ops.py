@@ -95,16 +95,18 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias: Optional[tor
     return out
 
 
-def gemm_batched(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, beta: float = 0.0):
-    """4-D views [z0, z1, rows, cols] with arbitrary strides (stride 0 broadcasts)."""
+def gemm_batched(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, beta: float = 0.0, tri=(0, 0)):
+    """4-D views [z0, z1, rows, cols] with arbitrary strides (stride 0 broadcasts).
+    ``tri`` = (mode, period): structural-zero hint for ``a`` (db1_gemm_strided_tri), an optimisation only."""
     Z0, Z1, M, K = a.shape
     _, _, K2, N = b.shape
     assert K == K2 and out.shape == (Z0, Z1, M, N) and b.shape[:2] == (Z0, Z1), (a.shape, b.shape, out.shape)
 
     def run():
-        lib.call("db1_gemm_strided", P(a), P(b), P(out), _vp(0), M, N, K, dt_code(a), dt_code(b), dt_code(out), 0,
+        lib.call("db1_gemm_strided_tri", P(a), P(b), P(out), _vp(0), M, N, K, dt_code(a), dt_code(b), dt_code(out), 0,
                  a.stride(2), a.stride(3), b.stride(2), b.stride(3), out.stride(2), out.stride(3), Z0, Z1,
-                 a.stride(0), a.stride(1), b.stride(0), b.stride(1), out.stride(0), out.stride(1), alpha, beta, stream())
+                 a.stride(0), a.stride(1), b.stride(0), b.stride(1), out.stride(0), out.stride(1), alpha, beta, int(tri[0]), int(tri[1]),
+                 stream())
 
     # the batched contractions of the attention backward (dq_r, dR) run on the same tile kernels: timed with the dense 2MNK they execute
     if _gemm_timer is not None and _is_tile_gemm(M, N, K, a, b, out, a.stride()[2:], b.stride()[2:], out.stride()[2:]):

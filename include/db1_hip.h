@@ -63,6 +63,14 @@ int db1_gemm_strided(const void* A, const void* B, void* C, const void* bias,
                      float alpha, float beta, void* stream);
 /* Row-major 2-D conveniences.  nt: C = A[M,K] * B[N,K]^T (y = x W^T);
  * nn: C = A[M,K] * B[K,N] (dx = dy W);  tn: C = A[K,M]^T * B[K,N] (dW = dy^T x). */
+/* db1_gemm_strided with a structural-zero hint for A (an optimisation only: results are those of the plain call):
+ *   tri_mode 1: A[m, k] == 0 for k > m;   tri_mode 2: A[m, k] == 0 for (k mod tri_period) < m.
+ * Used for the two contractions over dT (dS re-indexed by distance, zero above the causal diagonal): dq_r = dT.R (mode 1) and
+ * dR = dT^T.(q+v) over k = (batch, query) (mode 2, period = L): the k-tiles that are zero by construction are never read. */
+int db1_gemm_strided_tri(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int dtA, int dtB, int dtC, int dtBias,
+                         int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs, int64_t c_cs, int batch0, int batch1,
+                         int64_t a_bs0, int64_t a_bs1, int64_t b_bs0, int64_t b_bs1, int64_t c_bs0, int64_t c_bs1, float alpha, float beta,
+                         int tri_mode, int tri_period, void* stream);
 int db1_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
                 int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream);
 int db1_gemm_nn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,

@@ -33,6 +33,10 @@ def dev(a, dtype=torch.float32):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
 
 
+def dev16(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(torch.bfloat16)
+
+
 def bf(a):
     """round a float array to bf16 (returns float64 values that are exactly representable)"""
     return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
@@ -151,6 +155,36 @@ def test_gemm_skinny_few_rows(ops, M, N, K, od):
     out = dev(c0, td)
     ops.gemm(dev(x, torch.bfloat16), dev(w, torch.bfloat16).t(), out, bias=dev(bias, torch.bfloat16), alpha=0.5, beta=1.0)
     close(out, 0.5 * x @ w.T + c0 + bias, 2e-6 if od == "f32" else 6e-3, name=f"skinny gemm M={M}")
+
+
+def test_gemm_structural_zero_hints(ops):
+    """the two contractions over dT (zero above the causal diagonal) with the k-tile skipping hints: same results as the plain
+    calls; the skipped region really is skipped (it holds NaNs wherever a whole 64-wide k-tile lies above the diagonal)"""
+    rng = np.random.default_rng(17)
+    H, B, L, D = 2, 3, 512, 128
+    i = np.arange(L)[:, None]; dd = np.arange(L)[None, :]
+    dT = bf(rng.standard_normal((H, B, L, L))) * (dd <= i)
+    R = bf(rng.standard_normal((L, H, D)))
+    qv = bf(rng.standard_normal((B, L, H, D)))
+    poisoned = dT.copy()
+    tile_first_row = (i // 256) * 256
+    poisoned[..., (dd // 64) * 64 > tile_first_row + 255] = np.nan      # mode 1 never touches k-tiles right of the 256-row tile
+    dTd, dTp = dev16(dT), dev16(poisoned)
+    Rd, qvd = dev16(R), dev16(qv)
+    ref_dq = np.einsum("hbik,khd->bihd", dT, R)
+    ref_dR = np.einsum("hbik,bihd->khd", dT, qv)
+    for src, name in ((dTd, "zeros"), (dTp, "poisoned")):
+        dqv = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_batched(src, Rd.view(L, H, D).permute(1, 0, 2).unsqueeze(1).expand(H, B, L, D), dqv.permute(2, 0, 1, 3), tri=(1, 0))
+        close(dqv, ref_dq, 6e-3, name=f"dq_r tri ({name})")
+    poisoned2 = dT.copy()
+    dist_tile_first = (dd // 256) * 256
+    poisoned2[..., (i // 64) * 64 + 63 < dist_tile_first] = np.nan        # mode 2 never touches query k-tiles above the 256-distance tile
+    for src, name in ((dTd, "zeros"), (dev16(poisoned2), "poisoned")):
+        dR = torch.empty(L, H * D, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_batched(src.view(H, B * L, L).transpose(1, 2).unsqueeze(1), qvd.view(B * L, H, D).permute(1, 0, 2).unsqueeze(1),
+                         dR.view(L, H, D).permute(1, 0, 2).unsqueeze(1), tri=(2, L))
+        close(dR.view(L, H, D), ref_dR, 6e-3, name=f"dR tri ({name})")
 
 
 @pytest.mark.parametrize("case", ["weight_grad", "per_head_batched"])

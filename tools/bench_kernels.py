@@ -85,6 +85,14 @@ def small_out(B=16, L=1024):
     t = timeit(lambda: ops.gemm_batched(dT.view(H, B * L, L).transpose(1, 2).unsqueeze(1), qv.view(B * L, H, D).permute(1, 0, 2).unsqueeze(1),
                                         dR.view(L, H, D).permute(1, 0, 2).unsqueeze(1)))
     print(f"dR per head M={L} N={D} K={T} x{H}: {t * 1e3:8.1f} us  {dT.numel() * 2 / t / 1e6:7.1f} GB/s of dT")
+    t = timeit(lambda: ops.gemm_batched(dT.view(H, B * L, L).transpose(1, 2).unsqueeze(1), qv.view(B * L, H, D).permute(1, 0, 2).unsqueeze(1),
+                                        dR.view(L, H, D).permute(1, 0, 2).unsqueeze(1), tri=(2, L)))
+    print(f"dR with the zero hint: {t * 1e3:8.1f} us")
+    R = torch.randn(L, H, D, device=DEV).to(torch.bfloat16)
+    dqv = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
+    for tri in ((0, 0), (1, 0)):
+        t = timeit(lambda: ops.gemm_batched(dT, R.permute(1, 0, 2).unsqueeze(1).expand(H, B, L, D), dqv.permute(2, 0, 1, 3), tri=tri))
+        print(f"dq_r M={L} N={D} K={L} x{H * B} tri={tri[0]}: {t * 1e3:8.1f} us")
 
 
 if __name__ == "__main__":
