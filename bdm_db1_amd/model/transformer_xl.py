@@ -143,6 +143,8 @@ class TransformerXL(nn.Module):
         self.keep_logits = True          # False: the CE backward overwrites the logits buffer (training engines)
         self.use_flash = True            # fused attention when the shape is supported
         self.use_flash_bwd = True        # fused backward kernels (False: recompute through the materialised path)
+        self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
+        self._conv_ops = {}              # (weight name, weight version) -> tap-major GEMM operand
         self.use_decode = True           # inference with memory: K/V-cached path + fused decode attention when the shape allows
         self._wversion = 0               # bumped whenever the weights change (invalidates the inference caches)
         self._dec_state = None           # K/V cache of the memory returned by the last forward (see _decode_begin)
@@ -337,6 +339,79 @@ class TransformerXL(nn.Module):
         ops.add2d(w, wp[:, :K], wp[:, :K])
         return wp
 
+    # ---- channels-last pipeline (bf16, 16x16 patches): activations [N, 256, 64], tap-major column matrices, no layout shuffles
+    # between the convolutions (vision.hip).  The fp32 parity path below keeps the reference's NCHW order end to end.
+    def _conv_operand_cl(self, wname, Cin):
+        """GEMM operand [64, kpad] (tap-major columns, zero padded to a multiple of 8) of a 3x3 conv weight, per weight version"""
+        key = (wname, self._wversion)
+        if key not in self._conv_ops:
+            self._conv_ops = {k: v for k, v in self._conv_ops.items() if k[1] == self._wversion}
+            wp = torch.empty(64, _round_up(9 * Cin, 8), device=self.dev, dtype=self.compute_dtype)
+            ops.conv_weight_permute(self.W(wname), wp, 64, Cin)
+            self._conv_ops[key] = wp
+        return self._conv_ops[key]
+
+    def _conv3x3_fwd_cl(self, x_cl, wname, bname, N, Cin):
+        hw = self.patch_size * self.patch_size
+        wp = self._conv_operand_cl(wname, Cin)
+        cols = self._new(N * hw, wp.shape[1])
+        ops.im2col3x3_nhwc(x_cl, cols, N, Cin, self.patch_size)
+        out = self._new(N * hw, 64)
+        ops.gemm(cols, wp.t(), out, bias=self.W(bname))
+        return out, cols
+
+    def _conv3x3_bwd_cl(self, dy, cols, wname, bname, N, Cin, need_dx):
+        wp = self._conv_operand_cl(wname, Cin)
+        gp = torch.zeros(64, wp.shape[1], device=self.dev, dtype=torch.float32)
+        ops.gemm(dy.t(), cols, gp, beta=1.0)
+        ops.conv_wgrad_unpermute(gp, self.G(wname), 64, Cin)
+        ops.colsum_acc(dy, self.G(bname))
+        if not need_dx:
+            return None
+        dcols = self._new(cols.shape[0], wp.shape[1])
+        ops.gemm(dy, wp, dcols)
+        dx = self._new(N * self.patch_size * self.patch_size, Cin)
+        ops.col2im3x3_nhwc(dcols, dx, N, Cin, self.patch_size)
+        return dx
+
+    def _vision_fwd_cl(self, pixels, c, n_img, C, Hh, Ww):
+        p, d = self.patch_size, self.d_model
+        hw = p * p
+        N = n_img * (Hh // p) * (Ww // p)
+        pe = "vision_encoder.patch_embeddings."
+        patches = self._new(N * hw, C)
+        ops.patch_normalize_nhwc(pixels, patches, p)
+        c.c1, c.cols1 = self._conv3x3_fwd_cl(patches, pe + "conv1.weight", pe + "conv1.bias", N, C)
+        a0 = self._new(N * hw, 64)
+        c.m0, c.r0 = self._new(N * 32, dtype=torch.float32), self._new(N * 32, dtype=torch.float32)
+        ops.groupnorm_gelu_nhwc_fwd(c.c1, self.W(pe + "residual_path.0.weight"), self.W(pe + "residual_path.0.bias"), a0, c.m0, c.r0, N, 64, hw)
+        c.c2, c.cols2 = self._conv3x3_fwd_cl(a0, pe + "residual_path.2.weight", pe + "residual_path.2.bias", N, 64)
+        a1 = self._new(N * hw, 64)
+        c.m1, c.r1 = self._new(N * 32, dtype=torch.float32), self._new(N * 32, dtype=torch.float32)
+        ops.groupnorm_gelu_nhwc_fwd(c.c2, self.W(pe + "residual_path.3.weight"), self.W(pe + "residual_path.3.bias"), a1, c.m1, c.r1, N, 64, hw)
+        c3, c.cols3 = self._conv3x3_fwd_cl(a1, pe + "residual_path.5.weight", pe + "residual_path.5.bias", N, 64)
+        ops.add(c.c1, c3, c3)                                  # residual
+        c.y = self._new(N, 64 * hw)                            # (c, y, x) flattening = the projection weight's layout
+        ops.nhwc_to_nchw(c3, c.y, N, 64, hw)
+        emb = self._new(N, d)
+        ops.gemm(c.y, self.W(pe + "projection.weight").view(d, 64 * hw).t(), emb, bias=self.W(pe + "projection.bias"))
+        return emb, N
+
+    def _vision_bwd_cl(self, dy_cl, c, N):
+        """dy_cl [N*256, 64]: gradient w.r.t. the residual sum, channels-last"""
+        pe = "vision_encoder.patch_embeddings."
+        hw = self.patch_size * self.patch_size
+        da1 = self._conv3x3_bwd_cl(dy_cl, c.cols3, pe + "residual_path.5.weight", pe + "residual_path.5.bias", N, 64, True)
+        dc2 = self._new(N * hw, 64)
+        ops.groupnorm_gelu_nhwc_bwd(da1, c.c2, self.W(pe + "residual_path.3.weight"), self.W(pe + "residual_path.3.bias"), c.m1, c.r1, dc2,
+                                    self.G(pe + "residual_path.3.weight"), self.G(pe + "residual_path.3.bias"), N, 64, hw)
+        da0 = self._conv3x3_bwd_cl(dc2, c.cols2, pe + "residual_path.2.weight", pe + "residual_path.2.bias", N, 64, True)
+        dc1 = self._new(N * hw, 64)
+        ops.groupnorm_gelu_nhwc_bwd(da0, c.c1, self.W(pe + "residual_path.0.weight"), self.W(pe + "residual_path.0.bias"), c.m0, c.r0, dc1,
+                                    self.G(pe + "residual_path.0.weight"), self.G(pe + "residual_path.0.bias"), N, 64, hw)
+        ops.add(dc1, dy_cl, dc1)                               # residual branch
+        self._conv3x3_bwd_cl(dc1, c.cols1, pe + "conv1.weight", pe + "conv1.bias", N, c.C, False)
+
     def _vision_fwd(self, pixels: torch.Tensor, row_ids=None, col_ids=None):
         pixels = pixels.to(device=self.dev, dtype=torch.float32).contiguous()
         n_img, C, Hh, Ww = pixels.shape
@@ -346,6 +421,10 @@ class TransformerXL(nn.Module):
         N = n_img * h0 * w0
         pe = "vision_encoder.patch_embeddings."
         c = _Ctx()
+        c.cl = self.compute_dtype == torch.bfloat16 and hw == 256 and self.use_channels_last
+        if c.cl:
+            emb, N = self._vision_fwd_cl(pixels, c, n_img, C, Hh, Ww)
+            return self._vision_finish(emb, c, N, C, n_img, h0, w0, row_ids, col_ids)
         patches = self._new(N, C, p, p)
         ops.patch_normalize(pixels, patches, p)
         c1, c.cols1 = self._conv3x3_fwd(patches, pe + "conv1.weight", pe + "conv1.bias", N, C)
@@ -366,6 +445,10 @@ class TransformerXL(nn.Module):
         ops.nhwc_to_nchw(c3, c.y, N, 64, hw)
         emb = self._new(N, d)
         ops.gemm(c.y, self.W(pe + "projection.weight").view(d, 64 * hw).t(), emb, bias=self.W(pe + "projection.bias"))
+        return self._vision_finish(emb, c, N, C, n_img, h0, w0, row_ids, col_ids)
+
+    def _vision_finish(self, emb, c, N, C, n_img, h0, w0, row_ids, col_ids):
+        d = self.d_model
         if row_ids is None:
             row_ids, col_ids = self._vision_position_ids(h0, w0, n_img)
         c.row_ids, c.col_ids = self._dev_ids(row_ids).reshape(-1), self._dev_ids(col_ids).reshape(-1)
@@ -409,6 +492,8 @@ class TransformerXL(nn.Module):
         ops.gemm(demb, self.W(pe + "projection.weight").view(d, 64 * hw), dy)
         dy_nhwc = self._new(N * hw, 64)
         ops.nchw_to_nhwc(dy, dy_nhwc, N, 64, hw)
+        if c.cl:
+            return self._vision_bwd_cl(dy_nhwc, c, N)
         da1 = self._conv3x3_bwd(dy_nhwc, c.cols3, pe + "residual_path.5.weight", pe + "residual_path.5.bias", N, 64, True)
         dc2n = self._new(N, 64, hw)
         ops.groupnorm_gelu_bwd(da1, c.c2n, self.W(pe + "residual_path.3.weight"), self.W(pe + "residual_path.3.bias"), c.m1, c.r1, dc2n,

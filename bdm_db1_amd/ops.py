@@ -277,6 +277,39 @@ def groupnorm_gelu_bwd(dy, x, gamma, beta, mean, rstd, dx, dgamma_acc, dbeta_acc
              N, C, hw, groups, dt_code(x), dt_code(gamma), stream())
 
 
+# ---- channels-last vision pipeline (bf16 path)
+def patch_normalize_nhwc(pixels, patches, p):
+    n, C, Hh, Ww = pixels.shape
+    lib.call("db1_patch_normalize_nhwc", P(pixels), P(patches), n, C, Hh, Ww, p, dt_code(pixels), dt_code(patches), stream())
+
+
+def im2col3x3_nhwc(x, cols, N, C, p):
+    lib.call("db1_im2col3x3_nhwc", P(x), P(cols), N, C, p, cols.shape[-1], dt_code(x), stream())
+
+
+def col2im3x3_nhwc(dcols, dx, N, C, p):
+    lib.call("db1_col2im3x3_nhwc", P(dcols), P(dx), N, C, p, dcols.shape[-1], dt_code(dx), stream())
+
+
+def conv_weight_permute(w, wp, Cout, Cin):
+    lib.call("db1_conv_weight_permute", P(w), P(wp), Cout, Cin, wp.shape[-1], dt_code(w), dt_code(wp), stream())
+
+
+def conv_wgrad_unpermute(gp, g_acc, Cout, Cin):
+    assert gp.dtype == torch.float32 and g_acc.dtype == torch.float32
+    lib.call("db1_conv_wgrad_unpermute", P(gp), P(g_acc), Cout, Cin, gp.shape[-1], stream())
+
+
+def groupnorm_gelu_nhwc_fwd(x, gamma, beta, y, mean, rstd, N, C, hw, groups=32, eps=1e-5):
+    lib.call("db1_groupnorm_gelu_nhwc_fwd", P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), N, C, hw, groups, float(eps),
+             dt_code(x), dt_code(gamma), stream())
+
+
+def groupnorm_gelu_nhwc_bwd(dy, x, gamma, beta, mean, rstd, dx, dgamma_acc, dbeta_acc, N, C, hw, groups=32):
+    lib.call("db1_groupnorm_gelu_nhwc_bwd", P(dy), P(x), P(gamma), P(beta), P(mean), P(rstd), P(dx), P(dgamma_acc), P(dbeta_acc),
+             N, C, hw, groups, dt_code(x), dt_code(gamma), stream())
+
+
 def sumsq_acc(x, acc):
     lib.call("db1_sumsq_acc", P(x), P(acc), x.numel(), dt_code(x), stream())
 

@@ -194,6 +194,21 @@ int db1_patch_normalize(const void* pixels, void* patches, int n_img, int C, int
  * columns are zero-filled so that K is a multiple of 8 for the MFMA tile GEMM); col2im gathers the reverse. */
 int db1_im2col3x3(const void* x, void* cols, int64_t N, int C, int p, int kpad, int dt, void* stream);
 int db1_col2im3x3(const void* dcols, void* dx, int64_t N, int C, int p, int kpad, int dt, void* stream);
+/* Channels-last variants (the bf16 path): activations [N, p*p, C], column matrix tap-major cols[(n,y,x)][(ky*3+kx)*C + c], so every
+ * access is a 16-byte vector of consecutive channels.  db1_conv_weight_permute builds the matching GEMM operand [Cout, kpad] from
+ * the reference's [Cout, Cin, 3, 3] weight (vision_embedding.py:44-63), db1_conv_wgrad_unpermute adds a gradient computed in that
+ * order back to the parameter layout.  The GroupNorm+GELU pair is specialised to the embedder's C = 64, hw = 256. */
+int db1_patch_normalize_nhwc(const void* pixels, void* patches, int n_img, int C, int Himg, int Wimg, int p,
+                             int dtIn, int dtOut, void* stream);
+int db1_im2col3x3_nhwc(const void* x, void* cols, int64_t N, int C, int p, int kpad, int dt, void* stream);
+int db1_col2im3x3_nhwc(const void* dcols, void* dx, int64_t N, int C, int p, int kpad, int dt, void* stream);
+int db1_conv_weight_permute(const void* w, void* wp, int Cout, int Cin, int kpad, int dtIn, int dtOut, void* stream);
+int db1_conv_wgrad_unpermute(const float* gp, float* g_acc, int Cout, int Cin, int kpad, void* stream);
+int db1_groupnorm_gelu_nhwc_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                                int64_t N, int C, int hw, int groups, float eps, int dt, int dtParam, void* stream);
+int db1_groupnorm_gelu_nhwc_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean,
+                                const float* rstd, void* dx, float* dgamma_acc, float* dbeta_acc,
+                                int64_t N, int C, int hw, int groups, int dt, int dtParam, void* stream);
 /* layout shuffles between GEMM output [N*p*p, C] ("NHWC") and [N, C, p, p] ("NCHW") */
 int db1_nhwc_to_nchw(const void* x, void* y, int64_t N, int C, int hw, int dt, void* stream);
 int db1_nchw_to_nhwc(const void* x, void* y, int64_t N, int C, int hw, int dt, void* stream);

@@ -553,3 +553,56 @@ def test_patch_normalize_im2col_groupnorm(ops):
     close(dxx, dx_ref.reshape(N, 64, 256), 1e-5, name="gn+gelu dx")
     close(dga, dgam, 1e-5, name="gn dgamma")
     close(dbe, dbet, 1e-5, name="gn dbeta")
+
+
+def test_channels_last_vision_kernels(ops):
+    """the bf16 channels-last embedder kernels against the oracle's NCHW statements (same maths, transposed layouts)"""
+    rng = np.random.default_rng(29)
+    img = (rng.random((2, 3, 32, 48)) * 255).astype(np.float32)
+    ref = O.patch_normalize(O.patchify(img.astype(np.float64), 16), 16)            # [N, 3, 16, 16]
+    N = ref.shape[0]
+    out = torch.empty(N * 256, 3, device=DEV, dtype=torch.bfloat16)
+    ops.patch_normalize_nhwc(dev(img), out, 16)
+    close(out.view(N, 256, 3), ref.reshape(N, 3, 256).transpose(0, 2, 1), 6e-3, name="patch normalize (channels-last)")
+    for C, kpad in ((64, 576), (3, 32)):
+        x = bf(rng.standard_normal((N, C, 16, 16)))
+        x_cl = dev16(x.reshape(N, C, 256).transpose(0, 2, 1))                      # [N, 256, C]
+        cols = torch.full((N * 256, kpad), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.im2col3x3_nhwc(x_cl, cols, N, C, 16)
+        ref_cols = O._im2col3x3(x).reshape(N * 256, C, 9).transpose(0, 2, 1).reshape(N * 256, 9 * C)  # (c, tap) -> (tap, c)
+        got = cols.float().cpu().numpy()
+        assert np.array_equal(got[:, :9 * C], ref_cols.astype(np.float32)) and (got[:, 9 * C:] == 0).all(), f"im2col C={C}"
+        dcols = bf(rng.standard_normal((N * 256, kpad)))
+        dx = torch.empty(N * 256, C, device=DEV, dtype=torch.bfloat16)
+        ops.col2im3x3_nhwc(dev16(dcols), dx, N, C, 16)
+        dc_ref = dcols[:, :9 * C].reshape(N, 16, 16, 9, C).transpose(0, 1, 2, 4, 3).reshape(N, 16, 16, C * 9)
+        close(dx.view(N, 256, C), O._col2im3x3(dc_ref, C).reshape(N, C, 256).transpose(0, 2, 1), 6e-3, name=f"col2im C={C}")
+        # weight operand and gradient un-permutation
+        w = bf(rng.standard_normal((64, C, 3, 3)))
+        wp = torch.empty(64, kpad, device=DEV, dtype=torch.bfloat16)
+        ops.conv_weight_permute(dev16(w), wp, 64, C)
+        wref = np.zeros((64, kpad)); wref[:, :9 * C] = w.reshape(64, C, 9).transpose(0, 2, 1).reshape(64, 9 * C)
+        assert np.array_equal(wp.float().cpu().numpy(), wref.astype(np.float32))
+        gp = rng.standard_normal((64, kpad)).astype(np.float32)
+        g0 = rng.standard_normal((64, C, 3, 3)).astype(np.float32)
+        g = dev(g0)
+        ops.conv_wgrad_unpermute(dev(gp), g, 64, C)
+        close(g, g0 + gp[:, :9 * C].reshape(64, 9, C).transpose(0, 2, 1).reshape(64, C, 3, 3), 1e-6, name="wgrad unpermute")
+    # GroupNorm(32, 64) + GELU, channels-last
+    xg = bf(rng.standard_normal((N, 64, 16, 16)) * 2 + 0.3)
+    gam, bet = bf(1 + 0.2 * rng.standard_normal(64)), bf(0.2 * rng.standard_normal(64))
+    g_ref, cache = O.groupnorm_fwd(xg, gam, bet)
+    cl = lambda a: a.reshape(N, 64, 256).transpose(0, 2, 1)
+    yy = torch.empty(N * 256, 64, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(N * 32, device=DEV), torch.empty(N * 32, device=DEV)
+    ops.groupnorm_gelu_nhwc_fwd(dev16(cl(xg)), dev16(gam), dev16(bet), yy, mean, rstd, N, 64, 256)
+    close(yy.view(N, 256, 64), cl(O.gelu(g_ref)), 6e-3, name="gn+gelu fwd (channels-last)")
+    close(mean, xg.reshape(N * 32, -1).mean(1), 1e-5, name="gn mean")
+    dy = bf(rng.standard_normal((N, 64, 16, 16)))
+    dx_ref, dgam, dbet = O.groupnorm_bwd(dy * O.gelu_grad(g_ref), gam, cache)
+    dxx = torch.empty(N * 256, 64, device=DEV, dtype=torch.bfloat16)
+    dga, dbe = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    ops.groupnorm_gelu_nhwc_bwd(dev16(cl(dy)), dev16(cl(xg)), dev16(gam), dev16(bet), mean, rstd, dxx, dga, dbe, N, 64, 256)
+    close(dxx.view(N, 256, 64), cl(dx_ref), 8e-3, name="gn+gelu dx (channels-last)")
+    close(dga, dgam, 2e-4, name="gn dgamma (channels-last)")
+    close(dbe, dbet, 2e-4, name="gn dbeta (channels-last)")

@@ -235,3 +235,31 @@ def test_checkpoint_round_trip_deepspeed_layout(tmp_path):
     assert client3["iteration"] == 7
     for k, v in params.items():
         assert rel_err(model3.state_dict()[k], v) < 1e-7, k
+
+
+def test_bf16_channels_last_vision_path_matches_nchw_path_and_oracle():
+    """RL + caption batch in bf16: the channels-last image-patch embedder (default) against the NCHW kernels of the fp32 path, and
+    both against the CPU oracle.  Stated tolerance: loss 3e-2 abs; vision-encoder gradients 8e-2 of each tensor's max between a bf16
+    pipeline and the fp64 oracle, 3e-2 between the two bf16 pipelines (same maths, different rounding points)."""
+    name = "small_mixed"
+    names = ["vision_encoder.patch_embeddings.conv1.weight", "vision_encoder.patch_embeddings.conv1.bias",
+             "vision_encoder.patch_embeddings.residual_path.0.weight", "vision_encoder.patch_embeddings.residual_path.2.weight",
+             "vision_encoder.patch_embeddings.residual_path.3.bias", "vision_encoder.patch_embeddings.residual_path.5.weight",
+             "vision_encoder.patch_embeddings.residual_path.5.bias", "vision_encoder.patch_embeddings.projection.weight",
+             "vision_encoder.row_position_embeddings.weight", "h.0.dec_attn.qkv_net.weight"]
+    res = {}
+    for cl in (True, False):
+        cfg, params, gold, model, oracle, seed = build(name, compute_dtype=torch.bfloat16)
+        model.use_channels_last = cl
+        tasks = make_batch(name, cfg, seed)
+        logits, loss = model(to_inputs(tasks))
+        model.backward()
+        res[cl] = (float(loss), {n: model.G(n).detach().double().cpu().numpy().copy() for n in names})
+    _, ref_loss, _ = oracle.forward([O.TaskBatch(**t) for t in tasks])
+    ref_grads = oracle.backward()
+    for cl in (True, False):
+        assert abs(res[cl][0] - ref_loss) < 3e-2, (cl, res[cl][0], ref_loss)
+        for n in names:
+            assert rel_err(res[cl][1][n], ref_grads[n]) < 8e-2, (cl, n)
+    for n in names:
+        assert rel_err(res[True][1][n], res[False][1][n]) < 3e-2, n
