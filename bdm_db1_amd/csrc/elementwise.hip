@@ -617,7 +617,9 @@ extern "C" int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int c
     const int V = dt == DB1_F32 ? 4 : 8;
     if (cols % V == 0 && ldx % V == 0 && db1_aligned16(x)) {
         if (rows >= 1024) {  // long inputs: chunk partials + ordered reduce (deterministic, ~16 resident waves per CU)
-            const int rpc = 32, nchunks = (int)((rows + rpc - 1) / rpc);
+            int rpc = 32;
+            while (rows / rpc > 4096) rpc *= 2;  // the ordered reduce walks the chunks serially: keep them few (conv bias sums: 3.9 M rows)
+            const int nchunks = (int)((rows + rpc - 1) / rpc);
             float* ws = ln_workspace((size_t)nchunks * cols * sizeof(float));
             if (!ws) DB1_FAIL(DB1_ERR_HIP, "colsum: cannot allocate the partial-sum workspace");
             dim3 gc((unsigned)((cols / V + 63) / 64), (unsigned)nchunks);
@@ -766,44 +768,41 @@ extern "C" int db1_embed_scatter_add_bwd(const void* dout, const int64_t* ids, f
     return DB1_OK;
 }
 
-// RL assembly: one 256-thread block per sequence row.  The rank of each -1 placeholder inside its row
-// is a prefix count (ballot + popcount per 64-token chunk, chunk offsets through LDS).
+// RL assembly: grid (L / 32 token chunks, B).  The rank of a -1 placeholder inside its row = placeholders before the chunk (counted
+// by the whole block) + ballot / popcount prefix inside the chunk.  (One block per ROW left 240 of 256 CUs idle: 3.6 ms per call
+// at B = 16.)  dvis must be zero-initialised by the caller: only the rows that have a placeholder are written.
+#define RLA_TPB 32
 template <typename TT, typename T, bool BWD>
 __global__ __launch_bounds__(256) void rl_assemble_kernel(const TT* __restrict__ word_table, const TT* __restrict__ pos_table,
                                                           const T* vis, const int64_t* __restrict__ ids,
                                                           const int64_t* __restrict__ position_id, int64_t* labels, T* out,
                                                           float* dword, float* dpos, T* dvis, int L, int d, int nvis) {
-    extern __shared__ int rank_sm[];  // [L] rank of placeholder or -1
-    __shared__ int wave_cnt[4];
-    __shared__ int base_sm;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ int cnt_sm[4];
+    __shared__ int rank_sm[RLA_TPB];
+    const int b = blockIdx.y, c0 = blockIdx.x * RLA_TPB, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t* row = ids + (int64_t)b * L;
-    if (tid == 0) base_sm = 0;
+    int cnt = 0;
+    for (int t = tid; t < c0; t += 256) cnt += row[t] == -1 ? 1 : 0;
+    cnt = (int)wave_sum((float)cnt);  // < 2^24: exact in float
+    if (lane == 0) cnt_sm[w] = cnt;
     __syncthreads();
-    for (int c0 = 0; c0 < L; c0 += 256) {
-        const int t = c0 + tid;
-        const bool ph = t < L && row[t] == -1;
+    const int before = cnt_sm[0] + cnt_sm[1] + cnt_sm[2] + cnt_sm[3];
+    if (w == 0) {
+        const int t = c0 + lane;
+        const bool ph = lane < RLA_TPB && t < L && row[t] == -1;
         const unsigned long long m = __ballot(ph);
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[w] = __popcll(m);
-        __syncthreads();
-        int off = base_sm;
-        for (int k = 0; k < w; k++) off += wave_cnt[k];
-        if (t < L) rank_sm[t] = ph ? off + before : -1;
-        __syncthreads();
-        if (tid == 0) base_sm += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
+        if (lane < RLA_TPB) rank_sm[lane] = ph ? before + __popcll(m & ((1ull << lane) - 1ull)) : -1;
     }
+    __syncthreads();
     if (!BWD && labels) {
-        for (int t = tid; t < L; t += 256) if (labels[(int64_t)b * L + t] == -1) labels[(int64_t)b * L + t] = 0;
+        const int t = c0 + tid;
+        if (tid < RLA_TPB && t < L && labels[(int64_t)b * L + t] == -1) labels[(int64_t)b * L + t] = 0;
     }
-    if (BWD && dvis) {
-        for (int64_t i = tid; i < (int64_t)nvis * d; i += 256) stf(dvis + (int64_t)b * nvis * d + i, 0.f);
-        __syncthreads();
-    }
-    for (int t = w; t < L; t += 4) {
+    for (int tt = w; tt < RLA_TPB; tt += 4) {
+        const int t = c0 + tt;
+        if (t >= L) break;
         const int64_t id = row[t];
-        const int rk = rank_sm[t];
+        const int rk = rank_sm[tt];
         const int64_t pid = position_id[(int64_t)b * L + t];
         const int64_t o = ((int64_t)b * L + t) * d;
         for (int i = lane; i < d; i += 64) {
@@ -829,8 +828,8 @@ extern "C" int db1_rl_assemble_fwd(const void* word_table, const void* pos_table
     if (!db1_dt_ok(dt) || !db1_dt_ok(dtTable)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "rl_assemble_fwd: dtype");
     if (B <= 0 || L <= 0 || d <= 0 || L > 12288) DB1_FAIL(DB1_ERR_BAD_SHAPE, "rl_assemble_fwd: shape");
     hipStream_t st = (hipStream_t)stream;
-    size_t sm = (size_t)L * sizeof(int);
-#define L_(TT, T) rl_assemble_kernel<TT, T, false><<<B, 256, sm, st>>>((const TT*)word_table, (const TT*)pos_table, (const T*)vis, ids, position_id, labels, (T*)out, nullptr, nullptr, nullptr, L, d, n_vis_per_row)
+    const dim3 g((unsigned)((L + RLA_TPB - 1) / RLA_TPB), (unsigned)B);
+#define L_(TT, T) rl_assemble_kernel<TT, T, false><<<g, 256, 0, st>>>((const TT*)word_table, (const TT*)pos_table, (const T*)vis, ids, position_id, labels, (T*)out, nullptr, nullptr, nullptr, L, d, n_vis_per_row)
     if (dtTable == DB1_F32 && dt == DB1_F32) L_(float, float);
     else if (dtTable == DB1_BF16 && dt == DB1_BF16) L_(bf16_t, bf16_t);
     else if (dtTable == DB1_F32) L_(float, bf16_t);
@@ -845,8 +844,9 @@ extern "C" int db1_rl_assemble_bwd(const void* dout, const int64_t* ids, const i
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "rl_assemble_bwd: dtype");
     if (B <= 0 || L <= 0 || d <= 0 || L > 12288) DB1_FAIL(DB1_ERR_BAD_SHAPE, "rl_assemble_bwd: shape");
     hipStream_t st = (hipStream_t)stream;
-    size_t sm = (size_t)L * sizeof(int);
-    DB1_DISPATCH_DT(dt, T, (rl_assemble_kernel<float, T, true><<<B, 256, sm, st>>>(nullptr, nullptr, nullptr, ids, position_id, nullptr,
+    const dim3 g((unsigned)((L + RLA_TPB - 1) / RLA_TPB), (unsigned)B);
+    if (dvis && n_vis_per_row > 0) hipMemsetAsync(dvis, 0, (size_t)B * n_vis_per_row * d * (dt == DB1_F32 ? 4 : 2), st);
+    DB1_DISPATCH_DT(dt, T, (rl_assemble_kernel<float, T, true><<<g, 256, 0, st>>>(nullptr, nullptr, nullptr, ids, position_id, nullptr,
                                                                                   (T*)const_cast<void*>(dout), dword_acc, dpos_acc, (T*)dvis, L, d, n_vis_per_row)));
     DB1_CHECK_LAUNCH("rl_assemble_bwd");
     return DB1_OK;
