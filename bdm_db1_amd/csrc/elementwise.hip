@@ -859,7 +859,7 @@ extern "C" int db1_rl_assemble_bwd(const void* dout, const int64_t* ids, const i
 template <typename T>
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
                                                      const float* __restrict__ mask, float* __restrict__ lse, float* sums,
-                                                     int V, int64_t ld, int vec_ok) {
+                                                     float* __restrict__ tok_loss, int V, int64_t ld, int vec_ok) {
     __shared__ float sm[4];
     const int64_t t = blockIdx.x;
     const T* row = logits + t * ld;
@@ -871,12 +871,13 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
             Vec16<T> a;
             a.load(row + c);
 #pragma unroll
-            for (int j = 0; j < VN; j++) {
-                if (c + j < V) {
-                    float x = a.v[j];
-                    if (x > m) { s = s * __expf(m - x) + 1.f; m = x; } else s += __expf(x - m);
-                }
-            }
+            for (int j = 0; j < VN; j++) if (c + j >= V) a.v[j] = -3.0e38f;   // padded vocabulary columns
+            float vm = a.v[0];
+#pragma unroll
+            for (int j = 1; j < VN; j++) vm = fmaxf(vm, a.v[j]);
+            if (vm > m) { s *= __expf(m - vm); m = vm; }                        // one rescale per vector, rare after the first few
+#pragma unroll
+            for (int j = 0; j < VN; j++) s += __expf(a.v[j] - m);
         }
     } else {
         for (int c = tid; c < V; c += 256) {
@@ -892,9 +893,23 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
         const float mk = mask[t];
         int64_t y = labels[t];
         const float nll = l - ldf(row + y);
-        atomicAdd(sums + 0, mk * nll);
-        atomicAdd(sums + 1, mk);
+        if (tok_loss) tok_loss[t] = mk * nll;  // summed in a fixed order by ce_sum_kernel (65 536 same-address atomics took ~1 ms)
+        else { atomicAdd(sums + 0, mk * nll); atomicAdd(sums + 1, mk); }
     }
+}
+// sums[0] += sum_t tok_loss[t], sums[1] += sum_t mask[t]: one block, fixed order (deterministic loss)
+__global__ __launch_bounds__(1024) void ce_sum_kernel(const float* __restrict__ tok_loss, const float* __restrict__ mask, float* sums, int64_t T_) {
+    __shared__ float red[2][1024];
+    float a = 0.f, b = 0.f;
+    for (int64_t t = threadIdx.x; t < T_; t += 1024) { a += tok_loss[t]; b += mask[t]; }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { red[0][threadIdx.x] += red[0][threadIdx.x + st]; red[1][threadIdx.x] += red[1][threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sums[0] += red[0][0]; sums[1] += red[1][0]; }
 }
 
 template <typename T>
@@ -928,8 +943,12 @@ extern "C" int db1_masked_ce_fwd(const void* logits, const int64_t* labels, cons
     if (T_ <= 0 || V <= 0 || ld < V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "masked_ce_fwd: shape");
     const int VN = dt == DB1_F32 ? 4 : 8;
     const int vec_ok = (ld % VN == 0) && db1_aligned16(logits);
-    DB1_DISPATCH_DT(dt, T, (ce_fwd_kernel<T><<<(unsigned)T_, 256, 0, (hipStream_t)stream>>>((const T*)logits, labels, mask, lse, sums, V, ld, vec_ok)));
+    float* tok_loss = ln_workspace((size_t)T_ * sizeof(float));
+    if (!tok_loss) DB1_FAIL(DB1_ERR_HIP, "masked_ce_fwd: cannot allocate the per-token loss workspace");
+    DB1_DISPATCH_DT(dt, T, (ce_fwd_kernel<T><<<(unsigned)T_, 256, 0, (hipStream_t)stream>>>((const T*)logits, labels, mask, lse, sums, tok_loss, V, ld, vec_ok)));
     DB1_CHECK_LAUNCH("masked_ce_fwd");
+    ce_sum_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(tok_loss, mask, sums, T_);
+    DB1_CHECK_LAUNCH("masked_ce_fwd sum");
     return DB1_OK;
 }
 extern "C" int db1_masked_ce_bwd(const void* logits, const int64_t* labels, const float* mask, const float* lse, const float* sums,
