@@ -1,5 +1,7 @@
-// bf16 MFMA GEMM, 256x128x64 workgroup tile, 3-stage LDS ring, two wave layouts:
-//   NWM x NWN = 4 x 2 (8 waves, 64x64 wave tiles, 2 waves/SIMD)  or  2 x 2 (4 waves, 128x64 wave tiles, 1 wave/SIMD).
+// bf16 MFMA GEMM, 256x128x64 workgroup tile, 3-stage LDS ring, 8 waves as 4 x 2 (64x64 wave tiles, 2 waves/SIMD).
+// Used where the 256x256 ping-pong kernels do not apply (N % 256 != 0, e.g. the per-head N = 128 contractions over dT) or would
+// leave the chip under-filled.  Variants measured and dropped: 4 waves with 128x64 wave tiles (slower), and a staggered schedule
+// in which the second wave half defers one MFMA batch past the barrier (no gain; the idea lives on as gemm_pp.hip's ping-pong).
 //
 // Why this shape on gfx950: one k-step of the 128x128 kernel is ~0.25 us of MFMA work per workgroup while a
 // global_load_lds round trip is 1-2 us, so with a 2-stage buffer every k-step ends in a vmcnt(0) drain.  Here the
@@ -9,8 +11,7 @@
 // put `s_waitcnt vmcnt(0)` in front of every fragment read (measured: that made this kernel slower than the 2-stage
 // one), so the fragment reads are issued through inline asm with hand-counted lgkmcnt waits + sched_barrier
 // (cdna_hip_programming.md 5.7): reads of k-substep 1 are in flight under the MFMAs of k-substep 0.
-// One barrier per k-step.  The 64x64 wave tile needs 1 KiB of fragment reads per 16 MFMAs (LDS read bandwidth ~= MFMA time);
-// the 128x64 wave tile needs 25 % less and leaves the whole register file to one wave per SIMD.
+// One barrier per k-step.  The 64x64 wave tile needs 1 KiB of fragment reads per 16 MFMAs (LDS read bandwidth ~= MFMA time).
 // Operand forms, swizzles and the swapped-operand epilogue are those of gemm.hip (gemm_tile.h); an A tile is staged as two
 // independent 128-row sub-tiles.
 #include "gemm_tile.h"
@@ -51,9 +52,9 @@ template <> struct Frag<false> {
     __device__ __forceinline__ bf16x8_t get() const { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, typename TC, typename TBIAS, int NWM, int NWN, bool STAGGER>
-__global__ __launch_bounds__(NWM * NWN * 64, 1) void gemm_bf16_tile256_kernel(GemmTileArgs p) {
-    constexpr int NW = NWM * NWN, NI = 256 / NWM / 16, NJ = 128 / NWN / 16, PIECES = 16 / NW;
+template <bool A_KMAJOR, bool B_KMAJOR, typename TC, typename TBIAS>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_tile256_kernel(GemmTileArgs p) {
+    constexpr int NWM = 4, NWN = 2, NW = NWM * NWN, NI = 256 / NWM / 16, NJ = 128 / NWN / 16, PIECES = 16 / NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
@@ -122,67 +123,30 @@ __global__ __launch_bounds__(NWM * NWN * 64, 1) void gemm_bf16_tile256_kernel(Ge
     };
     auto tile_ready = [&](int t) {  // tile t has landed once at most the loads of tile t+1 are still outstanding
         if (t + 1 < nt) {
-            if (PIECES == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            static_assert(PIECES == 2, "the counted wait below assumes 3 sub-tiles x 2 pieces per wave and k-tile");
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();  // everyone's pieces of tile t are in LDS; everyone is done reading tile t-1
     };
     int buf = 0;
-    if (!STAGGER || wave < NW / 2) {
-        // waves 0 .. NW/2-1: [fragment reads of both k-substeps | 2 MFMA batches]
-        for (int t = 0; t < nt; t++) {
-            tile_ready(t);
-            if (t + 2 < nt) stage(t + 2, buf == 0 ? 2 : buf - 1);  // overwrites the stage read during iteration t-1
-            const unsigned sb = buf * T256_STAGE_BYTES;
-            Frag<A_KMAJOR> af0[NI], af1[NI];
-            Frag<B_KMAJOR> bf0[NJ], bf1[NJ];
-            reads(0, af0, bf0, sb);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            reads(1, af1, bf1, sb);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(af0, bf0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(af1, bf1);
-            buf = buf == 2 ? 0 : buf + 1;
-        }
-    } else {
-        // waves NW/2 .. NW-1 share their SIMDs with the first half (wave w and w + 4 sit on one SIMD): they run the SAME number of
-        // barriers but defer the second MFMA batch of every k-step to just after the next barrier, so that the matrix pipe has
-        // work while the partner wave is in its fragment-read phase.  The deferred operands live in alternating register sets.
-        Frag<A_KMAJOR> afx[NI], afy[NI];
-        Frag<B_KMAJOR> bfx[NJ], bfy[NJ];
-        auto half = [&](int t, Frag<A_KMAJOR>* afc, Frag<B_KMAJOR>* bfc, const Frag<A_KMAJOR>* afp, const Frag<B_KMAJOR>* bfp) {
-            tile_ready(t);
-            if (t + 2 < nt) stage(t + 2, buf == 0 ? 2 : buf - 1);
-            const unsigned sb = buf * T256_STAGE_BYTES;
-            Frag<A_KMAJOR> af0[NI];
-            Frag<B_KMAJOR> bf0[NJ];
-            if (t > 0) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(afp, bfp);  // second batch of k-step t-1
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            reads(0, af0, bf0, sb);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            reads(1, afc, bfc, sb);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(af0, bf0);
-            __builtin_amdgcn_sched_barrier(0);
-            buf = buf == 2 ? 0 : buf + 1;
-        };
-        for (int t = 0; t < nt; t += 2) {
-            half(t, afx, bfx, afy, bfy);
-            if (t + 1 < nt) half(t + 1, afy, bfy, afx, bfx);
-        }
+    for (int t = 0; t < nt; t++) {  // [fragment reads of both k-substeps | 2 MFMA batches]
+        tile_ready(t);
+        if (t + 2 < nt) stage(t + 2, buf == 0 ? 2 : buf - 1);  // overwrites the stage read during iteration t-1
+        const unsigned sb = buf * T256_STAGE_BYTES;
+        Frag<A_KMAJOR> af0[NI], af1[NI];
+        Frag<B_KMAJOR> bf0[NJ], bf1[NJ];
+        reads(0, af0, bf0, sb);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (nt & 1) mfmas(afx, bfx); else mfmas(afy, bfy);
+        reads(1, af1, bf1, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(af0, bf0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(af1, bf1);
+        buf = buf == 2 ? 0 : buf + 1;
     }
     TC* C = (TC*)p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
 #pragma unroll
@@ -193,30 +157,22 @@ __global__ __launch_bounds__(NWM * NWN * 64, 1) void gemm_bf16_tile256_kernel(Ge
                                   p.alpha, p.beta, p.bias);
 }
 
-template <bool AK, bool BK_, int NWM, int NWN, bool SG>
+template <bool AK, bool BK_>
 static void launch256(const GemmTileArgs& t, int dtC, int dtBias, dim3 grid, hipStream_t st) {
-    constexpr int TH = NWM * NWN * 64;
     static bool attr_set = false;
     if (!attr_set) {
-#define SET_ATTR(TC, TB) hipFuncSetAttribute((const void*)gemm_bf16_tile256_kernel<AK, BK_, TC, TB, NWM, NWN, SG>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS_BYTES)
+#define SET_ATTR(TC, TB) hipFuncSetAttribute((const void*)gemm_bf16_tile256_kernel<AK, BK_, TC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS_BYTES)
         SET_ATTR(float, float); SET_ATTR(float, bf16_t); SET_ATTR(bf16_t, float); SET_ATTR(bf16_t, bf16_t);
 #undef SET_ATTR
         attr_set = true;
     }
     if (dtC == DB1_F32) {
-        if (dtBias == DB1_BF16) gemm_bf16_tile256_kernel<AK, BK_, float, bf16_t, NWM, NWN, SG><<<grid, TH, T256_LDS_BYTES, st>>>(t);
-        else gemm_bf16_tile256_kernel<AK, BK_, float, float, NWM, NWN, SG><<<grid, TH, T256_LDS_BYTES, st>>>(t);
+        if (dtBias == DB1_BF16) gemm_bf16_tile256_kernel<AK, BK_, float, bf16_t><<<grid, 512, T256_LDS_BYTES, st>>>(t);
+        else gemm_bf16_tile256_kernel<AK, BK_, float, float><<<grid, 512, T256_LDS_BYTES, st>>>(t);
     } else {
-        if (dtBias == DB1_BF16) gemm_bf16_tile256_kernel<AK, BK_, bf16_t, bf16_t, NWM, NWN, SG><<<grid, TH, T256_LDS_BYTES, st>>>(t);
-        else gemm_bf16_tile256_kernel<AK, BK_, bf16_t, float, NWM, NWN, SG><<<grid, TH, T256_LDS_BYTES, st>>>(t);
+        if (dtBias == DB1_BF16) gemm_bf16_tile256_kernel<AK, BK_, bf16_t, bf16_t><<<grid, 512, T256_LDS_BYTES, st>>>(t);
+        else gemm_bf16_tile256_kernel<AK, BK_, bf16_t, float><<<grid, 512, T256_LDS_BYTES, st>>>(t);
     }
-}
-
-template <int NWM, int NWN, bool SG>
-static void launch256_form(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, dim3 grid, hipStream_t st) {
-    if (fa == 0 && fb == 0) launch256<true, true, NWM, NWN, SG>(t, dtC, dtBias, grid, st);
-    else if (fa == 0 && fb == 1) launch256<true, false, NWM, NWN, SG>(t, dtC, dtBias, grid, st);
-    else launch256<false, false, NWM, NWN, SG>(t, dtC, dtBias, grid, st);
 }
 
 int db1_gemm_tile256_launch(const GemmTileArgs& t_in, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st) {
@@ -224,14 +180,10 @@ int db1_gemm_tile256_launch(const GemmTileArgs& t_in, int fa, int fb, int dtC, i
     t.tiles_m = t.M / 256;
     t.tiles_n = t.N / TBN;
     t.ksplit = 1;
-    static int waves = -1;  // DB1_GEMM256_WAVES=4|8 pins a wave layout (A/B measurements)
-    if (waves < 0) { const char* e = getenv("DB1_GEMM256_WAVES"); waves = e ? atoi(e) : 8; }
     dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch);
-    static int stagger = -1;  // DB1_GEMM256_STAGGER=0 runs both wave halves in lockstep (A/B measurements)
-    if (stagger < 0) { const char* e = getenv("DB1_GEMM256_STAGGER"); stagger = e ? atoi(e) : 0; }
-    if (waves == 8 && stagger) launch256_form<4, 2, true>(t, fa, fb, dtC, dtBias, grid, st);
-    else if (waves == 8) launch256_form<4, 2, false>(t, fa, fb, dtC, dtBias, grid, st);
-    else launch256_form<2, 2, false>(t, fa, fb, dtC, dtBias, grid, st);
+    if (fa == 0 && fb == 0) launch256<true, true>(t, dtC, dtBias, grid, st);
+    else if (fa == 0 && fb == 1) launch256<true, false>(t, dtC, dtBias, grid, st);
+    else launch256<false, false>(t, dtC, dtBias, grid, st);
     DB1_CHECK_LAUNCH("gemm_bf16_tile256");
     return DB1_OK;
 }
