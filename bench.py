@@ -96,11 +96,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # DB1_DIST_BACKEND=gloo lets the multi-rank path be exercised on a single-GPU box (ranks share the device; RCCL refuses that)
+    backend = os.environ.get("DB1_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm: one process per GPU over xGMI
+        else:
+            dist.init_process_group(backend=backend)
 
     from bdm_db1_amd import TransformerXL, initialize, mpu, ops, synth
     from types import SimpleNamespace
