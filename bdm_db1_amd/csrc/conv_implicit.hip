@@ -1,0 +1,229 @@
+// Implicit-GEMM 3x3 convolutions of the image-patch embedder (vision_embedding.py:44-63: 64 -> 64 channels on 16x16 patches, zero
+// padding at the PATCH border), channels-last bf16.  The column matrix of im2col (295 KB per patch and conv) is never written:
+// the LDS-DMA that stages a GEMM operand tile simply takes a different SOURCE address per lane -- the pixel shifted by the tap --
+// and lanes whose shifted pixel falls outside the patch read a 128-byte page of zeros instead (LDS-DMA cannot write constants,
+// but it can read them).  Everything after the staging is the 128-row K-major / M-major tile machinery of gemm_tile.h.
+//   conv_implicit_kernel  (forward, and data gradient with sign = -1 and the transposed weight operand):
+//       Y[pix, o] = sum_{tap, c} X[pix + sign * s(tap), c] * Wop[o, tap*64 + c] (+ bias)
+//       one workgroup = one patch (256 pixels) x 64 outputs, 4 waves x (64 pixels x 64 outputs), 9 k-steps = the 9 taps.
+//   conv_wgrad_implicit_kernel:  gp[o, tap*64 + c] += sum_pix dY[pix, o] * X[pix + s(tap), c]
+//       a TN product with M = 64, N = 576, K = all pixels; the B operand tile (64 pixels x 128 columns = 2 taps) is gathered;
+//       the pixel range is split over blockIdx.z and the partial sums are added with fp32 atomics (as the explicit path did).
+#include "gemm_tile.h"
+
+#define CI_C 64
+#define CI_P 16
+#define CI_HW 256
+
+struct ConvArgs {
+    const bf16_t* x;      // gathered activations [n_patches * 256, 64]
+    const bf16_t* w;      // fwd / dgrad: weight operand [64, 576] (K-major);  wgrad: dY [n_patches * 256, 64]
+    const bf16_t* zeros;  // >= 256 bytes of zeros
+    void* y;              // fwd / dgrad: [n_patches * 256, 64] bf16;  wgrad: gp [64, 576] float32 (accumulated)
+    const void* bias;
+    int64_t n_patches;
+    int sign, ksplit;
+};
+
+// source of the 16-byte chunk `c` (8 channels) of pixel `pix` shifted by tap `tap`, or the zero page
+__device__ __forceinline__ const bf16_t* ci_src(const ConvArgs& p, int64_t pix, int tap, int sign, int c) {
+    const int yx = (int)(pix & (CI_HW - 1));
+    const int yy = (yx >> 4) + sign * (tap / 3 - 1), xx = (yx & 15) + sign * (tap % 3 - 1);
+    const bool ok = yy >= 0 && yy < CI_P && xx >= 0 && xx < CI_P;
+    return ok ? p.x + ((pix - yx) + yy * CI_P + xx) * CI_C + c * 8 : p.zeros + c * 8;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------- fwd / dgrad
+#define CI_STAGE_BYTES (2 * TILE_BYTES + TILE_BYTES / 2)   // A: 256 pixels x 64 ch (two 128-row images) | B: 64 outputs x 64 k
+template <typename TBIAS>
+__global__ __launch_bounds__(256, 2) void conv_implicit_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t pix0 = (int64_t)blockIdx.x * CI_HW;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](int tap, char* s) {
+        // A: 32 pieces of 8 rows (K-major image, chunk swizzle c ^ (r & 7)); wave w takes pieces 8w .. 8w+7
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int q = wave * 8 + it;                 // piece 0..31 -> rows 8q .. 8q+7 of the 256
+            const int r = q * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            __builtin_amdgcn_global_load_lds(ci_src(p, pix0 + r, tap, p.sign, c), LDS_PTR(void, s + (q >> 4) * TILE_BYTES + (q & 15) * 1024), 16, 0, 0);
+        }
+        // B: weight rows o = 0..63, k = tap*64 .. +63: 8 pieces, 2 per wave
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int q = wave * 2 + it;
+            const int r = q * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            __builtin_amdgcn_global_load_lds(p.w + (int64_t)r * (9 * CI_C) + tap * CI_C + c * 8, LDS_PTR(void, s + 2 * TILE_BYTES + q * 1024), 16, 0, 0);
+        }
+    };
+    stage(0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int tap = 0; tap < 9; tap++) {
+        char* sa = smem + cur * CI_STAGE_BYTES;
+        char* sb = sa + 2 * TILE_BYTES;
+        if (tap + 1 < 9) stage(tap + 1, smem + (cur ^ 1) * CI_STAGE_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8_t af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = wave * 64 + i * 16;
+                af[i] = load_frag<true>(sa + (row >> 7) * TILE_BYTES, row & 127, ks, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) bfr[j] = load_frag<true>(sb, j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // swapped: D[n][m]
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    bf16_t* Y = (bf16_t*)p.y + pix0 * CI_C;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            store_frag<bf16_t, TBIAS>(acc[i][j], Y, CI_C, wave * 64 + i * 16 + (lane & 15), j * 16 + (lane >> 4) * 4, 1.f, 0.f, p.bias);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------- wgrad
+// gp[o, n] += sum_pix dY[pix, o] * G[pix, n],  G[pix, tap*64 + c] = X[pix + s(tap), c].  Tile: M = 64 outputs (one M-major sub-tile,
+// half used), N = 128 columns = taps 2 tn, 2 tn + 1 (the fifth tile holds tap 8 only), k-tiles of 64 pixels (a quarter patch).
+// 4 waves as 2 x 2 over (64 outputs) x (128 columns): wave tile 32 x 64.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_implicit_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tn = blockIdx.x;                           // column tile: taps 2 tn (and 2 tn + 1 if < 9)
+    const int64_t nk_total = p.n_patches * (CI_HW / TBK);  // k-tiles of 64 pixels
+    const int64_t per = (nk_total + p.ksplit - 1) / p.ksplit;
+    const int64_t kt0 = (int64_t)blockIdx.z * per;
+    const int64_t kt1 = kt0 + per < nk_total ? kt0 + per : nk_total;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16_t* dY = p.w;
+    auto stage = [&](int64_t kt, char* s) {
+        const int64_t pixk = kt * TBK;
+        // A = dY^T, M-major image [64 k][256 B]: only the first 64 of the 128 "rows" exist (chunks 0..7); piece q = k-rows 4q..4q+3
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int q = wave * 4 + it;
+            const int kr = q * 4 + (lane >> 4);
+            const int f = ((kr & 3) << 1) | (kr & 8);
+            int c = (lane & 15) ^ f;
+            if (c > 7) c = 7;                            // columns 64..127 of the tile are never stored: any valid address will do
+            __builtin_amdgcn_global_load_lds(dY + (pixk + kr) * CI_C + c * 8, LDS_PTR(void, s + q * 1024), 16, 0, 0);
+        }
+        // B = gathered activations, M-major image [64 k = pixels][128 n]: chunk c (8 columns) -> tap 2 tn + c / 8, channels (c % 8) * 8 ..
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int q = wave * 4 + it;
+            const int kr = q * 4 + (lane >> 4);
+            const int f = ((kr & 3) << 1) | (kr & 8);
+            const int c = (lane & 15) ^ f;
+            int tap = 2 * tn + (c >> 3);
+            if (tap > 8) tap = 8;                        // second half of the last tile: masked in the epilogue
+            __builtin_amdgcn_global_load_lds(ci_src(p, pixk + kr, tap, 1, c & 7), LDS_PTR(void, s + TILE_BYTES + q * 1024), 16, 0, 0);
+        }
+    };
+    if (kt0 < kt1) stage(kt0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int64_t kt = kt0; kt < kt1; kt++) {
+        char* sa = smem + cur * 2 * TILE_BYTES;
+        char* sb = sa + TILE_BYTES;
+        if (kt + 1 < kt1) stage(kt + 1, smem + (cur ^ 1) * 2 * TILE_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8_t af[2], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 2; i++) af[i] = load_frag<false>(sa, wm * 32 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; j++) bfr[j] = load_frag<false>(sb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // swapped: D[n][m]
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* G = (float*)p.y;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int m = wm * 32 + i * 16 + (lane & 15);
+            const int n = tn * 128 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (n >= 9 * CI_C) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) atomicAdd(G + (int64_t)m * (9 * CI_C) + n + r, acc[i][j][r]);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------- host side
+static bf16_t* g_ci_zeros = nullptr;
+static const bf16_t* ci_zero_page() {
+    if (!g_ci_zeros) {
+        if (hipMalloc((void**)&g_ci_zeros, 256) != hipSuccess) return nullptr;
+        hipMemset(g_ci_zeros, 0, 256);
+    }
+    return g_ci_zeros;
+}
+
+extern "C" int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const void* bias, void* y, int64_t n_patches, int sign, int dtBias,
+                                        void* stream) {
+    if (n_patches <= 0 || (sign != 1 && sign != -1)) DB1_FAIL(DB1_ERR_BAD_SHAPE, "conv3x3_implicit_fwd: n_patches=%lld sign=%d", (long long)n_patches, sign);
+    if (!x || !w_op || !y || !db1_aligned16(x) || !db1_aligned16(w_op) || !db1_aligned16(y)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "conv3x3_implicit_fwd: operands must be 16-byte aligned");
+    if (n_patches > 8000000) DB1_FAIL(DB1_ERR_BAD_SHAPE, "conv3x3_implicit_fwd: too many patches");
+    ConvArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w_op; a.y = y; a.bias = bias; a.n_patches = n_patches; a.sign = sign; a.ksplit = 1;
+    a.zeros = ci_zero_page();
+    if (!a.zeros) DB1_FAIL(DB1_ERR_HIP, "conv3x3_implicit_fwd: cannot allocate the zero page");
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)conv_implicit_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CI_STAGE_BYTES);
+        hipFuncSetAttribute((const void*)conv_implicit_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CI_STAGE_BYTES);
+        attr = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (bias && dtBias == DB1_BF16) conv_implicit_kernel<bf16_t><<<(unsigned)n_patches, 256, 2 * CI_STAGE_BYTES, st>>>(a);
+    else conv_implicit_kernel<float><<<(unsigned)n_patches, 256, 2 * CI_STAGE_BYTES, st>>>(a);
+    DB1_CHECK_LAUNCH("conv3x3_implicit_fwd");
+    return DB1_OK;
+}
+
+extern "C" int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, int64_t n_patches, void* stream) {
+    if (n_patches <= 0 || n_patches > 8000000) DB1_FAIL(DB1_ERR_BAD_SHAPE, "conv3x3_implicit_wgrad: n_patches=%lld", (long long)n_patches);
+    if (!dy || !x || !gp_acc || !db1_aligned16(dy) || !db1_aligned16(x)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "conv3x3_implicit_wgrad: operands must be 16-byte aligned");
+    ConvArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)dy; a.y = gp_acc; a.bias = nullptr; a.n_patches = n_patches; a.sign = 1;
+    a.zeros = ci_zero_page();
+    if (!a.zeros) DB1_FAIL(DB1_ERR_HIP, "conv3x3_implicit_wgrad: cannot allocate the zero page");
+    const int64_t nk = n_patches * (CI_HW / TBK);
+    int ks = 128;                                        // 5 column tiles x 128 pixel ranges = 640 workgroups
+    while (ks > 1 && nk / ks < 8) ks >>= 1;
+    a.ksplit = ks;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)conv_wgrad_implicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); attr = true; }
+    conv_wgrad_implicit_kernel<<<dim3(5, 1, (unsigned)ks), 256, 4 * TILE_BYTES, (hipStream_t)stream>>>(a);
+    DB1_CHECK_LAUNCH("conv3x3_implicit_wgrad");
+    return DB1_OK;
+}

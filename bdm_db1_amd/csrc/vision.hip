@@ -412,6 +412,28 @@ extern "C" int db1_conv_weight_permute(const void* w, void* wp, int Cout, int Ci
     DB1_CHECK_LAUNCH("conv_weight_permute");
     return DB1_OK;
 }
+// data-gradient operand: wp[c, tap*Cout + o] = w[o, c, tap]  (the transposed weight of the same tap-major layout; conv_implicit.hip)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void conv_weight_permute_t_kernel(const TI* __restrict__ w, TO* __restrict__ wp, int Cout, int Cin) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cin * 9 * Cout) return;
+    const int c = idx / (9 * Cout), rem = idx % (9 * Cout), tap = rem / Cout, o = rem % Cout;
+    stf(wp + idx, ldf(w + ((int64_t)o * Cin + c) * 9 + tap));
+}
+extern "C" int db1_conv_weight_permute_t(const void* w, void* wp, int Cout, int Cin, int dtIn, int dtOut, void* stream) {
+    if (!db1_dt_ok(dtIn) || !db1_dt_ok(dtOut)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "conv_weight_permute_t: dtype");
+    if (Cout <= 0 || Cin <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "conv_weight_permute_t: shape");
+    const unsigned g = (unsigned)((Cin * 9 * Cout + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+#define L_(A, B) conv_weight_permute_t_kernel<A, B><<<g, 256, 0, st>>>((const A*)w, (B*)wp, Cout, Cin)
+    if (dtIn == DB1_F32 && dtOut == DB1_F32) L_(float, float);
+    else if (dtIn == DB1_F32) L_(float, bf16_t);
+    else if (dtOut == DB1_F32) L_(bf16_t, float);
+    else L_(bf16_t, bf16_t);
+#undef L_
+    DB1_CHECK_LAUNCH("conv_weight_permute_t");
+    return DB1_OK;
+}
 // g[o, c, tap] += gp[o, tap*Cin + c]   (float32 both: the weight gradient computed in tap-major order goes back to the parameter layout)
 __global__ __launch_bounds__(256) void conv_wgrad_unpermute_kernel(const float* __restrict__ gp, float* __restrict__ g, int Cout, int Cin, int K) {
     const int idx = blockIdx.x * 256 + threadIdx.x;

@@ -144,6 +144,7 @@ class TransformerXL(nn.Module):
         self.use_flash = True            # fused attention when the shape is supported
         self.use_flash_bwd = True        # fused backward kernels (False: recompute through the materialised path)
         self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
+        self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
         self._conv_ops = {}              # (weight name, weight version) -> tap-major GEMM operand
         self.use_decode = True           # inference with memory: K/V-cached path + fused decode attention when the shape allows
         self._wversion = 0               # bumped whenever the weights change (invalidates the inference caches)
@@ -351,23 +352,45 @@ class TransformerXL(nn.Module):
             self._conv_ops[key] = wp
         return self._conv_ops[key]
 
+    def _conv_operand_t_cl(self, wname):
+        """data-gradient operand [c_in, tap*64 + c_out] of a 64 -> 64 conv weight, per weight version"""
+        key = (wname + "^T", self._wversion)
+        if key not in self._conv_ops:
+            wt = torch.empty(64, 576, device=self.dev, dtype=self.compute_dtype)
+            ops.conv_weight_permute_t(self.W(wname), wt, 64, 64)
+            self._conv_ops[key] = wt
+        return self._conv_ops[key]
+
     def _conv3x3_fwd_cl(self, x_cl, wname, bname, N, Cin):
+        """returns (output [N*256, 64], what the backward needs: the input itself for the implicit 64-channel convs, else the
+        column matrix)"""
         hw = self.patch_size * self.patch_size
         wp = self._conv_operand_cl(wname, Cin)
+        out = self._new(N * hw, 64)
+        if Cin == 64 and self.use_implicit_conv:  # implicit GEMM: the shifted pixels are gathered by the LDS-DMA, no column matrix
+            ops.conv3x3_implicit_fwd(x_cl, wp, self.W(bname), out, N, sign=1)
+            return out, x_cl
         cols = self._new(N * hw, wp.shape[1])
         ops.im2col3x3_nhwc(x_cl, cols, N, Cin, self.patch_size)
-        out = self._new(N * hw, 64)
         ops.gemm(cols, wp.t(), out, bias=self.W(bname))
         return out, cols
 
     def _conv3x3_bwd_cl(self, dy, cols, wname, bname, N, Cin, need_dx):
         wp = self._conv_operand_cl(wname, Cin)
         gp = torch.zeros(64, wp.shape[1], device=self.dev, dtype=torch.float32)
-        ops.gemm(dy.t(), cols, gp, beta=1.0)
+        implicit = Cin == 64 and cols.shape[1] == 64  # `cols` is the conv input
+        if implicit:
+            ops.conv3x3_implicit_wgrad(dy, cols, gp, N)
+        else:
+            ops.gemm(dy.t(), cols, gp, beta=1.0)
         ops.conv_wgrad_unpermute(gp, self.G(wname), 64, Cin)
         ops.colsum_acc(dy, self.G(bname))
         if not need_dx:
             return None
+        if implicit:
+            dx = self._new(N * self.patch_size * self.patch_size, Cin)
+            ops.conv3x3_implicit_fwd(dy, self._conv_operand_t_cl(wname), None, dx, N, sign=-1)
+            return dx
         dcols = self._new(cols.shape[0], wp.shape[1])
         ops.gemm(dy, wp, dcols)
         dx = self._new(N * self.patch_size * self.patch_size, Cin)

@@ -300,6 +300,20 @@ def conv_wgrad_unpermute(gp, g_acc, Cout, Cin):
     lib.call("db1_conv_wgrad_unpermute", P(gp), P(g_acc), Cout, Cin, gp.shape[-1], stream())
 
 
+def conv_weight_permute_t(w, wp, Cout, Cin):
+    lib.call("db1_conv_weight_permute_t", P(w), P(wp), Cout, Cin, dt_code(w), dt_code(wp), stream())
+
+
+def conv3x3_implicit_fwd(x, w_op, bias, y, n_patches, sign=1):
+    """64 -> 64 channel 3x3 conv on 16x16 patches, channels-last bf16, no column matrix (sign=-1: data gradient)"""
+    lib.call("db1_conv3x3_implicit_fwd", P(x), P(w_op), P(bias), P(y), n_patches, sign, dt_code(bias) if bias is not None else 0, stream())
+
+
+def conv3x3_implicit_wgrad(dy, x, gp_acc, n_patches):
+    assert gp_acc.dtype == torch.float32 and gp_acc.shape[-1] == 576
+    lib.call("db1_conv3x3_implicit_wgrad", P(dy), P(x), P(gp_acc), n_patches, stream())
+
+
 def groupnorm_gelu_nhwc_fwd(x, gamma, beta, y, mean, rstd, N, C, hw, groups=32, eps=1e-5):
     lib.call("db1_groupnorm_gelu_nhwc_fwd", P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), N, C, hw, groups, float(eps),
              dt_code(x), dt_code(gamma), stream())

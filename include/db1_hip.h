@@ -204,6 +204,14 @@ int db1_im2col3x3_nhwc(const void* x, void* cols, int64_t N, int C, int p, int k
 int db1_col2im3x3_nhwc(const void* dcols, void* dx, int64_t N, int C, int p, int kpad, int dt, void* stream);
 int db1_conv_weight_permute(const void* w, void* wp, int Cout, int Cin, int kpad, int dtIn, int dtOut, void* stream);
 int db1_conv_wgrad_unpermute(const float* gp, float* g_acc, int Cout, int Cin, int kpad, void* stream);
+/* Implicit-GEMM 3x3 convolutions for the 64 -> 64 channel layers on 16x16 patches (channels-last bf16): no column matrix.
+ *   fwd (sign = +1): y[pix, o] = sum_{tap,c} x[pix + s(tap), c] * w_op[o, tap*64 + c] + bias[o], w_op from db1_conv_weight_permute;
+ *   data gradient (sign = -1): x := dy, w_op := db1_conv_weight_permute_t(weight)  ([c, tap*64 + o]), bias = NULL;
+ *   wgrad: gp_acc[o, tap*64 + c] += sum_pix dy[pix, o] * x[pix + s(tap), c]   (float32 [64, 576], fp32 atomics over pixel ranges). */
+int db1_conv_weight_permute_t(const void* w, void* wp, int Cout, int Cin, int dtIn, int dtOut, void* stream);
+int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const void* bias, void* y, int64_t n_patches, int sign, int dtBias,
+                             void* stream);
+int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, int64_t n_patches, void* stream);
 int db1_groupnorm_gelu_nhwc_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                                 int64_t N, int C, int hw, int groups, float eps, int dt, int dtParam, void* stream);
 int db1_groupnorm_gelu_nhwc_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean,

@@ -606,3 +606,36 @@ def test_channels_last_vision_kernels(ops):
     close(dxx.view(N, 256, 64), cl(dx_ref), 8e-3, name="gn+gelu dx (channels-last)")
     close(dga, dgam, 2e-4, name="gn dgamma (channels-last)")
     close(dbe, dbet, 2e-4, name="gn dbeta (channels-last)")
+
+
+def test_implicit_3x3_convolutions(ops):
+    """implicit-GEMM conv forward / data gradient / weight gradient (no column matrix) against the oracle's im2col statement"""
+    rng = np.random.default_rng(41)
+    N, C = 5, 64
+    x = bf(rng.standard_normal((N, C, 16, 16)))
+    w = bf(rng.standard_normal((64, C, 3, 3)) * 0.1)
+    bias = bf(rng.standard_normal(64))
+    cl = lambda a: np.ascontiguousarray(a.reshape(a.shape[0], a.shape[1], 256).transpose(0, 2, 1))   # NCHW -> [N, 256, C]
+    cols = O._im2col3x3(x).reshape(N * 256, C * 9)                        # columns (c, tap)
+    y_ref = cols @ w.reshape(64, C * 9).T + bias                           # [N*256, 64]
+    w_op = torch.empty(64, 576, device=DEV, dtype=torch.bfloat16)
+    ops.conv_weight_permute(dev16(w), w_op, 64, C)
+    X = dev16(cl(x)).view(N * 256, C)
+    y = torch.empty(N * 256, 64, device=DEV, dtype=torch.bfloat16)
+    ops.conv3x3_implicit_fwd(X, w_op, dev16(bias), y, N, sign=1)
+    close(y, y_ref, 6e-3, name="implicit conv fwd")
+    # data gradient: dx = col2im(dy . W)
+    dy = bf(rng.standard_normal((N * 256, 64)))
+    dcols = (dy @ w.reshape(64, C * 9)).reshape(N, 16, 16, C * 9)
+    dx_ref = cl(O._col2im3x3(dcols, C)).reshape(N * 256, C)
+    w_t = torch.empty(64, 576, device=DEV, dtype=torch.bfloat16)
+    ops.conv_weight_permute_t(dev16(w), w_t, 64, C)
+    dx = torch.empty(N * 256, C, device=DEV, dtype=torch.bfloat16)
+    ops.conv3x3_implicit_fwd(dev16(dy), w_t, None, dx, N, sign=-1)
+    close(dx, dx_ref, 6e-3, name="implicit conv dgrad")
+    # weight gradient, accumulated
+    gw_ref = (dy.T @ cols).reshape(64, C, 9).transpose(0, 2, 1).reshape(64, 576)       # tap-major columns
+    g0 = rng.standard_normal((64, 576)).astype(np.float32)
+    gp = dev(g0)
+    ops.conv3x3_implicit_wgrad(dev16(dy), X, gp, N)
+    close(gp, g0 + gw_ref, 1e-5, name="implicit conv wgrad")

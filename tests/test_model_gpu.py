@@ -248,18 +248,20 @@ def test_bf16_channels_last_vision_path_matches_nchw_path_and_oracle():
              "vision_encoder.patch_embeddings.residual_path.5.bias", "vision_encoder.patch_embeddings.projection.weight",
              "vision_encoder.row_position_embeddings.weight", "h.0.dec_attn.qkv_net.weight"]
     res = {}
-    for cl in (True, False):
+    for cl in (True, "explicit-columns", False):
         cfg, params, gold, model, oracle, seed = build(name, compute_dtype=torch.bfloat16)
-        model.use_channels_last = cl
+        model.use_channels_last = bool(cl)
+        model.use_implicit_conv = cl is True
         tasks = make_batch(name, cfg, seed)
         logits, loss = model(to_inputs(tasks))
         model.backward()
         res[cl] = (float(loss), {n: model.G(n).detach().double().cpu().numpy().copy() for n in names})
     _, ref_loss, _ = oracle.forward([O.TaskBatch(**t) for t in tasks])
     ref_grads = oracle.backward()
-    for cl in (True, False):
+    for cl in (True, "explicit-columns", False):
         assert abs(res[cl][0] - ref_loss) < 3e-2, (cl, res[cl][0], ref_loss)
         for n in names:
             assert rel_err(res[cl][1][n], ref_grads[n]) < 8e-2, (cl, n)
     for n in names:
         assert rel_err(res[True][1][n], res[False][1][n]) < 3e-2, n
+        assert rel_err(res[True][1][n], res["explicit-columns"][1][n]) < 3e-2, n
