@@ -199,6 +199,32 @@ __device__ __forceinline__ void rel_band_to_lds(const bf16x8_t* fa_regs, const c
         for (int r = 0; r < 16; r++) tw[((r & 3) + 8 * (r >> 2)) * 64 + 32 * blk] = acc_t[r];
     }
 }
+// Incremental form for the forward, whose waves keep their 32 queries and walk the key blocks upwards (in bwd_kv the queries
+// change every block, so nothing carries over; bwd_q reuses the scratch for the dS re-indexing): the band of block jb+1 is the band of block jb moved down
+// by 32 distances, so its upper half is the lower half just computed.  The scratch is used as a 2-slot ring with an XOR parity:
+// logical column c (0..63, distance dist_lo + c) lives at physical column c ^ (32 * PAR); consecutive processed blocks alternate
+// PAR (= the unrolled block instance), so the previous block's lower half IS this block's upper half without moving anything.
+// Only the new lower 32 distances are computed (8 MFMAs instead of 16, half the scratch writes and ring reads) unless the wave
+// did not process the previous block (`both`).
+template <int PAR>
+__device__ __forceinline__ void rel_band_incr_to_lds(const bf16x8_t* fa_regs, const LaneOffs& o, const char* ring, int dist_lo, float* Tw, int lane,
+                                                     bool both) {
+    const int a = lane & 31, hb = lane >> 5;
+    const int rr0 = ((dist_lo + a) & (FA_RING - 1)) << 8;
+    float* tw = Tw + hb * 256 + a;
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++) {  // blk 0 = the new lower 32 distances; blk 1 only for a wave's first processed block
+        if (blk == 1 && !both) break;
+        f32x16 acc_t;
+        zero16(acc_t);
+        const char* rrow = ring + ((rr0 + blk * 8192) & (FA_RING * 256 - 1));
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc_t = MFMA32(fa_regs[ks], *reinterpret_cast<const bf16x8_t*>(rrow + o.ring[ks]), acc_t);
+        const int phys = 32 * (blk ^ PAR);  // logical half blk lives in physical half blk ^ PAR
+#pragma unroll
+        for (int r = 0; r < 16; r++) tw[((r & 3) + 8 * (r >> 2)) * 64 + phys] = acc_t[r];
+    }
+}
 // Workgroup id -> (tile rank, head, batch).  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin and a free
 // CU takes the next id, so the id order is the schedule:
 //   * all tiles of one (batch, head) are given ids of ONE XCD, so its K / V / Q rows are shared in that XCD's L2;
@@ -272,6 +298,10 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    int toff1[16];  // odd-parity read offsets: a * 64 + ((a - crow(r, hb) + 31) ^ 32)
+#pragma unroll
+    for (int r = 0; r < 16; r++) toff1[r] = a * 64 + ((a - crow(r, hb) + 31) ^ 32);
+    bool have_prev = false;  // did this wave process the previous key block?  (wave-uniform)
     auto block = [&](auto CUR, int jb) {
         constexpr int cur = decltype(CUR)::value;
         const int j0 = jb * FA_BK;
@@ -282,15 +312,17 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
             stage_tile32(vg, p.kv_rs, j0 + FA_BK, Vs0 + (cur ^ 1) * 8192, wave, lane);
             stage_ring32(Rg, HD, i0 - j0 - 64, L, Rr, wave, lane);
         }
-        if (!(j0 > iw + 31 || j0 + 31 <= iw - p.shift)) {  // wave-uniform: skip blocks entirely outside this wave's window
+        if (j0 > iw + 31 || j0 + 31 <= iw - p.shift) have_prev = false;
+        else {  // wave-uniform: blocks entirely outside this wave's window are skipped
             f32x16 acc_s;
             zero16(acc_s);
 #pragma unroll
             for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(rowf(Ks, offs, ks), fqu[ks], acc_s);  // S^T[key][query]
-            rel_band_to_lds<true>(fqv, nullptr, offs, Rr, iw - j0 - 31, Tw, lane);
-            float s[16];
+            rel_band_incr_to_lds<cur>(fqv, offs, Rr, iw - j0 - 31, Tw, lane, !have_prev);
+            have_prev = true;
+            float s[16];  // this lane: query iw+a; register r: key j0+crow(r,hb); T element (a, (a - crow + 31) ^ (32 * cur))
 #pragma unroll
-            for (int r = 0; r < 16; r++) s[r] = acc_s[r] + twr[-((r & 3) + 8 * (r >> 2))];  // this lane: query iw+a; register r: key j0+crow(r,hb)
+            for (int r = 0; r < 16; r++) s[r] = acc_s[r] + (cur == 0 ? twr[-((r & 3) + 8 * (r >> 2))] : Tw[toff1[r]]);
             if (j0 + 31 > iw || j0 <= iw + 31 - p.shift) {  // only diagonal / window-edge blocks need the element mask
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
@@ -551,7 +583,7 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_kv_kernel(FlashArgs 
             for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(rowf(Qus, offs, ks), fk[ks], acc_s);    // S[query][key]
 #pragma unroll
             for (int ks = 0; ks < 8; ks++) acc_dp = MFMA32(rowf(dOs, offs, ks), fv[ks], acc_dp);  // dP[query][key]
-            rel_band_to_lds<false>(nullptr, Qvs, offs, Rr, i0q - kw - 31, Tw, lane);
+            rel_band_to_lds<false>(nullptr, Qvs, offs, Rr, i0q - kw - 31, Tw, lane);  // (queries change every block: nothing to reuse)
             float pr[16], ds[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {  // this lane: key kw + a; register r: query i0q + crow(r, hb)
