@@ -253,6 +253,8 @@ static unsigned flash_grid(int ntile, int H, int B) {
 #define FWD_OFF_R 32768
 #define FWD_OFF_T (32768 + FA_RING * 256)
 #define FWD_LDS_BYTES (FWD_OFF_T + 4 * FA_TW_BYTES)
+#define BQ_WAVE_BYTES 16384                 // bwd_q: two [32][64] f32 scratches per wave (also holds the [32][136] bf16 output tile)
+#define BQ_LDS_BYTES (FWD_OFF_T + 4 * BQ_WAVE_BYTES)   // = 160 KiB, all of the LDS
 
 __global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -405,8 +407,12 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
     char* Ks0 = smem + FWD_OFF_K;
     char* Vs0 = smem + FWD_OFF_V;
     char* Rr = smem + FWD_OFF_R;
-    float* Tw = reinterpret_cast<float*>(smem + FWD_OFF_T + wave * FA_TW_BYTES);
-    float* twr = Tw + a * 65 + 31 - 4 * hb;
+    // per-wave scratch: T ring [32][64] f32 (kept across blocks: incremental band, see rel_band_incr_to_lds) + a second [32][64] for
+    // the dS re-indexing (the two used to share one scratch, which forced the full 64-distance band every block)
+    float* Tw = reinterpret_cast<float*>(smem + FWD_OFF_T + wave * BQ_WAVE_BYTES);
+    float* Dw = Tw + 2048;
+    const float* twr = Tw + a * 65 + 31 - 4 * hb;
+    float* dwr = Dw + a * 65 + 31 - 4 * hb;
     const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
     const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
     const bf16_t* dog = p.dout + ((int64_t)b * L) * HD + h * FA_D;
@@ -440,6 +446,10 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    int toff1[16];  // odd-parity read offsets of the T ring: a * 64 + ((a - crow(r, hb) + 31) ^ 32)
+#pragma unroll
+    for (int r = 0; r < 16; r++) toff1[r] = a * 64 + ((a - crow(r, hb) + 31) ^ 32);
+    bool have_prev = false;  // did this wave process the previous key block?  (wave-uniform)
     auto block = [&](auto CUR, int jb) {
         constexpr int cur = decltype(CUR)::value;
         const int j0 = jb * FA_BK;
@@ -450,7 +460,8 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
             stage_tile32(vg, p.kv_rs, j0 + FA_BK, Vs0 + (cur ^ 1) * 8192, wave, lane);
             stage_ring32(Rg, HD, i0 - j0 - 64, L, Rr, wave, lane);
         }
-        if (!(j0 > iw + 31 || j0 + 31 <= iw - p.shift)) {
+        if (j0 > iw + 31 || j0 + 31 <= iw - p.shift) have_prev = false;
+        else {
             f32x16 acc_s, acc_dp;
             zero16(acc_s);
             zero16(acc_dp);
@@ -458,10 +469,12 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
             for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(rowf(Ks, offs, ks), fqu[ks], acc_s);    // S^T[key][query]
 #pragma unroll
             for (int ks = 0; ks < 8; ks++) acc_dp = MFMA32(rowf(Vs, offs, ks), fdo[ks], acc_dp);  // dP^T[key][query]
-            rel_band_to_lds<true>(fqv, nullptr, offs, Rr, iw - j0 - 31, Tw, lane);
+            rel_band_incr_to_lds<cur>(fqv, offs, Rr, iw - j0 - 31, Tw, lane, !have_prev);
+            have_prev = true;
             float ds[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) ds[r] = __builtin_amdgcn_exp2f(fmaf(acc_s[r] + twr[-((r & 3) + 8 * (r >> 2))], c2, nlse2));
+            for (int r = 0; r < 16; r++)
+                ds[r] = __builtin_amdgcn_exp2f(fmaf(acc_s[r] + (cur == 0 ? twr[-((r & 3) + 8 * (r >> 2))] : Tw[toff1[r]]), c2, nlse2));
             if (j0 + 31 > iw || j0 <= iw + 31 - p.shift) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
@@ -473,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
             for (int r = 0; r < 16; r++) ds[r] = ds[r] * (acc_dp[r] - delta_a) * p.scale;
             // dS re-indexed by distance: write into the scratch at (a, a - b + 31), then rows go out as 32 contiguous bf16
 #pragma unroll
-            for (int r = 0; r < 16; r++) twr[-((r & 3) + 8 * (r >> 2))] = ds[r];
+            for (int r = 0; r < 16; r++) dwr[-((r & 3) + 8 * (r >> 2))] = ds[r];
             const bf16x8_t db0 = pack8(ds), db1 = pack8(ds + 8);
 #pragma unroll
             for (int db = 0; db < 4; db++) {  // dq^T[d][query] += K^T . dS^T
@@ -483,7 +496,7 @@ __global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
             {
                 const int t = lane & 31;
                 bf16_t* drow = dTg + (int64_t)(iw + hb) * L + (iw + hb - j0 - 31 + t);  // row = 2*it + hb, dist = i - j with j = j0 + 31 - t
-                const float* trow = Tw + hb * 65 + t;
+                const float* trow = Dw + hb * 65 + t;
 #pragma unroll
                 for (int it = 0; it < 16; it++) {
                     const int dist = iw + 2 * it + hb - j0 - 31 + t;
@@ -671,7 +684,7 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)relattn_flash_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES);
+        hipFuncSetAttribute((const void*)relattn_flash_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BQ_LDS_BYTES);
         hipFuncSetAttribute((const void*)relattn_flash_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV_LDS_BYTES);
         attr = true;
     }
@@ -679,7 +692,7 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
     relattn_delta_kernel<<<(unsigned)((n_rows + 15) / 16), 256, 0, s>>>(a.out, a.dout, delta, n_rows, L, H);
     DB1_CHECK_LAUNCH("relattn_delta");
     dim3 grid(flash_grid(L / FA_BQ, H, B));
-    relattn_flash_bwd_q_kernel<<<grid, 256, FWD_LDS_BYTES, s>>>(a);
+    relattn_flash_bwd_q_kernel<<<grid, 256, BQ_LDS_BYTES, s>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_bwd_q");
     relattn_flash_bwd_kv_kernel<<<grid, 256, KV_LDS_BYTES, s>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_bwd_kv");
