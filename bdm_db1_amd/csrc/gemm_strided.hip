@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(GemmStridedArgs p) {
     const TA* A = (const TA*)p.A + z0 * p.a_bs0 + z1 * p.a_bs1;
     const TB* B = (const TB*)p.B + z0 * p.b_bs0 + z1 * p.b_bs1;
     TC* C = (TC*)p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
-    const int m0 = blockIdx.y * GS_BM, n0 = blockIdx.x * GS_BN;
+    const int m0 = blockIdx.x * GS_BM, n0 = blockIdx.y * GS_BN;  // M on grid.x: the conv1 GEMM of a large RL batch has millions of rows
     // loader index maps: pick the one whose fastest index follows the unit stride
     const bool a_kfast = (p.a_cs == 1);            // k contiguous in memory
     const bool b_kfast = (p.b_rs == 1 && p.b_cs != 1);
@@ -96,8 +96,8 @@ static void launch_strided(const GemmStridedArgs& a, int dtBias, dim3 grid, hipS
 }
 
 int db1_gemm_strided_generic(const GemmStridedArgs& a, int dtA, int dtB, int dtC, int dtBias, int batch, hipStream_t st) {
-    dim3 grid((unsigned)((a.N + GS_BN - 1) / GS_BN), (unsigned)((a.M + GS_BM - 1) / GS_BM), (unsigned)batch);
-    if (grid.y > 65535 || grid.z > 65535) DB1_FAIL(DB1_ERR_BAD_SHAPE, "gemm_strided: grid too large (M=%d batch=%d)", a.M, batch);
+    dim3 grid((unsigned)((a.M + GS_BM - 1) / GS_BM), (unsigned)((a.N + GS_BN - 1) / GS_BN), (unsigned)batch);
+    if (grid.y > 65535 || grid.z > 65535) DB1_FAIL(DB1_ERR_BAD_SHAPE, "gemm_strided: grid too large (N=%d batch=%d)", a.N, batch);
     const int key = (dtA << 2) | (dtB << 1) | dtC;
     switch (key) {
         case 0: launch_strided<float, float, float>(a, dtBias, grid, st); break;

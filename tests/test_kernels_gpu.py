@@ -84,6 +84,20 @@ def test_gemm_batched_strided(ops):
     close(out, np.einsum("xymk,ykn->xymn", A, B), 2e-6, name="gemm batched")
 
 
+def test_gemm_strided_millions_of_rows(ops):
+    """the first conv of the patch embedder at an RL batch of 64 sequences is a GEMM with 15 M rows and K = 32:
+    the row tiles must not sit on a 65535-limited grid dimension"""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, N, K = 65536 * 64 + 192, 64, 32
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = torch.randn(N, K, generator=g).to(torch.bfloat16).to(DEV)
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(a, w.t(), out)
+    for sl in (slice(0, 4096), slice(M // 2, M // 2 + 4096), slice(M - 4096, M)):
+        ref = a[sl].double().cpu().numpy() @ w.double().cpu().numpy().T
+        close(out[sl], ref, 1e-2, name=f"gemm rows {sl.start}")
+
+
 @pytest.mark.parametrize("form", ["nt", "nn", "tn"])
 @pytest.mark.parametrize("out_dtype", ["f32", "bf16"])
 def test_gemm_bf16_tile_kernels(ops, form, out_dtype):
