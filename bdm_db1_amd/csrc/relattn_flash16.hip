@@ -1,0 +1,679 @@
+// Relative-position flash attention, 8-wave form (two waves per SIMD): the same math and workgroup tiling as relattn_flash.hip
+// (128 queries of one (batch, head) per workgroup, 32-key blocks, a 256-row LDS ring of R rows, skewed read of the relative term),
+// but every wave owns 16 rows instead of 32 and works on v_mfma_f32_16x16x32_bf16.  The 4-wave kernels ran one wave per SIMD and were
+// bound by their own serial chain (LDS read -> MFMA -> scratch -> softmax -> MFMA: matrix pipe 14-21 % busy, VALU 19 %, LDS 14 %);
+// with two waves per SIMD the hardware overlaps one wave's softmax / LDS waits with the other wave's MFMAs.
+//
+// Fragment conventions (16x16x32): A[m][k]: lane (m = lane & 15, g = lane >> 4) holds k = 8g .. 8g+7; B[k][n]: lane (n, g) the same
+// k; C[m][n]: lane (n = lane & 15, g) holds rows m = 4g + r, r = 0..3.
+//   * S^T = K.Qu^T per 16-key tile t (two per block); MFMA row 4g + r of tile t is key   kk(t, g) + r,
+//         kk(t, g) = 16 ((g & 1) ^ t) + 8 (g >> 1) + 4 t
+//     (a bijection onto 0..31).  The permutation makes the skewed scratch read conflict-free: lanes g and g ^ 1 of one 32-lane LDS
+//     group differ by 16 keys = 16 banks.  A lane's 8 scores (tile 0: r = 0..3, tile 1: r = 0..3) are exactly k-slots 8g .. 8g+7 of
+//     the B operand of O^T += V^T.P^T, and the V^T fragment takes the same keys through ds_read_b64_tr_b16 (rows kk(t, g) + 0..3).
+//   * relative term: T = Qv.Rband^T for the 48 distances [iw - j0 - 32, iw - j0 + 16) of a 16 x 32 block (47 are needed; starting one
+//     lower keeps the ring slots of a tile 16-aligned), C[q][dist] written to a per-wave scratch [16 q][64] and read back at
+//     (q, q - key + 32).  Incremental like the 4-wave forward: the band of block jb+1 is the band of block jb moved down by 32, so
+//     two new 16-distance tiles are computed and the third is kept; logical column c lives at c ^ (32 * parity).
+//   * K / V tiles are prefetched TWO blocks ahead through three LDS stages (counted vmcnt): all query tiles of one (batch, head) walk the
+//     keys in step, so a tile's first touch is an HBM miss (~2 k cycles under load) that a one-block prefetch distance did not hide
+//     (a staging-only loop took 478 us of the 965 us kernel at B = 64; 329 us with two blocks of distance).
+//   * LDS images are row-major with the 16-byte chunk XOR-swizzled on the source side of the LDS-DMA:
+//       K / V tiles:  f(row)  = (b4 << 3) | (b1 << 2) | (b0 << 1) | b2        (conflict-free for the permuted row fragments AND the tr reads)
+//       ring rows:    fr(slot) = (((slot & 7) ^ ((slot & 8) >> 1)) << 1) | ((slot >> 3) & 1)
+#include "relattn_flash.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+#define W16_WAVES 8
+#define W16_STAGES 3
+#define W16_TP 68            // scratch row pitch (words): 64 columns + 4 -> the column-wise writes and the skewed reads are both conflict-free
+#define W16_TW_BYTES 4352    // per-wave scratch: T [16][68] f32 or the [16][136] bf16 output staging tile (both 4352 B)
+#define W16_DP 72            // bwd_q dS scratch row pitch (bytes): [16 q][32 keys, reversed] bf16 + 8
+#define W16_OFF_K 0          // three stages of 8 KiB
+#define W16_OFF_V (W16_STAGES * 8192)
+#define W16_OFF_R (2 * W16_STAGES * 8192)      // 256 ring rows of 256 B
+#define W16_OFF_T (W16_OFF_R + FA_RING * 256)
+#define W16_OFF_D (W16_OFF_T + W16_WAVES * W16_TW_BYTES)
+#define W16_FWD_LDS W16_OFF_D
+#define W16_BQ_LDS (W16_OFF_D + W16_WAVES * 16 * W16_DP)
+
+__device__ __forceinline__ int swz_kv(int row) { return (((row >> 4) & 1) << 3) | ((row & 3) << 1) | ((row >> 2) & 1); }
+__device__ __forceinline__ int swz_ring(int slot) { return ((((slot & 7) ^ ((slot & 8) >> 1))) << 1) | ((slot >> 3) & 1); }
+__device__ __forceinline__ int kk16(int t, int g) { return 16 * ((g & 1) ^ t) + 8 * (g >> 1) + 4 * t; }
+
+// LDS accesses go through absolute 32-bit LDS addresses kept in VGPRs (lane constants) plus immediate offsets: with pointer
+// arithmetic on the dynamic-LDS symbol hipcc emitted one `v_add_u32 v, 0, v` per access (a third of the loop's VALU work).
+typedef __attribute__((address_space(3))) const bf16x8_t* lds_b128_ptr;
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b64_ptr;
+typedef __attribute__((address_space(3))) float* lds_f32_ptr;
+typedef __attribute__((address_space(3))) unsigned* lds_u32_ptr;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((address_space(3))) u32x2_t* lds_u64_ptr;
+__device__ __forceinline__ bf16x8_t lds_ld128(unsigned addr) { return *(lds_b128_ptr)(size_t)addr; }
+__device__ __forceinline__ float lds_ldf(unsigned addr) { return *(lds_f32_ptr)(size_t)addr; }
+__device__ __forceinline__ void lds_stf(unsigned addr, float v) { *(lds_f32_ptr)(size_t)addr = v; }
+__device__ __forceinline__ bf16x8_t lds_tr_pair(unsigned a0, unsigned a1) {
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)(size_t)a0);
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)(size_t)a1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// one 1 KiB LDS-DMA piece = 4 rows of 256 B, lane -> (row = lane >> 4, destination chunk = lane & 15); src already points at the
+// lane's (swizzled) 16-byte source chunk, dst_lds is the wave-uniform LDS address of the piece.  Issued from inline asm so that
+// hipcc does not drain the prefetch (vmcnt(0)) in front of LDS accesses it cannot disambiguate (see relattn_flash.hip).
+__device__ __forceinline__ void glds16(const void* src, unsigned dst_lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst_lds) : "memory");
+}
+__device__ __forceinline__ float vmax3(float x, float y, float z) {  // no NaN canonicalisation (fmaxf costs a v_max x,x per input)
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+}
+__device__ __forceinline__ float vmax2(float x, float y) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+    return d;
+}
+__device__ __forceinline__ float max_x16(float x) {  // max with lane ^ 16 (v_permlane16_swap: no LDS round trip)
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_x32(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_x16(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_x32(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void zero4(f32x4& x) { x[0] = 0.f; x[1] = 0.f; x[2] = 0.f; x[3] = 0.f; }
+
+// lane-constant absolute LDS addresses (tile addresses are those of a tile at LDS offset 0: add W16_OFF_x + stage * 8192 as immediates)
+struct W16Lane {
+    unsigned rowf[2][4];  // A-operand row fragment of 16-row tile t, k-step ks: MFMA row a <-> tile row kk(t, a >> 2) + (a & 3)
+    unsigned tr[2][8];    // ds_read_b64_tr_b16 of tile rows kk(t, g) + 0..3, d-tile db
+    unsigned ring[4];     // natural-order row fragment (row & 15 == a) of a ring-swizzled image at LDS offset 0: + offset + (row16 << 8)
+    unsigned tsk[2][8];   // scratch element (a, a - key + 32), key = kk(t, g) + r, for both parities
+    unsigned twr;         // scratch write base: rows 4g + r, column a  (+ (r * W16_TP + (16 tile ^ 32 parity)) * 4)
+};
+// keep every address in its own VGPR: left alone, hipcc re-associates them into (common part) + (lane part) and re-adds per access
+#define W16_OPAQUE(x) asm volatile("" : "+v"(x))
+__device__ __forceinline__ void w16_lane_init(W16Lane& o, unsigned lds0, unsigned tw0, int lane) {  // tw0: LDS address of the wave scratch
+    const int a = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int rho = kk16(t, a >> 2) + (a & 3);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) { o.rowf[t][ks] = lds0 + rho * 256 + (((4 * ks + g) ^ swz_kv(rho)) << 4); W16_OPAQUE(o.rowf[t][ks]); }
+        const int row = kk16(t, g) + (a >> 2);
+#pragma unroll
+        for (int db = 0; db < 8; db++) {
+            o.tr[t][db] = lds0 + row * 256 + (((2 * db + ((a & 3) >> 1)) ^ swz_kv(row)) << 4) + (a & 1) * 8;
+            W16_OPAQUE(o.tr[t][db]);
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { o.ring[ks] = lds0 + (a << 8) + (((4 * ks + g) ^ swz_ring(a)) << 4); W16_OPAQUE(o.ring[ks]); }
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int c = a - kk16(t, g) - r + 32;
+            o.tsk[0][t * 4 + r] = tw0 + (a * W16_TP + c) * 4;
+            o.tsk[1][t * 4 + r] = tw0 + (a * W16_TP + (c ^ 32)) * 4;
+            W16_OPAQUE(o.tsk[0][t * 4 + r]);
+            W16_OPAQUE(o.tsk[1][t * 4 + r]);
+        }
+    o.twr = tw0 + ((4 * g) * W16_TP + a) * 4;
+    W16_OPAQUE(o.twr);
+}
+// staging state of one wave: every wave moves one 1 KiB piece (4 rows) of the K tile, of the V tile and of the 32 new ring rows per block
+struct W16Stage {
+    const bf16_t* kptr; const bf16_t* vptr;  // this lane's source chunk of the NEXT tile to stage (tiles are staged in key order)
+    const bf16_t* rbase;                     // R + head + this lane's ring source chunk
+    int64_t kv_step, r_rs;
+    int srow, L;
+    unsigned lds0;
+};
+__device__ __forceinline__ void w16_stage_init(W16Stage& s, const bf16_t* kg, const bf16_t* vg, const bf16_t* Rg, int64_t kv_rs, int64_t r_rs, int row0,
+                                               int L, unsigned lds0, int wave, int lane) {
+    s.srow = wave * 4 + (lane >> 4);
+    const int schunk = ((lane & 15) ^ swz_kv(s.srow)) << 3;
+    s.kptr = kg + (int64_t)(row0 + s.srow) * kv_rs + schunk;
+    s.vptr = vg + (int64_t)(row0 + s.srow) * kv_rs + schunk;
+    s.rbase = Rg + (((lane & 15) ^ swz_ring(s.srow & 15)) << 3);  // slot & 15 == srow & 15: distances are staged in multiples of 16
+    s.kv_step = (int64_t)FA_BK * kv_rs;
+    s.r_rs = r_rs;
+    s.L = L;
+    s.lds0 = lds0;
+}
+__device__ __forceinline__ void w16_stage_k(W16Stage& s, int stage, int wave) {
+    glds16(s.kptr, s.lds0 + W16_OFF_K + stage * 8192 + wave * 1024);
+    s.kptr += s.kv_step;
+}
+__device__ __forceinline__ void w16_stage_v(W16Stage& s, int stage, int wave) {
+    glds16(s.vptr, s.lds0 + W16_OFF_V + stage * 8192 + wave * 1024);
+    s.vptr += s.kv_step;
+}
+__device__ __forceinline__ void w16_stage_kv(W16Stage& s, int stage, int wave) {
+    w16_stage_k(s, stage, wave);
+    w16_stage_v(s, stage, wave);
+}
+template <int N> __device__ __forceinline__ void w16_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void w16_stage_ring(const W16Stage& s, int dist0, int wave) {  // distances dist0 .. dist0+31 (dist0 a multiple of 16)
+    const int slot0 = (dist0 + wave * 4) & (FA_RING - 1);
+    const int dist = dist0 + s.srow;
+    const int gr = dist < 0 ? 0 : (dist > s.L - 1 ? s.L - 1 : dist);  // out-of-range distances belong to masked pairs
+    glds16(s.rbase + (int64_t)gr * s.r_rs, s.lds0 + W16_OFF_R + slot0 * 256);
+}
+// relative-term tile: distances dist16 .. dist16+15 (dist16 a multiple of 16) for the wave's 16 queries -> scratch columns col .. col+15
+__device__ __forceinline__ void w16_rel_tile(const bf16x8_t* fqv, const W16Lane& o, int dist16, int col) {
+    const unsigned rs = (unsigned)(dist16 & (FA_RING - 1)) << 8;  // wave-uniform
+    f32x4 acc;
+    zero4(acc);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) acc = MFMA16(fqv[ks], lds_ld128(o.ring[ks] + rs + W16_OFF_R), acc);
+#pragma unroll
+    for (int r = 0; r < 4; r++) lds_stf(o.twr + (r * W16_TP + col) * 4, acc[r]);
+}
+// acc^T [8 d-tiles](rows = d, col = lane & 15) -> bf16 rows [16][128] at dst (row stride rs), staged through the wave scratch
+__device__ __forceinline__ void store_acc_t16(const f32x4* acc, float mul, bf16_t* Ow, bf16_t* dst, int64_t rs, int lane) {
+    const int a = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int db = 0; db < 8; db++) {
+        uint2 o;
+        o.x = pk_bf16(acc[db][0] * mul, acc[db][1] * mul);
+        o.y = pk_bf16(acc[db][2] * mul, acc[db][3] * mul);
+        *reinterpret_cast<uint2*>(Ow + a * 136 + 16 * db + 4 * g) = o;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int row = it * 4 + (lane >> 4), ch = lane & 15;
+        const uint4 v = *reinterpret_cast<const uint4*>(Ow + row * 136 + ch * 8);
+        *reinterpret_cast<uint4*>(dst + (int64_t)row * rs + ch * 8) = v;
+    }
+}
+#define W16_BLOCK_LOOP(block)                                                                                       \
+    for (int jb = jb_lo; jb <= jb_hi; jb += 6) {                                                                    \
+        block(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, jb);                              \
+        if (jb + 1 <= jb_hi) block(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, jb + 1);     \
+        if (jb + 2 <= jb_hi) block(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, jb + 2);     \
+        if (jb + 3 <= jb_hi) block(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, jb + 3);     \
+        if (jb + 4 <= jb_hi) block(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, jb + 4);     \
+        if (jb + 5 <= jb_hi) block(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, jb + 5);     \
+    }
+
+// ======================================================================================= forward
+__global__ __launch_bounds__(512, 1) void relattn_flash16_fwd_kernel(FlashArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rank, h, b;
+    if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, rank, h, b)) return;
+    const int qt = p.L / FA_BQ - 1 - rank;  // late query tiles have the longest key loops
+    const int H = p.H, L = p.L, HD = H * FA_D;
+    const int i0 = qt * FA_BQ, iw = i0 + 16 * wave;
+    const int a = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+    const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
+    W16Lane ln;
+    w16_lane_init(ln, lds0, lds0 + W16_OFF_T + wave * W16_TW_BYTES, lane);
+
+    bf16x8_t fqu[4], fqv[4];  // row iw + a, k = 32 ks + 8 g .. +7 (A and B operand images coincide)
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        fqu[ks] = *reinterpret_cast<const bf16x8_t*>(qu + (int64_t)(iw + a) * HD + ks * 32 + g * 8);
+        fqv[ks] = *reinterpret_cast<const bf16x8_t*>(qv + (int64_t)(iw + a) * HD + ks * 32 + g * 8);
+    }
+    int jlo = i0 - p.shift + 1;
+    if (jlo < 0) jlo = 0;
+    const int jb_lo = jlo / FA_BK, jb_hi = (i0 + FA_BQ - 1) / FA_BK;
+    W16Stage sg;
+    w16_stage_init(sg, p.k + (int64_t)b * p.kv_bs + h * FA_D, p.v + (int64_t)b * p.kv_bs + h * FA_D, p.R + h * FA_D, p.kv_rs, HD, jb_lo * FA_BK, L,
+                   lds0, wave, lane);
+    // prologue: ring rows for distances [i0-j0-64, i0-j0+128) (blocks jb_lo and jb_lo+1) and the first two K/V tiles
+    for (int c4 = -2; c4 < 4; c4++) w16_stage_ring(sg, i0 - jb_lo * FA_BK + 32 * c4, wave);
+    w16_stage_kv(sg, 0, wave);
+    if (jb_lo + 1 <= jb_hi) w16_stage_kv(sg, 1, wave);
+    f32x4 acc_o[8];
+#pragma unroll
+    for (int db = 0; db < 8; db++) zero4(acc_o[db]);
+    const float c2 = p.scale * LOG2E;
+    float m_i = -1.0e30f, l_i = 0.f;  // m_i in RAW score units; l_i is this lane's PARTIAL row sum (reduced over g at the end)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as a builtin so that hipcc's own bookkeeping sees the fragment loads retired
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    bool have_prev = false;  // did this wave process the previous key block?  (wave-uniform)
+    auto block = [&](auto STG, auto PARC, int jb) __attribute__((always_inline)) {
+        constexpr int stg = decltype(STG)::value, par = decltype(PARC)::value;
+        const int j0 = jb * FA_BK;
+        const bool pf = jb + 2 <= jb_hi;
+        if (pf) {  // prefetch block jb+2: its tiles and the 32 ring rows it adds land while this block and the next are computed
+            w16_stage_kv(sg, (stg + 2) % W16_STAGES, wave);
+            w16_stage_ring(sg, i0 - j0 - 96, wave);
+        }
+        if (j0 > iw + 15 || j0 + 31 <= iw - p.shift) have_prev = false;
+        else {  // wave-uniform: blocks entirely outside this wave's window are skipped
+            // relative term: logical tile t = distances dist_lo + 16 t .. -> scratch columns (16 t ..) ^ (32 par); tile 2 is the one
+            // kept from the previous block (computed only for a wave's first processed block)
+            const int dist_lo = iw - j0 - 32;
+            w16_rel_tile(fqv, ln, dist_lo, 0 ^ (32 * par));
+            w16_rel_tile(fqv, ln, dist_lo + 16, 16 ^ (32 * par));
+            if (!have_prev) w16_rel_tile(fqv, ln, dist_lo + 32, 32 ^ (32 * par));
+            have_prev = true;
+            f32x4 acc_s[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                zero4(acc_s[t]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) acc_s[t] = MFMA16(lds_ld128(ln.rowf[t][ks] + W16_OFF_K + stg * 8192), fqu[ks], acc_s[t]);  // S^T[key][query]
+            }
+            // skewed read of the relative term, then the V^T fragments of the P.V product (in flight during the softmax)
+            float s[8];  // this lane: query iw + a; s[4 t + r]: key j0 + kk(t, g) + r
+#pragma unroll
+            for (int r = 0; r < 8; r++) s[r] = lds_ldf(ln.tsk[par][r]);
+            bf16x8_t vt[8];
+#pragma unroll
+            for (int db = 0; db < 8; db++) vt[db] = lds_tr_pair(ln.tr[0][db] + W16_OFF_V + stg * 8192, ln.tr[1][db] + W16_OFF_V + stg * 8192);
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) s[t * 4 + r] += acc_s[t][r];
+            if (j0 + 31 > iw || j0 <= iw + 15 - p.shift) {  // only diagonal / window-edge blocks need the element mask
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = iw + a, j = j0 + kk16(t, g) + r;
+                        s[t * 4 + r] = ((j <= i) && (j > i - p.shift)) ? s[t * 4 + r] : -1.0e30f;
+                    }
+            }
+            float mblk = vmax3(vmax3(s[0], s[1], s[2]), vmax3(s[3], s[4], s[5]), vmax2(s[6], s[7]));
+            mblk = max_x32(max_x16(mblk));
+            const float m_new = vmax2(m_i, mblk);
+            if (!__all(m_new == m_i)) {  // the running maxima rarely move after the first blocks: skip the O-wide rescale then
+                const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c2);
+                l_i *= alpha;
+#pragma unroll
+                for (int db = 0; db < 8; db++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc_o[db][r] *= alpha;
+                m_i = m_new;
+            }
+            const float mc = -m_i * c2;
+#pragma unroll
+            for (int r = 0; r < 8; r++) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, mc)); l_i += s[r]; }
+            const bf16x8_t pb = pack8(s);
+#pragma unroll
+            for (int db = 0; db < 8; db++) acc_o[db] = MFMA16(vt[db], pb, acc_o[db]);  // O^T[d][query] += V^T . P^T
+        }
+        // block jb+1 must have landed: all but the three pieces issued at the top of this block
+        if (pf) w16_vmcnt<3>(); else w16_vmcnt<0>();
+        __syncthreads();  // every wave is done reading stage stg (refilled by the next block's prefetch)
+    };
+    W16_BLOCK_LOOP(block)
+    l_i = sum_x32(sum_x16(l_i));
+    bf16_t* Ow = reinterpret_cast<bf16_t*>(smem + W16_OFF_T + wave * W16_TW_BYTES);
+    store_acc_t16(acc_o, 1.f / l_i, Ow, p.o + ((int64_t)b * L + iw) * HD + h * FA_D, HD, lane);
+    if (g == 0) p.lse_out[((int64_t)b * H + h) * L + iw + a] = m_i * p.scale + logf(l_i);
+}
+
+// ======================================================================================= backward w.r.t. queries (+ dT)
+// per wave-block (16 queries x 32 keys): S^T = K.Qu^T, dP^T = V.dO^T, the relative-term band (incremental), dS^T -> dq^T += K^T.dS^T, and
+// dT[i][i - j] = dS[i][j]: in row i the 32 keys of a block are 32 CONSECUTIVE distances in reverse key order, so the lane's packed
+// bf16 pairs go to a small [16 q][32] scratch (two ds_write_b64) and leave as 64 contiguous bytes per row.
+typedef unsigned __attribute__((aligned(2))) u32_a2_t;
+__global__ __launch_bounds__(512, 1) void relattn_flash16_bwd_q_kernel(FlashArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rank, h, b;
+    if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, rank, h, b)) return;
+    const int qt = p.L / FA_BQ - 1 - rank;
+    const int H = p.H, L = p.L, HD = H * FA_D;
+    const int i0 = qt * FA_BQ, iw = i0 + 16 * wave;
+    const int a = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+    const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* dog = p.dout + ((int64_t)b * L) * HD + h * FA_D;
+    W16Lane ln;
+    w16_lane_init(ln, lds0, lds0 + W16_OFF_T + wave * W16_TW_BYTES, lane);
+    // dS scratch: lane (query a, g) writes keys kk(t, g) + 0..3 as element 31 - key: dwords 14 - kk/2, 15 - kk/2 of row a
+    const unsigned dw0 = lds0 + W16_OFF_D + wave * 16 * W16_DP;
+    unsigned dsw[2], dsr;
+#pragma unroll
+    for (int t = 0; t < 2; t++) { dsw[t] = dw0 + a * W16_DP + (14 - kk16(t, g) / 2) * 4; W16_OPAQUE(dsw[t]); }
+    dsr = dw0 + (lane >> 4) * W16_DP + (lane & 15) * 4;  // + it * 4 rows
+    W16_OPAQUE(dsr);
+
+    bf16x8_t fqu[4], fqv[4], fdo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        fqu[ks] = *reinterpret_cast<const bf16x8_t*>(qu + (int64_t)(iw + a) * HD + ks * 32 + g * 8);
+        fqv[ks] = *reinterpret_cast<const bf16x8_t*>(qv + (int64_t)(iw + a) * HD + ks * 32 + g * 8);
+        fdo[ks] = *reinterpret_cast<const bf16x8_t*>(dog + (int64_t)(iw + a) * HD + ks * 32 + g * 8);
+    }
+    const float c2 = p.scale * LOG2E;
+    const float nlse2 = -p.lse[((int64_t)b * H + h) * L + iw + a] * LOG2E;
+    const float delta_a = p.delta[((int64_t)b * H + h) * L + iw + a];
+    // dT row (iw + row) starts at distance (iw + row) - j0 - 31 for a block: row = 4 it + (lane >> 4), this lane's pair = elements 2 col, 2 col + 1
+    bf16_t* dtp = p.dT + (((int64_t)h * p.B + b) * L + iw + (lane >> 4)) * L + (iw + (lane >> 4) - 31 + 2 * (lane & 15));
+    const int drow0 = iw + (lane >> 4) - 31 + 2 * (lane & 15);  // distance of the pair's first element for j0 = 0, it = 0
+    int jlo = i0 - p.shift + 1;
+    if (jlo < 0) jlo = 0;
+    const int jb_lo = jlo / FA_BK, jb_hi = (i0 + FA_BQ - 1) / FA_BK;
+    W16Stage sg;
+    w16_stage_init(sg, p.k + (int64_t)b * p.kv_bs + h * FA_D, p.v + (int64_t)b * p.kv_bs + h * FA_D, p.R + h * FA_D, p.kv_rs, HD, jb_lo * FA_BK, L,
+                   lds0, wave, lane);
+    for (int c4 = -2; c4 < 4; c4++) w16_stage_ring(sg, i0 - jb_lo * FA_BK + 32 * c4, wave);
+    w16_stage_kv(sg, 0, wave);
+    if (jb_lo + 1 <= jb_hi) w16_stage_kv(sg, 1, wave);
+    f32x4 acc_dq[8];
+#pragma unroll
+    for (int db = 0; db < 8; db++) zero4(acc_dq[db]);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    bool have_prev = false;
+    auto block = [&](auto STG, auto PARC, int jb) __attribute__((always_inline)) {
+        constexpr int stg = decltype(STG)::value, par = decltype(PARC)::value;
+        const int j0 = jb * FA_BK;
+        const bool pf = jb + 2 <= jb_hi;
+        if (pf) {
+            w16_stage_kv(sg, (stg + 2) % W16_STAGES, wave);
+            w16_stage_ring(sg, i0 - j0 - 96, wave);
+        }
+        if (j0 > iw + 15 || j0 + 31 <= iw - p.shift) have_prev = false;
+        else {
+            const int dist_lo = iw - j0 - 32;
+            w16_rel_tile(fqv, ln, dist_lo, 0 ^ (32 * par));
+            w16_rel_tile(fqv, ln, dist_lo + 16, 16 ^ (32 * par));
+            if (!have_prev) w16_rel_tile(fqv, ln, dist_lo + 32, 32 ^ (32 * par));
+            have_prev = true;
+            f32x4 acc_s[2], acc_dp[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                zero4(acc_s[t]);
+                zero4(acc_dp[t]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) acc_s[t] = MFMA16(lds_ld128(ln.rowf[t][ks] + W16_OFF_K + stg * 8192), fqu[ks], acc_s[t]);   // S^T[key][query]
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) acc_dp[t] = MFMA16(lds_ld128(ln.rowf[t][ks] + W16_OFF_V + stg * 8192), fdo[ks], acc_dp[t]);  // dP^T[key][query]
+            }
+            float ds[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) ds[r] = lds_ldf(ln.tsk[par][r]);
+            bf16x8_t kt[8];
+#pragma unroll
+            for (int db = 0; db < 8; db++) kt[db] = lds_tr_pair(ln.tr[0][db] + W16_OFF_K + stg * 8192, ln.tr[1][db] + W16_OFF_K + stg * 8192);
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) ds[t * 4 + r] = __builtin_amdgcn_exp2f(fmaf(ds[t * 4 + r] + acc_s[t][r], c2, nlse2));
+            const bool edge = j0 + 31 > iw || j0 <= iw + 15 - p.shift;
+            if (edge) {
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = iw + a, j = j0 + kk16(t, g) + r;
+                        ds[t * 4 + r] = ((j <= i) && (j > i - p.shift)) ? ds[t * 4 + r] : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) ds[t * 4 + r] = ds[t * 4 + r] * (acc_dp[t][r] - delta_a) * p.scale;
+            const bf16x8_t db8 = pack8(ds);
+#pragma unroll
+            for (int db = 0; db < 8; db++) acc_dq[db] = MFMA16(kt[db], db8, acc_dq[db]);  // dq^T[d][query] += K^T . dS^T
+            // dT: element 31 - key of row a; the pairs are (key+1, key) in memory order
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                u32x2_t w;
+                w[0] = pk_bf16(ds[t * 4 + 3], ds[t * 4 + 2]);
+                w[1] = pk_bf16(ds[t * 4 + 1], ds[t * 4 + 0]);
+                *(lds_u64_ptr)(size_t)dsw[t] = w;
+            }
+            bf16_t* drow = dtp - j0;
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const unsigned v = *(lds_u32_ptr)(size_t)(dsr + it * 4 * W16_DP);
+                bf16_t* dst = drow + (int64_t)(4 * it) * (L + 1);
+                if (!edge) *reinterpret_cast<u32_a2_t*>(dst) = v;
+                else {
+                    const int d = drow0 - j0 + 4 * it;  // distance of the pair's first element (negative: above the diagonal, never stored)
+                    if (d >= 0) *reinterpret_cast<u32_a2_t*>(dst) = v;
+                    else if (d == -1) dst[1] = (bf16_t)(v >> 16);
+                }
+            }
+        }
+        if (pf) w16_vmcnt<3>(); else w16_vmcnt<0>();
+        __syncthreads();
+    };
+    W16_BLOCK_LOOP(block)
+    bf16_t* Ow = reinterpret_cast<bf16_t*>(smem + W16_OFF_T + wave * W16_TW_BYTES);
+    store_acc_t16(acc_dq, 1.f, Ow, p.dq + (int64_t)b * p.dq_bs + (int64_t)iw * p.dq_rs + h * FA_D, p.dq_rs, lane);
+}
+
+// ======================================================================================= backward w.r.t. keys / values
+// One workgroup = 128 keys of one (batch, head), wave = 16 keys (K / V fragments in registers), loop over 32-query blocks whose Qu, Qv,
+// dO tiles and {lse, delta} come through two LDS stages.  Per wave-block (32 queries x 16 keys):
+//   S[q][key] = Qu.K^T and dP = dO.V^T (8 + 8 MFMA; MFMA row 4g + r of tile t is query kk(t, g) + r, like the keys of the other kernels);
+//   the relative term for the 47 distances of the block: T tiles (q-tile tq, 16-distance tile td) are only needed for td - tq in {0, 1}
+//   (16 MFMA, Qv rows in natural order against ring rows), written to a scratch [32 q][32] (row q holds distances dist_lo + 16 (q >> 4) ..)
+//   and read back at (q, q - key + 16); P and dS feed dV^T += dO^T.P and dK^T += Qu^T.dS as B operands straight from registers.
+#define KV16_OFF_QU 0                          // two stages of 8 KiB each for Qu, Qv, dO
+#define KV16_OFF_QV 16384
+#define KV16_OFF_DO 32768
+#define KV16_OFF_ST 49152                      // two stages of {lse[32], delta[32]} floats (raw, via LDS-DMA)
+#define KV16_OFF_R 49664
+#define KV16_OFF_T (KV16_OFF_R + FA_RING * 256)
+#define KV16_LDS (KV16_OFF_T + W16_WAVES * W16_TW_BYTES)
+#define KV16_TP 33                             // scratch row pitch (words): odd, so that queries 16 apart (lanes g, g ^ 1) land 16 banks apart
+typedef __attribute__((address_space(3))) const f32x4* lds_f32x4_ptr;
+
+__global__ __launch_bounds__(512, 1) void relattn_flash16_bwd_kv_kernel(FlashArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int kt, h, b;  // early key tiles see the most queries: rank == tile index
+    if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, kt, h, b)) return;
+    const int H = p.H, L = p.L, HD = H * FA_D;
+    const int j0 = kt * FA_BQ, kw = j0 + 16 * wave;
+    const int a = lane & 15, g = lane >> 4;   // a = key column of this lane
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+    const unsigned tw0 = lds0 + KV16_OFF_T + wave * W16_TW_BYTES;
+    const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* dog = p.dout + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* kg = p.k + (int64_t)b * p.kv_bs + h * FA_D;
+    const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * FA_D;
+    const bf16_t* Rg = p.R + h * FA_D;
+    const float* lseg = p.lse + ((int64_t)b * H + h) * L;
+    const float* delg = p.delta + ((int64_t)b * H + h) * L;
+    W16Lane ln;
+    w16_lane_init(ln, lds0, tw0, lane);  // (its scratch addresses are not used here: the block is 32 x 16, see tsk / twr below)
+    unsigned tsk[8];   // scratch element (q, q - a + 16) of row q = kk(t, g) + r, stored at column q - a + 16 - 16 (q >> 4)
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int q = kk16(t, g) + r;
+            tsk[t * 4 + r] = tw0 + (q * KV16_TP + q - a + 16 - 16 * (q >> 4)) * 4;
+            W16_OPAQUE(tsk[t * 4 + r]);
+        }
+    unsigned twr = tw0 + ((4 * g) * KV16_TP + a) * 4;  // tile (tq, td): rows 16 tq + 4g + r, columns 16 (td - tq) + a
+    W16_OPAQUE(twr);
+    unsigned sta[2];   // {lse, delta} of queries kk(t, g) .. +3 (one 16-byte read each)
+#pragma unroll
+    for (int t = 0; t < 2; t++) { sta[t] = lds0 + KV16_OFF_ST + kk16(t, g) * 4; W16_OPAQUE(sta[t]); }
+
+    bf16x8_t fk[4], fv[4];  // B-operand images: column = key kw + a
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        fk[ks] = *reinterpret_cast<const bf16x8_t*>(kg + (int64_t)(kw + a) * p.kv_rs + ks * 32 + g * 8);
+        fv[ks] = *reinterpret_cast<const bf16x8_t*>(vg + (int64_t)(kw + a) * p.kv_rs + ks * 32 + g * 8);
+    }
+    const float c2 = p.scale * LOG2E;
+    const int ib_lo = j0 / FA_BK;
+    int ihi = j0 + FA_BQ - 1 + p.shift - 1;  // last query that can see the last key of the tile
+    if (ihi > L - 1) ihi = L - 1;
+    const int ib_hi = ihi / FA_BK;
+    // staging: one piece (4 rows) of each of the three tiles and of the 32 new ring rows per wave and block; Qu / dO images use the
+    // K / V swizzle (permuted row fragments + tr reads), the Qv image the ring swizzle (natural-order row fragments)
+    const int srow = wave * 4 + (lane >> 4);
+    const int64_t soff_kv = (int64_t)(ib_lo * FA_BK + srow) * HD + (((lane & 15) ^ swz_kv(srow)) << 3);
+    const int64_t soff_rg = (int64_t)(ib_lo * FA_BK + srow) * HD + (((lane & 15) ^ swz_ring(srow & 15)) << 3);
+    const bf16_t* quptr = qu + soff_kv;
+    const bf16_t* doptr = dog + soff_kv;
+    const bf16_t* qvptr = qv + soff_rg;
+    const bf16_t* rbase = Rg + (((lane & 15) ^ swz_ring(srow & 15)) << 3);
+    const int64_t q_step = (int64_t)FA_BK * HD;
+    auto stage_q = [&](int stage, int i0n) __attribute__((always_inline)) {  // the next query block (rows i0n ..) -> stage
+        glds16(quptr, lds0 + KV16_OFF_QU + stage * 8192 + wave * 1024);
+        glds16(qvptr, lds0 + KV16_OFF_QV + stage * 8192 + wave * 1024);
+        glds16(doptr, lds0 + KV16_OFF_DO + stage * 8192 + wave * 1024);
+        quptr += q_step; qvptr += q_step; doptr += q_step;
+        if (wave == 0) glds_stat(lseg, delg, i0n, reinterpret_cast<float*>(smem + KV16_OFF_ST + stage * 256), lane);
+    };
+    auto stage_ring = [&](int dist0) __attribute__((always_inline)) {
+        const int slot0 = (dist0 + wave * 4) & (FA_RING - 1);
+        const int dist = dist0 + srow;
+        const int gr = dist < 0 ? 0 : (dist > L - 1 ? L - 1 : dist);
+        glds16(rbase + (int64_t)gr * HD, lds0 + KV16_OFF_R + slot0 * 256);
+    };
+    // ring: distances [i0q - j0 - 128, i0q - j0 + 32) for the first block; every block prefetches the next 32
+    for (int c4 = 0; c4 < 5; c4++) stage_ring(ib_lo * FA_BK - j0 - 128 + 32 * c4);
+    stage_q(0, ib_lo * FA_BK);
+    f32x4 acc_dk[8], acc_dv[8];
+#pragma unroll
+    for (int db = 0; db < 8; db++) { zero4(acc_dk[db]); zero4(acc_dv[db]); }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto block = [&](auto CUR, int ib) __attribute__((always_inline)) {
+        constexpr int cur = decltype(CUR)::value;
+        const int i0q = ib * FA_BK;
+        if (ib < ib_hi) {  // prefetch the next query block
+            stage_q(cur ^ 1, i0q + FA_BK);
+            stage_ring(i0q + FA_BK - j0);
+        }
+        if (!(i0q + 31 < kw || i0q >= kw + 15 + p.shift)) {  // some (i, j) of this block pair is visible
+            // ---- relative term: distances dist_lo + 16 td .., dist_lo = i0q - kw - 16; (tq, td) in {(0,0), (0,1), (1,1), (1,2)}
+            const int dist_lo = i0q - kw - 16;
+            bf16x8_t qvf[2][4];
+#pragma unroll
+            for (int tq = 0; tq < 2; tq++)
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) qvf[tq][ks] = lds_ld128(ln.ring[ks] + KV16_OFF_QV + cur * 8192 + tq * 4096);
+#pragma unroll
+            for (int td = 0; td < 3; td++) {
+                const unsigned rs = (unsigned)((dist_lo + 16 * td) & (FA_RING - 1)) << 8;
+                bf16x8_t rf[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) rf[ks] = lds_ld128(ln.ring[ks] + rs + KV16_OFF_R);
+#pragma unroll
+                for (int tq = 0; tq < 2; tq++) {
+                    if (td - tq != 0 && td - tq != 1) continue;
+                    f32x4 acc;
+                    zero4(acc);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) acc = MFMA16(qvf[tq][ks], rf[ks], acc);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) lds_stf(twr + ((16 * tq + r) * KV16_TP + 16 * (td - tq)) * 4, acc[r]);
+                }
+            }
+            f32x4 acc_s[2], acc_dp[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                zero4(acc_s[t]);
+                zero4(acc_dp[t]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) acc_s[t] = MFMA16(lds_ld128(ln.rowf[t][ks] + KV16_OFF_QU + cur * 8192), fk[ks], acc_s[t]);    // S[query][key]
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) acc_dp[t] = MFMA16(lds_ld128(ln.rowf[t][ks] + KV16_OFF_DO + cur * 8192), fv[ks], acc_dp[t]);  // dP[query][key]
+            }
+            float pr[8], ds[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) pr[r] = lds_ldf(tsk[r]);
+            f32x4 lse4[2], del4[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                lse4[t] = *(lds_f32x4_ptr)(size_t)(sta[t] + cur * 256);
+                del4[t] = *(lds_f32x4_ptr)(size_t)(sta[t] + cur * 256 + 128);
+            }
+            bf16x8_t dot[8], qut[8];
+#pragma unroll
+            for (int db = 0; db < 8; db++) {
+                dot[db] = lds_tr_pair(ln.tr[0][db] + KV16_OFF_DO + cur * 8192, ln.tr[1][db] + KV16_OFF_DO + cur * 8192);
+                qut[db] = lds_tr_pair(ln.tr[0][db] + KV16_OFF_QU + cur * 8192, ln.tr[1][db] + KV16_OFF_QU + cur * 8192);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)  // this lane: key kw + a; register 4t + r: query i0q + kk(t, g) + r
+                    pr[t * 4 + r] = __builtin_amdgcn_exp2f(fmaf(pr[t * 4 + r] + acc_s[t][r], c2, -LOG2E * lse4[t][r]));
+            if (i0q < kw + 15 || i0q + 31 >= kw + p.shift) {  // diagonal / window-edge block pairs need the element mask
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = i0q + kk16(t, g) + r, j = kw + a;
+                        pr[t * 4 + r] = ((j <= i) && (j > i - p.shift)) ? pr[t * 4 + r] : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) ds[t * 4 + r] = pr[t * 4 + r] * (acc_dp[t][r] - del4[t][r]) * p.scale;
+            const bf16x8_t pb = pack8(pr), sb = pack8(ds);
+#pragma unroll
+            for (int db = 0; db < 8; db++) {
+                acc_dv[db] = MFMA16(dot[db], pb, acc_dv[db]);   // dV^T[d][key] += dO^T . P
+                acc_dk[db] = MFMA16(qut[db], sb, acc_dk[db]);   // dK^T[d][key] += Qu^T . dS
+            }
+        }
+        w16_vmcnt<0>();
+        __syncthreads();
+    };
+    for (int ib = ib_lo; ib <= ib_hi; ib += 2) {
+        block(std::integral_constant<int, 0>{}, ib);
+        if (ib + 1 <= ib_hi) block(std::integral_constant<int, 1>{}, ib + 1);
+    }
+    bf16_t* Ow = reinterpret_cast<bf16_t*>(smem + KV16_OFF_T + wave * W16_TW_BYTES);
+    store_acc_t16(acc_dk, 1.f, Ow, p.dk + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
+    store_acc_t16(acc_dv, 1.f, Ow, p.dv + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
+}
+
+// ======================================================================================= host side
+int db1_flash16_fwd_launch(const FlashArgs& a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)relattn_flash16_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W16_FWD_LDS); attr = true; }
+    relattn_flash16_fwd_kernel<<<dim3(flash_grid(a.L / FA_BQ, a.H, a.B)), 512, W16_FWD_LDS, st>>>(a);
+    DB1_CHECK_LAUNCH("relattn_flash16_fwd");
+    return DB1_OK;
+}
+int db1_flash16_bwd_q_launch(const FlashArgs& a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)relattn_flash16_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W16_BQ_LDS); attr = true; }
+    relattn_flash16_bwd_q_kernel<<<dim3(flash_grid(a.L / FA_BQ, a.H, a.B)), 512, W16_BQ_LDS, st>>>(a);
+    DB1_CHECK_LAUNCH("relattn_flash16_bwd_q");
+    return DB1_OK;
+}
+int db1_flash16_bwd_kv_launch(const FlashArgs& a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)relattn_flash16_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV16_LDS); attr = true; }
+    relattn_flash16_bwd_kv_kernel<<<dim3(flash_grid(a.L / FA_BQ, a.H, a.B)), 512, KV16_LDS, st>>>(a);
+    DB1_CHECK_LAUNCH("relattn_flash16_bwd_kv");
+    return DB1_OK;
+}
