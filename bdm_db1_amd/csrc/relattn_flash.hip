@@ -1,268 +1,738 @@
 // Relative-position flash attention for gfx950 (bf16, d_head = 128): Transformer-XL scores
 //     s[i,j] = ((q_i+u).k_j + (q_i+v).R[i-j]) / sqrt(d),   visible iff  i - shift < j <= i
-// (closed form of AC + _rel_shift(BD) + mask, transformer_xl.py:98-110,160-209,551-567) with online softmax
-// and P.V fused, never materialising an (L x L) tensor in HBM in the forward.
-//
-// Common machinery (all three kernels; v_mfma_f32_32x32x16_bf16, 4 waves x 32 rows per workgroup, 32-column blocks):
-//   * "swapped" products put the query (fwd, bwd_q) or the key (bwd_kv) on the LANE axis of the accumulator, so
-//     per-row softmax statistics are lane-local and P / dS feed the next MFMA as the B operand straight from registers;
-//   * the relative term T = Qv.Rband^T is computed for the 64 distances a 32x32 block can touch, written to a per-wave
-//     LDS scratch [32 q][64 dist] and read back SKEWED (element (a, a - b + 31)); write (lanes = consecutive distances)
-//     and read (lane stride 65 or -1 words) are both bank-conflict free;
-//   * transposed operands (V^T, K^T, dO^T, Qu^T) come from row-major LDS tiles through ds_read_b64_tr_b16;
-//   * tiles and a 256-row ring of R rows (the band of distances slides by 32 per block) are staged with global_load_lds
-//     (16 B/lane, lane-linear destination); 16-B chunks are XOR-swizzled on the SOURCE side with
-//     swz(row) = ((row & 3) << 2) | ((row >> 2) & 3), which makes BOTH the ds_read_b128 row fragments and the tr reads
-//     conflict-free on the same image.
-// Backward = delta pre-pass + two kernels without atomics (deterministic):
-//   bwd_q : per 128 queries, loop keys  -> dq_k = dS.K (the (q+u).k branch) and dT = dS re-indexed by distance (bf16, HBM);
+// (closed form of AC + _rel_shift(BD) + mask, transformer_xl.py:98-110,160-209,551-567) with online softmax and P.V fused, never
+// materialising an (L x L) tensor in HBM in the forward.  Inputs qu = q+u and qv = q+v_bias are materialised once per layer by
+// db1_relattn_add_head_bias.  Backward = delta pre-pass + two kernels without atomics (deterministic):
+//   bwd_q : per 128 queries, loop keys    -> dq_k = dS.K (the (q+u).k branch) and dT = dS re-indexed by distance (bf16, HBM);
 //   bwd_kv: per 128 keys,    loop queries -> dV = P^T.dO, dK = dS^T.Qu.
 // dq_r = dT.R and dR = dT^T.Qv are plain batched GEMMs on dT (exact causal FLOPs, no band overhead) run by the caller.
-// Inputs qu = q+u and qv = q+v_bias are materialised once per layer by db1_relattn_add_head_bias.
-#include "relattn_flash.h"
-#include <cstdlib>
-// transposed A-fragment from a row-major [row][128] tile: d-block db (32 columns), 16 tile rows starting at row0.
-// slot t of lane (d = lane & 31, hb) <-> tile row row0 + (t & 3) + 8 * (t >> 2) + 4 * hb == the C-layout row order.
-__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int row0, int db, int lane) {
-    const int g4 = lane >> 4, t = lane & 15, hb = g4 >> 1;
-    const int gran = ((32 * db + 16 * (g4 & 1)) >> 2) + (t & 3);  // 8-byte granule inside the 256-B row
-    bf16x8_t out;
-#pragma unroll
-    for (int h2 = 0; h2 < 2; h2++) {
-        const int row = row0 + 4 * hb + 8 * h2 + (t >> 2);
-        const int off = row * 256 + (((gran >> 1) ^ swz(row)) << 4) + (gran & 1) * 8;
-        bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4_t, const_cast<char*>(tile) + off));
-        out[h2 * 4 + 0] = v[0]; out[h2 * 4 + 1] = v[1]; out[h2 * 4 + 2] = v[2]; out[h2 * 4 + 3] = v[3];
-    }
-    return out;
+//
+// All three kernels: one workgroup = 128 rows of one (batch, head) = 8 waves x 16 rows (two waves per SIMD) on
+// v_mfma_f32_16x16x32_bf16, 32-column blocks, a 256-row LDS ring of R rows (the band of distances slides by 32 per block), operand
+// tiles staged with global_load_lds.  (The first version ran 4 waves x 32 rows on the 32x32x16 MFMA, one wave per SIMD with up to 352
+// VGPRs: every wave was bound by its own serial chain LDS read -> MFMA -> scratch -> softmax -> MFMA, matrix pipe 14-21 % busy.  With
+// two lighter waves per SIMD one wave's LDS / VALU phases overlap the other's MFMAs: bwd_q 2104 -> ~1050 us, bwd_kv 1589 -> ~1200 us,
+// fwd 968 -> 945 us at B = 64.)
+//
+// Fragment conventions (16x16x32): A[m][k]: lane (m = lane & 15, g = lane >> 4) holds k = 8g .. 8g+7; B[k][n]: lane (n, g) the same
+// k; C[m][n]: lane (n = lane & 15, g) holds rows m = 4g + r, r = 0..3.
+//   * "swapped" products put the query (fwd, bwd_q) or the key (bwd_kv) on the LANE axis of the accumulator: S^T = K.Qu^T per 16-row
+//     tile t (two per block); MFMA row 4g + r of tile t is block row   kk(t, g) + r,   kk(t, g) = 16 ((g & 1) ^ t) + 8 (g >> 1) + 4 t
+//     (a bijection onto 0..31).  The permutation makes the skewed scratch read conflict-free: lanes g and g ^ 1 of one 32-lane LDS
+//     group differ by 16 rows = 16 banks.  A lane's 8 scores (tile 0: r = 0..3, tile 1: r = 0..3) are exactly k-slots 8g .. 8g+7 of
+//     the B operand of O^T += V^T.P^T, and the V^T fragment takes the same rows through ds_read_b64_tr_b16 (rows kk(t, g) + 0..3):
+//     P / dS feed the next MFMA straight from registers, softmax statistics need two v_permlane swaps.
+//   * relative term (fwd, bwd_q): T = Qv.Rband^T for the 48 distances [iw - j0 - 32, iw - j0 + 16) of a 16 x 32 block (47 are needed;
+//     starting one lower keeps the ring slots of a tile 16-aligned), C[q][dist] written to a per-wave scratch [16 q][64 (+4)] and read
+//     back SKEWED at (q, q - key + 32).  Incremental: the band of block jb+1 is the band of block jb moved down by 32, so two new
+//     16-distance tiles are computed and the third is kept; logical column c lives at c ^ (32 * parity), parity = unrolled instance.
+//   * K / V tiles are prefetched TWO blocks ahead through three LDS stages (counted vmcnt): all query tiles of one (batch, head) walk the
+//     keys in step, so a tile's first touch is an HBM miss (~2 k cycles under load) that a one-block prefetch distance did not hide
+//     (a staging-only loop took 478 us of the 965 us forward at B = 64; 329 us with two blocks of distance).
+//   * LDS images are row-major with the 16-byte chunk XOR-swizzled on the source side of the LDS-DMA:
+//       K / V (Qu / dO) tiles:  f(row)  = (b4 << 3) | (b1 << 2) | (b0 << 1) | b2     (conflict-free for the permuted row fragments AND the tr reads)
+//       ring rows, Qv tiles:    fr(row) = (((row & 7) ^ ((row & 8) >> 1)) << 1) | ((row >> 3) & 1)      (natural-order row fragments)
+#include "db1_common.h"
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define LOG2E 1.4426950408889634f
+
+#define FA_D 128
+#define FA_BQ 128     // rows (queries, or keys in bwd_kv) per workgroup
+#define FA_BK 32      // columns per block
+#define FA_RING 256    // rows of the LDS ring of R
+
+struct FlashArgs {
+    const bf16_t* qu; const bf16_t* qv; const bf16_t* k; const bf16_t* v; const bf16_t* R;
+    const bf16_t* out; const bf16_t* dout; const float* lse; float* delta;
+    bf16_t* o; float* lse_out;
+    bf16_t* dq; bf16_t* dk; bf16_t* dv; bf16_t* dT;
+    int64_t kv_rs, kv_bs;     // row / batch strides (elements) of k and v (they live inside the packed qkv activations)
+    int64_t dq_rs, dq_bs;     // same for dq / dk / dv
+    int B, L, H, shift;
+    float scale;
+};
+
+// {lse[i0 .. i0+32), delta[i0 .. i0+32)} -> 64 floats in LDS, one 4-byte LDS-DMA per lane of ONE wave
+__device__ __forceinline__ void glds_stat(const float* lse, const float* delta, int i0, float* dst_lds, int lane) {
+    const float* src = (lane < 32 ? lse : delta - 32) + i0 + lane;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(float, dst_lds));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
-// fragment "tile row `row`, k = ks*16 + (lane>>5)*8 .. +8" (A or B operand image) from a swizzled row-major tile
-__device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row, int ks, int lane) {
-    return *reinterpret_cast<const bf16x8_t*>(tile + row * 256 + (((ks * 2 + (lane >> 5)) ^ swz(row)) << 4));
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+    f32x2_t v = {lo, hi};
+    bf16x2_hw r = __builtin_convertvector(v, bf16x2_hw);
+    return *reinterpret_cast<unsigned*>(&r);
 }
-__device__ __forceinline__ void zero16(f32x16& x) {
+__device__ __forceinline__ bf16x8_t pack8(const float* p) {
+    union { unsigned u[4]; bf16x8_t v; } o;
 #pragma unroll
-    for (int r = 0; r < 16; r++) x[r] = 0.f;
+    for (int t = 0; t < 4; t++) o.u[t] = pk_bf16(p[2 * t], p[2 * t + 1]);
+    return o.v;
 }
-// acc^T [4 d-blocks](rows = d, col = lane) -> bf16 rows [32][128] at dst (row stride rs), staged through the wave scratch
-__device__ __forceinline__ void store_acc_t(const f32x16* acc, float mul, bf16_t* Ow, bf16_t* dst, int64_t rs, int lane) {
-    const int a = lane & 31, hb = lane >> 5;
+
+// Workgroup id -> (tile rank, head, batch).  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin and a free
+// CU takes the next id, so the id order is the schedule:
+//   * all tiles of one (batch, head) are given ids of ONE XCD, so its K / V / Q rows are shared in that XCD's L2;
+//   * inside a chunk of 4 (batch, head) pairs per XCD (= 256 workgroups chip-wide at L = 1024) the ids go heaviest tile first
+//     (rank 0 = the tile with the longest loop), so the light tiles fill the tail instead of one 32-block tile ending alone.
+// returns false for the padding ids of a ragged last chunk
+__device__ __forceinline__ bool flash_wg_coords(int ntile, int H, int B, int& rank, int& h, int& b) {
+    const int i = blockIdx.x, xcd = i & 7, j = i >> 3;
+    const int per_chunk = 4 * ntile, chunk = j / per_chunk, jl = j % per_chunk;
+    rank = jl >> 2;
+    const int bh = (chunk * 4 + (jl & 3)) * 8 + xcd;
+    if (bh >= B * H) return false;
+    h = bh % H;
+    b = bh / H;
+    return true;
+}
+static unsigned flash_grid(int ntile, int H, int B) {
+    const int per_xcd = (B * H + 7) / 8, chunks = (per_xcd + 3) / 4;
+    return (unsigned)(8 * chunks * 4 * ntile);
+}
+
+
+#define W16_WAVES 8
+#define W16_STAGES 3
+#define W16_TP 68            // scratch row pitch (words): 64 columns + 4 -> the column-wise writes and the skewed reads are both conflict-free
+#define W16_TW_BYTES 4352    // per-wave scratch: T [16][68] f32 or the [16][136] bf16 output staging tile (both 4352 B)
+#define W16_DP 72            // bwd_q dS scratch row pitch (bytes): [16 q][32 keys, reversed] bf16 + 8
+#define W16_OFF_K 0          // three stages of 8 KiB
+#define W16_OFF_V (W16_STAGES * 8192)
+#define W16_OFF_R (2 * W16_STAGES * 8192)      // 256 ring rows of 256 B
+#define W16_OFF_T (W16_OFF_R + FA_RING * 256)
+#define W16_OFF_D (W16_OFF_T + W16_WAVES * W16_TW_BYTES)
+#define W16_FWD_LDS W16_OFF_D
+#define W16_BQ_LDS (W16_OFF_D + W16_WAVES * 16 * W16_DP)
+
+__device__ __forceinline__ int swz_kv(int row) { return (((row >> 4) & 1) << 3) | ((row & 3) << 1) | ((row >> 2) & 1); }
+__device__ __forceinline__ int swz_ring(int slot) { return ((((slot & 7) ^ ((slot & 8) >> 1))) << 1) | ((slot >> 3) & 1); }
+__device__ __forceinline__ int kk16(int t, int g) { return 16 * ((g & 1) ^ t) + 8 * (g >> 1) + 4 * t; }
+
+// LDS accesses go through absolute 32-bit LDS addresses kept in VGPRs (lane constants) plus immediate offsets: with pointer
+// arithmetic on the dynamic-LDS symbol hipcc emitted one `v_add_u32 v, 0, v` per access (a third of the loop's VALU work).
+typedef __attribute__((address_space(3))) const bf16x8_t* lds_b128_ptr;
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b64_ptr;
+typedef __attribute__((address_space(3))) float* lds_f32_ptr;
+typedef __attribute__((address_space(3))) unsigned* lds_u32_ptr;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((address_space(3))) u32x2_t* lds_u64_ptr;
+__device__ __forceinline__ bf16x8_t lds_ld128(unsigned addr) { return *(lds_b128_ptr)(size_t)addr; }
+__device__ __forceinline__ float lds_ldf(unsigned addr) { return *(lds_f32_ptr)(size_t)addr; }
+__device__ __forceinline__ void lds_stf(unsigned addr, float v) { *(lds_f32_ptr)(size_t)addr = v; }
+__device__ __forceinline__ bf16x8_t lds_tr_pair(unsigned a0, unsigned a1) {
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)(size_t)a0);
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)(size_t)a1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// one 1 KiB LDS-DMA piece = 4 rows of 256 B, lane -> (row = lane >> 4, destination chunk = lane & 15); src already points at the
+// lane's (swizzled) 16-byte source chunk, dst_lds is the wave-uniform LDS address of the piece.  Issued from inline asm on purpose:
+// with the builtin, hipcc knows an LDS write is pending on vmcnt and puts `s_waitcnt vmcnt(0)` in front of the first LDS access it
+// cannot disambiguate (tr reads, scratch writes), i.e. it drains the prefetch in the middle of the block.  The kernels wait for
+// their own prefetch explicitly (counted vmcnt + barrier at the end of every block).
+__device__ __forceinline__ void glds16(const void* src, unsigned dst_lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst_lds) : "memory");
+}
+__device__ __forceinline__ float vmax3(float x, float y, float z) {  // no NaN canonicalisation (fmaxf costs a v_max x,x per input)
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+}
+__device__ __forceinline__ float vmax2(float x, float y) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+    return d;
+}
+__device__ __forceinline__ float max_x16(float x) {  // max with lane ^ 16 (v_permlane16_swap: no LDS round trip)
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_x32(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_x16(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_x32(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void zero4(f32x4& x) { x[0] = 0.f; x[1] = 0.f; x[2] = 0.f; x[3] = 0.f; }
+
+// lane-constant absolute LDS addresses (tile addresses are those of a tile at LDS offset 0: add W16_OFF_x + stage * 8192 as immediates)
+struct W16Lane {
+    unsigned rowf[2][4];  // A-operand row fragment of 16-row tile t, k-step ks: MFMA row a <-> tile row kk(t, a >> 2) + (a & 3)
+    unsigned tr[2][8];    // ds_read_b64_tr_b16 of tile rows kk(t, g) + 0..3, d-tile db
+    unsigned ring[4];     // natural-order row fragment (row & 15 == a) of a ring-swizzled image at LDS offset 0: + offset + (row16 << 8)
+    unsigned tsk[2][8];   // scratch element (a, a - key + 32), key = kk(t, g) + r, for both parities
+    unsigned twr;         // scratch write base: rows 4g + r, column a  (+ (r * W16_TP + (16 tile ^ 32 parity)) * 4)
+};
+// keep every address in its own VGPR: left alone, hipcc re-associates them into (common part) + (lane part) and re-adds per access
+#define W16_OPAQUE(x) asm volatile("" : "+v"(x))
+__device__ __forceinline__ void w16_lane_init(W16Lane& o, unsigned lds0, unsigned tw0, int lane) {  // tw0: LDS address of the wave scratch
+    const int a = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int db = 0; db < 4; db++)
+    for (int t = 0; t < 2; t++) {
+        const int rho = kk16(t, a >> 2) + (a & 3);
 #pragma unroll
-        for (int rq = 0; rq < 4; rq++) {
-            uint2 o;
-            o.x = pk_bf16(acc[db][rq * 4 + 0] * mul, acc[db][rq * 4 + 1] * mul);
-            o.y = pk_bf16(acc[db][rq * 4 + 2] * mul, acc[db][rq * 4 + 3] * mul);
-            *reinterpret_cast<uint2*>(Ow + a * 136 + 32 * db + 8 * rq + 4 * hb) = o;
+        for (int ks = 0; ks < 4; ks++) { o.rowf[t][ks] = lds0 + rho * 256 + (((4 * ks + g) ^ swz_kv(rho)) << 4); W16_OPAQUE(o.rowf[t][ks]); }
+        const int row = kk16(t, g) + (a >> 2);
+#pragma unroll
+        for (int db = 0; db < 8; db++) {
+            o.tr[t][db] = lds0 + row * 256 + (((2 * db + ((a & 3) >> 1)) ^ swz_kv(row)) << 4) + (a & 1) * 8;
+            W16_OPAQUE(o.tr[t][db]);
         }
+    }
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
+    for (int ks = 0; ks < 4; ks++) { o.ring[ks] = lds0 + (a << 8) + (((4 * ks + g) ^ swz_ring(a)) << 4); W16_OPAQUE(o.ring[ks]); }
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int c = a - kk16(t, g) - r + 32;
+            o.tsk[0][t * 4 + r] = tw0 + (a * W16_TP + c) * 4;
+            o.tsk[1][t * 4 + r] = tw0 + (a * W16_TP + (c ^ 32)) * 4;
+            W16_OPAQUE(o.tsk[0][t * 4 + r]);
+            W16_OPAQUE(o.tsk[1][t * 4 + r]);
+        }
+    o.twr = tw0 + ((4 * g) * W16_TP + a) * 4;
+    W16_OPAQUE(o.twr);
+}
+// staging state of one wave: every wave moves one 1 KiB piece (4 rows) of the K tile, of the V tile and of the 32 new ring rows per block
+struct W16Stage {
+    const bf16_t* kptr; const bf16_t* vptr;  // this lane's source chunk of the NEXT tile to stage (tiles are staged in key order)
+    const bf16_t* rbase;                     // R + head + this lane's ring source chunk
+    int64_t kv_step, r_rs;
+    int srow, L;
+    unsigned lds0;
+};
+__device__ __forceinline__ void w16_stage_init(W16Stage& s, const bf16_t* kg, const bf16_t* vg, const bf16_t* Rg, int64_t kv_rs, int64_t r_rs, int row0,
+                                               int L, unsigned lds0, int wave, int lane) {
+    s.srow = wave * 4 + (lane >> 4);
+    const int schunk = ((lane & 15) ^ swz_kv(s.srow)) << 3;
+    s.kptr = kg + (int64_t)(row0 + s.srow) * kv_rs + schunk;
+    s.vptr = vg + (int64_t)(row0 + s.srow) * kv_rs + schunk;
+    s.rbase = Rg + (((lane & 15) ^ swz_ring(s.srow & 15)) << 3);  // slot & 15 == srow & 15: distances are staged in multiples of 16
+    s.kv_step = (int64_t)FA_BK * kv_rs;
+    s.r_rs = r_rs;
+    s.L = L;
+    s.lds0 = lds0;
+}
+__device__ __forceinline__ void w16_stage_k(W16Stage& s, int stage, int wave) {
+    glds16(s.kptr, s.lds0 + W16_OFF_K + stage * 8192 + wave * 1024);
+    s.kptr += s.kv_step;
+}
+__device__ __forceinline__ void w16_stage_v(W16Stage& s, int stage, int wave) {
+    glds16(s.vptr, s.lds0 + W16_OFF_V + stage * 8192 + wave * 1024);
+    s.vptr += s.kv_step;
+}
+__device__ __forceinline__ void w16_stage_kv(W16Stage& s, int stage, int wave) {
+    w16_stage_k(s, stage, wave);
+    w16_stage_v(s, stage, wave);
+}
+template <int N> __device__ __forceinline__ void w16_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void w16_stage_ring(const W16Stage& s, int dist0, int wave) {  // distances dist0 .. dist0+31 (dist0 a multiple of 16)
+    const int slot0 = (dist0 + wave * 4) & (FA_RING - 1);
+    const int dist = dist0 + s.srow;
+    const int gr = dist < 0 ? 0 : (dist > s.L - 1 ? s.L - 1 : dist);  // out-of-range distances belong to masked pairs
+    glds16(s.rbase + (int64_t)gr * s.r_rs, s.lds0 + W16_OFF_R + slot0 * 256);
+}
+// relative-term tile: distances dist16 .. dist16+15 (dist16 a multiple of 16) for the wave's 16 queries -> scratch columns col .. col+15
+__device__ __forceinline__ void w16_rel_tile(const bf16x8_t* fqv, const W16Lane& o, int dist16, int col) {
+    const unsigned rs = (unsigned)(dist16 & (FA_RING - 1)) << 8;  // wave-uniform
+    f32x4 acc;
+    zero4(acc);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) acc = MFMA16(fqv[ks], lds_ld128(o.ring[ks] + rs + W16_OFF_R), acc);
+#pragma unroll
+    for (int r = 0; r < 4; r++) lds_stf(o.twr + (r * W16_TP + col) * 4, acc[r]);
+}
+// acc^T [8 d-tiles](rows = d, col = lane & 15) -> bf16 rows [16][128] at dst (row stride rs), staged through the wave scratch
+__device__ __forceinline__ void store_acc_t16(const f32x4* acc, float mul, bf16_t* Ow, bf16_t* dst, int64_t rs, int lane) {
+    const int a = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int db = 0; db < 8; db++) {
+        uint2 o;
+        o.x = pk_bf16(acc[db][0] * mul, acc[db][1] * mul);
+        o.y = pk_bf16(acc[db][2] * mul, acc[db][3] * mul);
+        *reinterpret_cast<uint2*>(Ow + a * 136 + 16 * db + 4 * g) = o;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
         const int row = it * 4 + (lane >> 4), ch = lane & 15;
         const uint4 v = *reinterpret_cast<const uint4*>(Ow + row * 136 + ch * 8);
         *reinterpret_cast<uint4*>(dst + (int64_t)row * rs + ch * 8) = v;
     }
 }
-// lane-constant LDS byte offsets (computed once per kernel: the loops then issue LDS reads with almost no address VALU)
-struct LaneOffs {
-    int row[8];    // row_frag of tile row (lane & 31):   a*256 + (((ks*2 + hb) ^ swz(a)) << 4)
-    int ring[8];   // chunk part of a ring row_frag:      ((ks*2 + hb) ^ swz((a + 1) & 15)) << 4   (slot & 15 never changes)
-    int tr[4][2];  // tr_frag(tile, row0 = 0, db) halves: add 4096 for row0 = 16
-};
-__device__ __forceinline__ void make_offs(LaneOffs& o, int lane) {
-    const int a = lane & 31, hb = lane >> 5;
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-        o.row[ks] = a * 256 + (((ks * 2 + hb) ^ swz(a)) << 4);
-        o.ring[ks] = ((ks * 2 + hb) ^ swz((a + 1) & 15)) << 4;
+#define W16_BLOCK_LOOP(block)                                                                                       \
+    for (int jb = jb_lo; jb <= jb_hi; jb += 6) {                                                                    \
+        block(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, jb);                              \
+        if (jb + 1 <= jb_hi) block(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, jb + 1);     \
+        if (jb + 2 <= jb_hi) block(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, jb + 2);     \
+        if (jb + 3 <= jb_hi) block(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, jb + 3);     \
+        if (jb + 4 <= jb_hi) block(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, jb + 4);     \
+        if (jb + 5 <= jb_hi) block(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, jb + 5);     \
     }
-    const int g4 = lane >> 4, t = lane & 15, hb4 = g4 >> 1;
-#pragma unroll
-    for (int db = 0; db < 4; db++)
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++) {
-            const int gran = ((32 * db + 16 * (g4 & 1)) >> 2) + (t & 3);
-            const int row = 4 * hb4 + 8 * h2 + (t >> 2);
-            o.tr[db][h2] = row * 256 + (((gran >> 1) ^ swz(row)) << 4) + (gran & 1) * 8;
-        }
-}
-__device__ __forceinline__ bf16x8_t rowf(const char* tile, const LaneOffs& o, int ks) { return *reinterpret_cast<const bf16x8_t*>(tile + o.row[ks]); }
-__device__ __forceinline__ bf16x8_t trf(const char* tile, const LaneOffs& o, int row0, int db) {
-    bf16x8_t out;
-#pragma unroll
-    for (int h2 = 0; h2 < 2; h2++) {
-        bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4_t, const_cast<char*>(tile) + o.tr[db][h2] + row0 * 256));
-        out[h2 * 4 + 0] = v[0]; out[h2 * 4 + 1] = v[1]; out[h2 * 4 + 2] = v[2]; out[h2 * 4 + 3] = v[3];
-    }
-    return out;
-}
-// T = Arows . Rband^T for the 64 distances starting at dist_lo (dist_lo + a == 1 mod 16 by construction), into Tw[32][64]
-template <bool A_REGS>
-__device__ __forceinline__ void rel_band_to_lds(const bf16x8_t* fa_regs, const char* a_tile, const LaneOffs& o, const char* ring, int dist_lo,
-                                                float* Tw, int lane) {
-    const int a = lane & 31, hb = lane >> 5;
-    const int rr0 = ((dist_lo + a) & (FA_RING - 1)) << 8;
-    float* tw = Tw + hb * 256 + a;
-#pragma unroll
-    for (int blk = 0; blk < 2; blk++) {
-        f32x16 acc_t;
-        zero16(acc_t);
-        const char* rrow = ring + ((rr0 + blk * 8192) & (FA_RING * 256 - 1));
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++)
-            acc_t = MFMA32(A_REGS ? fa_regs[ks] : rowf(a_tile, o, ks), *reinterpret_cast<const bf16x8_t*>(rrow + o.ring[ks]), acc_t);
-#pragma unroll
-        for (int r = 0; r < 16; r++) tw[((r & 3) + 8 * (r >> 2)) * 64 + 32 * blk] = acc_t[r];
-    }
-}
-// Incremental form for the forward, whose waves keep their 32 queries and walk the key blocks upwards (in bwd_kv the queries
-// change every block, so nothing carries over; bwd_q reuses the scratch for the dS re-indexing): the band of block jb+1 is the band of block jb moved down
-// by 32 distances, so its upper half is the lower half just computed.  The scratch is used as a 2-slot ring with an XOR parity:
-// logical column c (0..63, distance dist_lo + c) lives at physical column c ^ (32 * PAR); consecutive processed blocks alternate
-// PAR (= the unrolled block instance), so the previous block's lower half IS this block's upper half without moving anything.
-// Only the new lower 32 distances are computed (8 MFMAs instead of 16, half the scratch writes and ring reads) unless the wave
-// did not process the previous block (`both`).
-template <int PAR>
-__device__ __forceinline__ void rel_band_incr_to_lds(const bf16x8_t* fa_regs, const LaneOffs& o, const char* ring, int dist_lo, float* Tw, int lane,
-                                                     bool both) {
-    const int a = lane & 31, hb = lane >> 5;
-    const int rr0 = ((dist_lo + a) & (FA_RING - 1)) << 8;
-    float* tw = Tw + hb * 256 + a;
-#pragma unroll
-    for (int blk = 0; blk < 2; blk++) {  // blk 0 = the new lower 32 distances; blk 1 only for a wave's first processed block
-        if (blk == 1 && !both) break;
-        f32x16 acc_t;
-        zero16(acc_t);
-        const char* rrow = ring + ((rr0 + blk * 8192) & (FA_RING * 256 - 1));
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc_t = MFMA32(fa_regs[ks], *reinterpret_cast<const bf16x8_t*>(rrow + o.ring[ks]), acc_t);
-        const int phys = 32 * (blk ^ PAR);  // logical half blk lives in physical half blk ^ PAR
-#pragma unroll
-        for (int r = 0; r < 16; r++) tw[((r & 3) + 8 * (r >> 2)) * 64 + phys] = acc_t[r];
-    }
-}
 
 // ======================================================================================= forward
-#define FWD_OFF_K 0          // two stages of 8 KiB
-#define FWD_OFF_V 16384      // two stages of 8 KiB
-#define FWD_OFF_R 32768
-#define FWD_OFF_T (32768 + FA_RING * 256)
-#define FWD_LDS_BYTES (FWD_OFF_T + 4 * FA_TW_BYTES)
-#define BQ_WAVE_BYTES 16384                 // bwd_q: two [32][64] f32 scratches per wave (also holds the [32][136] bf16 output tile)
-#define BQ_LDS_BYTES (FWD_OFF_T + 4 * BQ_WAVE_BYTES)   // = 160 KiB, all of the LDS
-
-__global__ __launch_bounds__(256, 1) void relattn_flash_fwd_kernel(FlashArgs p) {
+__global__ __launch_bounds__(512, 1) void relattn_flash_fwd_kernel(FlashArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rank, h, b;
     if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, rank, h, b)) return;
     const int qt = p.L / FA_BQ - 1 - rank;  // late query tiles have the longest key loops
     const int H = p.H, L = p.L, HD = H * FA_D;
-    const int i0 = qt * FA_BQ, iw = i0 + 32 * wave;
-    const int a = lane & 31, hb = lane >> 5;
-    char* Ks0 = smem + FWD_OFF_K;
-    char* Vs0 = smem + FWD_OFF_V;
-    char* Rr = smem + FWD_OFF_R;
-    float* Tw = reinterpret_cast<float*>(smem + FWD_OFF_T + wave * FA_TW_BYTES);
-    const float* twr = Tw + a * 65 + 31 - 4 * hb;  // skewed read base: element (a, a - crow(r,hb) + 31)
+    const int i0 = qt * FA_BQ, iw = i0 + 16 * wave;
+    const int a = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
     const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
     const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
-    const bf16_t* kg = p.k + (int64_t)b * p.kv_bs + h * FA_D;
-    const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * FA_D;
-    const bf16_t* Rg = p.R + h * FA_D;
-    LaneOffs offs;
-    make_offs(offs, lane);
+    W16Lane ln;
+    w16_lane_init(ln, lds0, lds0 + W16_OFF_T + wave * W16_TW_BYTES, lane);
 
-    bf16x8_t fqu[8], fqv[8];  // row iw + a, k = ks*16 + hb*8 (A and B operand images coincide)
+    bf16x8_t fqu[4], fqv[4];  // row iw + a, k = 32 ks + 8 g .. +7 (A and B operand images coincide)
 #pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-        fqu[ks] = *reinterpret_cast<const bf16x8_t*>(qu + (int64_t)(iw + a) * HD + ks * 16 + hb * 8);
-        fqv[ks] = *reinterpret_cast<const bf16x8_t*>(qv + (int64_t)(iw + a) * HD + ks * 16 + hb * 8);
+    for (int ks = 0; ks < 4; ks++) {
+        fqu[ks] = *reinterpret_cast<const bf16x8_t*>(qu + (int64_t)(iw + a) * HD + ks * 32 + g * 8);
+        fqv[ks] = *reinterpret_cast<const bf16x8_t*>(qv + (int64_t)(iw + a) * HD + ks * 32 + g * 8);
     }
     int jlo = i0 - p.shift + 1;
     if (jlo < 0) jlo = 0;
     const int jb_lo = jlo / FA_BK, jb_hi = (i0 + FA_BQ - 1) / FA_BK;
-    // prologue: ring rows for distances [i0-j0lo-32, i0-j0lo+128) and the first K/V tiles
-    for (int c4 = -1; c4 < 4; c4++) stage_ring32(Rg, HD, i0 - jb_lo * FA_BK + 32 * c4, L, Rr, wave, lane);
-    stage_tile32(kg, p.kv_rs, jb_lo * FA_BK, Ks0, wave, lane);
-    stage_tile32(vg, p.kv_rs, jb_lo * FA_BK, Vs0, wave, lane);
-    f32x16 acc_o[4];
+    W16Stage sg;
+    w16_stage_init(sg, p.k + (int64_t)b * p.kv_bs + h * FA_D, p.v + (int64_t)b * p.kv_bs + h * FA_D, p.R + h * FA_D, p.kv_rs, HD, jb_lo * FA_BK, L,
+                   lds0, wave, lane);
+    // prologue: ring rows for distances [i0-j0-64, i0-j0+128) (blocks jb_lo and jb_lo+1) and the first two K/V tiles
+    for (int c4 = -2; c4 < 4; c4++) w16_stage_ring(sg, i0 - jb_lo * FA_BK + 32 * c4, wave);
+    w16_stage_kv(sg, 0, wave);
+    if (jb_lo + 1 <= jb_hi) w16_stage_kv(sg, 1, wave);
+    f32x4 acc_o[8];
 #pragma unroll
-    for (int db = 0; db < 4; db++) zero16(acc_o[db]);
+    for (int db = 0; db < 8; db++) zero4(acc_o[db]);
     const float c2 = p.scale * LOG2E;
-    float m_i = -1.0e30f, l_i = 0.f;  // m_i in RAW score units (before the 1/sqrt(d) scale)
+    float m_i = -1.0e30f, l_i = 0.f;  // m_i in RAW score units; l_i is this lane's PARTIAL row sum (reduced over g at the end)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as a builtin so that hipcc's own bookkeeping sees the fragment loads retired
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int toff1[16];  // odd-parity read offsets: a * 64 + ((a - crow(r, hb) + 31) ^ 32)
-#pragma unroll
-    for (int r = 0; r < 16; r++) toff1[r] = a * 64 + ((a - crow(r, hb) + 31) ^ 32);
     bool have_prev = false;  // did this wave process the previous key block?  (wave-uniform)
-    auto block = [&](auto CUR, int jb) {
-        constexpr int cur = decltype(CUR)::value;
+    auto block = [&](auto STG, auto PARC, int jb) __attribute__((always_inline)) {
+        constexpr int stg = decltype(STG)::value, par = decltype(PARC)::value;
         const int j0 = jb * FA_BK;
-        const char* Ks = Ks0 + cur * 8192;
-        const char* Vs = Vs0 + cur * 8192;
-        if (jb < jb_hi) {  // prefetch the next block's tiles and ring rows; they land while this block is computed
-            stage_tile32(kg, p.kv_rs, j0 + FA_BK, Ks0 + (cur ^ 1) * 8192, wave, lane);
-            stage_tile32(vg, p.kv_rs, j0 + FA_BK, Vs0 + (cur ^ 1) * 8192, wave, lane);
-            stage_ring32(Rg, HD, i0 - j0 - 64, L, Rr, wave, lane);
+        const bool pf = jb + 2 <= jb_hi;
+        if (pf) {  // prefetch block jb+2: its tiles and the 32 ring rows it adds land while this block and the next are computed
+            w16_stage_kv(sg, (stg + 2) % W16_STAGES, wave);
+            w16_stage_ring(sg, i0 - j0 - 96, wave);
         }
-        if (j0 > iw + 31 || j0 + 31 <= iw - p.shift) have_prev = false;
+        if (j0 > iw + 15 || j0 + 31 <= iw - p.shift) have_prev = false;
         else {  // wave-uniform: blocks entirely outside this wave's window are skipped
-            f32x16 acc_s;
-            zero16(acc_s);
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(rowf(Ks, offs, ks), fqu[ks], acc_s);  // S^T[key][query]
-            rel_band_incr_to_lds<cur>(fqv, offs, Rr, iw - j0 - 31, Tw, lane, !have_prev);
+            // relative term: logical tile t = distances dist_lo + 16 t .. -> scratch columns (16 t ..) ^ (32 par); tile 2 is the one
+            // kept from the previous block (computed only for a wave's first processed block)
+            const int dist_lo = iw - j0 - 32;
+            w16_rel_tile(fqv, ln, dist_lo, 0 ^ (32 * par));
+            w16_rel_tile(fqv, ln, dist_lo + 16, 16 ^ (32 * par));
+            if (!have_prev) w16_rel_tile(fqv, ln, dist_lo + 32, 32 ^ (32 * par));
             have_prev = true;
-            float s[16];  // this lane: query iw+a; register r: key j0+crow(r,hb); T element (a, (a - crow + 31) ^ (32 * cur))
+            f32x4 acc_s[2];
 #pragma unroll
-            for (int r = 0; r < 16; r++) s[r] = acc_s[r] + (cur == 0 ? twr[-((r & 3) + 8 * (r >> 2))] : Tw[toff1[r]]);
-            if (j0 + 31 > iw || j0 <= iw + 31 - p.shift) {  // only diagonal / window-edge blocks need the element mask
+            for (int t = 0; t < 2; t++) {
+                zero4(acc_s[t]);
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int i = iw + a, j = j0 + crow(r, hb);
-                    s[r] = ((j <= i) && (j > i - p.shift)) ? s[r] : -1.0e30f;
-                }
+                for (int ks = 0; ks < 4; ks++) acc_s[t] = MFMA16(lds_ld128(ln.rowf[t][ks] + W16_OFF_K + stg * 8192), fqu[ks], acc_s[t]);  // S^T[key][query]
             }
-            float mblk = s[0];
+            // skewed read of the relative term, then the V^T fragments of the P.V product (in flight during the softmax)
+            float s[8];  // this lane: query iw + a; s[4 t + r]: key j0 + kk(t, g) + r
 #pragma unroll
-            for (int r = 1; r < 16; r++) mblk = fmaxf(mblk, s[r]);
-            mblk = fmaxf(mblk, __shfl_xor(mblk, 32, 64));
-            const float m_new = fmaxf(m_i, mblk);
+            for (int r = 0; r < 8; r++) s[r] = lds_ldf(ln.tsk[par][r]);
+            bf16x8_t vt[8];
+#pragma unroll
+            for (int db = 0; db < 8; db++) vt[db] = lds_tr_pair(ln.tr[0][db] + W16_OFF_V + stg * 8192, ln.tr[1][db] + W16_OFF_V + stg * 8192);
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) s[t * 4 + r] += acc_s[t][r];
+            if (j0 + 31 > iw || j0 <= iw + 15 - p.shift) {  // only diagonal / window-edge blocks need the element mask
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = iw + a, j = j0 + kk16(t, g) + r;
+                        s[t * 4 + r] = ((j <= i) && (j > i - p.shift)) ? s[t * 4 + r] : -1.0e30f;
+                    }
+            }
+            float mblk = vmax3(vmax3(s[0], s[1], s[2]), vmax3(s[3], s[4], s[5]), vmax2(s[6], s[7]));
+            mblk = max_x32(max_x16(mblk));
+            const float m_new = vmax2(m_i, mblk);
             if (!__all(m_new == m_i)) {  // the running maxima rarely move after the first blocks: skip the O-wide rescale then
                 const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c2);
                 l_i *= alpha;
 #pragma unroll
-                for (int db = 0; db < 4; db++)
+                for (int db = 0; db < 8; db++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc_o[db][r] *= alpha;
+                    for (int r = 0; r < 4; r++) acc_o[db][r] *= alpha;
                 m_i = m_new;
             }
             const float mc = -m_i * c2;
-            float rs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; r++) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, mc)); rs += s[r]; }
-            rs += __shfl_xor(rs, 32, 64);
-            l_i += rs;
-            const bf16x8_t pb0 = pack8(s), pb1 = pack8(s + 8);
+            for (int r = 0; r < 8; r++) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, mc)); l_i += s[r]; }
+            const bf16x8_t pb = pack8(s);
 #pragma unroll
-            for (int db = 0; db < 4; db++) {  // O^T[d][query] += V^T . P^T
-                acc_o[db] = MFMA32(trf(Vs, offs, 0, db), pb0, acc_o[db]);
-                acc_o[db] = MFMA32(trf(Vs, offs, 16, db), pb1, acc_o[db]);
+            for (int db = 0; db < 8; db++) acc_o[db] = MFMA16(vt[db], pb, acc_o[db]);  // O^T[d][query] += V^T . P^T
+        }
+        // block jb+1 must have landed: all but the three pieces issued at the top of this block
+        if (pf) w16_vmcnt<3>(); else w16_vmcnt<0>();
+        __syncthreads();  // every wave is done reading stage stg (refilled by the next block's prefetch)
+    };
+    W16_BLOCK_LOOP(block)
+    l_i = sum_x32(sum_x16(l_i));
+    bf16_t* Ow = reinterpret_cast<bf16_t*>(smem + W16_OFF_T + wave * W16_TW_BYTES);
+    store_acc_t16(acc_o, 1.f / l_i, Ow, p.o + ((int64_t)b * L + iw) * HD + h * FA_D, HD, lane);
+    if (g == 0) p.lse_out[((int64_t)b * H + h) * L + iw + a] = m_i * p.scale + logf(l_i);
+}
+
+// ======================================================================================= backward w.r.t. queries (+ dT)
+// per wave-block (16 queries x 32 keys): S^T = K.Qu^T, dP^T = V.dO^T, the relative-term band (incremental), dS^T -> dq^T += K^T.dS^T, and
+// dT[i][i - j] = dS[i][j]: in row i the 32 keys of a block are 32 CONSECUTIVE distances in reverse key order, so the lane's packed
+// bf16 pairs go to a small [16 q][32] scratch (two ds_write_b64) and leave as 64 contiguous bytes per row.
+typedef unsigned __attribute__((aligned(2))) u32_a2_t;
+__global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q_kernel(FlashArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rank, h, b;
+    if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, rank, h, b)) return;
+    const int qt = p.L / FA_BQ - 1 - rank;
+    const int H = p.H, L = p.L, HD = H * FA_D;
+    const int i0 = qt * FA_BQ, iw = i0 + 16 * wave;
+    const int a = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+    const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* dog = p.dout + ((int64_t)b * L) * HD + h * FA_D;
+    W16Lane ln;
+    w16_lane_init(ln, lds0, lds0 + W16_OFF_T + wave * W16_TW_BYTES, lane);
+    // dS scratch: lane (query a, g) writes keys kk(t, g) + 0..3 as element 31 - key: dwords 14 - kk/2, 15 - kk/2 of row a
+    const unsigned dw0 = lds0 + W16_OFF_D + wave * 16 * W16_DP;
+    unsigned dsw[2], dsr;
+#pragma unroll
+    for (int t = 0; t < 2; t++) { dsw[t] = dw0 + a * W16_DP + (14 - kk16(t, g) / 2) * 4; W16_OPAQUE(dsw[t]); }
+    dsr = dw0 + (lane >> 4) * W16_DP + (lane & 15) * 4;  // + it * 4 rows
+    W16_OPAQUE(dsr);
+
+    bf16x8_t fqu[4], fqv[4], fdo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        fqu[ks] = *reinterpret_cast<const bf16x8_t*>(qu + (int64_t)(iw + a) * HD + ks * 32 + g * 8);
+        fqv[ks] = *reinterpret_cast<const bf16x8_t*>(qv + (int64_t)(iw + a) * HD + ks * 32 + g * 8);
+        fdo[ks] = *reinterpret_cast<const bf16x8_t*>(dog + (int64_t)(iw + a) * HD + ks * 32 + g * 8);
+    }
+    const float c2 = p.scale * LOG2E;
+    const float nlse2 = -p.lse[((int64_t)b * H + h) * L + iw + a] * LOG2E;
+    const float delta_a = p.delta[((int64_t)b * H + h) * L + iw + a];
+    // dT row (iw + row) starts at distance (iw + row) - j0 - 31 for a block: row = 4 it + (lane >> 4), this lane's pair = elements 2 col, 2 col + 1
+    bf16_t* dtp = p.dT + (((int64_t)h * p.B + b) * L + iw + (lane >> 4)) * L + (iw + (lane >> 4) - 31 + 2 * (lane & 15));
+    const int drow0 = iw + (lane >> 4) - 31 + 2 * (lane & 15);  // distance of the pair's first element for j0 = 0, it = 0
+    int jlo = i0 - p.shift + 1;
+    if (jlo < 0) jlo = 0;
+    const int jb_lo = jlo / FA_BK, jb_hi = (i0 + FA_BQ - 1) / FA_BK;
+    W16Stage sg;
+    w16_stage_init(sg, p.k + (int64_t)b * p.kv_bs + h * FA_D, p.v + (int64_t)b * p.kv_bs + h * FA_D, p.R + h * FA_D, p.kv_rs, HD, jb_lo * FA_BK, L,
+                   lds0, wave, lane);
+    for (int c4 = -2; c4 < 4; c4++) w16_stage_ring(sg, i0 - jb_lo * FA_BK + 32 * c4, wave);
+    w16_stage_kv(sg, 0, wave);
+    if (jb_lo + 1 <= jb_hi) w16_stage_kv(sg, 1, wave);
+    f32x4 acc_dq[8];
+#pragma unroll
+    for (int db = 0; db < 8; db++) zero4(acc_dq[db]);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    bool have_prev = false;
+    auto block = [&](auto STG, auto PARC, int jb) __attribute__((always_inline)) {
+        constexpr int stg = decltype(STG)::value, par = decltype(PARC)::value;
+        const int j0 = jb * FA_BK;
+        const bool pf = jb + 2 <= jb_hi;
+        if (pf) {
+            w16_stage_kv(sg, (stg + 2) % W16_STAGES, wave);
+            w16_stage_ring(sg, i0 - j0 - 96, wave);
+        }
+        if (j0 > iw + 15 || j0 + 31 <= iw - p.shift) have_prev = false;
+        else {
+            const int dist_lo = iw - j0 - 32;
+            w16_rel_tile(fqv, ln, dist_lo, 0 ^ (32 * par));
+            w16_rel_tile(fqv, ln, dist_lo + 16, 16 ^ (32 * par));
+            if (!have_prev) w16_rel_tile(fqv, ln, dist_lo + 32, 32 ^ (32 * par));
+            have_prev = true;
+            f32x4 acc_s[2], acc_dp[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                zero4(acc_s[t]);
+                zero4(acc_dp[t]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) acc_s[t] = MFMA16(lds_ld128(ln.rowf[t][ks] + W16_OFF_K + stg * 8192), fqu[ks], acc_s[t]);   // S^T[key][query]
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) acc_dp[t] = MFMA16(lds_ld128(ln.rowf[t][ks] + W16_OFF_V + stg * 8192), fdo[ks], acc_dp[t]);  // dP^T[key][query]
+            }
+            float ds[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) ds[r] = lds_ldf(ln.tsk[par][r]);
+            bf16x8_t kt[8];
+#pragma unroll
+            for (int db = 0; db < 8; db++) kt[db] = lds_tr_pair(ln.tr[0][db] + W16_OFF_K + stg * 8192, ln.tr[1][db] + W16_OFF_K + stg * 8192);
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) ds[t * 4 + r] = __builtin_amdgcn_exp2f(fmaf(ds[t * 4 + r] + acc_s[t][r], c2, nlse2));
+            const bool edge = j0 + 31 > iw || j0 <= iw + 15 - p.shift;
+            if (edge) {
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = iw + a, j = j0 + kk16(t, g) + r;
+                        ds[t * 4 + r] = ((j <= i) && (j > i - p.shift)) ? ds[t * 4 + r] : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) ds[t * 4 + r] = ds[t * 4 + r] * (acc_dp[t][r] - delta_a) * p.scale;
+            const bf16x8_t db8 = pack8(ds);
+#pragma unroll
+            for (int db = 0; db < 8; db++) acc_dq[db] = MFMA16(kt[db], db8, acc_dq[db]);  // dq^T[d][query] += K^T . dS^T
+            // dT: element 31 - key of row a; the pairs are (key+1, key) in memory order
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                u32x2_t w;
+                w[0] = pk_bf16(ds[t * 4 + 3], ds[t * 4 + 2]);
+                w[1] = pk_bf16(ds[t * 4 + 1], ds[t * 4 + 0]);
+                *(lds_u64_ptr)(size_t)dsw[t] = w;
+            }
+            bf16_t* drow = dtp - j0;
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const unsigned v = *(lds_u32_ptr)(size_t)(dsr + it * 4 * W16_DP);
+                bf16_t* dst = drow + (int64_t)(4 * it) * (L + 1);
+                if (!edge) *reinterpret_cast<u32_a2_t*>(dst) = v;
+                else {
+                    const int d = drow0 - j0 + 4 * it;  // distance of the pair's first element (negative: above the diagonal, never stored)
+                    if (d >= 0) *reinterpret_cast<u32_a2_t*>(dst) = v;
+                    else if (d == -1) dst[1] = (bf16_t)(v >> 16);
+                }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // next tiles have landed; every wave is done reading the current ones
+        if (pf) w16_vmcnt<3>(); else w16_vmcnt<0>();
+        __syncthreads();
     };
-    for (int jb = jb_lo; jb <= jb_hi; jb += 2) {
-        block(std::integral_constant<int, 0>{}, jb);
-        if (jb + 1 <= jb_hi) block(std::integral_constant<int, 1>{}, jb + 1);
+    W16_BLOCK_LOOP(block)
+    bf16_t* Ow = reinterpret_cast<bf16_t*>(smem + W16_OFF_T + wave * W16_TW_BYTES);
+    store_acc_t16(acc_dq, 1.f, Ow, p.dq + (int64_t)b * p.dq_bs + (int64_t)iw * p.dq_rs + h * FA_D, p.dq_rs, lane);
+}
+
+// ======================================================================================= backward w.r.t. keys / values
+// One workgroup = 128 keys of one (batch, head), wave = 16 keys (K / V fragments in registers), loop over 32-query blocks whose Qu, Qv,
+// dO tiles and {lse, delta} come through two LDS stages.  Per wave-block (32 queries x 16 keys):
+//   S[q][key] = Qu.K^T and dP = dO.V^T (8 + 8 MFMA; MFMA row 4g + r of tile t is query kk(t, g) + r, like the keys of the other kernels);
+//   the relative term for the 47 distances of the block: T tiles (q-tile tq, 16-distance tile td) are only needed for td - tq in {0, 1}
+//   (16 MFMA, Qv rows in natural order against ring rows), written to a scratch [32 q][32] (row q holds distances dist_lo + 16 (q >> 4) ..)
+//   and read back at (q, q - key + 16); P and dS feed dV^T += dO^T.P and dK^T += Qu^T.dS as B operands straight from registers.
+#define KV16_OFF_QU 0                          // two stages of 8 KiB each for Qu, Qv, dO
+#define KV16_OFF_QV 16384
+#define KV16_OFF_DO 32768
+#define KV16_OFF_ST 49152                      // two stages of {lse[32], delta[32]} floats (raw, via LDS-DMA)
+#define KV16_OFF_R 49664
+#define KV16_OFF_T (KV16_OFF_R + FA_RING * 256)
+#define KV16_LDS (KV16_OFF_T + W16_WAVES * W16_TW_BYTES)
+#define KV16_TP 33                             // scratch row pitch (words): odd, so that queries 16 apart (lanes g, g ^ 1) land 16 banks apart
+typedef __attribute__((address_space(3))) const f32x4* lds_f32x4_ptr;
+
+__global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv_kernel(FlashArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int kt, h, b;  // early key tiles see the most queries: rank == tile index
+    if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, kt, h, b)) return;
+    const int H = p.H, L = p.L, HD = H * FA_D;
+    const int j0 = kt * FA_BQ, kw = j0 + 16 * wave;
+    const int a = lane & 15, g = lane >> 4;   // a = key column of this lane
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+    const unsigned tw0 = lds0 + KV16_OFF_T + wave * W16_TW_BYTES;
+    const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* dog = p.dout + ((int64_t)b * L) * HD + h * FA_D;
+    const bf16_t* kg = p.k + (int64_t)b * p.kv_bs + h * FA_D;
+    const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * FA_D;
+    const bf16_t* Rg = p.R + h * FA_D;
+    const float* lseg = p.lse + ((int64_t)b * H + h) * L;
+    const float* delg = p.delta + ((int64_t)b * H + h) * L;
+    W16Lane ln;
+    w16_lane_init(ln, lds0, tw0, lane);  // (its scratch addresses are not used here: the block is 32 x 16, see tsk / twr below)
+    unsigned tsk[8];   // scratch element (q, q - a + 16) of row q = kk(t, g) + r, stored at column q - a + 16 - 16 (q >> 4)
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int q = kk16(t, g) + r;
+            tsk[t * 4 + r] = tw0 + (q * KV16_TP + q - a + 16 - 16 * (q >> 4)) * 4;
+            W16_OPAQUE(tsk[t * 4 + r]);
+        }
+    unsigned twr = tw0 + ((4 * g) * KV16_TP + a) * 4;  // tile (tq, td): rows 16 tq + 4g + r, columns 16 (td - tq) + a
+    W16_OPAQUE(twr);
+    unsigned sta[2];   // {lse, delta} of queries kk(t, g) .. +3 (one 16-byte read each)
+#pragma unroll
+    for (int t = 0; t < 2; t++) { sta[t] = lds0 + KV16_OFF_ST + kk16(t, g) * 4; W16_OPAQUE(sta[t]); }
+
+    bf16x8_t fk[4], fv[4];  // B-operand images: column = key kw + a
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        fk[ks] = *reinterpret_cast<const bf16x8_t*>(kg + (int64_t)(kw + a) * p.kv_rs + ks * 32 + g * 8);
+        fv[ks] = *reinterpret_cast<const bf16x8_t*>(vg + (int64_t)(kw + a) * p.kv_rs + ks * 32 + g * 8);
     }
-    store_acc_t(acc_o, 1.f / l_i, reinterpret_cast<bf16_t*>(Tw), p.o + ((int64_t)b * L + iw) * HD + h * FA_D, HD, lane);
-    if (hb == 0) p.lse_out[((int64_t)b * H + h) * L + iw + a] = m_i * p.scale + logf(l_i);
+    const float c2 = p.scale * LOG2E;
+    const int ib_lo = j0 / FA_BK;
+    int ihi = j0 + FA_BQ - 1 + p.shift - 1;  // last query that can see the last key of the tile
+    if (ihi > L - 1) ihi = L - 1;
+    const int ib_hi = ihi / FA_BK;
+    // staging: one piece (4 rows) of each of the three tiles and of the 32 new ring rows per wave and block; Qu / dO images use the
+    // K / V swizzle (permuted row fragments + tr reads), the Qv image the ring swizzle (natural-order row fragments)
+    const int srow = wave * 4 + (lane >> 4);
+    const int64_t soff_kv = (int64_t)(ib_lo * FA_BK + srow) * HD + (((lane & 15) ^ swz_kv(srow)) << 3);
+    const int64_t soff_rg = (int64_t)(ib_lo * FA_BK + srow) * HD + (((lane & 15) ^ swz_ring(srow & 15)) << 3);
+    const bf16_t* quptr = qu + soff_kv;
+    const bf16_t* doptr = dog + soff_kv;
+    const bf16_t* qvptr = qv + soff_rg;
+    const bf16_t* rbase = Rg + (((lane & 15) ^ swz_ring(srow & 15)) << 3);
+    const int64_t q_step = (int64_t)FA_BK * HD;
+    auto stage_q = [&](int stage, int i0n) __attribute__((always_inline)) {  // the next query block (rows i0n ..) -> stage
+        glds16(quptr, lds0 + KV16_OFF_QU + stage * 8192 + wave * 1024);
+        glds16(qvptr, lds0 + KV16_OFF_QV + stage * 8192 + wave * 1024);
+        glds16(doptr, lds0 + KV16_OFF_DO + stage * 8192 + wave * 1024);
+        quptr += q_step; qvptr += q_step; doptr += q_step;
+        if (wave == 0) glds_stat(lseg, delg, i0n, reinterpret_cast<float*>(smem + KV16_OFF_ST + stage * 256), lane);
+    };
+    auto stage_ring = [&](int dist0) __attribute__((always_inline)) {
+        const int slot0 = (dist0 + wave * 4) & (FA_RING - 1);
+        const int dist = dist0 + srow;
+        const int gr = dist < 0 ? 0 : (dist > L - 1 ? L - 1 : dist);
+        glds16(rbase + (int64_t)gr * HD, lds0 + KV16_OFF_R + slot0 * 256);
+    };
+    // ring: distances [i0q - j0 - 128, i0q - j0 + 32) for the first block; every block prefetches the next 32
+    for (int c4 = 0; c4 < 5; c4++) stage_ring(ib_lo * FA_BK - j0 - 128 + 32 * c4);
+    stage_q(0, ib_lo * FA_BK);
+    f32x4 acc_dk[8], acc_dv[8];
+#pragma unroll
+    for (int db = 0; db < 8; db++) { zero4(acc_dk[db]); zero4(acc_dv[db]); }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto block = [&](auto CUR, int ib) __attribute__((always_inline)) {
+        constexpr int cur = decltype(CUR)::value;
+        const int i0q = ib * FA_BK;
+        if (ib < ib_hi) {  // prefetch the next query block
+            stage_q(cur ^ 1, i0q + FA_BK);
+            stage_ring(i0q + FA_BK - j0);
+        }
+        if (!(i0q + 31 < kw || i0q >= kw + 15 + p.shift)) {  // some (i, j) of this block pair is visible
+            // ---- relative term: distances dist_lo + 16 td .., dist_lo = i0q - kw - 16; (tq, td) in {(0,0), (0,1), (1,1), (1,2)}
+            const int dist_lo = i0q - kw - 16;
+            bf16x8_t qvf[2][4];
+#pragma unroll
+            for (int tq = 0; tq < 2; tq++)
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) qvf[tq][ks] = lds_ld128(ln.ring[ks] + KV16_OFF_QV + cur * 8192 + tq * 4096);
+#pragma unroll
+            for (int td = 0; td < 3; td++) {
+                const unsigned rs = (unsigned)((dist_lo + 16 * td) & (FA_RING - 1)) << 8;
+                bf16x8_t rf[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) rf[ks] = lds_ld128(ln.ring[ks] + rs + KV16_OFF_R);
+#pragma unroll
+                for (int tq = 0; tq < 2; tq++) {
+                    if (td - tq != 0 && td - tq != 1) continue;
+                    f32x4 acc;
+                    zero4(acc);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) acc = MFMA16(qvf[tq][ks], rf[ks], acc);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) lds_stf(twr + ((16 * tq + r) * KV16_TP + 16 * (td - tq)) * 4, acc[r]);
+                }
+            }
+            f32x4 acc_s[2], acc_dp[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                zero4(acc_s[t]);
+                zero4(acc_dp[t]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) acc_s[t] = MFMA16(lds_ld128(ln.rowf[t][ks] + KV16_OFF_QU + cur * 8192), fk[ks], acc_s[t]);    // S[query][key]
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) acc_dp[t] = MFMA16(lds_ld128(ln.rowf[t][ks] + KV16_OFF_DO + cur * 8192), fv[ks], acc_dp[t]);  // dP[query][key]
+            }
+            float pr[8], ds[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) pr[r] = lds_ldf(tsk[r]);
+            f32x4 lse4[2], del4[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                lse4[t] = *(lds_f32x4_ptr)(size_t)(sta[t] + cur * 256);
+                del4[t] = *(lds_f32x4_ptr)(size_t)(sta[t] + cur * 256 + 128);
+            }
+            bf16x8_t dot[8], qut[8];
+#pragma unroll
+            for (int db = 0; db < 8; db++) {
+                dot[db] = lds_tr_pair(ln.tr[0][db] + KV16_OFF_DO + cur * 8192, ln.tr[1][db] + KV16_OFF_DO + cur * 8192);
+                qut[db] = lds_tr_pair(ln.tr[0][db] + KV16_OFF_QU + cur * 8192, ln.tr[1][db] + KV16_OFF_QU + cur * 8192);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)  // this lane: key kw + a; register 4t + r: query i0q + kk(t, g) + r
+                    pr[t * 4 + r] = __builtin_amdgcn_exp2f(fmaf(pr[t * 4 + r] + acc_s[t][r], c2, -LOG2E * lse4[t][r]));
+            if (i0q < kw + 15 || i0q + 31 >= kw + p.shift) {  // diagonal / window-edge block pairs need the element mask
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = i0q + kk16(t, g) + r, j = kw + a;
+                        pr[t * 4 + r] = ((j <= i) && (j > i - p.shift)) ? pr[t * 4 + r] : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) ds[t * 4 + r] = pr[t * 4 + r] * (acc_dp[t][r] - del4[t][r]) * p.scale;
+            const bf16x8_t pb = pack8(pr), sb = pack8(ds);
+#pragma unroll
+            for (int db = 0; db < 8; db++) {
+                acc_dv[db] = MFMA16(dot[db], pb, acc_dv[db]);   // dV^T[d][key] += dO^T . P
+                acc_dk[db] = MFMA16(qut[db], sb, acc_dk[db]);   // dK^T[d][key] += Qu^T . dS
+            }
+        }
+        w16_vmcnt<0>();
+        __syncthreads();
+    };
+    for (int ib = ib_lo; ib <= ib_hi; ib += 2) {
+        block(std::integral_constant<int, 0>{}, ib);
+        if (ib + 1 <= ib_hi) block(std::integral_constant<int, 1>{}, ib + 1);
+    }
+    bf16_t* Ow = reinterpret_cast<bf16_t*>(smem + KV16_OFF_T + wave * W16_TW_BYTES);
+    store_acc_t16(acc_dk, 1.f, Ow, p.dk + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
+    store_acc_t16(acc_dv, 1.f, Ow, p.dv + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
 }
 
 // ======================================================================================= backward: delta = rowsum(dO * O)
@@ -289,259 +759,11 @@ __global__ __launch_bounds__(256) void relattn_delta_kernel(const bf16_t* __rest
     }
 }
 
-// ======================================================================================= backward w.r.t. queries (+ dT)
-__global__ __launch_bounds__(256, 1) void relattn_flash_bwd_q_kernel(FlashArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int rank, h, b;
-    if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, rank, h, b)) return;
-    const int qt = p.L / FA_BQ - 1 - rank;
-    const int H = p.H, L = p.L, HD = H * FA_D;
-    const int i0 = qt * FA_BQ, iw = i0 + 32 * wave;
-    const int a = lane & 31, hb = lane >> 5;
-    char* Ks0 = smem + FWD_OFF_K;
-    char* Vs0 = smem + FWD_OFF_V;
-    char* Rr = smem + FWD_OFF_R;
-    // per-wave scratch: T ring [32][64] f32 (kept across blocks: incremental band, see rel_band_incr_to_lds) + a second [32][64] for
-    // the dS re-indexing (the two used to share one scratch, which forced the full 64-distance band every block)
-    float* Tw = reinterpret_cast<float*>(smem + FWD_OFF_T + wave * BQ_WAVE_BYTES);
-    float* Dw = Tw + 2048;
-    const float* twr = Tw + a * 65 + 31 - 4 * hb;
-    float* dwr = Dw + a * 65 + 31 - 4 * hb;
-    const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
-    const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
-    const bf16_t* dog = p.dout + ((int64_t)b * L) * HD + h * FA_D;
-    const bf16_t* kg = p.k + (int64_t)b * p.kv_bs + h * FA_D;
-    const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * FA_D;
-    const bf16_t* Rg = p.R + h * FA_D;
-    bf16_t* dTg = p.dT + (((int64_t)h * p.B + b) * L) * L;
-    LaneOffs offs;
-    make_offs(offs, lane);
-
-    bf16x8_t fqu[8], fqv[8], fdo[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-        fqu[ks] = *reinterpret_cast<const bf16x8_t*>(qu + (int64_t)(iw + a) * HD + ks * 16 + hb * 8);
-        fqv[ks] = *reinterpret_cast<const bf16x8_t*>(qv + (int64_t)(iw + a) * HD + ks * 16 + hb * 8);
-        fdo[ks] = *reinterpret_cast<const bf16x8_t*>(dog + (int64_t)(iw + a) * HD + ks * 16 + hb * 8);
-    }
-    const float c2 = p.scale * LOG2E;
-    const float nlse2 = -p.lse[((int64_t)b * H + h) * L + iw + a] * LOG2E;
-    const float delta_a = p.delta[((int64_t)b * H + h) * L + iw + a];
-    int jlo = i0 - p.shift + 1;
-    if (jlo < 0) jlo = 0;
-    const int jb_lo = jlo / FA_BK, jb_hi = (i0 + FA_BQ - 1) / FA_BK;
-    for (int c4 = -1; c4 < 4; c4++) stage_ring32(Rg, HD, i0 - jb_lo * FA_BK + 32 * c4, L, Rr, wave, lane);
-    stage_tile32(kg, p.kv_rs, jb_lo * FA_BK, Ks0, wave, lane);
-    stage_tile32(vg, p.kv_rs, jb_lo * FA_BK, Vs0, wave, lane);
-    f32x16 acc_dq[4];
-#pragma unroll
-    for (int db = 0; db < 4; db++) zero16(acc_dq[db]);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as a builtin so that hipcc's own bookkeeping sees the fragment loads retired
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    int toff1[16];  // odd-parity read offsets of the T ring: a * 64 + ((a - crow(r, hb) + 31) ^ 32)
-#pragma unroll
-    for (int r = 0; r < 16; r++) toff1[r] = a * 64 + ((a - crow(r, hb) + 31) ^ 32);
-    bool have_prev = false;  // did this wave process the previous key block?  (wave-uniform)
-    auto block = [&](auto CUR, int jb) {
-        constexpr int cur = decltype(CUR)::value;
-        const int j0 = jb * FA_BK;
-        const char* Ks = Ks0 + cur * 8192;
-        const char* Vs = Vs0 + cur * 8192;
-        if (jb < jb_hi) {
-            stage_tile32(kg, p.kv_rs, j0 + FA_BK, Ks0 + (cur ^ 1) * 8192, wave, lane);
-            stage_tile32(vg, p.kv_rs, j0 + FA_BK, Vs0 + (cur ^ 1) * 8192, wave, lane);
-            stage_ring32(Rg, HD, i0 - j0 - 64, L, Rr, wave, lane);
-        }
-        if (j0 > iw + 31 || j0 + 31 <= iw - p.shift) have_prev = false;
-        else {
-            f32x16 acc_s, acc_dp;
-            zero16(acc_s);
-            zero16(acc_dp);
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(rowf(Ks, offs, ks), fqu[ks], acc_s);    // S^T[key][query]
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) acc_dp = MFMA32(rowf(Vs, offs, ks), fdo[ks], acc_dp);  // dP^T[key][query]
-            rel_band_incr_to_lds<cur>(fqv, offs, Rr, iw - j0 - 31, Tw, lane, !have_prev);
-            have_prev = true;
-            float ds[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                ds[r] = __builtin_amdgcn_exp2f(fmaf(acc_s[r] + (cur == 0 ? twr[-((r & 3) + 8 * (r >> 2))] : Tw[toff1[r]]), c2, nlse2));
-            if (j0 + 31 > iw || j0 <= iw + 31 - p.shift) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int i = iw + a, j = j0 + crow(r, hb);
-                    ds[r] = ((j <= i) && (j > i - p.shift)) ? ds[r] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) ds[r] = ds[r] * (acc_dp[r] - delta_a) * p.scale;
-            // dS re-indexed by distance: write into the scratch at (a, a - b + 31), then rows go out as 32 contiguous bf16
-#pragma unroll
-            for (int r = 0; r < 16; r++) dwr[-((r & 3) + 8 * (r >> 2))] = ds[r];
-            const bf16x8_t db0 = pack8(ds), db1 = pack8(ds + 8);
-#pragma unroll
-            for (int db = 0; db < 4; db++) {  // dq^T[d][query] += K^T . dS^T
-                acc_dq[db] = MFMA32(trf(Ks, offs, 0, db), db0, acc_dq[db]);
-                acc_dq[db] = MFMA32(trf(Ks, offs, 16, db), db1, acc_dq[db]);
-            }
-            {
-                const int t = lane & 31;
-                bf16_t* drow = dTg + (int64_t)(iw + hb) * L + (iw + hb - j0 - 31 + t);  // row = 2*it + hb, dist = i - j with j = j0 + 31 - t
-                const float* trow = Dw + hb * 65 + t;
-#pragma unroll
-                for (int it = 0; it < 16; it++) {
-                    const int dist = iw + 2 * it + hb - j0 - 31 + t;
-                    if (dist >= 0) drow[(int64_t)(2 * it) * (L + 1)] = f2bf(trow[2 * it * 65]);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-    for (int jb = jb_lo; jb <= jb_hi; jb += 2) {
-        block(std::integral_constant<int, 0>{}, jb);
-        if (jb + 1 <= jb_hi) block(std::integral_constant<int, 1>{}, jb + 1);
-    }
-    store_acc_t(acc_dq, 1.f, reinterpret_cast<bf16_t*>(Tw), p.dq + (int64_t)b * p.dq_bs + (int64_t)iw * p.dq_rs + h * FA_D, p.dq_rs, lane);
-}
-
-// ======================================================================================= backward w.r.t. keys / values
-#define KV_OFF_QU 0                          // two stages of 8 KiB each for Qu, Qv, dO
-#define KV_OFF_QV 16384
-#define KV_OFF_DO 32768
-#define KV_OFF_ST 49152                      // two stages of {lse[32], delta[32]} floats (raw, via LDS-DMA)
-#define KV_OFF_R 49664
-#define KV_OFF_T (KV_OFF_R + FA_RING * 256)
-#define KV_LDS_BYTES (KV_OFF_T + 4 * FA_TW_BYTES)
-
-__global__ __launch_bounds__(256, 1) void relattn_flash_bwd_kv_kernel(FlashArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int kt, h, b;  // early key tiles see the most queries: rank == tile index
-    if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, kt, h, b)) return;
-    const int H = p.H, L = p.L, HD = H * FA_D;
-    const int j0 = kt * FA_BQ, kw = j0 + 32 * wave;
-    const int a = lane & 31, hb = lane >> 5;   // a = key column of this lane
-    char* Qus0 = smem + KV_OFF_QU;
-    char* Qvs0 = smem + KV_OFF_QV;
-    char* dOs0 = smem + KV_OFF_DO;
-    float* stat0 = reinterpret_cast<float*>(smem + KV_OFF_ST);
-    char* Rr = smem + KV_OFF_R;
-    float* Tw = reinterpret_cast<float*>(smem + KV_OFF_T + wave * FA_TW_BYTES);
-    const float* twr = Tw + 4 * hb * 65 + 31 - a;  // element (aq, aq - a + 31) with aq = crow(r, hb)
-    const bf16_t* qu = p.qu + ((int64_t)b * L) * HD + h * FA_D;
-    const bf16_t* qv = p.qv + ((int64_t)b * L) * HD + h * FA_D;
-    const bf16_t* dog = p.dout + ((int64_t)b * L) * HD + h * FA_D;
-    const bf16_t* kg = p.k + (int64_t)b * p.kv_bs + h * FA_D;
-    const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * FA_D;
-    const bf16_t* Rg = p.R + h * FA_D;
-    const float* lseg = p.lse + ((int64_t)b * H + h) * L;
-    const float* delg = p.delta + ((int64_t)b * H + h) * L;
-    LaneOffs offs;
-    make_offs(offs, lane);
-
-    bf16x8_t fk[8], fv[8];  // B-operand images: column = key kw + a
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-        fk[ks] = *reinterpret_cast<const bf16x8_t*>(kg + (int64_t)(kw + a) * p.kv_rs + ks * 16 + hb * 8);
-        fv[ks] = *reinterpret_cast<const bf16x8_t*>(vg + (int64_t)(kw + a) * p.kv_rs + ks * 16 + hb * 8);
-    }
-    const float c2 = p.scale * LOG2E;
-    const int ib_lo = j0 / FA_BK;
-    int ihi = j0 + FA_BQ - 1 + p.shift - 1;  // last query that can see the last key of the tile
-    if (ihi > L - 1) ihi = L - 1;
-    const int ib_hi = ihi / FA_BK;
-    // ring: distances [i0q - j0 - 128, i0q - j0 + 32) for the first block; every block prefetches the next 32
-    for (int c4 = 0; c4 < 5; c4++) stage_ring32(Rg, HD, ib_lo * FA_BK - j0 - 128 + 32 * c4, L, Rr, wave, lane);
-    stage_tile32(qu, HD, ib_lo * FA_BK, Qus0, wave, lane);
-    stage_tile32(qv, HD, ib_lo * FA_BK, Qvs0, wave, lane);
-    stage_tile32(dog, HD, ib_lo * FA_BK, dOs0, wave, lane);
-    if (wave == 0) glds_stat(lseg, delg, ib_lo * FA_BK, stat0, lane);
-    f32x16 acc_dk[4], acc_dv[4];
-#pragma unroll
-    for (int db = 0; db < 4; db++) { zero16(acc_dk[db]); zero16(acc_dv[db]); }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as a builtin so that hipcc's own bookkeeping sees the fragment loads retired
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    auto block = [&](auto CUR, int ib) {
-        constexpr int cur = decltype(CUR)::value;
-        const int i0q = ib * FA_BK;
-        const char* Qus = Qus0 + cur * 8192;
-        const char* Qvs = Qvs0 + cur * 8192;
-        const char* dOs = dOs0 + cur * 8192;
-        const float* stat = stat0 + cur * 64 + 4 * hb;
-        if (ib < ib_hi) {  // prefetch the next query block
-            const int nx = i0q + FA_BK;
-            stage_tile32(qu, HD, nx, Qus0 + (cur ^ 1) * 8192, wave, lane);
-            stage_tile32(qv, HD, nx, Qvs0 + (cur ^ 1) * 8192, wave, lane);
-            stage_tile32(dog, HD, nx, dOs0 + (cur ^ 1) * 8192, wave, lane);
-            stage_ring32(Rg, HD, nx - j0, L, Rr, wave, lane);
-            if (wave == 0) glds_stat(lseg, delg, nx, stat0 + (cur ^ 1) * 64, lane);
-        }
-        if (!(i0q + 31 < kw || i0q >= kw + 31 + p.shift)) {  // some (i, j) of this block pair is visible
-            f32x16 acc_s, acc_dp;
-            zero16(acc_s);
-            zero16(acc_dp);
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) acc_s = MFMA32(rowf(Qus, offs, ks), fk[ks], acc_s);    // S[query][key]
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) acc_dp = MFMA32(rowf(dOs, offs, ks), fv[ks], acc_dp);  // dP[query][key]
-            rel_band_to_lds<false>(nullptr, Qvs, offs, Rr, i0q - kw - 31, Tw, lane);  // (queries change every block: nothing to reuse)
-            float pr[16], ds[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {  // this lane: key kw + a; register r: query i0q + crow(r, hb)
-                const int q8 = (r & 3) + 8 * (r >> 2);
-                pr[r] = __builtin_amdgcn_exp2f(fmaf(acc_s[r] + twr[q8 * 65], c2, -LOG2E * stat[q8]));
-            }
-            if (i0q < kw + 31 || i0q + 31 >= kw + p.shift) {  // diagonal / window-edge block pairs need the element mask
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int i = i0q + crow(r, hb), j = kw + a;
-                    pr[r] = ((j <= i) && (j > i - p.shift)) ? pr[r] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) ds[r] = pr[r] * (acc_dp[r] - stat[32 + (r & 3) + 8 * (r >> 2)]) * p.scale;
-            const bf16x8_t pb0 = pack8(pr), pb1 = pack8(pr + 8), sb0 = pack8(ds), sb1 = pack8(ds + 8);
-#pragma unroll
-            for (int db = 0; db < 4; db++) {
-                acc_dv[db] = MFMA32(trf(dOs, offs, 0, db), pb0, acc_dv[db]);   // dV^T[d][key] += dO^T . P
-                acc_dv[db] = MFMA32(trf(dOs, offs, 16, db), pb1, acc_dv[db]);
-                acc_dk[db] = MFMA32(trf(Qus, offs, 0, db), sb0, acc_dk[db]);   // dK^T[d][key] += Qu^T . dS
-                acc_dk[db] = MFMA32(trf(Qus, offs, 16, db), sb1, acc_dk[db]);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-    for (int ib = ib_lo; ib <= ib_hi; ib += 2) {
-        block(std::integral_constant<int, 0>{}, ib);
-        if (ib + 1 <= ib_hi) block(std::integral_constant<int, 1>{}, ib + 1);
-    }
-    bf16_t* Ow = reinterpret_cast<bf16_t*>(Tw);
-    store_acc_t(acc_dk, 1.f, Ow, p.dk + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
-    store_acc_t(acc_dv, 1.f, Ow, p.dv + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
-}
-
-
 // ======================================================================================= host side
 extern "C" int db1_relattn_flash_supported(int B, int L, int H, int D, int dt) {
     return (dt == DB1_BF16 && D == FA_D && B > 0 && H > 0 && L >= FA_BQ && (L % FA_BQ) == 0 && B <= 65535 && H <= 65535) ? 1 : 0;
 }
 
-int db1_flash16_fwd_launch(const FlashArgs& a, hipStream_t st);
-int db1_flash16_bwd_q_launch(const FlashArgs& a, hipStream_t st);
-int db1_flash16_bwd_kv_launch(const FlashArgs& a, hipStream_t st);
-static bool flash_impl16() {  // the 8-wave kernels (relattn_flash16.hip) are the default; DB1_FLASH_IMPL=32 selects the 4-wave ones (A/B timing)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DB1_FLASH_IMPL"); v = (e && atoi(e) == 32) ? 0 : 1; }
-    return v == 1;
-}
 static int flash_check(const FlashArgs& a, int D, const char* what) {
     if (!db1_relattn_flash_supported(a.B, a.L, a.H, D, DB1_BF16)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "%s: needs bf16, d_head = 128, L %% 128 == 0 (got L=%d D=%d)", what, a.L, D);
     if (a.shift < 1) DB1_FAIL(DB1_ERR_BAD_SHAPE, "%s: empty attention window (shift=%d)", what, a.shift);
@@ -561,11 +783,9 @@ extern "C" int db1_relattn_flash_fwd(const void* qu, const void* qv, const void*
     int st = flash_check(a, D, "relattn_flash_fwd");
     if (st) return st;
     if (!db1_aligned16(out)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_flash_fwd: out alignment");
-    if (flash_impl16()) return db1_flash16_fwd_launch(a, (hipStream_t)stream);
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)relattn_flash_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES); attr = true; }
-    dim3 grid(flash_grid(L / FA_BQ, H, B));
-    relattn_flash_fwd_kernel<<<grid, 256, FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
+    if (!attr) { hipFuncSetAttribute((const void*)relattn_flash_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W16_FWD_LDS); attr = true; }
+    relattn_flash_fwd_kernel<<<dim3(flash_grid(L / FA_BQ, H, B)), 512, W16_FWD_LDS, (hipStream_t)stream>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_fwd");
     return DB1_OK;
 }
@@ -588,23 +808,17 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)relattn_flash_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BQ_LDS_BYTES);
-        hipFuncSetAttribute((const void*)relattn_flash_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV_LDS_BYTES);
+        hipFuncSetAttribute((const void*)relattn_flash_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W16_BQ_LDS);
+        hipFuncSetAttribute((const void*)relattn_flash_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV16_LDS);
         attr = true;
     }
     const int64_t n_rows = (int64_t)B * L * H;
     relattn_delta_kernel<<<(unsigned)((n_rows + 15) / 16), 256, 0, s>>>(a.out, a.dout, delta, n_rows, L, H);
     DB1_CHECK_LAUNCH("relattn_delta");
-    dim3 grid(flash_grid(L / FA_BQ, H, B));
-    if (flash_impl16()) {
-        st = db1_flash16_bwd_q_launch(a, s);
-        if (st) return st;
-    } else {
-        relattn_flash_bwd_q_kernel<<<grid, 256, BQ_LDS_BYTES, s>>>(a);
-        DB1_CHECK_LAUNCH("relattn_flash_bwd_q");
-    }
-    if (flash_impl16() && !getenv("DB1_FLASH_KV32")) return db1_flash16_bwd_kv_launch(a, s);
-    relattn_flash_bwd_kv_kernel<<<grid, 256, KV_LDS_BYTES, s>>>(a);
+    const dim3 grid(flash_grid(L / FA_BQ, H, B));
+    relattn_flash_bwd_q_kernel<<<grid, 512, W16_BQ_LDS, s>>>(a);
+    DB1_CHECK_LAUNCH("relattn_flash_bwd_q");
+    relattn_flash_bwd_kv_kernel<<<grid, 512, KV16_LDS, s>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_bwd_kv");
     return DB1_OK;
 }
