@@ -2,8 +2,8 @@
 //     s[i,j] = ((q_i+u).k_j + (q_i+v).R[i-j]) / sqrt(d),   visible iff  i - shift < j <= i
 // (closed form of AC + _rel_shift(BD) + mask, transformer_xl.py:98-110,160-209,551-567) with online softmax and P.V fused, never
 // materialising an (L x L) tensor in HBM in the forward.  Inputs qu = q+u and qv = q+v_bias are materialised once per layer by
-// db1_relattn_add_head_bias.  Backward = delta pre-pass + two kernels without atomics (deterministic):
-//   bwd_q : per 128 queries, loop keys    -> dq_k = dS.K (the (q+u).k branch) and dT = dS re-indexed by distance (bf16, HBM);
+// db1_relattn_add_head_bias.  Backward = two kernels without atomics (deterministic):
+//   bwd_q : per 128 queries, loop keys    -> delta = rowsum(dO * O), dq_k = dS.K (the (q+u).k branch) and dT = dS re-indexed by distance (bf16, HBM);
 //   bwd_kv: per 128 keys,    loop queries -> dV = P^T.dO, dK = dS^T.Qu.
 // dq_r = dT.R and dR = dT^T.Qv are plain batched GEMMs on dT (exact causal FLOPs, no band overhead) run by the caller.
 //
@@ -443,7 +443,21 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
     }
     const float c2 = p.scale * LOG2E;
     const float nlse2 = -p.lse[((int64_t)b * H + h) * L + iw + a] * LOG2E;
-    const float delta_a = p.delta[((int64_t)b * H + h) * L + iw + a];
+    // delta_i = sum_d dO[i][d] * O[i][d] (the softmax backward's row term): this wave's 16 queries, 32 of the 128 d per lane, reduced
+    // over the four lane groups; bwd_q visits every (b, h, i) exactly once, so it also publishes delta for bwd_kv (launched after it)
+    float delta_a = 0.f;
+    {
+        const bf16_t* og = p.out + ((int64_t)b * L + iw + a) * HD + h * FA_D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const bf16x8_t fo = *reinterpret_cast<const bf16x8_t*>(og + ks * 32);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                delta_a += __uint_as_float((unsigned)(unsigned short)fo[e] << 16) * __uint_as_float((unsigned)(unsigned short)fdo[ks][e] << 16);
+        }
+        delta_a = sum_x32(sum_x16(delta_a));
+        if (g == 0) p.delta[((int64_t)b * H + h) * L + iw + a] = delta_a;
+    }
     // dT row (iw + row) starts at distance (iw + row) - j0 - 31 for a block: row = 4 it + (lane >> 4), this lane's pair = elements 2 col, 2 col + 1
     bf16_t* dtp = p.dT + (((int64_t)h * p.B + b) * L + iw + (lane >> 4)) * L + (iw + (lane >> 4) - 31 + 2 * (lane & 15));
     const int drow0 = iw + (lane >> 4) - 31 + 2 * (lane & 15);  // distance of the pair's first element for j0 = 0, it = 0
@@ -735,30 +749,6 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv_kernel(FlashArgs 
     store_acc_t16(acc_dv, 1.f, Ow, p.dv + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
 }
 
-// ======================================================================================= backward: delta = rowsum(dO * O)
-__global__ __launch_bounds__(256) void relattn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta,
-                                                            int64_t n_rows, int L, int H) {
-    // 16 lanes per (b, i, h) row of 128 elements (16 B per lane), 16 rows per 256-thread block
-    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (row >= n_rows) return;
-    const int sub = threadIdx.x & 15;
-    const uint4 x = *reinterpret_cast<const uint4*>(o + row * FA_D + sub * 8);
-    const uint4 y = *reinterpret_cast<const uint4*>(dout + row * FA_D + sub * 8);
-    const unsigned xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
-    float s = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-        s += __uint_as_float(xs[t] << 16) * __uint_as_float(ys[t] << 16) + __uint_as_float(xs[t] & 0xffff0000u) * __uint_as_float(ys[t] & 0xffff0000u);
-#pragma unroll
-    for (int m = 8; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
-    if (sub == 0) {
-        const int64_t bi = row / H;
-        const int hh = (int)(row - bi * H);
-        const int64_t bb = bi / L, i = bi - bb * L;
-        delta[(bb * H + hh) * L + i] = s;
-    }
-}
-
 // ======================================================================================= host side
 extern "C" int db1_relattn_flash_supported(int B, int L, int H, int D, int dt) {
     return (dt == DB1_BF16 && D == FA_D && B > 0 && H > 0 && L >= FA_BQ && (L % FA_BQ) == 0 && B <= 65535 && H <= 65535) ? 1 : 0;
@@ -812,9 +802,6 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
         hipFuncSetAttribute((const void*)relattn_flash_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV16_LDS);
         attr = true;
     }
-    const int64_t n_rows = (int64_t)B * L * H;
-    relattn_delta_kernel<<<(unsigned)((n_rows + 15) / 16), 256, 0, s>>>(a.out, a.dout, delta, n_rows, L, H);
-    DB1_CHECK_LAUNCH("relattn_delta");
     const dim3 grid(flash_grid(L / FA_BQ, H, B));
     relattn_flash_bwd_q_kernel<<<grid, 512, W16_BQ_LDS, s>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_bwd_q");

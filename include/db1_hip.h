@@ -179,7 +179,7 @@ int db1_relattn_flash_fwd(const void* qu, const void* qv, const void* k, const v
                           int B, int L, int H, int D, int shift, float scale, void* stream);
 /* dq (the (q+u).k branch only), dk, dv are written with their own row / batch strides (they live inside dqkv);
  * dT [H,B,L,L] bf16 = dS re-indexed by distance (input of the dq_r / dR GEMMs, zero where nothing is visible);
- * delta [B,H,L] f32 scratch. */
+ * delta [B,H,L] f32 scratch (rowsum(dout * out): written by the query-side kernel, read by the key-side kernel). */
 int db1_relattn_flash_bwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
                           int64_t kv_batch_stride, const void* R, const void* out, const void* dout, const float* lse,
                           float* delta, void* dq, void* dk, void* dv, int64_t dqkv_row_stride, int64_t dqkv_batch_stride,

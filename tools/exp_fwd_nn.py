@@ -6,7 +6,7 @@ import torch
 from bdm_db1_amd import ops
 from bench_kernels import timeit
 DEV = "cuda"
-T, d = 16384, 2048
+T, d = int(sys.argv[1]) * 1024 if len(sys.argv) > 1 else 16384, 2048
 for name, M, N, K in [("qkv", T, 3 * d, d), ("o_net", T, d, d), ("ff1", T, 4 * d, d), ("ff2", T, d, 2 * d), ("head", T, 33280, d)]:
     x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
     w = (torch.randn(N, K, device=DEV) * 0.02).to(torch.bfloat16)
