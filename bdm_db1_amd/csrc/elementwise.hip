@@ -465,19 +465,27 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const T* __restrict__
         for (int j = 0; j < V; j += 4) *reinterpret_cast<float4*>(dst + n + j) = make_float4(s2[j], s2[j + 1], s2[j + 2], s2[j + 3]);
     }
 }
-// out[c] += sum over chunks of part[chunk][c]; 64 columns per workgroup, wave w takes chunks w, w+4, ... in order
-__global__ __launch_bounds__(256) void colsum_part_reduce_kernel(const float* __restrict__ part, float* out, int nchunks, int cols) {
-    __shared__ float red[4][64];
+// out[c] += sum over chunks of part[chunk][c]; 64 columns per workgroup, 16 waves: wave w takes chunks w, w+16, ... in order and the 16
+// partial sums are added in wave order (deterministic).  (With 4 waves per workgroup the 32 workgroups of a 2048-column sum walked
+// 512 chunks each, one dependent load chain per wave: 31 us, latency-bound.)
+#define CSR_WAVES 16
+__global__ __launch_bounds__(64 * CSR_WAVES) void colsum_part_reduce_kernel(const float* __restrict__ part, float* out, int nchunks, int cols) {
+    __shared__ float red[CSR_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float acc = 0.f;
     if (c < cols) {
 #pragma unroll 8
-        for (int b = wave; b < nchunks; b += 4) acc += part[(int64_t)b * cols + c];
+        for (int b = wave; b < nchunks; b += CSR_WAVES) acc += part[(int64_t)b * cols + c];
     }
     red[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && c < cols) out[c] += ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (wave == 0 && c < cols) {
+        float s = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < CSR_WAVES; w++) s += red[w][lane];
+        out[c] += s;
+    }
 }
 
 static inline unsigned grid_for(int64_t work_items) {
@@ -524,7 +532,7 @@ extern "C" int db1_ffn_act_bwd_bias(const void* z, const void* dout, void* dz, f
     if (!dbias_acc) DB1_FAIL(DB1_ERR_BAD_SHAPE, "ffn_act_bwd_bias: null accumulator");
     hipStream_t st = (hipStream_t)stream;
     const int ld = act == DB1_ACT_GEGLU ? 2 * n : n;
-    const int rpc = 32, nchunks = (int)((rows + rpc - 1) / rpc);
+    const int rpc = rows >= 32768 ? 64 : 32, nchunks = (int)((rows + rpc - 1) / rpc);  // (8 workgroups per CU are enough to stream)
     float* ws = ln_workspace((size_t)nchunks * ld * sizeof(float));
     if (!ws) DB1_FAIL(DB1_ERR_HIP, "ffn_act_bwd_bias: cannot allocate the partial-sum workspace");
     dim3 g((unsigned)((n / V + 255) / 256), (unsigned)nchunks);
@@ -532,7 +540,7 @@ extern "C" int db1_ffn_act_bwd_bias(const void* z, const void* dout, void* dz, f
     DB1_DISPATCH_DT(dt, T, { if (act == 0) L(T, 0); else if (act == 1) L(T, 1); else L(T, 2); });
 #undef L
     DB1_CHECK_LAUNCH("ffn_act_bwd_bias");
-    colsum_part_reduce_kernel<<<(ld + 63) / 64, 256, 0, st>>>(ws, dbias_acc, nchunks, ld);
+    colsum_part_reduce_kernel<<<(ld + 63) / 64, 64 * CSR_WAVES, 0, st>>>(ws, dbias_acc, nchunks, ld);
     DB1_CHECK_LAUNCH("ffn_act_bwd_bias reduce");
     return DB1_OK;
 }
@@ -618,14 +626,14 @@ extern "C" int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int c
     if (cols % V == 0 && ldx % V == 0 && db1_aligned16(x)) {
         if (rows >= 1024) {  // long inputs: chunk partials + ordered reduce (deterministic, ~16 resident waves per CU)
             int rpc = 32;
-            while (rows / rpc > 4096) rpc *= 2;  // the ordered reduce walks the chunks serially: keep them few (conv bias sums: 3.9 M rows)
+            while (rows / rpc > 1024) rpc *= 2;  // the ordered reduce walks the chunks serially: keep them few (conv bias sums: 3.9 M rows)
             const int nchunks = (int)((rows + rpc - 1) / rpc);
             float* ws = ln_workspace((size_t)nchunks * cols * sizeof(float));
             if (!ws) DB1_FAIL(DB1_ERR_HIP, "colsum: cannot allocate the partial-sum workspace");
             dim3 gc((unsigned)((cols / V + 63) / 64), (unsigned)nchunks);
             DB1_DISPATCH_DT(dt, T, (colsum_chunk_kernel<T><<<gc, 256, 0, (hipStream_t)stream>>>((const T*)x, ws, rows, cols, ldx, rpc)));
             DB1_CHECK_LAUNCH("colsum_chunk");
-            colsum_part_reduce_kernel<<<(cols + 63) / 64, 256, 0, (hipStream_t)stream>>>(ws, out_acc, nchunks, cols);
+            colsum_part_reduce_kernel<<<(cols + 63) / 64, 64 * CSR_WAVES, 0, (hipStream_t)stream>>>(ws, out_acc, nchunks, cols);
             DB1_CHECK_LAUNCH("colsum reduce");
             return DB1_OK;
         }
