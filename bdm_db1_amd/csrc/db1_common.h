@@ -26,12 +26,16 @@ static inline bool db1_dt_ok(int dt) { return dt == DB1_F32 || dt == DB1_BF16; }
 static inline bool db1_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                        // round to nearest even
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 (the integer sequence it replaces was ~10 VALU
+// instructions and a divergent NaN branch per element: the bf16 activation kernels were VALU-bound on it)
+typedef __attribute__((ext_vector_type(2))) float db1_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 db1_bf16x2_t;
+__device__ __forceinline__ unsigned f2bf_pk(float lo, float hi) {  // {bf16(lo), bf16(hi)} in one dword
+    db1_f32x2_t v = {lo, hi};
+    db1_bf16x2_t r = __builtin_convertvector(v, db1_bf16x2_t);
+    return *reinterpret_cast<unsigned*>(&r);
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(f2bf_pk(f, 0.f) & 0xffffu); }
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
@@ -60,7 +64,7 @@ template <> struct Vec16<bf16_t> {
     __device__ __forceinline__ void store(bf16_t* p) const {
         unsigned w[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; i++) w[i] = f2bf_pk(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };

@@ -241,18 +241,22 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const T* __restrict__
     float* dst = part + (int64_t)blockIdx.x * 2 * d;
     for (int c = threadIdx.x; c < 2 * d; c += 256) dst[c] = red[c];
 }
-// 64 columns per workgroup; wave w adds the partial rows w, w+4, ... in order, then the four wave sums are added in wave order
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, float* dgamma, float* dbeta, int nblocks, int d) {
-    __shared__ float red[4][64];
+// 64 columns per workgroup; wave w adds the partial rows w, w+16, ... in order, then the 16 wave sums are added in wave order
+// (4 waves per workgroup left each wave a chain of nblocks / 4 dependent loads: 35 us per call, latency-bound)
+#define LNR_WAVES 16
+__global__ __launch_bounds__(64 * LNR_WAVES) void ln_param_reduce_kernel(const float* __restrict__ part, float* dgamma, float* dbeta, int nblocks, int d) {
+    __shared__ float red[LNR_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;  // < 2 * d (d is a multiple of 64 here)
     float acc = 0.f;
 #pragma unroll 8
-    for (int b = wave; b < nblocks; b += 4) acc += part[(int64_t)b * 2 * d + c];
+    for (int b = wave; b < nblocks; b += LNR_WAVES) acc += part[(int64_t)b * 2 * d + c];
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0) {
-        const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        float t = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < LNR_WAVES; w++) t += red[w][lane];
         if (c < d) dgamma[c] += t; else dbeta[c - d] += t;
     }
 }
@@ -328,7 +332,7 @@ extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const v
 #undef LN_BWD_F
         DB1_CHECK_LAUNCH("layernorm bwd (fused)");
         if (params) {
-            ln_param_reduce_kernel<<<2 * d / 64, 256, 0, st>>>(ws, dgamma_acc, dbeta_acc, nblocks, d);
+            ln_param_reduce_kernel<<<2 * d / 64, 64 * LNR_WAVES, 0, st>>>(ws, dgamma_acc, dbeta_acc, nblocks, d);
             DB1_CHECK_LAUNCH("layernorm bwd param reduce");
         }
         return DB1_OK;
