@@ -358,14 +358,17 @@ extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const v
 // =====================================================================================
 // feed-forward activation (GEGLU = a * gelu_erf(b), activations.py:19-32)
 // =====================================================================================
+// thread = one 16-byte column vector, block = 256 vectors x a chunk of rows (two rows in flight per thread; no index division)
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void act_fwd_kernel(const T* __restrict__ z, T* __restrict__ out, int64_t rows, int n) {
+__global__ __launch_bounds__(256) void act_fwd_kernel(const T* __restrict__ z, T* __restrict__ out, int64_t rows, int n, int rows_per_chunk) {
     constexpr int V = Vec16<T>::N;
-    const int64_t nv = (int64_t)rows * (n / V);
     const int ld = ACT == DB1_ACT_GEGLU ? 2 * n : n;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nv; idx += (int64_t)gridDim.x * 256) {
-        int64_t r = idx / (n / V);
-        int c = (int)(idx % (n / V)) * V;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (c >= n) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+#pragma unroll 2
+    for (int64_t r = r0; r < r1; r++) {
         Vec16<T> a, o;
         a.load(z + r * ld + c);
         if (ACT == DB1_ACT_GEGLU) {
@@ -432,6 +435,7 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const T* __restrict__
     float s1[V], s2[V];
 #pragma unroll
     for (int j = 0; j < V; j++) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll 2
     for (int64_t r = r0; r < r1; r++) {
         Vec16<T> a, g, o;
         a.load(z + r * ld + c);
@@ -505,8 +509,10 @@ extern "C" int db1_ffn_act_fwd(const void* z, void* out, int64_t rows, int n, in
     if (rows <= 0 || n <= 0 || n % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "ffn_act_fwd: n=%d must be a multiple of %d", n, V);
     if (act < 0 || act > 2) DB1_FAIL(DB1_ERR_UNSUPPORTED, "ffn_act_fwd: act %d", act);
     hipStream_t st = (hipStream_t)stream;
-    unsigned g = grid_for(rows * (n / V));
-#define L(T, A) act_fwd_kernel<T, A><<<g, 256, 0, st>>>((const T*)z, (T*)out, rows, n)
+    int rpc = rows >= 32768 ? 64 : (rows >= 4096 ? 32 : 8);
+    while ((rows + rpc - 1) / rpc > 65535) rpc *= 2;
+    dim3 g((unsigned)((n / V + 255) / 256), (unsigned)((rows + rpc - 1) / rpc));
+#define L(T, A) act_fwd_kernel<T, A><<<g, 256, 0, st>>>((const T*)z, (T*)out, rows, n, rpc)
     DB1_DISPATCH_DT(dt, T, { if (act == 0) L(T, 0); else if (act == 1) L(T, 1); else L(T, 2); });
 #undef L
     DB1_CHECK_LAUNCH("ffn_act_fwd");
