@@ -53,7 +53,8 @@ def masked_for(L, shift):
     return (~((j <= i) & (j > i - shift))).astype(np.uint8)
 
 
-@pytest.mark.parametrize("B,L,H,shift", [(2, 256, 2, 256), (1, 512, 2, 512), (1, 512, 1, 130), (1, 384, 3, 33), (1, 1024, 1, 1024)])
+@pytest.mark.parametrize("B,L,H,shift", [(2, 256, 2, 256), (1, 512, 2, 512), (1, 512, 1, 130), (1, 384, 3, 33), (1, 1024, 1, 1024),
+                                         (1, 128, 1, 128), (3, 256, 3, 70), (1, 2048, 1, 2048), (1, 640, 2, 1)])
 def test_flash_forward_matches_oracle(B, L, H, shift):
     from bdm_db1_amd import ops
     D = 128
@@ -110,7 +111,8 @@ def test_flash_forward_matches_materialised_path_full_size():
     assert float((lse - lse2.permute(1, 0, 2)).abs().max()) < 5e-2
 
 
-@pytest.mark.parametrize("B,L,H,shift", [(2, 256, 2, 256), (1, 512, 2, 130), (1, 384, 1, 384)])
+@pytest.mark.parametrize("B,L,H,shift", [(2, 256, 2, 256), (1, 512, 2, 130), (1, 384, 1, 384), (1, 128, 1, 128), (3, 256, 3, 70),
+                                         (1, 1024, 1, 1024), (1, 640, 1, 40)])
 def test_flash_backward_matches_oracle(B, L, H, shift):
     from bdm_db1_amd import ops
     D = 128
