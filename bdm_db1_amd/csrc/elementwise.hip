@@ -477,14 +477,14 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const T* __restrict__
 // partial sums are added in wave order (deterministic).  (With 4 waves per workgroup the 32 workgroups of a 2048-column sum walked
 // 512 chunks each, one dependent load chain per wave: 31 us, latency-bound.)
 #define CSR_WAVES 16
-__global__ __launch_bounds__(64 * CSR_WAVES) void colsum_part_reduce_kernel(const float* __restrict__ part, float* out, int nchunks, int cols) {
+__device__ __forceinline__ void colsum_part_reduce_body(const float* __restrict__ part, float* out, int nchunks, int cols, int64_t pitch) {
     __shared__ float red[CSR_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float acc = 0.f;
     if (c < cols) {
 #pragma unroll 8
-        for (int b = wave; b < nchunks; b += CSR_WAVES) acc += part[(int64_t)b * cols + c];
+        for (int b = wave; b < nchunks; b += CSR_WAVES) acc += part[(int64_t)b * pitch + c];
     }
     red[wave][lane] = acc;
     __syncthreads();
@@ -494,6 +494,13 @@ __global__ __launch_bounds__(64 * CSR_WAVES) void colsum_part_reduce_kernel(cons
         for (int w = 1; w < CSR_WAVES; w++) s += red[w][lane];
         out[c] += s;
     }
+}
+__global__ __launch_bounds__(64 * CSR_WAVES) void colsum_part_reduce_kernel(const float* __restrict__ part, float* out, int nchunks, int cols) {
+    colsum_part_reduce_body(part, out, nchunks, cols, cols);
+}
+// partial rows `pitch` floats apart (several sums interleaved per chunk)
+__global__ __launch_bounds__(64 * CSR_WAVES) void colsum_part_reduce_strided_kernel(const float* __restrict__ part, float* out, int nchunks, int cols, int pitch) {
+    colsum_part_reduce_body(part, out, nchunks, cols, pitch);
 }
 
 static inline unsigned grid_for(int64_t work_items) {
@@ -718,6 +725,65 @@ extern "C" int db1_add2d(const void* a, int64_t lda, const void* b, int64_t ldb,
     else L_(bf16_t, float);
 #undef L_
     DB1_CHECK_LAUNCH("add2d");
+    return DB1_OK;
+}
+
+// y = a + b together with the column sums of a and of b (the attention backward: dq = dq_k + dq_r, du = colsum(dq_k),
+// dv_bias = colsum(dq_r) -- three passes over the same two matrices before).  thread = one 16-byte column vector, block = 64 vectors x 4
+// waves over a chunk of rows; per-chunk partials [chunk][2][cols] are added in chunk order by colsum_part_reduce_kernel (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void add2d_colsums_kernel(const T* __restrict__ a, int64_t lda, const T* b, int64_t ldb, T* y, int64_t ldy,
+                                                            float* __restrict__ part, int64_t rows, int cols, int rpc) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float red[4][2][64 * 8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + lane) * V;
+    const int64_t r0 = (int64_t)blockIdx.y * rpc;
+    const int64_t r1 = r0 + rpc < rows ? r0 + rpc : rows;
+    float sa[V], sb[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) { sa[j] = 0.f; sb[j] = 0.f; }
+    if (c0 < cols) {
+#pragma unroll 4
+        for (int64_t r = r0 + w; r < r1; r += 4) {
+            Vec16<T> va, vb, vo;
+            va.load(a + r * lda + c0);
+            vb.load(b + r * ldb + c0);
+#pragma unroll
+            for (int j = 0; j < V; j++) { sa[j] += va.v[j]; sb[j] += vb.v[j]; vo.v[j] = va.v[j] + vb.v[j]; }
+            vo.store(y + r * ldy + c0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; j++) { red[w][0][lane * V + j] = sa[j]; red[w][1][lane * V + j] = sb[j]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * 64 * V; i += 256) {
+        const int which = i / (64 * V), ii = i % (64 * V);
+        const int c = blockIdx.x * 64 * V + ii;
+        if (c < cols) part[((int64_t)blockIdx.y * 2 + which) * cols + c] = ((red[0][which][ii] + red[1][which][ii]) + red[2][which][ii]) + red[3][which][ii];
+    }
+}
+// y may alias b.  sum_a_acc[c] += sum_r a[r, c], sum_b_acc[c] += sum_r b[r, c] (float32, fixed summation order).
+extern "C" int db1_add2d_colsums(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, float* sum_a_acc,
+                                 float* sum_b_acc, int64_t rows, int cols, int dt, void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "add2d_colsums: dtype");
+    const int V = dt == DB1_F32 ? 4 : 8;
+    if (rows <= 0 || cols <= 0 || lda < cols || ldb < cols || ldy < cols) DB1_FAIL(DB1_ERR_BAD_SHAPE, "add2d_colsums: shape");
+    if (cols % V || lda % V || ldb % V || ldy % V || !db1_aligned16(a) || !db1_aligned16(b) || !db1_aligned16(y))
+        DB1_FAIL(DB1_ERR_BAD_ALIGN, "add2d_colsums: needs 16-byte aligned rows (cols, strides multiples of %d)", V);
+    if (!sum_a_acc || !sum_b_acc) DB1_FAIL(DB1_ERR_BAD_SHAPE, "add2d_colsums: null accumulator");
+    hipStream_t st = (hipStream_t)stream;
+    int rpc = 32;
+    while (rows / rpc > 1024) rpc *= 2;
+    const int nchunks = (int)((rows + rpc - 1) / rpc);
+    float* ws = ln_workspace((size_t)nchunks * 2 * cols * sizeof(float));
+    if (!ws) DB1_FAIL(DB1_ERR_HIP, "add2d_colsums: cannot allocate the partial-sum workspace");
+    dim3 g((unsigned)((cols / V + 63) / 64), (unsigned)nchunks);
+    DB1_DISPATCH_DT(dt, T, (add2d_colsums_kernel<T><<<g, 256, 0, st>>>((const T*)a, lda, (const T*)b, ldb, (T*)y, ldy, ws, rows, cols, rpc)));
+    DB1_CHECK_LAUNCH("add2d_colsums");
+    colsum_part_reduce_strided_kernel<<<(cols + 63) / 64, 64 * CSR_WAVES, 0, st>>>(ws, sum_a_acc, nchunks, cols, 2 * cols);
+    colsum_part_reduce_strided_kernel<<<(cols + 63) / 64, 64 * CSR_WAVES, 0, st>>>(ws + cols, sum_b_acc, nchunks, cols, 2 * cols);
+    DB1_CHECK_LAUNCH("add2d_colsums reduce");
     return DB1_OK;
 }
 

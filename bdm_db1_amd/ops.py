@@ -163,6 +163,15 @@ def add2d(a2d, b2d, y2d):
              dt_code(a2d), dt_code(y2d), stream())
 
 
+def add2d_colsums(a2d, b2d, y2d, sum_a_acc, sum_b_acc):
+    """y = a + b (y may alias b) and the float32 column sums of a and of b accumulated into sum_a_acc / sum_b_acc, one pass."""
+    rows, cols = y2d.shape
+    assert a2d.stride(1) == 1 and b2d.stride(1) == 1 and y2d.stride(1) == 1 and a2d.dtype == y2d.dtype == b2d.dtype
+    assert sum_a_acc.dtype == torch.float32 and sum_b_acc.dtype == torch.float32
+    lib.call("db1_add2d_colsums", P(a2d), a2d.stride(0), P(b2d), b2d.stride(0), P(y2d), y2d.stride(0), P(sum_a_acc), P(sum_b_acc),
+             rows, cols, dt_code(y2d), stream())
+
+
 def cast(x, y):
     lib.call("db1_cast", P(x), P(y), x.numel(), dt_code(x), dt_code(y), stream())
 

@@ -111,6 +111,10 @@ int db1_ffn_act_bwd_bias(const void* z, const void* dout, void* dz, float* dbias
 int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int cols, int64_t ldx, int dt, void* stream);
 /* y = a + b (elementwise), used by pre-LN residuals and dq = dq_k + dq_r */
 int db1_add(const void* a, const void* b, void* y, int64_t n, int dt, void* stream);
+/* y = a + b and, from the same pass, sum_a_acc[c] += sum_r a[r, c], sum_b_acc[c] += sum_r b[r, c] (float32, fixed order; y may alias b).
+ * The attention backward's dq = dq_k + dq_r with the r_w_bias / r_r_bias gradients (transformer_xl.py:160-209): one pass instead of three. */
+int db1_add2d_colsums(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, float* sum_a_acc, float* sum_b_acc,
+                      int64_t rows, int cols, int dt, void* stream);
 /* y[r, c] = a[r, c] + b[r, c] with row strides (a may have a different dtype; y may alias b) */
 int db1_add2d(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows, int cols,
               int dtA, int dt, void* stream);

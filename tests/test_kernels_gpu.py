@@ -374,6 +374,19 @@ def test_colsum_add_cast(ops):
     c = torch.empty(300, 70, device=DEV, dtype=torch.bfloat16)
     ops.cast(a, c)
     assert torch.equal(c, a.to(torch.bfloat16))
+    # fused: y = a + b (y aliasing the strided b) with both column sums, as used for dq = dq_k + dq_r, du, dv_bias
+    for td, rows, cols in ((torch.float32, 1000, 64), (torch.bfloat16, 2500, 256)):
+        ra = rng.standard_normal((rows, cols))
+        rb_ = rng.standard_normal((rows, 3 * cols))
+        if td == torch.bfloat16:
+            ra, rb_ = bf(ra), bf(rb_)
+        a_t, b_t = dev(ra, td), dev(rb_, td)
+        sa, sb = torch.full((cols,), 3.0, device=DEV), torch.full((cols,), -2.0, device=DEV)
+        ops.add2d_colsums(a_t, b_t[:, :cols], b_t[:, :cols], sa, sb)
+        close(sa, ra.sum(0) + 3, 2e-6, name=f"add2d_colsums sum a {td}")
+        close(sb, rb_[:, :cols].sum(0) - 2, 2e-6, name=f"add2d_colsums sum b {td}")
+        close(b_t[:, :cols], ra + rb_[:, :cols], 1e-6 if td == torch.float32 else 4e-3, name=f"add2d_colsums y {td}")
+        assert torch.equal(b_t[:, cols:], dev(rb_, td)[:, cols:]), "add2d_colsums must leave the other columns alone"
 
 
 # ------------------------------------------------------------------------------- embeddings
