@@ -268,7 +268,10 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
             int S = 0;
             for (int cand = 8; cand >= 2; cand >>= 1)
                 if (wg * cand <= 288 && (K / TBK) % cand == 0 && (K / TBK) / cand >= 32) { S = cand; break; }
-            if (S && wg <= 96 && (!pp_shape || wg * S >= 160)) {  // measured: 128 tiles x 2 slices (ff2 dW) gains nothing
+            // half a wave of 256x256 tiles (ff2 dW: 128) in two slices: nothing at K = 16 384, but 1184 -> 978 us at K = 65 536 (the 256x128
+            // kernel it would otherwise take runs at 930 TFLOP/s, the ping-pong kernel at 1120 incl. the reduce)
+            const bool half_wave = pp_shape && fb == 1 && wg > 96 && wg <= 128 && S == 2 && (K / TBK) / S >= 256;
+            if (S && (wg <= 96 || half_wave) && (!pp_shape || wg * S >= 160)) {
                 float* ws = splitk_workspace((size_t)batch * S * M * N * sizeof(float));
                 if (!ws) DB1_FAIL(DB1_ERR_HIP, "gemm: cannot allocate %zu bytes of split-K workspace", (size_t)batch * S * M * N * sizeof(float));
                 GemmTileArgs u = t;
