@@ -274,6 +274,23 @@ def test_gemm_bf16_split_k_weight_gradient(ops):
     close(cols, ref, 1e-7, name="padded im2col")
 
 
+def test_gemm_bf16_short_last_wave_and_half_wave_split(ops):
+    """dispatcher paths of the weight gradients at 65 536 tokens: (a) 264 tiles of 256x256 = one full wave + one tile row, the
+    remainder rows go through a second call on the split-K path; (b) 128 tiles in two K slices.  Reference: fp32 matmul of the
+    same bf16 operands on the device (sampled rows incl. the remainder rows)."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for M, N, K in ((33 * 256, 2048, 16384), (2048, 4096, 32768)):
+        a_t = (torch.randn(K, M, generator=g) * 0.1).to(torch.bfloat16).to(DEV)   # TN: A is stored [K, M]
+        b = (torch.randn(K, N, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+        c0 = torch.randn(M, N, generator=g).to(DEV)
+        out = c0.clone()
+        ops.gemm(a_t.t(), b, out, beta=1.0)
+        rows = torch.cat([torch.arange(0, 64), torch.arange(M // 2, M // 2 + 64), torch.arange(M - 300, M)]).to(DEV)
+        ref = a_t.t()[rows].float() @ b.float() + c0[rows]
+        err = float((out[rows] - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, f"M={M} N={N} K={K}: {err:.3e}"
+
+
 def test_gemm_bf16_tile_large_k_and_batch(ops):
     rng = np.random.default_rng(4)
     Z, M, N, K = 3, 128, 128, 1024
