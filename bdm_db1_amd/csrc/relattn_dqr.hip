@@ -1,0 +1,173 @@
+// dq_r = dT . R for the relative-position attention backward (transformer_xl.py:160-209): per (head, batch)
+//     dq_r[b, i, h, :] = sum_{dist <= i} dT[h, b, i, dist] * R[dist, h, :]                (dT = dS re-indexed by distance, bf16)
+// This contraction is HBM-bound on dT (1.07 GB per layer at 64 x 1024 tokens, a 128-wide output): as a batched tile GEMM it ran at
+// 2.7 TB/s (441 us): 128 bytes per row and k-tile, and causal k-loops of 4..16 tiles that never filled the 3-stage pipeline
+// (this kernel: 373 us).
+// Here dT is a STREAM and R is stationary:
+//   * one workgroup per CU works for one head; wave w keeps R_h^T for its 16 output columns d in registers for all distances
+//     (32 k-steps x 8 bf16 = 128 VGPRs, loaded once from a transposed copy of R);
+//   * the (batch, 64-row tile) items of the head are walked as ONE continuous stream of [64 rows][128 dist] tiles (256 contiguous
+//     bytes per row, only the tiles up to the causal diagonal) through a 4-stage LDS ring filled by the LDS-DMA three tiles ahead;
+//   * per tile and wave: 16 row fragments (ds_read_b128, the B operand: lane = row i) x the stationary A fragments ->
+//     out^T[d][i] accumulators, so a lane ends with 4 consecutive d of one row (8-byte stores, 256 B per row over the 8 waves).
+#include "db1_common.h"
+
+typedef __attribute__((ext_vector_type(8))) short dqr_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float dqr_f32x4;
+#define DQR_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+typedef __attribute__((address_space(3))) const dqr_bf16x8* dqr_lds_rd;
+
+#define DQR_ROWS 64
+#define DQR_KT 128                 // distances per tile
+#define DQR_TILE_BYTES (DQR_ROWS * DQR_KT * 2)
+#define DQR_STAGES 4                // (8 stages / 7 tiles in flight were slower: 430 vs 373 us -- the per-tile barrier + issue work bounds it, not latency)
+#define DQR_MAX_L 1024             // 32 k-steps of R^T per lane in registers
+
+struct DqrArgs {
+    const bf16_t* dT; const bf16_t* Rt; bf16_t* out;
+    int B, L, H, wph;              // wph = workgroups per head
+    int64_t o_rs, o_bs;            // row / batch strides of out (elements); head h at + h * 128
+};
+
+__device__ __forceinline__ int dqr_swz(int row) { return ((((row & 7) ^ ((row & 8) >> 1))) << 1) | ((row >> 3) & 1); }  // natural-order row fragments
+
+__device__ __forceinline__ void dqr_glds(const void* src, unsigned dst_lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst_lds) : "memory");
+}
+template <int N> __device__ __forceinline__ void dqr_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(512, 1) void relattn_dqr_kernel(DqrArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x / p.wph, j = blockIdx.x % p.wph;
+    const int L = p.L, NT = L / DQR_ROWS;
+    const int a = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)DQR_LDS_PTR(char, smem);
+
+    // stationary operand: R_h^T rows d = 16 wave + a, k = 32 ks + 8 g .. +7
+    dqr_bf16x8 rfr[DQR_MAX_L / 32];
+    {
+        const bf16_t* rt = p.Rt + ((int64_t)h * 128 + 16 * wave + a) * L + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < DQR_MAX_L / 32; ks++)
+            rfr[ks] = ks * 32 < L ? *reinterpret_cast<const dqr_bf16x8*>(rt + ks * 32) : (dqr_bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    // row-fragment read addresses inside a stage: row = 16 rt + a, 16-byte chunk 4 ks + g of the 256-byte row
+    unsigned faddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { faddr[ks] = lds0 + a * 256 + (((4 * ks + g) ^ dqr_swz(a)) << 4); asm volatile("" : "+v"(faddr[ks])); }
+    // staging: a tile = 16 pieces of 4 rows; wave w moves pieces 2w, 2w+1 (rows 8w .. 8w+7)
+    const int srow = 8 * wave + (lane >> 4);
+    const int schunk0 = ((lane & 15) ^ dqr_swz(srow & 15)) << 3, schunk1 = ((lane & 15) ^ dqr_swz((srow + 4) & 15)) << 3;
+
+    // the stream of tiles: items t = j, j + wph, ... (t -> batch b = t / NT, row tile (t + b) % NT: every workgroup sees every row tile
+    // equally often), and inside an item the k-tiles 0 .. (i0 + 63) / 128
+    const int n_items = p.B * NT;
+    struct Cur { int t, kt, nk, b, i0; };
+    auto item_of = [&](int t, Cur& c) __attribute__((always_inline)) {
+        c.t = t; c.kt = 0; c.b = t / NT; c.i0 = ((t + c.b) % NT) * DQR_ROWS; c.nk = (c.i0 + DQR_ROWS - 1) / DQR_KT + 1;
+    };
+    auto advance = [&](Cur& c) __attribute__((always_inline)) {  // next tile of the stream (c.t >= n_items: past the end)
+        if (++c.kt >= c.nk) { const int t = c.t + p.wph; if (t < n_items) item_of(t, c); else { c.t = t; c.kt = 0; c.nk = 1; } }
+    };
+    auto stage = [&](const Cur& c, int st) __attribute__((always_inline)) {
+        const bf16_t* src = p.dT + (((int64_t)h * p.B + c.b) * L + c.i0 + srow) * L + c.kt * DQR_KT;
+        const unsigned dst = lds0 + st * DQR_TILE_BYTES + wave * 2048;
+        dqr_glds(src + schunk0, dst);
+        dqr_glds(src + (int64_t)4 * L + schunk1, dst + 1024);
+    };
+    Cur cs, cc;                      // staging cursor (DQR_STAGES - 1 tiles ahead), compute cursor
+    if (j >= n_items) return;
+    item_of(j, cs);
+    cc = cs;
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < DQR_STAGES - 1; s++) {
+        if (cs.t < n_items) { stage(cs, s); issued++; advance(cs); }
+    }
+    dqr_f32x4 acc[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; rt++) acc[rt] = (dqr_f32x4){0.f, 0.f, 0.f, 0.f};
+    int st = 0;  // stage of the compute cursor's tile
+    for (; cc.t < n_items;) {
+        // the tile of the compute cursor must have landed: all but the (issued - 1) pieces pairs issued after it
+        switch (issued) {
+            case 7: dqr_vmcnt<12>(); break; case 6: dqr_vmcnt<10>(); break; case 5: dqr_vmcnt<8>(); break; case 4: dqr_vmcnt<6>(); break;
+            case 3: dqr_vmcnt<4>(); break; case 2: dqr_vmcnt<2>(); break; default: dqr_vmcnt<0>(); break;
+        }
+        __syncthreads();             // tile visible to all waves; the stage consumed last step is free
+        if (cs.t < n_items) { stage(cs, (st + DQR_STAGES - 1) % DQR_STAGES); advance(cs); } else issued--;
+        const unsigned sb = st * DQR_TILE_BYTES;
+        // k-step kk of the tile is k-step cc.kt * 4 + kk of R^T: a runtime index into the register array -> a switch on cc.kt
+#define DQR_TILE(KT)                                                                                                     \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ks++) {                                                               \
+            _Pragma("unroll") for (int rt = 0; rt < 4; rt++) {                                                           \
+                const dqr_bf16x8 bf = *(dqr_lds_rd)(size_t)(faddr[ks] + sb + rt * 4096);                                 \
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rfr[(KT) * 4 + ks], bf, acc[rt], 0, 0, 0);             \
+            }                                                                                                            \
+        }
+        switch (cc.kt) {
+            case 0: DQR_TILE(0) break; case 1: DQR_TILE(1) break; case 2: DQR_TILE(2) break; case 3: DQR_TILE(3) break;
+            case 4: DQR_TILE(4) break; case 5: DQR_TILE(5) break; case 6: DQR_TILE(6) break; default: DQR_TILE(7) break;
+        }
+        if (cc.kt == cc.nk - 1) {    // item done: out[b][i0 + 16 rt + a][h][16 wave + 4 g .. +3]
+#pragma unroll
+            for (int rt = 0; rt < 4; rt++) {
+                uint2 o;
+                o.x = f2bf_pk(acc[rt][0], acc[rt][1]);
+                o.y = f2bf_pk(acc[rt][2], acc[rt][3]);
+                *reinterpret_cast<uint2*>(p.out + (int64_t)cc.b * p.o_bs + (int64_t)(cc.i0 + 16 * rt + a) * p.o_rs + h * 128 + 16 * wave + 4 * g) = o;
+                acc[rt] = (dqr_f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        advance(cc);
+        st = (st + 1) % DQR_STAGES;
+    }
+}
+
+// R [nd][H * 128] -> Rt [H * 128][nd]
+__global__ __launch_bounds__(256) void relattn_dqr_transpose_kernel(const bf16_t* __restrict__ R, bf16_t* __restrict__ Rt, int nd, int HD, int64_t r_rs) {
+    __shared__ bf16_t tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = (r0 + r < nd && c0 + tx < HD) ? R[(int64_t)(r0 + r) * r_rs + c0 + tx] : (bf16_t)0;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (c0 + r < HD && r0 + tx < nd) Rt[(int64_t)(c0 + r) * nd + r0 + tx] = tile[tx][r];
+}
+
+static bf16_t* g_dqr_rt = nullptr;  // grow-only transposed copy of R (single compute stream, like the other workspaces)
+static size_t g_dqr_rt_bytes = 0;
+
+extern "C" int db1_relattn_dqr_supported(int B, int L, int H, int D, int dt) {
+    return (dt == DB1_BF16 && D == 128 && B > 0 && H > 0 && H <= 256 && L >= 128 && (L % 128) == 0 && L <= DQR_MAX_L) ? 1 : 0;
+}
+
+/* dq_r[b, i, h, :] = sum_dist dT[h, b, i, dist] * R[dist, h, :]; dT [H, B, L, L] bf16 (zero for dist > i), R [L, H, 128] with row stride r_rs,
+ * out [B, L, H, 128] with row / batch strides (elements) */
+extern "C" int db1_relattn_dqr(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride,
+                               int B, int L, int H, int D, void* stream) {
+    if (!db1_relattn_dqr_supported(B, L, H, D, DB1_BF16)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_dqr: needs bf16, d_head = 128, L %% 128 == 0, L <= 1024 (got L=%d D=%d)", L, D);
+    if (!dT || !R || !out) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_dqr: null buffer");
+    if (!db1_aligned16(dT) || !db1_aligned16(out) || (out_row_stride % 4) || (out_batch_stride % 4)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_dqr: alignment");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = (size_t)H * 128 * L * sizeof(bf16_t);
+    if (need > g_dqr_rt_bytes) {
+        if (g_dqr_rt) { hipDeviceSynchronize(); hipFree(g_dqr_rt); }
+        g_dqr_rt = nullptr; g_dqr_rt_bytes = 0;
+        if (hipMalloc((void**)&g_dqr_rt, need) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "relattn_dqr: cannot allocate %zu bytes", need);
+        g_dqr_rt_bytes = need;
+    }
+    relattn_dqr_transpose_kernel<<<dim3((unsigned)((H * 128 + 31) / 32), (unsigned)((L + 31) / 32)), 256, 0, st>>>((const bf16_t*)R, g_dqr_rt, L, H * 128, r_row_stride);
+    DB1_CHECK_LAUNCH("relattn_dqr transpose");
+    DqrArgs a;
+    a.dT = (const bf16_t*)dT; a.Rt = g_dqr_rt; a.out = (bf16_t*)out; a.B = B; a.L = L; a.H = H;
+    a.wph = 256 / H > 0 ? 256 / H : 1;
+    a.o_rs = out_row_stride; a.o_bs = out_batch_stride;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)relattn_dqr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQR_STAGES * DQR_TILE_BYTES); attr = true; }
+    relattn_dqr_kernel<<<dim3((unsigned)(H * a.wph)), 512, DQR_STAGES * DQR_TILE_BYTES, st>>>(a);
+    DB1_CHECK_LAUNCH("relattn_dqr");
+    return DB1_OK;
+}

@@ -741,8 +741,11 @@ class TransformerXL(nn.Module):
         dq2d = dqkv.view(B * L, 3 * d)[:, :d]
         dqv = self._new(B, L, H, D)
         tri = c.flash and self.use_flash_bwd  # the fused backward's dT is zero above the causal diagonal (dist > i): skip those k-tiles
-        ops.gemm_batched(dT, R.view(nd, H, D).permute(1, 0, 2).unsqueeze(1).expand(H, B, nd, D), dqv.permute(2, 0, 1, 3),
-                         tri=(1, 0) if tri else (0, 0))                                                                   # dq_r
+        if tri and nd == L and ops.relattn_dqr_supported(B, L, H, D, self.compute_dtype):
+            ops.relattn_dqr(dT, R, dqv)                                                                                   # dq_r, dT streamed once
+        else:
+            ops.gemm_batched(dT, R.view(nd, H, D).permute(1, 0, 2).unsqueeze(1).expand(H, B, nd, D), dqv.permute(2, 0, 1, 3),
+                             tri=(1, 0) if tri else (0, 0))                                                               # dq_r
         dR = self._new(nd, d)
         ops.gemm_batched(dT.view(H, B * L, nd).transpose(1, 2).unsqueeze(1), qv.view(B * L, H, D).permute(1, 0, 2).unsqueeze(1),
                          dR.view(nd, H, D).permute(1, 0, 2).unsqueeze(1), tri=(2, L) if tri else (0, 0))

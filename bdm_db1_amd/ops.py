@@ -116,6 +116,18 @@ def gemm_batched(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: flo
     return out
 
 
+def relattn_dqr_supported(B, L, H, D, dtype) -> bool:
+    return bool(lib.load().db1_relattn_dqr_supported(B, L, H, D, dt_code(dtype)))
+
+
+def relattn_dqr(dT, R, dqv):
+    """dqv[b, i, h, :] = sum_dist dT[h, b, i, dist] R[dist, h, :]  (dT [H,B,L,L] bf16 zero above the causal diagonal, R [L, H*D], dqv [B,L,H,D])"""
+    H, B, L, _ = dT.shape
+    D = dqv.shape[-1]
+    assert dT.is_contiguous() and R.stride(1) == 1 and dqv.stride(3) == 1 and dqv.stride(2) == D
+    lib.call("db1_relattn_dqr", P(dT), P(R), R.stride(0), P(dqv), dqv.stride(1), dqv.stride(0), B, L, H, D, stream())
+
+
 def layernorm_residual_fwd(x, r, alpha, gamma, beta, y, s_out, mean, rstd, eps):
     rows, d = x.numel() // x.shape[-1], x.shape[-1]
     lib.call("db1_layernorm_residual_fwd", P(x), P(r), float(alpha), P(gamma), P(beta), P(y), P(s_out), P(mean), P(rstd),

@@ -189,6 +189,13 @@ int db1_relattn_flash_bwd(const void* qu, const void* qv, const void* k, const v
                           float* delta, void* dq, void* dk, void* dv, int64_t dqkv_row_stride, int64_t dqkv_batch_stride,
                           void* dT, int B, int L, int H, int D, int shift, float scale, void* stream);
 
+/* dq_r[b, i, h, :] = sum_{dist} dT[h, b, i, dist] * R[dist, h, :] (the (q+v).R branch of the query gradient, transformer_xl.py:160-209) as a
+ * stream over dT with R stationary in registers: dT [H,B,L,L] bf16 (zero for dist > i), R [L, H*128] bf16 with row stride r_row_stride,
+ * out [B,L,H,128] bf16 with row / batch strides in elements.  Same result as db1_gemm_strided_tri on the same operands. */
+int db1_relattn_dqr_supported(int B, int L, int H, int D, int dt);
+int db1_relattn_dqr(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride,
+                    int B, int L, int H, int D, void* stream);
+
 /* ------------------------------------------------------------------ image-patch embedder pieces
  * (src/tokenizer/vision_embedding.py:65-86).  pixels [N_img, C, Himg, Wimg] -> normalised patches
  * [(n h w), C, p, p]: (x-mean)/(1e-6+std_unbiased)/sqrt(p) per (patch, channel). */

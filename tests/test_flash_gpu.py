@@ -186,3 +186,21 @@ def test_model_bf16_flash_vs_oracle_and_vs_materialised():
         for n in ("h.0.dec_attn.qkv_net.weight", "h.1.dec_attn.o_net.weight", "r_w_bias", "r_r_bias", "h.0.dec_attn.r_net.weight", "word_embedding.weight"):
             assert rel_err(results[flash][2][n], ref_grads[n]) < 6e-2, (flash, n)
     assert np.abs(results[True][0] - results[False][0]).max() / np.abs(ref_logits).max() < 2e-2
+
+
+@pytest.mark.parametrize("B,L,H", [(2, 256, 2), (3, 1024, 3), (1, 640, 1), (20, 128, 16)])
+def test_dq_r_stream_kernel_matches_the_batched_gemm(B, L, H):
+    """dq_r = dT.R with dT streamed once and R stationary in registers vs the same contraction on the tile GEMM"""
+    from bdm_db1_amd import ops
+    D = 128
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + L)
+    dT = (torch.randn(H, B, L, L, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    ii = torch.arange(L, device=DEV)
+    dT = dT * (ii[None, :] <= ii[:, None]).to(torch.bfloat16)          # zero above the causal diagonal (dist > i)
+    R = torch.randn(L, H * D, generator=g).to(torch.bfloat16).to(DEV)
+    assert ops.relattn_dqr_supported(B, L, H, D, torch.bfloat16)
+    out = torch.full((B, L, H, D), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.relattn_dqr(dT, R, out)
+    ref = torch.einsum("hbik,khd->bihd", dT.float(), R.view(L, H, D).float())
+    err = float((out.float() - ref).abs().max() / ref.abs().max())
+    assert err < 6e-3, err

@@ -93,6 +93,10 @@ def small_out(B=16, L=1024):
     for tri in ((0, 0), (1, 0)):
         t = timeit(lambda: ops.gemm_batched(dT, R.permute(1, 0, 2).unsqueeze(1).expand(H, B, L, D), dqv.permute(2, 0, 1, 3), tri=tri))
         print(f"dq_r M={L} N={D} K={L} x{H * B} tri={tri[0]}: {t * 1e3:8.1f} us")
+    if ops.relattn_dqr_supported(B, L, H, D, torch.bfloat16):
+        dTc = dT * torch.tril(torch.ones(L, L, device=DEV)).to(torch.bfloat16)
+        t = timeit(lambda: ops.relattn_dqr(dTc, R.view(L, H * D), dqv))
+        print(f"dq_r stream kernel: {t * 1e3:8.1f} us  ({dT.numel() / t / 1e6:7.1f} GB/s of the causal half of dT)")
 
 
 if __name__ == "__main__":
