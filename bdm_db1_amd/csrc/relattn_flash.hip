@@ -5,7 +5,7 @@
 // db1_relattn_add_head_bias.  Backward = two kernels without atomics (deterministic):
 //   bwd_q : per 128 queries, loop keys    -> delta = rowsum(dO * O), dq_k = dS.K (the (q+u).k branch) and dT = dS re-indexed by distance (bf16, HBM);
 //   bwd_kv: per 128 keys,    loop queries -> dV = P^T.dO, dK = dS^T.Qu.
-// dq_r = dT.R and dR = dT^T.Qv are plain batched GEMMs on dT (exact causal FLOPs, no band overhead) run by the caller.
+// dq_r = dT.R (relattn_dqr.hip, a stream over dT) and dR = dT^T.Qv (a batched tile GEMM) are run by the caller on dT: exact causal FLOPs, no band overhead.
 //
 // All three kernels: one workgroup = 128 rows of one (batch, head) = 8 waves x 16 rows (two waves per SIMD) on
 // v_mfma_f32_16x16x32_bf16, 32-column blocks, a 256-row LDS ring of R rows (the band of distances slides by 32 per block), operand
