@@ -251,6 +251,7 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
         t.batch1 = batch1; t.a_bs0 = a_bs0; t.a_bs1 = a_bs1; t.b_bs0 = b_bs0; t.b_bs1 = b_bs1; t.c_bs0 = c_bs0; t.c_bs1 = c_bs1;
         t.alpha = alpha; t.beta = beta; t.tiles_m = (M + TBM - 1) / TBM; t.tiles_n = (N + TBN - 1) / TBN;
         t.tri_mode = g_tri_mode; t.tri_period = g_tri_period;
+        t.split_n = 0; t.Cu = nullptr; t.Cv = nullptr; t.bias_u = nullptr; t.bias_v = nullptr; t.ld_uv = 0;
         if (t.tri_mode == 2 && (t.tri_period <= 0 || (t.tri_period % TBK) || (K % t.tri_period))) t.tri_mode = 0;
         // measured on MI355X at the DB1-1.3B shapes (tools/bench_kernels.py gemm; table in DESIGN.md): the 256x256 ping-pong
         // kernel wins by 15-35 % wherever it has >= ~160 output tiles to spread over the 256 CUs; below that the 3-stage
@@ -370,6 +371,27 @@ extern "C" int db1_gemm_strided_tri(const void* A, const void* B, void* C, const
 extern "C" int db1_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                            int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream) {
     return db1_gemm_strided(A, B, C, bias, M, N, K, dtAB, dtAB, dtC, dtAB, lda, 1, 1, ldb, ldc, 1, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, stream);
+}
+// y = x W^T for the attention input projection with the two head biases folded into the epilogue (see GemmTileArgs::split_n)
+extern "C" int db1_gemm_nt_headbias_supported(int M, int N, int K, int split_n) {
+    return (M > 0 && (M % 256) == 0 && (N % 256) == 0 && (K % TBK) == 0 && split_n > 0 && (split_n % 256) == 0 && split_n < N &&
+            (int64_t)(M / 256) * (N / 256) >= 160) ? 1 : 0;
+}
+extern "C" int db1_gemm_nt_headbias(const void* A, const void* W, void* C, void* Cu, void* Cv, const void* bias_u, const void* bias_v, int M, int N, int K,
+                                    int split_n, int64_t lda, int64_t ldw, int64_t ldc, int64_t ld_uv, void* stream) {
+    if (!db1_gemm_nt_headbias_supported(M, N, K, split_n)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "gemm_nt_headbias: M=%d N=%d K=%d split=%d", M, N, K, split_n);
+    if (!A || !W || !C || !Cu || !Cv || !bias_u || !bias_v) DB1_FAIL(DB1_ERR_BAD_SHAPE, "gemm_nt_headbias: null operand");
+    if (!db1_aligned16(A) || !db1_aligned16(W) || !db1_aligned16(C) || !db1_aligned16(Cu) || !db1_aligned16(Cv) || (lda % 8) || (ldw % 8) || (ldc % 4) ||
+        (ld_uv % 4) || lda < K || ldw < K || ldc < N || ld_uv < split_n)
+        DB1_FAIL(DB1_ERR_BAD_ALIGN, "gemm_nt_headbias: alignment / leading dimensions");
+    GemmTileArgs t;
+    t.A = (const bf16_t*)A; t.B = (const bf16_t*)W; t.C = C; t.bias = nullptr;
+    t.M = M; t.N = N; t.K = K; t.lda = lda; t.ldb = ldw; t.ldc = ldc;
+    t.batch1 = 1; t.a_bs0 = t.a_bs1 = t.b_bs0 = t.b_bs1 = t.c_bs0 = t.c_bs1 = 0;
+    t.alpha = 1.f; t.beta = 0.f; t.tiles_m = M / 256; t.tiles_n = N / 256; t.ksplit = 1;
+    t.tri_mode = 0; t.tri_period = 0;
+    t.split_n = split_n; t.Cu = Cu; t.Cv = Cv; t.bias_u = bias_u; t.bias_v = bias_v; t.ld_uv = ld_uv;
+    return db1_gemm_pp_launch(t, 0, 0, DB1_BF16, DB1_BF16, 1, (hipStream_t)stream);
 }
 extern "C" int db1_gemm_nn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                            int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream) {

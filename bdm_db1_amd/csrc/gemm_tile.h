@@ -26,6 +26,12 @@ struct GemmTileArgs {
     //   1: A[m, k] == 0 for k > m                      -> k-tiles beyond the tile's last row are skipped (dq_r = dT . R)
     //   2: A[m, k] == 0 for (k mod tri_period) < m     -> per period only the k-tiles from the tile's first row on (dR = dT^T . qv)
     int tri_mode, tri_period;
+    // head-bias epilogue of the attention input projection (ping-pong NT kernel only): columns n < split_n are written TWICE, as
+    // acc + bias_u[n] to Cu and acc + bias_v[n] to Cv (row stride ld_uv) instead of to C: q + r_w_bias and q + r_r_bias straight from
+    // the accumulators (db1_gemm_nt_headbias); 0 = off
+    int split_n;
+    void* Cu; void* Cv; const void* bias_u; const void* bias_v;
+    int64_t ld_uv;
 };
 
 // ---- staging of one 16 KiB operand (sub-)tile = 16 wave-instructions of 1 KiB, PIECES per wave (wave w takes w*PIECES ..)

@@ -143,6 +143,7 @@ class TransformerXL(nn.Module):
         self.keep_logits = True          # False: the CE backward overwrites the logits buffer (training engines)
         self.use_flash = True            # fused attention when the shape is supported
         self.use_flash_bwd = True        # fused backward kernels (False: recompute through the materialised path)
+        self.use_headbias_epilogue = True  # q + r_w_bias / q + r_r_bias written by the qkv projection's epilogue (large bf16 batches)
         self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
         self._conv_ops = {}              # (weight name, weight version) -> tap-major GEMM operand
@@ -626,14 +627,18 @@ class TransformerXL(nn.Module):
         ops.relattn_softmax_fwd(AC, T, None, H, B, Lq, Lk, nd, mlen, shift, 1.0 / math.sqrt(D))
         return AC, T, qu, qv
 
-    def _attention_fwd(self, qkv, R, i, B, Lq, Lk, mlen, shift, c: Optional[_Ctx]):
+    def _attention_fwd(self, qkv, R, i, B, Lq, Lk, mlen, shift, c: Optional[_Ctx], quv=None):
         H, D = self.n_head, self.d_head
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
         av = self._new(B, Lq, H, D)
         flash = (self.use_flash and mlen == 0 and Lq == Lk and ops.relattn_flash_supported(B, Lq, H, D, self.compute_dtype))
+        assert quv is None or flash
         if flash:
-            qu, qv = self._new(B, Lq, H, D), self._new(B, Lq, H, D)
-            ops.relattn_add_head_bias(qkv, u, vb, qu, qv, B, Lq, Lk, H, D)
+            if quv is not None:  # written by the projection's epilogue (db1_gemm_nt_headbias)
+                qu, qv = quv
+            else:
+                qu, qv = self._new(B, Lq, H, D), self._new(B, Lq, H, D)
+                ops.relattn_add_head_bias(qkv, u, vb, qu, qv, B, Lq, Lk, H, D)
             lse = self._new(B, H, Lq, dtype=torch.float32)
             ops.relattn_flash_fwd(qu, qv, qkv.view(B, Lk, 3, H, D), R, av, lse, B, Lq, H, D, shift, 1.0 / math.sqrt(D))
             if c is not None:
@@ -772,10 +777,19 @@ class TransformerXL(nn.Module):
             else:
                 Lk, xin = L, x
             qkv = self._new(B * Lk, 3 * d)
-            ops.gemm(xin, self.W(p + "dec_attn.qkv_net.weight").t(), qkv)
+            quv = None
+            Wqkv = self.W(p + "dec_attn.qkv_net.weight")
+            if (mem is None and self.use_flash and self.use_flash_bwd and self.compute_dtype == torch.bfloat16 and self.use_headbias_epilogue and
+                    ops.relattn_flash_supported(B, L, self.n_head, self.d_head, self.compute_dtype) and
+                    ops.gemm_nt_headbias_supported(T, 3 * d, d, d)):
+                # q + r_w_bias and q + r_r_bias leave the projection's accumulators directly (the q columns of qkv stay unwritten)
+                quv = (self._new(B, L, self.n_head, self.d_head), self._new(B, L, self.n_head, self.d_head))
+                ops.gemm_nt_headbias(xin, Wqkv, qkv, quv[0], quv[1], self._bias("r_w_bias", i), self._bias("r_r_bias", i), d)
+            else:
+                ops.gemm(xin, Wqkv.t(), qkv)
             R = self._new(R_in.shape[0], d)
             ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
-            av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c)
+            av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c, quv=quv)
         o = self._new(T, d)
         ops.gemm(av.view(T, d), self.W(p + "dec_attn.o_net.weight").t(), o)
         h1 = self._new(T, d)

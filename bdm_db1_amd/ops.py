@@ -95,6 +95,27 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias: Optional[tor
     return out
 
 
+def gemm_nt_headbias_supported(M, N, K, split_n) -> bool:
+    return bool(lib.load().db1_gemm_nt_headbias_supported(M, N, K, split_n))
+
+
+def gemm_nt_headbias(x, w, out, qu, qv, bias_u, bias_v, split_n):
+    """out[:, split_n:] = (x w^T)[:, split_n:];  qu = (x w^T)[:, :split_n] + bias_u, qv = ... + bias_v (bf16; out[:, :split_n] is NOT written)"""
+    M, K = x.shape
+    N = w.shape[0]
+    assert x.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1 and qu.is_contiguous() and qv.is_contiguous()
+    assert x.dtype == w.dtype == out.dtype == qu.dtype == bias_u.dtype == torch.bfloat16 and bias_u.numel() == split_n == bias_v.numel()
+
+    def run():
+        lib.call("db1_gemm_nt_headbias", P(x), P(w), P(out), P(qu), P(qv), P(bias_u), P(bias_v), M, N, K, split_n, x.stride(0), w.stride(0),
+                 out.stride(0), split_n, stream())
+
+    if _gemm_timer is not None:
+        _gemm_timer.wrap(2.0 * M * N * K, run)
+    else:
+        run()
+
+
 def gemm_batched(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, beta: float = 0.0, tri=(0, 0)):
     """4-D views [z0, z1, rows, cols] with arbitrary strides (stride 0 broadcasts).
     ``tri`` = (mode, period): structural-zero hint for ``a`` (db1_gemm_strided_tri), an optimisation only."""

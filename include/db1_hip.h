@@ -73,6 +73,12 @@ int db1_gemm_strided_tri(const void* A, const void* B, void* C, const void* bias
                          int tri_mode, int tri_period, void* stream);
 int db1_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
                 int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream);
+/* The attention input projection (transformer_xl.py:136-141,160-175): C[M,N] = A[M,K] * W[N,K]^T in bf16, except that the columns n < split_n
+ * (the query block) are written as acc + bias_u[n] to Cu and acc + bias_v[n] to Cv (row stride ld_uv) instead of to C: q + r_w_bias and
+ * q + r_r_bias leave the GEMM's accumulators directly (no separate pass, one rounding).  Large shapes only (see _supported). */
+int db1_gemm_nt_headbias_supported(int M, int N, int K, int split_n);
+int db1_gemm_nt_headbias(const void* A, const void* W, void* C, void* Cu, void* Cv, const void* bias_u, const void* bias_v, int M, int N, int K,
+                         int split_n, int64_t lda, int64_t ldw, int64_t ldc, int64_t ld_uv, void* stream);
 int db1_gemm_nn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
                 int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream);
 int db1_gemm_tn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,

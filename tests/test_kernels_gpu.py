@@ -291,6 +291,27 @@ def test_gemm_bf16_short_last_wave_and_half_wave_split(ops):
         assert err < 2e-5, f"M={M} N={N} K={K}: {err:.3e}"
 
 
+def test_gemm_nt_head_bias_epilogue(ops):
+    """the attention input projection with q + r_w_bias / q + r_r_bias written from the accumulators (db1_gemm_nt_headbias)"""
+    g = torch.Generator(device="cpu").manual_seed(9)
+    M, d, K = 4096 * 4, 1024, 512   # 64 x 12 tiles of 256x256
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(3 * d, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    u = torch.randn(d, generator=g).to(torch.bfloat16).to(DEV)
+    v = torch.randn(d, generator=g).to(torch.bfloat16).to(DEV)
+    assert ops.gemm_nt_headbias_supported(M, 3 * d, K, d)
+    out = torch.full((M, 3 * d), 5.0, device=DEV, dtype=torch.bfloat16)
+    qu = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    qv = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt_headbias(x, w, out, qu, qv, u, v, d)
+    ref = x.float() @ w.float().t()
+    sc = float(ref.abs().max())
+    assert float((out[:, d:].float() - ref[:, d:]).abs().max()) / sc < 6e-3
+    assert float((qu.float() - (ref[:, :d] + u.float())).abs().max()) / sc < 6e-3
+    assert float((qv.float() - (ref[:, :d] + v.float())).abs().max()) / sc < 6e-3
+    assert bool((out[:, :d] == 5.0).all()), "the query columns of the packed output are not written"
+
+
 def test_gemm_bf16_tile_large_k_and_batch(ops):
     rng = np.random.default_rng(4)
     Z, M, N, K = 3, 128, 128, 1024
