@@ -265,3 +265,25 @@ def test_bf16_channels_last_vision_path_matches_nchw_path_and_oracle():
     for n in names:
         assert rel_err(res[True][1][n], res[False][1][n]) < 3e-2, n
         assert rel_err(res[True][1][n], res["explicit-columns"][1][n]) < 3e-2, n
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the driver's keys, the roofline and (here skipped) cpu_baseline objects; tiny debug geometry"""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--layers", "2", "--batch", "4",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"].startswith("synthetic") and "workload" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 4 * 1024 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
