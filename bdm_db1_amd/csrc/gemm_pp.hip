@@ -183,18 +183,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmTileArgs p) {
             __builtin_amdgcn_s_barrier();
         }
     }
-    if (A_KMAJOR && B_KMAJOR && p.split_n > 0 && n0 < p.split_n) {  // (workgroup-uniform: split_n is a multiple of the tile width)
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int m = m0 + grp * 128 + i * 16 + (lane & 15), n = n0 + u * 64 + j * 16 + (lane >> 4) * 4;
-                store_frag<TC, TBIAS>(acc[i][j], (TC*)p.Cu, p.ld_uv, m, n, p.alpha, 0.f, p.bias_u);
-                store_frag<TC, TBIAS>(acc[i][j], (TC*)p.Cv, p.ld_uv, m, n, p.alpha, 0.f, p.bias_v);
-            }
+    if (A_KMAJOR && B_KMAJOR && sizeof(TC) == 2 && p.split_n > 0 && n0 < p.split_n) {  // (workgroup-uniform: split_n is a multiple of the tile width)
+        __syncthreads();
+        store_wave_tile_bf16<TBIAS>(acc, smem + wave * 16384, (bf16_t*)p.Cu, p.ld_uv, m0 + grp * 128, n0 + u * 64, p.alpha, p.bias_u, lane);
+        store_wave_tile_bf16<TBIAS>(acc, smem + wave * 16384, (bf16_t*)p.Cv, p.ld_uv, m0 + grp * 128, n0 + u * 64, p.alpha, p.bias_v, lane);
         return;
     }
     TC* C = (TC*)p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
+    if (sizeof(TC) == 2 && p.beta == 0.f) {  // bf16 output, nothing to accumulate: full-line stores through the (now free) operand stages
+        __syncthreads();
+        store_wave_tile_bf16<TBIAS>(acc, smem + wave * 16384, (bf16_t*)C, p.ldc, m0 + grp * 128, n0 + u * 64, p.alpha, p.bias, lane);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll

@@ -168,6 +168,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp32_kernel(GemmTileArgs p) 
         }
     }
     TC* C = (TC*)p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
+    if (sizeof(TC) == 2 && p.beta == 0.f) {  // bf16 output, nothing to accumulate: full-line stores through the (now free) operand stages
+        __syncthreads();
+        store_wave_tile_bf16<TBIAS>(acc, smem + wave * 16384, (bf16_t*)C, p.ldc, m0 + grp * 128, n0 + u * 64, p.alpha, p.bias, lane);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll

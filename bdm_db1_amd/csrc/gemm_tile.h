@@ -118,6 +118,45 @@ __device__ __forceinline__ void store_frag(const f32x4& acc, TC* C, int64_t ldc,
     }
 }
 
+// ---- bf16 epilogue of a 128 x 64 wave tile (8 x 4 swapped-layout fragments) through a 16 KiB LDS region private to the wave.
+// The per-fragment store (store_frag: 8 bytes per lane = 16 rows x 32-byte pieces per instruction) made the epilogue store-ISSUE bound:
+// 256 store instructions per 256 x 256 tile at ~60 cycles each = 13-20 % of a K = 2048 GEMM, exposed because the tile's workgroup is
+// alone on its CU (measured by skipping the stores: ff1 NT 1867 -> 1625 us).  Staged, a wave issues 16 stores of 8 rows x one full
+// 128-byte line.  LDS image: row r at r * 128 bytes, 8-byte granule q at q ^ (r & 14) (conflict-free for the fragment writes and the
+// 16-byte row reads, and it keeps the two granules of a 16-byte chunk in order).  beta must be 0 (the staged value is already rounded).
+typedef __attribute__((ext_vector_type(2))) unsigned gt_u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned gt_u32x4;
+template <typename TBIAS>
+__device__ __forceinline__ void store_wave_tile_bf16(const f32x4 (&acc)[8][4], char* lds_wave, bf16_t* C, int64_t ldc, int m_base, int n_base,
+                                                     float alpha, const void* bias, int lane) {
+    const int m = lane & 15, g = lane >> 4;
+    const unsigned w0 = (unsigned)(size_t)LDS_PTR(char, lds_wave);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) b[r] = ldf((const TBIAS*)bias + n_base + j * 16 + g * 4 + r);
+        }
+        const unsigned wa = w0 + m * 128 + (((4 * j + g) ^ (m & 14)) << 3);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            gt_u32x2 o;
+            o[0] = f2bf_pk(alpha * acc[i][j][0] + b[0], alpha * acc[i][j][1] + b[1]);
+            o[1] = f2bf_pk(alpha * acc[i][j][2] + b[2], alpha * acc[i][j][3] + b[3]);
+            *(__attribute__((address_space(3))) gt_u32x2*)(size_t)(wa + i * 2048) = o;
+        }
+    }
+    const int rr = lane >> 3, c = lane & 7;
+    bf16_t* dst = C + (int64_t)(m_base + rr) * ldc + n_base + c * 8;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {  // rows 8 it + rr:  (8 it + rr) & 14 == rr & 14 | (8 it & 14) -> the XOR term changes with it & 1
+        const unsigned a = w0 + (8 * it + rr) * 128 + (((2 * c) ^ ((8 * it + rr) & 14)) << 3);
+        const gt_u32x4 v = *(__attribute__((address_space(3))) const gt_u32x4*)(size_t)a;
+        *reinterpret_cast<gt_u32x4*>(dst + (int64_t)(8 * it) * ldc) = v;
+    }
+}
+
 // XCD-aware tile walk: hardware block ids round-robin over the 8 XCDs (private L2s); give each XCD a contiguous span of
 // tiles, walked column-major inside bands of `band` tile-rows so neighbouring workgroups share A and B panels in L2.
 __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int band, int& tm, int& tn) {
