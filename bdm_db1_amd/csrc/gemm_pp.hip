@@ -195,6 +195,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmTileArgs p) {
         store_wave_tile_bf16<TBIAS>(acc, smem + wave * 16384, (bf16_t*)C, p.ldc, m0 + grp * 128, n0 + u * 64, p.alpha, p.bias, lane);
         return;
     }
+    if (sizeof(TC) == 2) {  // bf16 output accumulated onto C: fp32 staging, two halves of 64 rows
+        __syncthreads();
+        store_wave_half_bf16_beta<TBIAS, 0>(acc, smem + wave * 16384, (bf16_t*)C, p.ldc, m0 + grp * 128, n0 + u * 64, p.alpha, p.beta, p.bias, lane);
+        store_wave_half_bf16_beta<TBIAS, 4>(acc, smem + wave * 16384, (bf16_t*)C, p.ldc, m0 + grp * 128, n0 + u * 64, p.alpha, p.beta, p.bias, lane);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll

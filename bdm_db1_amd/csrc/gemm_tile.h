@@ -157,6 +157,46 @@ __device__ __forceinline__ void store_wave_tile_bf16(const f32x4 (&acc)[8][4], c
     }
 }
 
+// The same for beta != 0 (bf16 C is read, scaled and added before the ONE rounding): the alpha * acc + bias values are staged in fp32,
+// 64 rows at a time (16 KiB per wave: row r at r * 256 bytes, 16-byte chunk q at q ^ (r & 15)), and every lane then handles 4 consecutive
+// columns of a row: 8-byte C loads and stores that cover 4 rows x one full 128-byte line per instruction.
+template <typename TBIAS, int I0>
+__device__ __forceinline__ void store_wave_half_bf16_beta(const f32x4 (&acc)[8][4], char* lds_wave, bf16_t* C, int64_t ldc, int m_base, int n_base,
+                                                          float alpha, float beta, const void* bias, int lane) {
+    const int m = lane & 15, g = lane >> 4;
+    const unsigned w0 = (unsigned)(size_t)LDS_PTR(char, lds_wave);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) b[r] = ldf((const TBIAS*)bias + n_base + j * 16 + g * 4 + r);
+        }
+        const unsigned wa = w0 + m * 256 + (((4 * j + g) ^ m) << 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = alpha * acc[I0 + i][j][r] + b[r];
+            *(__attribute__((address_space(3))) f32x4*)(size_t)(wa + i * 4096) = o;
+        }
+    }
+    const int rr = lane >> 4, c = lane & 15;
+    bf16_t* dst = C + (int64_t)(m_base + I0 * 16 + rr) * ldc + n_base + c * 4;
+    const int64_t step = 4 * ldc;
+#pragma unroll 4
+    for (int it = 0; it < 16; it++) {  // rows 4 it + rr
+        const int row = 4 * it + rr;
+        const f32x4 v = *(__attribute__((address_space(3))) const f32x4*)(size_t)(w0 + row * 256 + ((c ^ (row & 15)) << 4));
+        const gt_u32x2 o = *reinterpret_cast<const gt_u32x2*>(dst);
+        gt_u32x2 w;
+        w[0] = f2bf_pk(v[0] + beta * __uint_as_float(o[0] << 16), v[1] + beta * __uint_as_float(o[0] & 0xffff0000u));
+        w[1] = f2bf_pk(v[2] + beta * __uint_as_float(o[1] << 16), v[3] + beta * __uint_as_float(o[1] & 0xffff0000u));
+        *reinterpret_cast<gt_u32x2*>(dst) = w;
+        dst += step;
+    }
+}
+
 // XCD-aware tile walk: hardware block ids round-robin over the 8 XCDs (private L2s); give each XCD a contiguous span of
 // tiles, walked column-major inside bands of `band` tile-rows so neighbouring workgroups share A and B panels in L2.
 __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int band, int& tm, int& tn) {

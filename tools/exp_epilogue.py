@@ -1,16 +1,15 @@
-import torch, sys
-sys.path.insert(0, '.')
+"""Experiment: epilogue cost of the bf16-output ping-pong GEMMs (beta = 0: bf16 staging; beta != 0: fp32 staging + C read)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
 from bdm_db1_amd import ops
-sys.path.insert(0, 'tools')
 from bench_kernels import timeit
-DEV='cuda'
-M,N,K=65536,8192,2048
-x=torch.randn(M,K,device=DEV).to(torch.bfloat16); w=(torch.randn(N,K,device=DEV)*0.02).to(torch.bfloat16)
-y=torch.empty(M,N,device=DEV,dtype=torch.bfloat16)
-for alpha in (1.0, 12345.0, 1.0, 12345.0):
-    t=timeit(lambda: ops.gemm(x,w.t(),y,alpha=alpha))
-    print('NT ff1 alpha',alpha, f'{t*1e3:.1f} us')
-yf=torch.empty(M,N,device=DEV,dtype=torch.float32)
-for alpha in (1.0, 12345.0):
-    t=timeit(lambda: ops.gemm(x,w.t(),yf,alpha=alpha))
-    print('NT ff1 f32 out alpha',alpha, f'{t*1e3:.1f} us')
+DEV = "cuda"
+M, N, K = 65536, 2048, 8192
+dz = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+w = (torch.randn(K, N, device=DEV) * 0.02).to(torch.bfloat16)
+y = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+for beta in (0.0, 0.9, 0.0, 0.9):
+    t = timeit(lambda: ops.gemm(dz, w, y, beta=beta))
+    print(f"NN M={M} N={N} K={K} beta={beta}: {t * 1e3:8.1f} us  {2.0 * M * N * K / t / 1e9:7.1f} TFLOP/s")
