@@ -33,7 +33,7 @@ def _digest() -> str:
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
         p = os.path.join(CSRC, f)
-        if os.path.isfile(p) and f.endswith((".hip", ".h")):
+        if os.path.isfile(p) and f.endswith((".hip", ".h", ".inc")):
             h.update(f.encode())
             h.update(open(p, "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "db1_hip.h"), "rb").read())
