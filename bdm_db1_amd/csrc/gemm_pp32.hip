@@ -206,6 +206,7 @@ static void launch_pp32(const GemmTileArgs& t, int dtC, int dtBias, dim3 grid, h
 }
 
 int db1_gemm_pp32_launch(const GemmTileArgs& t_in, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st) {
+    if (db1_gemm_w4_supported(t_in, fa, fb, dtC, batch)) return db1_gemm_w4_launch(t_in, fa, fb, dtC, dtBias, batch, st);
     GemmTileArgs t = t_in;
     t.tiles_m = t.M / 256;
     t.tiles_n = t.N / 256;

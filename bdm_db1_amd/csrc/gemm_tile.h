@@ -213,7 +213,7 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
 int db1_gemm_tile256_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);
 int db1_gemm_pp_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);
 bool db1_gemm_w4_supported(const GemmTileArgs& t, int fa, int fb, int dtC, int batch);
-int db1_gemm_w4_launch(const GemmTileArgs& t, int dtBias, hipStream_t st);
+int db1_gemm_w4_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);
 int db1_gemm_pp32_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);
 int db1_gemm_skinny_launch(const bf16_t* x, const bf16_t* w, void* y, const void* bias, int M, int N, int K, int64_t ldx, int64_t ldw,
                            int64_t ldy, float alpha, float beta, int dtC, int dtBias, hipStream_t st);

@@ -132,9 +132,11 @@ def test_gemm_bf16_tile_kernels(ops, form, out_dtype):
 
 @pytest.mark.parametrize("form", ["nt", "nn", "tn"])
 @pytest.mark.parametrize("tile", [256, 512, 1024])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 320), (768, 512, 1024)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 320), (768, 512, 1024), (512, 768, 256), (768, 512, 384)])
 def test_gemm_bf16_large_tile_kernels(ops, form, tile, M, N, K):
-    """the 256x128 3-stage and the two 256x256 ping-pong kernels, pinned through the ABI hook: 1, odd and even k-tile counts"""
+    """the 256x128 3-stage and the 256x256 kernels, pinned through the ABI hook: 1, odd and even k-tile counts (tiles 512 / 1024 with K a
+    multiple of 128 from 256 on take the hand-scheduled 4-wave loops: 4, 6 and 16 k-tiles, all three operand layouts, fp32 and bf16
+    outputs accumulated onto C with bias)"""
     rng = np.random.default_rng(7)
     A = bf(rng.standard_normal((M, K)))
     B = bf(rng.standard_normal((K, N)))
