@@ -198,7 +198,7 @@ def main():
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
                            "traffic_source": traffic_src,
-                           "kernel": "bf16 MFMA tile GEMM family gemm_bf16_{pp,pp32,tile256,tile}_kernel (every tile-GEMM launch of the timed steps incl. the batched dR contraction and split-K reduces, rank 0)",
+                           "kernel": "bf16 MFMA tile GEMM family gemm_bf16_{w4,pp,pp32,tile256,tile}_kernel (every tile-GEMM launch of the timed steps incl. the batched dR contraction and split-K reduces, rank 0)",
                            "launches": timer.launches, "avg_launch_us": round(ms * 1e3 / timer.launches, 2),
                            "flop_per_launch_avg": round(timer.flops / timer.launches),
                            "kernel_time_share_of_step": round(ms / (dt * 1e3), 4)}

@@ -7,10 +7,10 @@ fragment reads and the LDS-DMA issue behind, so the loop is software-pipelined b
 stream (physical registers, counted waits) as ONE inline-asm string; hipcc's scheduler, waitcnt pass and register allocator
 never see it.  Timeline of k-tile t (stage s = t & 1), one "slot" = one MFMA (16 cycles):
 
-  P0  64 MFMAs on fragment set F0 = (t, ks 0)   | slots 0-15: fragment reads (t, ks 1) -> F1 | after 31: lgkmcnt(0), barrier A
-      (stage s is free now) | slots 33..61: 8 LDS-DMA of k-tile t+2 -> stage s
-  P1  64 MFMAs on F1                            | slots 1..29: 8 LDS-DMA | slot 32: pointer step | after 39: vmcnt, barrier B
-      (k-tile t+1 has landed) | slots 44-59: fragment reads (t+1, ks 0) -> F0 | end: lgkmcnt(0)
+  P0  64 MFMAs on fragment set F0 = (t, ks 0)   | slots 0-15: fragment reads (t, ks 1) -> F1 | after 19: lgkmcnt(0), barrier A
+      (stage s is free now) | from slot 20, every 7th slot until slot 62 of P1: one of the 16 LDS-DMA requests of k-tile t+2 -> stage s
+  P1  64 MFMAs on F1                            | after 39: counted vmcnt (k-tile t+1 has landed, 12 requests of t+2 may be in flight),
+      barrier B | slots 40-55: fragment reads (t+1, ks 0) -> F0 | after the last request: pointer step | end: lgkmcnt(0)
 
 Operand layouts (gemm_tile.h): K-major = memory [row][k], LDS image [128 rows][128 B], one ds_read_b128 per fragment, fragment f at
 +f * 2048, ks 1 at address ^ 64;  M-major = memory [k][row], LDS image [64 k][256 B], two ds_read_b64_tr_b16 per fragment (+1024 for
@@ -19,7 +19,7 @@ the second), fragment f at address ^ (f << 5), ks 1 at +8192.  (The XOR forms ne
 Physical registers: a[0:255] accumulators, acc[i][j] = a[4 (8 i + j) ..]; v[0:31] F0.A, v[32:63] F0.B, v[64:95] F1.A,
 v[96:127] F1.B; v128-v143 A / v144-v159 B fragment read addresses (K-major: [stage][ks], M-major: [stage][fragment]);
 v160-v175 DMA lane offsets [operand][sub-tile][piece]; s[72:73] / s[74:75] A / B pointers of the next k-tile to request,
-s76-s78 temporaries, s79 saved M0, s80 loop counter, s81 wrap counter.  Named operands: see gemm_w4.hip.
+s76-s77 / s82-s83 temporaries, s79 saved M0, s80 loop counter, s81 wrap counter.  Named operands: see gemm_w4.hip.
 """
 import os
 import sys
@@ -56,34 +56,42 @@ class Gen:
         return (f"s_add_u32 m0, %[ldsw], {imm}", f"global_load_lds_dwordx4 v{VOFF + op * 8 + sub * 4 + it}, {ptr}")
 
     def ptr_step(self):
-        return ["s_sub_u32 s81, s81, 1", "s_cmp_eq_u32 s81, 0", "s_cselect_b32 s77, -1, 0",   # (all selects before the adds rewrite scc)
-                "s_cselect_b32 s76, %[backa], %[stepka]", "s_cselect_b32 s78, %[backb], %[stepkb]",
-                "s_add_u32 s72, s72, s76", "s_addc_u32 s73, s73, s77", "s_add_u32 s74, s74, s78", "s_addc_u32 s75, s75, s77"]
+        return ["s_sub_u32 s81, s81, 1", "s_cmp_eq_u32 s81, 0",   # (both selects before the adds rewrite scc; 64-bit steps: one pass over k can exceed 2 GiB)
+                "s_cselect_b64 s[76:77], %[backa], %[stepka]", "s_cselect_b64 s[82:83], %[backb], %[stepkb]",
+                "s_add_u32 s72, s72, s76", "s_addc_u32 s73, s73, s77", "s_add_u32 s74, s74, s82", "s_addc_u32 s75, s75, s83"]
 
-    def body(self, stage, do_dma, do_next):
+    def body(self, stage, do_dma, do_next, woff=0):
+        # slots of barrier A, barrier B, the first read of the next k-tile, and the spacing of the 16 LDS-DMA requests.  Measured on the twelve
+        # in-step GEMM shapes (tools/exp_w4.py, sum of their times): A 31 / spacing 4 / B 39 / reads from 44: 12.21 ms; A 19: 12.09;
+        # spacing 5 / 6 / 7: 11.92 / 11.80 / 11.53 (2 or 3: 13.1 -- the requests must not queue up); reads from 40: 11.43; A 17 or 23,
+        # B 35: worse; B 43: same.  (W4_* environment variables: for such experiments only.)
+        A, B, RD = (int(os.environ.get(k, d)) for k, d in (("W4_A", 19), ("W4_B", 39), ("W4_RD", 40)))
+        SPF = float(os.environ.get("W4_SP", 7))
+        # DMA d: M0 setup after global slot A + 1 + SP * d, load one slot later (global slot = P0 slot, or 64 + P1 slot)
+        ev = {}
+        if do_dma:
+            for d in range(16):
+                g = A + 1 + int(SPF * d) + woff
+                ev.setdefault(g, []).append(self.dma(stage, d)[0])
+                ev.setdefault(g + 1, []).append(self.dma(stage, d)[1])
+            ev.setdefault(A + 1 + int(SPF * 15) + woff + 1, []).extend(self.ptr_step())
+            assert A + 1 + int(SPF * 15) + woff + 1 < 128
+        before_b = sum(1 for d in range(16) if A + 1 + int(SPF * d) + woff + 1 <= 64 + B) if do_dma else 0   # loads of k-tile t+2 already issued at barrier B
         out = []
         for slot in range(64):  # ---- P0
             out.append(self.mfma(0, slot))
             if slot < 16:
                 out += self.frag_read(1, stage, 1, slot)
-            if slot == 31:
+            if slot == A:
                 out += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
-            if do_dma and slot >= 32:
-                k, ph = (slot - 32) >> 2, (slot - 32) & 3
-                if ph < 2:
-                    out.append(self.dma(stage, k)[ph])
+            out += ev.get(slot, [])
         for slot in range(64):  # ---- P1
             out.append(self.mfma(1, slot))
-            if do_dma and slot < 32:
-                k, ph = 8 + (slot >> 2), slot & 3
-                if ph < 2:
-                    out.append(self.dma(stage, k)[ph])
-            if do_dma and slot == 32:
-                out += self.ptr_step()
-            if do_next and slot == 39:
-                out += [f"s_waitcnt vmcnt({16 if do_dma else 0})", "s_barrier"]
-            if do_next and 44 <= slot < 60:
-                out += self.frag_read(0, stage ^ 1, 0, slot - 44)
+            out += ev.get(64 + slot, [])
+            if do_next and slot == B:
+                out += [f"s_waitcnt vmcnt({before_b})", "s_barrier"]
+            if do_next and RD <= slot < RD + 16:
+                out += self.frag_read(0, stage ^ 1, 0, slot - RD)
         if do_next:
             out.append("s_waitcnt lgkmcnt(0)")
         return out
