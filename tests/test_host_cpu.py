@@ -242,3 +242,25 @@ def test_rl_packers_match_reference_golden():
     assert (_truncate_or_pad_to_match_seq_len(gold["pad_in"], 8) == gold["pad8"]).all()
     assert (_truncate_or_pad_to_match_seq_len(gold["pad_in"], 3) == gold["pad3"]).all()
     assert _truncate_or_pad_to_match_seq_len(gold["pad_in"], 5) is gold["pad_in"]
+
+
+def test_generated_gemm_loops_are_in_sync_with_their_generator(tmp_path):
+    """bdm_db1_amd/csrc/gemm_w4_loop_{nt,nn,tn}.inc are generated (tools/gen_gemm_w4.py): the committed files must be what the
+    generator emits with its defaults, and every loop must hold 4 k-tile bodies x 128 MFMAs with one accumulator tuple per slot"""
+    import re
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("W4_")}
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_gemm_w4.py"), str(tmp_path)], check=True, env=env, capture_output=True)
+    for name in ("nt", "nn", "tn"):
+        fresh = open(os.path.join(tmp_path, f"gemm_w4_loop_{name}.inc")).read()
+        committed = open(os.path.join(root, "bdm_db1_amd", "csrc", f"gemm_w4_loop_{name}.inc")).read()
+        assert fresh == committed, f"gemm_w4_loop_{name}.inc is stale: run python tools/gen_gemm_w4.py"
+        mf = re.findall(r"v_mfma_f32_16x16x32_bf16 a\[(\d+):(\d+)\]", committed)
+        assert len(mf) == 4 * 128
+        for body in range(4):   # every k-tile touches each of the 64 accumulator tuples exactly twice (ks 0 and ks 1)
+            starts = sorted(int(a) for a, _ in mf[body * 128:(body + 1) * 128])
+            assert starts == sorted(list(range(0, 256, 4)) * 2)
+        # the LDS-DMA requests: 2 prologue k-tiles + 2 loop bodies, 16 each; none in the two peeled k-tiles
+        assert committed.count("global_load_lds_dwordx4") == 64
+        assert committed.count("s_barrier") == 1 + 2 * 3 + 1

@@ -30,6 +30,10 @@ RD = (128, 144)        # per operand
 VOFF = 160             # + op * 8 + sub * 4 + it
 
 
+def EARLY():
+    return int(os.environ.get("W4_EARLY", 0))
+
+
 class Gen:
     def __init__(self, a_kmajor, b_kmajor):
         self.km = (a_kmajor, b_kmajor)
@@ -64,7 +68,8 @@ class Gen:
         # slots of barrier A, barrier B, the first read of the next k-tile, and the spacing of the 16 LDS-DMA requests.  Measured on the twelve
         # in-step GEMM shapes (tools/exp_w4.py, sum of their times): A 31 / spacing 4 / B 39 / reads from 44: 12.21 ms; A 19: 12.09;
         # spacing 5 / 6 / 7: 11.92 / 11.80 / 11.53 (2 or 3: 13.1 -- the requests must not queue up); reads from 40: 11.43; A 17 or 23,
-        # B 35: worse; B 43: same.  (W4_* environment variables: for such experiments only.)
+        # B 35: worse; B 43: same; W4_EARLY=7 (seven A fragments of the next ks-1 set read at the end of the previous half, barrier A after
+        # slot 13-19): 11.48-11.71, no gain.  (W4_* environment variables: for such experiments only.)
         A, B, RD = (int(os.environ.get(k, d)) for k, d in (("W4_A", 19), ("W4_B", 39), ("W4_RD", 40)))
         SPF = float(os.environ.get("W4_SP", 7))
         # DMA d: M0 setup after global slot A + 1 + SP * d, load one slot later (global slot = P0 slot, or 64 + P1 slot)
@@ -77,14 +82,16 @@ class Gen:
             ev.setdefault(A + 1 + int(SPF * 15) + woff + 1, []).extend(self.ptr_step())
             assert A + 1 + int(SPF * 15) + woff + 1 < 128
         before_b = sum(1 for d in range(16) if A + 1 + int(SPF * d) + woff + 1 <= 64 + B) if do_dma else 0   # loads of k-tile t+2 already issued at barrier B
+        E = EARLY()
         out = []
         for slot in range(64):  # ---- P0
             out.append(self.mfma(0, slot))
-            if slot < 16:
-                out += self.frag_read(1, stage, 1, slot)
+            if slot < 16 - E:
+                out += self.frag_read(1, stage, 1, slot + E)
             if slot == A:
                 out += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
             out += ev.get(slot, [])
+        pending = 0
         for slot in range(64):  # ---- P1
             out.append(self.mfma(1, slot))
             out += ev.get(64 + slot, [])
@@ -92,8 +99,14 @@ class Gen:
                 out += [f"s_waitcnt vmcnt({before_b})", "s_barrier"]
             if do_next and RD <= slot < RD + 16:
                 out += self.frag_read(0, stage ^ 1, 0, slot - RD)
+            if do_next and RD + 16 <= slot < RD + 16 + E:   # the first E A-fragments of (t+1, ks 1): A fragment i of F1 was last used in slot 8 i + 7
+                i = slot - RD - 16
+                assert slot >= 8 * i + 8
+                r = self.frag_read(1, stage ^ 1, 1, i)
+                pending += len(r)
+                out += r
         if do_next:
-            out.append("s_waitcnt lgkmcnt(0)")
+            out.append(f"s_waitcnt lgkmcnt({pending})")
         return out
 
     def prologue(self):
@@ -127,6 +140,8 @@ class Gen:
         out += ["s_waitcnt vmcnt(16)", "s_barrier"]
         for n in range(16):
             out += self.frag_read(0, 0, 0, n)
+        for n in range(EARLY()):
+            out += self.frag_read(1, 0, 1, n)
         out.append("s_waitcnt lgkmcnt(0)")
         return out
 
