@@ -286,7 +286,11 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
             // half a wave of 256x256 tiles (ff2 dW: 128) in two slices: nothing at K = 16 384, but 1184 -> 978 us at K = 65 536 (the 256x128
             // kernel it would otherwise take runs at 930 TFLOP/s, the ping-pong kernel at 1120 incl. the reduce)
             const bool half_wave = pp_shape && fb == 1 && wg > 96 && wg <= 128 && S == 2 && (K / TBK) / S >= 256;
-            if (S && (wg <= 96 || half_wave) && (!pp_shape || wg * S >= 160)) {
+            // three quarters of a wave (qkv dW: 192 tiles) in four slices = three whole waves: 1310-1324 -> 1196-1221 us at K = 65 536 with
+            // the 4-wave kernel (with the 8-wave kernels this gained 2 %)
+            const bool three_quarters = pp_shape && fb == 1 && wg == 192 && (K / TBK) % 4 == 0 && (K / TBK) / 4 >= 128;
+            if (three_quarters) S = 4;
+            if (S && (wg <= 96 || half_wave || three_quarters) && (!pp_shape || wg * S >= 160)) {
                 float* ws = splitk_workspace((size_t)batch * S * M * N * sizeof(float));
                 if (!ws) DB1_FAIL(DB1_ERR_HIP, "gemm: cannot allocate %zu bytes of split-K workspace", (size_t)batch * S * M * N * sizeof(float));
                 GemmTileArgs u = t;

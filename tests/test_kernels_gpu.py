@@ -278,10 +278,10 @@ def test_gemm_bf16_split_k_weight_gradient(ops):
 
 def test_gemm_bf16_short_last_wave_and_half_wave_split(ops):
     """dispatcher paths of the weight gradients at 65 536 tokens: (a) 264 tiles of 256x256 = one full wave + one tile row, the
-    remainder rows go through a second call on the split-K path; (b) 128 tiles in two K slices.  Reference: fp32 matmul of the
-    same bf16 operands on the device (sampled rows incl. the remainder rows)."""
+    remainder rows go through a second call on the split-K path; (b) 128 tiles in two K slices; (c) 192 tiles in four K slices.
+    Reference: fp32 matmul of the same bf16 operands on the device (sampled rows incl. the remainder rows)."""
     g = torch.Generator(device="cpu").manual_seed(5)
-    for M, N, K in ((33 * 256, 2048, 16384), (2048, 4096, 32768)):
+    for M, N, K in ((33 * 256, 2048, 16384), (2048, 4096, 32768), (6144, 2048, 32768)):
         a_t = (torch.randn(K, M, generator=g) * 0.1).to(torch.bfloat16).to(DEV)   # TN: A is stored [K, M]
         b = (torch.randn(K, N, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
         c0 = torch.randn(M, N, generator=g).to(DEV)
