@@ -36,9 +36,9 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     tot += tm("qkv", 65536, 6144, 2048, "NT")
     tot += tm("ff2", 65536, 2048, 4096, "NT")
     tot += tm("proj", 65536, 2048, 2048, "NT")
-    tot += tm("dff1", 65536, 2048, 8192, "NN")
+    tot += tm("dff1", 65536, 2048, 8192, "NN", beta=1.0)    # in the step (post-LN): accumulated in place onto the residual gradient
     tot += tm("dff2", 65536, 4096, 2048, "NN")
-    tot += tm("dqkv", 65536, 2048, 6144, "NN")
+    tot += tm("dqkv", 65536, 2048, 6144, "NN", beta=1.0)
     tot += tm("dproj", 65536, 2048, 2048, "NN")
     tot += tm("wff1", 8192, 2048, 65536, "TN", torch.float32, 1.0)
     tot += tm("wqkv", 6144, 2048, 65536, "TN", torch.float32, 1.0)
