@@ -57,3 +57,16 @@ print(f"    -> {2 * M * N * K / t / 1e9:.0f} TFLOP/s")
 a = torch.randn(M, N, device=DEV).to(torch.bfloat16); b = torch.empty(M, N // 2, device=DEV, dtype=torch.bfloat16)
 t = run("GEGLU forward (HBM-bound)", lambda: ops.ffn_act_fwd(a, b, "geglu"))
 print(f"    -> {(M * N * 2 + M * N) / t / 1e9:.2f} TB/s")
+
+# the relative-position flash attention kernels (64 sequences x 1024 tokens x 16 heads x 128)
+Bq, L, H, D = 64, 1024, 16, 128
+qkv5 = torch.randn(Bq, L, 3, H, D, device=DEV).to(torch.bfloat16)
+qu = torch.randn(Bq, L, H, D, device=DEV).to(torch.bfloat16); qv = torch.randn(Bq, L, H, D, device=DEV).to(torch.bfloat16)
+R = torch.randn(L, H, D, device=DEV).to(torch.bfloat16)
+o = torch.empty(Bq, L, H, D, device=DEV, dtype=torch.bfloat16); lse = torch.empty(Bq, H, L, device=DEV)
+sc = 1.0 / D ** 0.5
+t = run("flash forward", lambda: ops.relattn_flash_fwd(qu, qv, qkv5, R, o, lse, Bq, L, H, D, L, sc))
+print(f"    -> {3 * 2 * Bq * H * (L * (L + 1) / 2) * D / t / 1e9:.0f} TFLOP/s (3 causal contractions)")
+do = torch.randn_like(o); delta = torch.empty(Bq, H, L, device=DEV); dqkv5 = torch.empty_like(qkv5); dT = torch.empty(Bq, H, L, L, device=DEV, dtype=torch.bfloat16)
+t = run("flash backward (q + kv)", lambda: ops.relattn_flash_bwd(qu, qv, qkv5, R, o, do, lse, delta, dqkv5, dT, Bq, L, H, D, L, sc))
+print(f"    -> {9 * 2 * Bq * H * (L * (L + 1) / 2) * D / t / 1e9:.0f} TFLOP/s (9 causal contractions incl. the recomputed ones)")
