@@ -152,6 +152,25 @@ class Gen:
         lines += ["s_sub_u32 s80, s80, 1", "s_cmp_lg_u32 s80, 0", "s_cbranch_scc1 L_w4_loop_%="]
         lines += self.body(0, False, True) + self.body(1, False, False)
         lines += ["s_nop 15", "s_nop 15", "s_mov_b32 m0, s79"]
+        abl = os.environ.get("W4_ABLATE", "")   # timing / power ablations of the loop (results wrong): dma, reads, barriers, mfma
+        if abl:
+            pro = len(self.prologue())
+
+            def keep(i, ln):
+                if i < pro:
+                    return True
+                if "dma" in abl and (ln.startswith("global_load_lds") or ln.startswith("s_add_u32 m0")):
+                    return False
+                if "reads" in abl and ln.startswith("ds_read"):
+                    return False
+                if "barriers" in abl and ln == "s_barrier":
+                    return False
+                if "mfma" in abl and ln.startswith("v_mfma") and (int(ln.split("a[")[1].split(":")[0]) // 4) % 8 != 0:
+                    return False
+                return True
+            lines = [ln for i, ln in enumerate(lines) if keep(i, ln)]
+            if "dma" in abl:
+                lines = [("s_waitcnt vmcnt(0)" if ln.startswith("s_waitcnt vmcnt") else ln) for ln in lines]
         with open(path, "w") as f:
             f.write("// GENERATED by tools/gen_gemm_w4.py -- do not edit; the schedule is described there.\n")
             for ln in lines:
