@@ -293,6 +293,30 @@ def test_gemm_bf16_short_last_wave_and_half_wave_split(ops):
         assert err < 2e-5, f"M={M} N={N} K={K}: {err:.3e}"
 
 
+@pytest.mark.parametrize("form", ["nt", "nn", "tn"])
+def test_gemm_4wave_loops_are_bitwise_repeatable(ops, form):
+    """the hand-scheduled 4-wave loops reuse two LDS stages under counted waits and barriers of their own: a stage overwritten too early
+    or read too early would show as run-to-run differences.  20 launches of an 8-rounds-per-CU product must agree bit for bit
+    (and with an fp32 matmul to bf16 accuracy)."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, N, K = 8192, 4096, 1280   # 512 tiles of 256x256, 20 k-tiles
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    B = (torch.randn(K, N, generator=g) * 0.1).to(torch.bfloat16)
+    a_store = (A if form != "tn" else A.t().contiguous()).to(DEV)
+    b_store = (B.t().contiguous() if form == "nt" else B).to(DEV)
+    a = a_store if form != "tn" else a_store.t()
+    b = b_store.t() if form == "nt" else b_store
+    first = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(a, b, first)
+    ref = A[:512].to(DEV).float() @ B.to(DEV).float()
+    assert float((first[:512].float() - ref).abs().max() / ref.abs().max()) < 6e-3
+    out = torch.empty_like(first)
+    for _ in range(20):
+        out.fill_(1.0)
+        ops.gemm(a, b, out)
+        assert torch.equal(out, first)
+
+
 def test_gemm_nt_head_bias_epilogue(ops):
     """the attention input projection with q + r_w_bias / q + r_r_bias written from the accumulators (db1_gemm_nt_headbias)"""
     g = torch.Generator(device="cpu").manual_seed(9)
