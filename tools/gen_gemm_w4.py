@@ -131,12 +131,12 @@ class Gen:
                 out += [f"v_add_u32 v{b + 4 + it}, s76, v{b + it}" for it in range(4)]
             else:
                 out += [f"v_add_u32 v{b + 4 + it}, 0x100, v{b + it}" for it in range(4)]   # 128 rows = 256 bytes further along the k-row
-        out += [f"v_accvgpr_write_b32 a{n}, 0" for n in range(256)]
         for t in range(2):
             for d in range(16):
                 m0set, ld = self.dma(t, d)
                 out += [m0set, "s_nop 0", ld]
             out += self.ptr_step()
+        out += [f"v_accvgpr_write_b32 a{n}, 0" for n in range(256)]   # (while the first two k-tiles are on their way)
         out += ["s_waitcnt vmcnt(16)", "s_barrier"]
         for n in range(16):
             out += self.frag_read(0, 0, 0, n)
