@@ -1075,8 +1075,8 @@ extern "C" int db1_sumsq_acc(const void* x, float* acc, int64_t n, int dt, void*
     return DB1_OK;
 }
 
-template <bool HAS_WORK>
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+template <bool HAS_WORK, typename GT>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ pw, int64_t n, float lr, float b1,
                                                    float b2, float omb1, float omb2, float eps, float wd, int adamw, float bc1, float rsqrt_bc2,
                                                    float gscale, float clip, const float* norm_sq) {
@@ -1088,9 +1088,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float step_size = lr / bc1;
     const int64_t nv = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
-        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
+        float4 P = reinterpret_cast<float4*>(p)[i];
+        float gg[4];
+        if (sizeof(GT) == 4) {
+            float4 G = reinterpret_cast<const float4*>(g)[i];
+            gg[0] = G.x; gg[1] = G.y; gg[2] = G.z; gg[3] = G.w;
+        } else {  // bf16 gradients: the all-reduced staging copy of the data-parallel engine (8 B per 4 elements)
+            uint2 G = reinterpret_cast<const uint2*>(g)[i];
+            gg[0] = __uint_as_float(G.x << 16); gg[1] = __uint_as_float(G.x & 0xffff0000u);
+            gg[2] = __uint_as_float(G.y << 16); gg[3] = __uint_as_float(G.y & 0xffff0000u);
+        }
         float4 M = reinterpret_cast<float4*>(m)[i], Vv = reinterpret_cast<float4*>(v)[i];
-        float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {Vv.x, Vv.y, Vv.z, Vv.w};
+        float pp[4] = {P.x, P.y, P.z, P.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {Vv.x, Vv.y, Vv.z, Vv.w};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float gr = gg[j] * gs;
@@ -1105,25 +1114,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
         if (HAS_WORK) {
             uint2 o;
-            o.x = (unsigned)f2bf(pp[0]) | ((unsigned)f2bf(pp[1]) << 16);
-            o.y = (unsigned)f2bf(pp[2]) | ((unsigned)f2bf(pp[3]) << 16);
+            o.x = f2bf_pk(pp[0], pp[1]);
+            o.y = f2bf_pk(pp[2], pp[3]);
             reinterpret_cast<uint2*>(pw)[i] = o;
         }
     }
 }
-extern "C" int db1_adam_step(float* p32, const float* g, float* m, float* v, void* p_work, int64_t n, double lr, double beta1,
+extern "C" int db1_adam_step(float* p32, const void* g, float* m, float* v, void* p_work, int64_t n, double lr, double beta1,
                              double beta2, double eps, double wd, int adamw, int step, float gscale, float clip,
-                             const float* norm_sq, int dtWork, void* stream) {
+                             const float* norm_sq, int dtGrad, int dtWork, void* stream) {
     if (n <= 0 || (n & 3)) DB1_FAIL(DB1_ERR_BAD_SHAPE, "adam: n=%lld must be a positive multiple of 4", (long long)n);
     if (step < 1) DB1_FAIL(DB1_ERR_BAD_SHAPE, "adam: step must be >= 1");
-    if (!db1_aligned16(p32) || !db1_aligned16(g) || !db1_aligned16(m) || !db1_aligned16(v) || (p_work && (((uintptr_t)p_work) & 7)))
+    if (!db1_dt_ok(dtGrad)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "adam: gradient dtype");
+    if (!db1_aligned16(p32) || (((uintptr_t)g) & (dtGrad == DB1_F32 ? 15 : 7)) || !db1_aligned16(m) || !db1_aligned16(v) || (p_work && (((uintptr_t)p_work) & 7)))
         DB1_FAIL(DB1_ERR_BAD_ALIGN, "adam: alignment");
     if (p_work && dtWork != DB1_BF16) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "adam: working copy must be bf16");
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipStream_t st = (hipStream_t)stream;
     unsigned gr = grid_for(n / 4);
-    if (p_work) adam_kernel<true><<<gr, 256, 0, st>>>(p32, g, m, v, (bf16_t*)p_work, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd, adamw, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, clip, norm_sq);
-    else adam_kernel<false><<<gr, 256, 0, st>>>(p32, g, m, v, nullptr, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd, adamw, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, clip, norm_sq);
+#define DB1_ADAM_LAUNCH(HW, GT) adam_kernel<HW, GT><<<gr, 256, 0, st>>>(p32, (const GT*)g, m, v, (bf16_t*)p_work, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd, adamw, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, clip, norm_sq)
+    if (p_work) { if (dtGrad == DB1_F32) DB1_ADAM_LAUNCH(true, float); else DB1_ADAM_LAUNCH(true, bf16_t); }
+    else { if (dtGrad == DB1_F32) DB1_ADAM_LAUNCH(false, float); else DB1_ADAM_LAUNCH(false, bf16_t); }
+#undef DB1_ADAM_LAUNCH
     DB1_CHECK_LAUNCH("adam");
     return DB1_OK;
 }

@@ -28,23 +28,41 @@ from .optim import OptimizerParamScheduler
 
 class GradSync:
     """Bucketed asynchronous all-reduce (SUM) over slices of one flat gradient tensor.
-    Backend-agnostic (RCCL on the GPUs; gloo in the CPU tests of the sharding logic)."""
+    Backend-agnostic (RCCL on the GPUs; gloo in the CPU tests of the sharding logic).
 
-    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[str, int, int]], group=None):
+    With ``stage`` (a bf16 tensor of the arena's size) each bucket is first cast into its staging slice by ``cast(src, dst)`` on
+    the compute stream and the STAGING slice is what travels: 2 bytes per gradient over xGMI (2.42 GB per step for DB1-1.3B, the
+    volume SURVEY 8e budgets) instead of 4; the optimizer then reads the reduced staging copy (``reduced``).  torch's process group
+    orders the collective behind the cast (it waits for the launching stream's work) and ``finish`` orders the optimizer behind it."""
+
+    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[str, int, int]], group=None, stage: Optional[torch.Tensor] = None,
+                 cast=None):
         self.flat = flat_grad
         self.buckets = {n: (s, e) for n, s, e in buckets}
         self.order = [n for n, _, _ in buckets]
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.stage = stage
+        self.cast = cast
+        assert stage is None or (stage.numel() == flat_grad.numel() and cast is not None)
         self.handles = []
         self.launched = set()
+
+    @property
+    def reduced(self) -> torch.Tensor:
+        """the tensor that holds the all-reduced gradients after ``finish``"""
+        return self.flat if (self.stage is None or self.world == 1) else self.stage
 
     def launch(self, name: str):
         if self.world == 1 or name in self.launched:
             return
         s, e = self.buckets[name]
         self.launched.add(name)
-        self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        buf = self.flat[s:e]
+        if self.stage is not None:
+            self.cast(buf, self.stage[s:e])
+            buf = self.stage[s:e]
+        self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """launch whatever was not launched by a hook, then wait for everything"""
@@ -95,7 +113,14 @@ class DB1Engine:
             ar.exp_avg = torch.zeros_like(ar.master)
             ar.exp_avg_sq = torch.zeros_like(ar.master)
         self._norm_sq = torch.zeros(1, device=model.device, dtype=torch.float32)
-        self.sync = GradSync(ar.grad, model.grad_buckets(), self.group)
+        # gradients cross xGMI in bf16 (the reference's DeepSpeed fp16 engine reduces 2-byte gradients too: 2.42 GB per step,
+        # SURVEY 8e); "fp32" keeps the 4-byte arena on the wire (bit-comparable with a single-rank run up to summation order)
+        rdt = str(g("grad_reduce_dtype", "bf16")).lower()
+        assert rdt in ("bf16", "fp32"), rdt
+        stage = None
+        if self.dp_world > 1 and rdt == "bf16":
+            stage = torch.zeros(ar.numel, device=model.device, dtype=torch.bfloat16)
+        self.sync = GradSync(ar.grad, model.grad_buckets(), self.group, stage=stage, cast=ops.cast)
         self.last_grad_norm_sq = None
 
     # ---- what the reference's drivers call
@@ -141,13 +166,14 @@ class DB1Engine:
             return
         self.sync.finish()
         ar = self.module.arena
-        gscale = 1.0 / self.dp_world  # arena holds the SUM over ranks
+        grad = self.sync.reduced      # the fp32 arena, or the all-reduced bf16 staging copy
+        gscale = 1.0 / self.dp_world  # it holds the SUM over ranks
         self._norm_sq.zero_()
         if self.clip > 0:
-            ops.sumsq_acc(ar.grad, self._norm_sq)
+            ops.sumsq_acc(grad, self._norm_sq)
         self.global_steps += 1
         grp = self.optimizer.param_groups[0]
-        ops.adam_step(ar.master, ar.grad, ar.exp_avg, ar.exp_avg_sq, None if ar.work is ar.master else ar.work,
+        ops.adam_step(ar.master, grad, ar.exp_avg, ar.exp_avg_sq, None if ar.work is ar.master else ar.work,
                       grp["lr"], self.beta1, self.beta2, self.eps, grp["weight_decay"], self.adamw, self.global_steps,
                       gscale=gscale, clip=self.clip, norm_sq=self._norm_sq if self.clip > 0 else None)
         ar.grad.zero_()
@@ -199,17 +225,26 @@ class DB1Engine:
 
 
 def init_distributed(dist_backend: str = "nccl", distributed_port: Optional[int] = None, **_):
-    """``deepspeed.init_distributed`` stand-in (evaluate_rl.py:492): one process per GPU, RCCL over xGMI."""
+    """``deepspeed.init_distributed`` stand-in (evaluate_rl.py:492): one process per GPU, RCCL over xGMI.
+
+    The RCCL communicator runs its kernels on a HIGH-PRIORITY stream: a bucket's all-reduce is a few hundred microseconds of
+    xGMI traffic that must not queue behind the seconds of GEMM work already enqueued on the compute stream; bound to the GPU
+    at creation (``device_id``) so the communicator is built eagerly, once, before the first step."""
     if dist.is_available() and dist.is_initialized():
         return
     if "RANK" not in os.environ:
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL's intra-node transport on this driver)
     if distributed_port is not None:
         os.environ.setdefault("MASTER_PORT", str(distributed_port))
     if dist_backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-    dist.init_process_group(backend=dist_backend)
+        local = int(os.environ.get("LOCAL_RANK", 0))
+        torch.cuda.set_device(local)
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        dist.init_process_group(backend="nccl", pg_options=opts, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend=dist_backend)
 
 
 def initialize(args=None, model=None, mpu=None, lr_scheduler=None, **_):

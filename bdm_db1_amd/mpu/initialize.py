@@ -2,10 +2,11 @@
 
 The reference copies Megatron's tensor/pipeline/data group builder but only ever runs it with
 tensor = pipeline = 1 (evaluate_rl.py:493; README.md:129 "we only use distributed data parallel").
-Here the data-parallel group is the one real communicator (all ranks; RCCL when the backend is "nccl");
-model-parallel groups are per-rank singleton groups so that callers that ask for them (DeepSpeed-style
-``mpu=`` consumers) get a valid group of size 1.  Asking for tensor or pipeline parallel sizes > 1 raises:
-the reference has no such implementation to reproduce.
+Here the data-parallel group is the one real communicator: it IS the default (world) process group, so no
+second RCCL communicator over the same 8 GPUs is created (the reference's builder makes world + 4 of them).
+Model-parallel groups are per-rank singleton groups, created LAZILY the first time a caller asks for one
+(DeepSpeed-style ``mpu=`` consumers get a valid group of size 1; a training run that never asks pays for none).
+Asking for tensor or pipeline parallel sizes > 1 raises: the reference has no such implementation to reproduce.
 """
 import torch
 
@@ -49,15 +50,18 @@ def initialize_model_parallel(tensor_model_parallel_size_=1, pipeline_model_para
     if not _dist_on():
         _PIPELINE_GLOBAL_RANKS = [0]
         return
-    world = torch.distributed.get_world_size()
-    rank = torch.distributed.get_rank()
-    _DATA_PARALLEL_GROUP = torch.distributed.new_group(list(range(world)))
-    # every rank must take part in every new_group call, in the same order
-    for r in range(world):
-        g = torch.distributed.new_group([r])
-        if r == rank:
-            _MODEL_PARALLEL_GROUP = _TENSOR_MODEL_PARALLEL_GROUP = _PIPELINE_MODEL_PARALLEL_GROUP = _EMBEDDING_GROUP = g
-    _PIPELINE_GLOBAL_RANKS = [rank]
+    _DATA_PARALLEL_GROUP = torch.distributed.group.WORLD   # all ranks: the default communicator, nothing new is created
+    _PIPELINE_GLOBAL_RANKS = [torch.distributed.get_rank()]
+
+
+def _singleton_group():
+    """this rank's size-1 group for the tensor / pipeline / embedding getters: created on first use, by this rank alone
+    (``use_local_synchronization``: only the members of a new group take part in its creation)"""
+    global _MODEL_PARALLEL_GROUP, _TENSOR_MODEL_PARALLEL_GROUP, _PIPELINE_MODEL_PARALLEL_GROUP, _EMBEDDING_GROUP
+    if _MODEL_PARALLEL_GROUP is None and _dist_on():
+        g = torch.distributed.new_group([torch.distributed.get_rank()], use_local_synchronization=True)
+        _MODEL_PARALLEL_GROUP = _TENSOR_MODEL_PARALLEL_GROUP = _PIPELINE_MODEL_PARALLEL_GROUP = _EMBEDDING_GROUP = g
+    return _MODEL_PARALLEL_GROUP
 
 
 def model_parallel_is_initialized():
@@ -70,17 +74,17 @@ def _need():
 
 def get_model_parallel_group():
     _need()
-    return _MODEL_PARALLEL_GROUP
+    return _singleton_group()
 
 
 def get_tensor_model_parallel_group():
     _need()
-    return _TENSOR_MODEL_PARALLEL_GROUP
+    return _singleton_group()
 
 
 def get_pipeline_model_parallel_group():
     _need()
-    return _PIPELINE_MODEL_PARALLEL_GROUP
+    return _singleton_group()
 
 
 def get_data_parallel_group():
@@ -90,7 +94,7 @@ def get_data_parallel_group():
 
 def get_embedding_group():
     _need()
-    return _EMBEDDING_GROUP
+    return _singleton_group()
 
 
 def set_tensor_model_parallel_world_size(world_size):

@@ -372,7 +372,7 @@ def sumsq_acc(x, acc):
 
 def adam_step(p32, g, m, v, p_work, lr, beta1, beta2, eps, wd, adamw, step, gscale=1.0, clip=0.0, norm_sq=None):
     lib.call("db1_adam_step", P(p32), P(g), P(m), P(v), P(p_work), p32.numel(), float(lr), float(beta1), float(beta2), float(eps),
-             float(wd), int(bool(adamw)), int(step), float(gscale), float(clip), P(norm_sq),
+             float(wd), int(bool(adamw)), int(step), float(gscale), float(clip), P(norm_sq), dt_code(g),
              dt_code(p_work) if p_work is not None else 0, stream())
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """DB1-1.3B pre-training throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: spawns its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = forward + backward + gradient all-reduce (N > 1) + global-norm clip + fused Adam on one
@@ -78,6 +78,40 @@ def cpu_baseline(max_seconds: float = 45.0):
                       f"{os.cpu_count()} logical CPUs on the box, {threads} BLAS threads"}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start N copies of this script, one rank per GPU, with the
+    rendezvous environment torch.distributed.run would have set (127.0.0.1, a free port).  Rank 0's stdout is ours, so
+    its ONE JSON line is the output.  If any rank fails, the others are stopped (by PID) and its exit code is returned."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL's intra-node transport needs on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:       # a dead rank leaves the others waiting in a collective forever
+                    q.terminate()
+        time.sleep(0.2)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +128,8 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     # DB1_DIST_BACKEND=gloo lets the multi-rank path be exercised on a single-GPU box (ranks share the device; RCCL refuses that)
@@ -103,11 +139,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm: one process per GPU over xGMI
-        else:
-            dist.init_process_group(backend=backend)
+        from bdm_db1_amd.engine import init_distributed
+        init_distributed(dist_backend=backend)   # "nccl" is RCCL on ROCm: one process per GPU over xGMI, high-priority comm stream
 
     from bdm_db1_amd import TransformerXL, initialize, mpu, ops, synth
     from types import SimpleNamespace

@@ -248,11 +248,12 @@ int db1_groupnorm_gelu_bwd(const void* dy, const void* x, const void* gamma, con
  * acc[0] += sum(x^2)  (global-norm clipping, train_config.py:211-215) */
 int db1_sumsq_acc(const void* x, float* acc, int64_t n, int dt, void* stream);
 /* One fused Adam/AdamW step over a flat segment (DeepSpeed FusedAdam stand-in; torch.optim semantics).
- * g: float32 gradients; p32/m/v: float32 state; p_work (nullable): bf16 working copy written alongside.
- * grad scale = gscale * min(1, clip / (sqrt(*norm_sq) + 1e-6)) when clip > 0 and norm_sq != NULL. */
-int db1_adam_step(float* p32, const float* g, float* m, float* v, void* p_work, int64_t n,
+ * g: gradients, float32 or (dtGrad = DB1_BF16) the bf16 copy the data-parallel engine all-reduces (train.py:231-232);
+ * p32/m/v: float32 state; p_work (nullable): bf16 working copy written alongside.
+ * grad scale = gscale * min(1, clip / (sqrt(*norm_sq) * gscale + 1e-6)) when clip > 0 and norm_sq != NULL. */
+int db1_adam_step(float* p32, const void* g, float* m, float* v, void* p_work, int64_t n,
                   double lr, double beta1, double beta2, double eps, double wd, int adamw, int step,
-                  float gscale, float clip, const float* norm_sq, int dtWork, void* stream);
+                  float gscale, float clip, const float* norm_sq, int dtGrad, int dtWork, void* stream);
 
 /* ------------------------------------------------------------------ scalar tokenizer
  * ContinuousScalarTokenizer.discretize (src/tokenizer/scalar_tokenizer.py:28-45), bit-exact ids. */

@@ -58,9 +58,9 @@ def _batch(cfg, rows):
 ARGS = dict(lr=2e-3, weight_decay=0.01, clip_grad=0.5, optimizer="adamw", keep_logits=True, adam_eps=1e-3)
 
 
-def _train(model, cfg, rows, mpu=None, steps=3):
+def _train(model, cfg, rows, mpu=None, steps=3, reduce_dtype="fp32"):
     from bdm_db1_amd import initialize
-    engine, _, _, _ = initialize(SimpleNamespace(**ARGS), model, mpu=mpu)
+    engine, _, _, _ = initialize(SimpleNamespace(grad_reduce_dtype=reduce_dtype, **ARGS), model, mpu=mpu)
     engine.train()
     losses = []
     for _ in range(steps):
@@ -71,27 +71,29 @@ def _train(model, cfg, rows, mpu=None, steps=3):
     return losses
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, port, q, backend="gloo", reduce_dtype="fp32"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    if backend == "nccl":   # RCCL over xGMI: one process per GPU, the engine's own initialiser (high-priority comm stream)
+        from bdm_db1_amd.engine import init_distributed
+        init_distributed(dist_backend="nccl")
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from bdm_db1_amd import mpu
     mpu.initialize_model_parallel()
     cfg, model = _make()
-    losses = _train(model, cfg, [2 * rank, 2 * rank + 1], mpu=mpu)
+    losses = _train(model, cfg, [2 * rank, 2 * rank + 1], mpu=mpu, reduce_dtype=reduce_dtype)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     q.put((rank, losses, sd if rank == 0 else None))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank_with_the_whole_batch():
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
+def _two_ranks_vs_one(backend, reduce_dtype, tol):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, reduce_dtype)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in procs]
@@ -102,13 +104,57 @@ def test_two_ranks_equal_one_rank_with_the_whole_batch():
     cfg, model = _make()
     ref_losses = _train(model, cfg, [0, 1, 2, 3])
     # the full-batch loss is the mean of the two half-batch losses (equal mask sums)
+    ltol = 2e-5 if reduce_dtype == "fp32" else 2e-3
     for s in range(len(ref_losses)):
-        assert abs(0.5 * (got[0][1][s] + got[1][1][s]) - ref_losses[s]) < 2e-5 * max(1.0, abs(ref_losses[s])), s
+        assert abs(0.5 * (got[0][1][s] + got[1][1][s]) - ref_losses[s]) < ltol * max(1.0, abs(ref_losses[s])), s
     sd = got[0][2]
     worst = 0.0
     for k, v in model.state_dict().items():
         ref = v.detach().cpu().numpy().astype(np.float64)
         worst = max(worst, float(np.abs(sd[k] - ref).max() / (np.abs(ref).max() + 1e-30)))
-    # fp32 sums in a different order (two half-batch gradients added by the all-reduce vs one full-batch reduction) -> ~1e-5 after 3 steps;
-    # a wrong mean / clip scale would show as >= 1e-3 here
-    assert worst < 2e-4, f"parameters after 3 data-parallel steps differ from the single-rank run: {worst:.2e}"
+    assert worst < tol, f"parameters after 3 data-parallel steps differ from the single-rank run: {worst:.2e}"
+
+
+def test_two_ranks_equal_one_rank_with_the_whole_batch():
+    """fp32 on the wire: fp32 sums in a different order (two half-batch gradients added by the all-reduce vs one full-batch
+    reduction) -> ~1e-5 after 3 steps; a wrong mean / clip scale would show as >= 1e-3 here"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    _two_ranks_vs_one("gloo", "fp32", 2e-4)
+
+
+def test_two_ranks_bf16_gradient_reduction():
+    """the default: each bucket is cast to bf16, the staging copy is all-reduced and Adam reads it.  Three AdamW steps at lr 2e-3
+    with 2^-9-relative gradient rounding: parameters within 3e-3 of the fp32 single-rank run (a wrong scale moves them by > 1e-2)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    _two_ranks_vs_one("gloo", "bf16", 3e-3)
+
+
+@pytest.mark.parametrize("reduce_dtype,tol", [("fp32", 2e-4), ("bf16", 3e-3)])
+def test_two_ranks_rccl(reduce_dtype, tol):
+    """the same check over RCCL (backend "nccl"), one process per GPU: runs wherever two GPUs are visible (the 1-GPU test box skips)"""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    _two_ranks_vs_one("nccl", reduce_dtype, tol)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it must start two ranks itself and print ONE JSON line from rank 0
+    (the bare command exited non-zero).  Two GPUs -> RCCL; one GPU -> DB1_DIST_BACKEND=gloo with both ranks on it."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["DB1_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--layers", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0 and "cpu_baseline" not in out

@@ -160,7 +160,23 @@ def _dp_worker(rank, world, port, q):
     g.copy_(local)
     sync.finish()
     ok = ok and torch.allclose(g, expect, atol=1e-6)
+    # bf16 staging (what the GPUs send over xGMI): each bucket is cast into its slice of the staging tensor, the STAGING slice is
+    # reduced, the fp32 arena stays this rank's own sum; `reduced` is what the optimizer reads
+    g.copy_(local)
+    stage = torch.zeros(n, dtype=torch.bfloat16)
+    sync16 = GradSync(g, buckets, mpu.get_data_parallel_group(), stage=stage, cast=lambda src, dst: dst.copy_(src))
+    sync16.launch("h.0")
+    sync16.finish()
+    expect16 = sum(x.to(torch.bfloat16).float() for x in gathered)
+    ok = ok and sync16.reduced is stage and torch.equal(g, local)
+    ok = ok and torch.allclose(stage.float(), expect16, atol=2e-2, rtol=1e-2)   # one bf16 rounding of the sum
+    all16 = [torch.zeros(n, dtype=torch.bfloat16) for _ in range(world)]
+    dist.all_gather(all16, stage)
+    ok = ok and all(torch.equal(all16[0], x) for x in all16)                    # every rank holds the same reduced gradients
+    # the data-parallel group is the default communicator itself: no second communicator over the same ranks
+    ok = ok and mpu.get_data_parallel_group() is dist.group.WORLD
     # mean-of-ranks via the optimizer's gradient scale (the arena holds the SUM): the update every rank applies is identical
+    g.copy_(expect)
     p = torch.ones(n)
     upd = p - 0.1 * g * (1.0 / world)
     allp = [torch.zeros(n) for _ in range(world)]
