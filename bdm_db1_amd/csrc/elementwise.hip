@@ -1169,3 +1169,33 @@ extern "C" int db1_mulaw_discretize(const float* x, int32_t* ids, int64_t n, int
     DB1_CHECK_LAUNCH("mulaw");
     return DB1_OK;
 }
+
+// ContinuousScalarTokenizer.decode (scalar_tokenizer.py:47-63): ids clipped to [0, nb-1]; x = id/nb*2 - 1 in the reference's float32 op
+// order; observations: sign(x) * (base^|x| - 1) / mu with base = 1 + M*mu, the power taken in float64 and rounded once (within 1 ulp of
+// torch's float32 pow).  *oob (nullable) is set to 1 if any id was outside [0, nb-1] (the reference prints a warning there).
+template <typename IT>
+__global__ __launch_bounds__(256) void mulaw_decode_kernel(const IT* __restrict__ ids, float* __restrict__ out, int64_t n, int is_action,
+                                                           int nb, float mu, float base, int* oob) {
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        long long id = (long long)ids[i];
+        if (id < 0 || id > nb - 1) { bad = 1; id = id < 0 ? 0 : nb - 1; }
+        float x = __fsub_rn(__fmul_rn(__fdiv_rn((float)id, (float)nb), 2.0f), 1.0f);
+        if (!is_action) {
+            const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+            const float pw = (float)pow((double)base, (double)fabsf(x));
+            x = __fdiv_rn(__fmul_rn(sg, __fsub_rn(pw, 1.0f)), mu);
+        }
+        out[i] = x;
+    }
+    if (oob && bad) atomicOr(oob, 1);
+}
+extern "C" int db1_mulaw_decode(const void* ids, float* out, int64_t n, int ids_are_int64, int is_action, int num_bins, float mu, float M,
+                                int* oob_flag, void* stream) {
+    if (n <= 0 || num_bins <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "mulaw_decode: shape");
+    const float base = (float)(1.0 + (double)M * (double)mu);
+    if (ids_are_int64) mulaw_decode_kernel<int64_t><<<grid_for(n), 256, 0, (hipStream_t)stream>>>((const int64_t*)ids, out, n, is_action, num_bins, mu, base, oob_flag);
+    else mulaw_decode_kernel<int32_t><<<grid_for(n), 256, 0, (hipStream_t)stream>>>((const int32_t*)ids, out, n, is_action, num_bins, mu, base, oob_flag);
+    DB1_CHECK_LAUNCH("mulaw_decode");
+    return DB1_OK;
+}

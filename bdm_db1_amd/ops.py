@@ -381,6 +381,13 @@ def mulaw_discretize(x, ids, is_action, num_bins=1024, mu=100.0, M=256.0):
     lib.call("db1_mulaw_discretize", P(x), P(ids), x.numel(), int(bool(is_action)), num_bins, float(mu), float(M), stream())
 
 
+def mulaw_decode(ids, out, is_action, num_bins=1024, mu=100.0, M=256.0, oob_flag=None):
+    assert ids.dtype in (torch.int32, torch.int64) and out.dtype == torch.float32 and ids.numel() == out.numel()
+    assert oob_flag is None or oob_flag.dtype == torch.int32
+    lib.call("db1_mulaw_decode", P(ids), P(out), ids.numel(), int(ids.dtype == torch.int64), int(bool(is_action)), num_bins, float(mu),
+             float(M), P(oob_flag), stream())
+
+
 def gemm_force_generic(on: bool):
     lib.load().db1_gemm_force_generic(1 if on else 0)
 

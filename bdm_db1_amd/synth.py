@@ -1,8 +1,9 @@
-"""Synthetic batches of the shapes BASELINE.json's configs name.  Host-side index
-building only; the layouts restate the reference's packers:
-  * text:     ids uniform [0, 32000), label = ids shifted by one                       (gpt_dataset.py:86-180)
-  * RL:       [obs patches (-1 placeholders), SEP, action]* truncated to L+1, split     (rl_dataset.py:44-71, 614-752)
-  * caption:  prompt + image patches + text; loss on the last image position and text   (coco_token_dataset.py:58-152)
+"""Synthetic batches of the shapes BASELINE.json's configs name.  Only the RAW data is synthetic
+(random token ids, random images, random actions); the samples are built by the package's own sample builders and batched by its
+collate function, i.e. by the path a real data loader takes:
+  * text:     ids uniform [0, 32000), label = ids shifted by one                                  (gpt_dataset.py:86-180)
+  * RL:       synthetic image-observation trajectories -> data.rl_dataset.RLFullDataset.get        (rl_dataset.py:590-752)
+  * caption:  synthetic (prompt, image, caption) records -> data.coco_token_dataset.ICDataset      (coco_token_dataset.py:104-152)
 and the data-parallel sharding rule of SequentialPretrainingSampler (data_samplers.py:152-170)."""
 from __future__ import annotations
 
@@ -11,7 +12,9 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
-from .data import ICTaskInput, NLPTaskInput, RLTaskInput
+from .data import ICTaskInput, NLPTaskInput, RLTaskInput, my_collate_fn
+from .data.coco_token_dataset import ICDataset
+from .data.rl_dataset import RLFullDataset
 
 
 def db1_config(size: str = "1.3B", **over) -> SimpleNamespace:
@@ -46,51 +49,45 @@ def text_batch(B: int, L: int, seed: int, device, vocab: int = 32000) -> NLPTask
 
 
 def rl_batch(B: int, L: int, seed: int, device, cfg, img_hw=(64, 80), n_actions: int = 18) -> RLTaskInput:
-    """Atari-like transitions: (h/16 * w/16) image patches, SEP, one discrete action."""
+    """Atari-like trajectories: one (h/16 * w/16)-patch image per observation, one discrete action, packed by
+    RLFullDataset: [patch placeholders (-1), SEP, action]* truncated to L + 1 and split into input / label, position ids 1..npatch+1
+    on observation + separator and 0 on the action, loss where the label is an action."""
     rng = np.random.default_rng(seed)
     p = cfg.vision_patch_size
-    npatch = (img_hw[0] // p) * (img_hw[1] // p)
-    step = npatch + 2
-    sep = cfg.text_vocab_size + cfg.num_continuous_bin + (0 if cfg.overlap_with_text else cfg.num_discrete_values)
-    ntr = (L + step - 1) // step  # transition_num (rl_dataset.py:229-231)
-    seq = np.empty((B, ntr * step), np.int64)
-    for t in range(ntr):
-        seq[:, t * step:t * step + npatch] = -1
-        seq[:, t * step + npatch] = sep
-        seq[:, t * step + npatch + 1] = rng.integers(0, n_actions, B)
-    seq = np.concatenate([seq, np.full((B, 1), -1, np.int64)], axis=1)[:, :L + 1]
-    inp, lab = seq[:, :-1], seq[:, 1:]
-    within = np.arange(L) % step
-    pos = np.where(within <= npatch, within + 1, 0).astype(np.int64)          # obs + separator: 1..npatch+1, action: 0
-    loss_mask = (within == npatch).astype(np.float32)                          # the label at the separator is the action
-    nimg = int(np.ceil((inp[0] == -1).sum() / npatch))
-    vision = rng.random((B, nimg, cfg.vision_num_input_channels, img_hw[0], img_hw[1]), dtype=np.float32) * 255.0
-    T = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)
-    return RLTaskInput(position_id=T(np.tile(pos, (B, 1))), attention_mask=None, loss_mask=T(np.tile(loss_mask, (B, 1))),
-                       label=T(lab), text_seq=None, vision_seq=T(vision), tensor_seq=T(inp))
+    step = (img_hw[0] // p) * (img_hw[1] // p) + 2
+    ntr = (L + step - 1) // step  # transition_num (rl_dataset.py:229-231): each synthetic trajectory is exactly one sample long
+    trajs = [(rng.random((ntr, cfg.vision_num_input_channels, img_hw[0], img_hw[1]), dtype=np.float32) * 255.0,
+              rng.integers(0, n_actions, ntr).astype(np.int64)) for _ in range(B)]
+    tokenizers = (SimpleNamespace(vocab_size=cfg.text_vocab_size), SimpleNamespace(num_continuous_bin=cfg.num_continuous_bin))
+    ds = RLFullDataset(trajs, L, tokenizers, overlap_with_text=cfg.overlap_with_text, num_discrete_values=cfg.num_discrete_values,
+                       vision_patch_size=p, use_prompt=False)
+    assert ds.transition_num == ntr
+    first = [i for i, row in enumerate(ds.indices) if row[1] == 0]   # the sample that starts at step 0 of each trajectory
+    (batch,) = my_collate_fn([ds[i] for i in first])
+    batch.loss_mask = batch.loss_mask.to(torch.float32)
+    return batch.to(device=device)
 
 
 def caption_batch(B: int, L: int, seed: int, device, cfg, img_hw=(224, 224), prompt_len: int = 8) -> ICTaskInput:
+    """prompt + image patches + caption filling L tokens; loss on the last image position and on the caption (ICDataset)"""
     rng = np.random.default_rng(seed)
     p = cfg.vision_patch_size
     nv = (img_hw[0] // p) * (img_hw[1] // p)
     Tt = L - prompt_len - nv
     assert Tt > 0
     V = cfg.text_vocab_size
-    prompt = rng.integers(0, V, (B, prompt_len))
-    text = rng.integers(1, V, (B, Tt))
-    img = rng.random((B, cfg.vision_num_input_channels, img_hw[0], img_hw[1]), dtype=np.float32)
-    mean = np.array([0.485, 0.456, 0.406], np.float32)[None, :, None, None]
-    std = np.array([0.229, 0.224, 0.225], np.float32)[None, :, None, None]
-    img = (img - mean[:, :img.shape[1]]) / std[:, :img.shape[1]]
-    label = np.zeros((B, L), np.int64)
-    label[:, prompt_len + nv - 1:L - 1] = text          # next-token targets start at the last image position
-    label[:, L - 1] = 0                                  # eos
-    mask = np.zeros((B, L), np.float32)
-    mask[:, prompt_len + nv - 1:] = 1.0
-    T = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)
-    return ICTaskInput(position_id=None, attention_mask=None, loss_mask=T(mask), label=T(label), prompt_seq=T(prompt),
-                       img_seq=T(img), text_seq=T(text), img_id_seq=None)
+    mean = np.array([0.485, 0.456, 0.406], np.float32)[:, None, None]
+    std = np.array([0.229, 0.224, 0.225], np.float32)[:, None, None]
+    C = cfg.vision_num_input_channels
+    records = []
+    for b in range(B):
+        img = (rng.random((C, img_hw[0], img_hw[1]), dtype=np.float32) - mean[:C]) / std[:C]   # vit_dataset.py:42-43
+        caption = np.concatenate([rng.integers(1, V, Tt), [0]]).astype(np.int32)                # Tt tokens + eos
+        records.append(dict(text=caption, img=torch.from_numpy(img), prompt=rng.integers(0, V, prompt_len).tolist(), img_id=b))
+    ds = ICDataset(SimpleNamespace(n_position=L), records, SimpleNamespace(eos_token_id=0))
+    (batch,) = my_collate_fn([ds[i] for i in range(B)])
+    batch.label, batch.prompt_seq, batch.text_seq = batch.label.long(), batch.prompt_seq.long(), batch.text_seq.long()
+    return batch.to(device=device)
 
 
 def mixture_batch(B: int, L: int, seed: int, device, cfg):

@@ -259,6 +259,11 @@ int db1_adam_step(float* p32, const void* g, float* m, float* v, void* p_work, i
  * ContinuousScalarTokenizer.discretize (src/tokenizer/scalar_tokenizer.py:28-45), bit-exact ids. */
 int db1_mulaw_discretize(const float* x, int32_t* ids, int64_t n, int is_action, int num_bins, float mu, float M,
                          void* stream);
+/* ContinuousScalarTokenizer.decode (scalar_tokenizer.py:47-63; caller evaluate_rl.py:263): ids (int32, or int64 when ids_are_int64)
+ * clipped to [0, num_bins-1] -> x = id/num_bins*2 - 1; observations additionally sign(x) * ((1 + M*mu)^|x| - 1) / mu.
+ * *oob_flag (device int, nullable) is OR-ed with 1 when an id was out of range (the reference warns and clips). */
+int db1_mulaw_decode(const void* ids, float* out, int64_t n, int ids_are_int64, int is_action, int num_bins, float mu, float M,
+                     int* oob_flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -165,3 +165,66 @@ def make_batch(name: str, cfg: dict, seed: int):
     elif name == "small_mems":
         pass
     return tasks
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# inputs of the RL / caption sample-builder fixtures (rl_dataset.npz, caption_vqa.npz): regenerated on both sides
+# ---------------------------------------------------------------------------------------------------------------------
+RL_DS_CASES = {
+    # name: (observation kind, action kind, seq_length, constructor options, sample indices, numpy global seed)
+    "vec_cont_noprompt": ("vec5", "cont2", 64, dict(use_prompt=False), [0, 7, 40, 10 ** 6], 1),
+    "vec_cont_prompt_subseq": ("vec5", "cont2", 64, dict(use_prompt=True, prompt_prob=1.0, prompt_at_final_transition_prob=0.0), [0, 3, 33], 2),
+    "vec_cont_prompt_final": ("vec5", "cont2", 64, dict(use_prompt=True, prompt_prob=1.0, prompt_at_final_transition_prob=1.0), [1, 20], 3),
+    "vec_cont_prompt_timestep": ("vec5", "cont2", 64, dict(use_prompt=True, prompt_prob=1.0, prompt_at_final_transition_prob=0.0,
+                                                            prompt_strategy="stochastic_timestep"), [2, 11], 4),
+    "vec_cont_prompt_mixed": ("vec5", "cont2", 96, dict(use_prompt=True, prompt_prob=0.5, prompt_ratio=0.25), [0, 5, 9, 14, 21, 30], 5),
+    "img_disc": ("img32", "disc", 48, dict(use_prompt=False), [0, 2, 12], 6),
+    "img_disc_nooverlap_prompt": ("img32", "disc", 48, dict(use_prompt=True, prompt_prob=1.0, overlap_with_text=False, num_discrete_values=18), [0, 6], 7),
+    "dict_img_vec_disc": ("dict", "disc2", 80, dict(use_prompt=True, prompt_prob=0.7), [0, 4, 8], 8),
+    "discobs_cont": ("disc3", "cont1", 40, dict(use_prompt=False, overlap_with_text=False), [0, 9], 9),
+}
+
+
+def rl_trajectories(obs_kind: str, act_kind: str, seed: int = 31):
+    """a handful of short synthetic trajectories [(observations, actions)] of unequal lengths"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for n in (9, 4, 13, 2, 7):
+        if obs_kind == "vec5":
+            obs = (rng.standard_normal((n, 5)) * 3).astype(np.float32)
+        elif obs_kind == "disc3":
+            obs = rng.integers(0, 16, (n, 3)).astype(np.int64)
+        elif obs_kind == "img32":
+            obs = (rng.random((n, 3, 32, 32)) * 255).astype(np.float32)
+        elif obs_kind == "dict":
+            obs = {"rgb": (rng.random((n, 3, 16, 32)) * 255).astype(np.float32), "state": rng.standard_normal((n, 3)).astype(np.float32),
+                   "aux": rng.integers(0, 10, (n, 2)).astype(np.int64)}
+        else:
+            raise ValueError(obs_kind)
+        if act_kind.startswith("cont"):
+            act = rng.uniform(-1, 1, (n, int(act_kind[4:]))).astype(np.float32)
+        elif act_kind == "disc":
+            act = rng.integers(0, 18, (n,)).astype(np.int64)
+        else:
+            act = rng.integers(0, 18, (n, int(act_kind[4:]))).astype(np.int64)
+        out.append((obs, act))
+    return out
+
+
+def caption_samples(seed: int = 41, eos: int = 0):
+    """samples as the reference's RandomCOCO / VQA readers yield them (dicts of token arrays and an image tensor)"""
+    import torch
+    rng = np.random.default_rng(seed)
+    ic, vqa = [], []
+    for k, tlen in enumerate((12, 30, 5)):
+        text = rng.integers(1, 300, tlen).astype(np.int32)
+        text[rng.integers(0, tlen)] = eos                      # an eos inside / at the end: masked positions
+        ic.append(dict(text=text, img=torch.from_numpy(rng.standard_normal((3, 32, 48)).astype(np.float32)),
+                       prompt=[5, 6, 7, 8], img_id=100 + k))
+    for k, (ql, al) in enumerate(((6, 3), (9, 2), (4, 5))):
+        ans = rng.integers(1, 300, al).astype(np.int32)
+        ans[-1] = eos
+        vqa.append(dict(ques=rng.integers(1, 300, ql).astype(np.int32), ans=ans if k != 1 else ans.tolist(),
+                        img=torch.from_numpy(rng.standard_normal((3, 32, 32)).astype(np.float32)), ques_id=7000 + k, img_id=200 + k,
+                        prompt=np.array([9, 10, 11], np.int32), ques_len=ql))
+    return ic, vqa

@@ -218,6 +218,118 @@ def gen_rl_packing():
     return out
 
 
+class _FakeTextTokenizer:
+    """the two things the sample builders read from the text tokenizer"""
+    vocab_size = 32000
+    eos_token_id = 0
+
+
+def _tree_stub():
+    """dm-tree is not installed: the three functions the reference's RL dataset uses, for the two observation forms it supports (one
+    array, or a flat dict of arrays; dm-tree visits dict keys in sorted order and rebuilds the dict in the original key order)"""
+    m = types.ModuleType("tree")
+
+    def map_structure(fn, *structs):
+        s0 = structs[0]
+        if isinstance(s0, dict):
+            vals = {k: map_structure(fn, *[s[k] for s in structs]) for k in sorted(s0)}
+            return {k: vals[k] for k in s0}
+        return fn(*structs)
+
+    def flatten(s):
+        return [x for k in sorted(s) for x in flatten(s[k])] if isinstance(s, dict) else [s]
+
+    m.map_structure, m.flatten = map_structure, flatten
+    return m
+
+
+def gen_rl_dataset():
+    """RLFullDataset.get (src/data/rl_dataset.py:590-752, with prepend_prompt :475-578 and postprocess_obs_and_act :393-473) run by
+    the reference itself on in-memory trajectories.  gym / d4rl (a private fork) are absent, so __init__ (which opens a d4rl
+    environment and an on-disk cache) is bypassed: the object is created with __new__, given the trajectories, and everything else
+    -- type spec, dims, transition counts, index table -- is computed by the reference's own methods and its compiled helpers."""
+    from golden_util import RL_DS_CASES, rl_trajectories
+    for n in ("gym", "d4rl"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["tree"] = _tree_stub()
+    from src.data import rl_dataset as R
+    from src.tokenizer.scalar_tokenizer import ContinuousScalarTokenizer
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref"))
+    import helpers as ref_helpers
+    out = {}
+    for name, (ok, ak, L, opts, idxs, seed) in RL_DS_CASES.items():
+        trajs = rl_trajectories(ok, ak)
+        ds = R.RLFullDataset.__new__(R.RLFullDataset)
+        o = dict(overlap_with_text=True, num_discrete_values=1024, prompt_ratio=0.5, prompt_prob=0.25, prompt_at_final_transition_prob=0.5,
+                 use_prompt=True, prompt_strategy="stochastic_subseq")
+        o.update(opts)
+        ds.env, ds.name, ds.output_sequence_length = object(), name, L
+        ds.prompt_strategy, ds.use_prompt, ds.vision_patch_size = o["prompt_strategy"], o["use_prompt"], 16
+        ds.prompt_prob, ds.prompt_at_final_transition_prob, ds.prompt_ratio = o["prompt_prob"], o["prompt_at_final_transition_prob"], o["prompt_ratio"]
+        ds.text_tokenizer, ds.discretizer = _FakeTextTokenizer(), ContinuousScalarTokenizer()
+        ds.num_discrete_values, ds.overlap_with_text = o["num_discrete_values"], o["overlap_with_text"]
+        ds.is_lazy, ds.cached = False, False
+        ds.observations, ds.actions = [t[0] for t in trajs], [t[1] for t in trajs]
+        ds.path_lengths = np.array([len(a) for a in ds.actions], dtype=np.int32)
+        tmp_obs, tmp_act = ds.get_obs_action_by_path_idx(0)                    # rl_dataset.py:220-236
+        ds.obs_type_spec = ds.get_obs_type_spec(tmp_obs)
+        ds.observation_dims_for_spec = ds.get_observation_dim(tmp_obs)
+        ds.observation_dim = sum(sys.modules["tree"].flatten(ds.observation_dims_for_spec))
+        ds.action_dim = ds.get_action_dim(tmp_act[0])
+        trans_dim = ds.observation_dim + ds.action_dim
+        ds.transition_num = (L + trans_dim) // (trans_dim + 1)
+        ds.prompt_transition_num = int(o["prompt_ratio"] * ds.transition_num)
+        ds.predicted_transition_num = ds.transition_num - ds.prompt_transition_num
+        ds.indices = np.array(ref_helpers.build_rl_sample_idx(ds.path_lengths, ds.transition_num))
+        out[f"{name}/meta"] = np.array([ds.observation_dim, ds.action_dim, ds.transition_num, ds.prompt_transition_num, len(ds.indices)])
+        np.random.seed(seed)
+        for j, idx in enumerate(idxs):
+            r = ds.get(idx)
+            for f in ("position_id", "loss_mask", "label", "tensor_seq"):
+                out[f"{name}/{j}/{f}"] = getattr(r, f).numpy()
+            if r.vision_seq is not None:
+                out[f"{name}/{j}/vision_seq"] = r.vision_seq.numpy()
+        if name == "vec_cont_noprompt":   # demonstrations for evaluation prompts (:812-862)
+            np.random.seed(99)
+            for j, (strategy, strict) in enumerate((("fixed_prompt", False), ("moving_prompt", True))):
+                d = ds.sample_expert_demonstration(strategy, strict, False)
+                out[f"{name}/demo{j}/actions"], out[f"{name}/demo{j}/tensor"] = d["actions"], d["obs/tensor"]
+    return out
+
+
+def gen_caption_vqa():
+    """ICDataset / VQADataset / get_ltor_masks_and_position_ids / get_loss_mask_vqa (src/data/coco_token_dataset.py:58-210) and the
+    caption length fitting of RandomCOCO.__getitem__ (:43-48) run by the reference; torchvision (absent) is only the base class of a
+    reader that is not used here."""
+    from golden_util import caption_samples
+    tv = types.ModuleType("torchvision")
+    tv.datasets = types.ModuleType("torchvision.datasets")
+    tv.datasets.CocoCaptions = object
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.datasets", tv.datasets)
+    from src.data import coco_token_dataset as C
+    import torch.nn.functional as F
+    ic, vqa = caption_samples()
+    out = {}
+    args = SimpleNamespace(n_position=48, eod_mask_loss=False)
+    tok = _FakeTextTokenizer()
+    for name, cls, samples in (("ic", C.ICDataset, ic), ("vqa", C.VQADataset, vqa)):
+        ds = cls(args, samples, tok)
+        for j in range(len(ds)):
+            r = ds[j]
+            for f in ("loss_mask", "label", "prompt_seq", "text_seq", "img_seq"):
+                out[f"{name}/{j}/{f}"] = getattr(r, f).float().numpy() if f == "img_seq" else getattr(r, f).numpy()
+    for j, (n, full) in enumerate(((5, 12), (11, 12), (1, 4))):
+        data = np.array([3, 0, 7, 0, 9, 2, 0, 4, 1, 8, 6][:n], np.int32)
+        _, lm, pid = C.get_ltor_masks_and_position_ids(data, 0, full)
+        out[f"ltor/{j}/data"], out[f"ltor/{j}/full"], out[f"ltor/{j}/loss_mask"], out[f"ltor/{j}/position_ids"] = data, np.int64(full), lm, pid
+    for j, seq_length in enumerate((4, 9, 20)):   # RandomCOCO.__getitem__ :43-48 on a 9-token caption
+        text = torch.IntTensor([[11, 12, 13, 14, 15, 16, 17, 18, 19]]).squeeze()
+        text = text[..., :seq_length] if text.shape[-1] >= seq_length else F.pad(text, (0, seq_length - text.shape[-1]), "constant", 0)
+        out[f"fit/{j}"] = text.numpy()
+    return out
+
+
 SAMPLER_CASES = [  # (total, consumed, micro_batch, rank, world)
     (100, 0, 4, 0, 2), (100, 0, 4, 1, 2), (64, 16, 2, 3, 4), (37, 0, 5, 0, 1), (1000, 256, 8, 5, 8), (96, 192, 4, 1, 2),
 ]
@@ -310,6 +422,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "data":
         np.savez_compressed(os.path.join(HERE, "data_ingest.npz"), **gen_data_ingest())
         print("wrote data_ingest + data_fixture.idx/.bin")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "packers":
+        np.savez_compressed(os.path.join(HERE, "rl_dataset.npz"), **gen_rl_dataset())
+        np.savez_compressed(os.path.join(HERE, "caption_vqa.npz"), **gen_caption_vqa())
+        print("wrote rl_dataset + caption_vqa")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "samplers":
         np.savez_compressed(os.path.join(HERE, "samplers.npz"), **gen_samplers())

@@ -623,6 +623,46 @@ def test_mulaw_discretize_bit_exact(ops):
     assert np.array_equal(ids.cpu().numpy(), O.mulaw_discretize(x, False))
 
 
+def test_mulaw_decode_all_ids_and_tokenizer_class(ops, capsys):
+    """db1_mulaw_decode over EVERY bin id against the reference's own decode output (scalar_tokenizer.npz: dec_obs / dec_act), and the
+    product ContinuousScalarTokenizer (reference surface, scalar_tokenizer.py:20-63) on NumPy / CPU / device inputs"""
+    from bdm_db1_amd.tokenizer import ContinuousScalarTokenizer
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "scalar_tokenizer.npz")))
+    ids = torch.from_numpy(gold["dec_ids"]).to(DEV)
+    assert ids.numel() == 1024
+    for idt in (torch.int64, torch.int32):
+        for key, is_action in (("dec_obs", False), ("dec_act", True)):
+            out = torch.empty(ids.numel(), device=DEV, dtype=torch.float32)
+            ops.mulaw_decode(ids.to(idt), out, is_action)
+            # actions: pure float32 arithmetic -> bit-exact; observations: (base^|x| - 1) / mu with the float32 power within 2 ulp of
+            # torch's (the kernel rounds a float64 pow once; torch-CPU's vectorised powf is itself ~1 ulp)
+            if is_action:
+                assert np.array_equal(out.cpu().numpy(), gold[key]), key
+            else:
+                tol = 2 * 2.0 ** -23 * (np.abs(gold[key].astype(np.float64)) * 100 + 1) / 100
+                assert (np.abs(out.cpu().numpy().astype(np.float64) - gold[key]) <= tol).all(), key
+    tok = ContinuousScalarTokenizer()
+    assert (tok.num_continuous_bin, tok.mu, tok.M) == (1024, 100.0, 256.0)
+    for src in (gold["known_obs"], torch.from_numpy(gold["known_obs"]), torch.from_numpy(gold["known_obs"]).to(DEV)):
+        got = tok.discretize(src, is_action=False)
+        assert got.dtype == torch.int32 and np.array_equal(got.cpu().numpy(), gold["known_obs_ids"])
+        assert got.device.type == ("cuda" if torch.is_tensor(src) and src.is_cuda else "cpu")
+    assert np.array_equal(tok.discretize(gold["act"], is_action=True).numpy(), gold["act_ids"])
+    dec = tok.decode(gold["dec_ids"], is_action=True)
+    assert dec.dtype == torch.float32 and dec.device.type == "cpu" and np.array_equal(dec.numpy(), gold["dec_act"])
+    # discretize(decode(id)) is the identity on the action path (bin lower edges), and lands in the same bin for observations
+    # except at id 512 (x = 0 decodes to 0 exactly -> bin 512) -- checked against the oracle, which is pinned to the reference
+    rt = tok.discretize(tok.decode(ids, is_action=True), is_action=True)
+    assert torch.equal(rt.cpu(), ids.cpu().to(torch.int32))
+    rt_obs = tok.discretize(tok.decode(ids, is_action=False), is_action=False).cpu().numpy()
+    assert np.array_equal(rt_obs, O.mulaw_discretize(O.mulaw_decode(gold["dec_ids"], False), False))
+    # out-of-range ids: clipped, with the reference's warning (scalar_tokenizer.py:50-57)
+    capsys.readouterr()
+    clipped = tok.decode(np.array([-3, 0, 1023, 5000], np.int64), is_action=True).numpy()
+    assert np.array_equal(clipped, gold["dec_act"][[0, 0, 1023, 1023]])
+    assert "exceeded range" in capsys.readouterr().out
+
+
 # ------------------------------------------------------------------------------- patch embedder pieces
 def test_patch_normalize_im2col_groupnorm(ops):
     rng = np.random.default_rng(13)
