@@ -36,7 +36,8 @@ def _digest() -> str:
         if os.path.isfile(p) and f.endswith((".hip", ".h", ".inc")):
             h.update(f.encode())
             h.update(open(p, "rb").read())
-    h.update(open(os.path.join(HERE, "..", "include", "db1_hip.h"), "rb").read())
+    for hdr in ("db1_hip.h", "db1_hip_test.h"):
+        h.update(open(os.path.join(HERE, "..", "include", hdr), "rb").read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 

@@ -15,10 +15,12 @@
 #define CI_P 16
 #define CI_HW 256
 
+// 256 bytes of zeros in device memory (module data, never written): the source of the LDS-DMA lanes that fall outside the patch
+__device__ __attribute__((aligned(256))) bf16_t ci_zero_page[128] = {};
+
 struct ConvArgs {
     const bf16_t* x;      // gathered activations [n_patches * 256, 64]
     const bf16_t* w;      // fwd / dgrad: weight operand [64, 576] (K-major);  wgrad: dY [n_patches * 256, 64]
-    const bf16_t* zeros;  // >= 256 bytes of zeros
     void* y;              // fwd / dgrad: [n_patches * 256, 64] bf16;  wgrad: gp [64, 576] float32 (accumulated)
     const void* bias;
     int64_t n_patches;
@@ -30,7 +32,7 @@ __device__ __forceinline__ const bf16_t* ci_src(const ConvArgs& p, int64_t pix, 
     const int yx = (int)(pix & (CI_HW - 1));
     const int yy = (yx >> 4) + sign * (tap / 3 - 1), xx = (yx & 15) + sign * (tap % 3 - 1);
     const bool ok = yy >= 0 && yy < CI_P && xx >= 0 && xx < CI_P;
-    return ok ? p.x + ((pix - yx) + yy * CI_P + xx) * CI_C + c * 8 : p.zeros + c * 8;
+    return ok ? p.x + ((pix - yx) + yy * CI_P + xx) * CI_C + c * 8 : ci_zero_page + c * 8;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------- fwd / dgrad
@@ -179,15 +181,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_implicit_kernel(ConvArgs p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------- host side
-static bf16_t* g_ci_zeros = nullptr;
-static const bf16_t* ci_zero_page() {
-    if (!g_ci_zeros) {
-        if (hipMalloc((void**)&g_ci_zeros, 256) != hipSuccess) return nullptr;
-        hipMemset(g_ci_zeros, 0, 256);
-    }
-    return g_ci_zeros;
-}
-
 extern "C" int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const void* bias, void* y, int64_t n_patches, int sign, int dtBias,
                                         void* stream) {
     if (n_patches <= 0 || (sign != 1 && sign != -1)) DB1_FAIL(DB1_ERR_BAD_SHAPE, "conv3x3_implicit_fwd: n_patches=%lld sign=%d", (long long)n_patches, sign);
@@ -195,14 +188,11 @@ extern "C" int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const v
     if (n_patches > 8000000) DB1_FAIL(DB1_ERR_BAD_SHAPE, "conv3x3_implicit_fwd: too many patches");
     ConvArgs a;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w_op; a.y = y; a.bias = bias; a.n_patches = n_patches; a.sign = sign; a.ksplit = 1;
-    a.zeros = ci_zero_page();
-    if (!a.zeros) DB1_FAIL(DB1_ERR_HIP, "conv3x3_implicit_fwd: cannot allocate the zero page");
-    static bool attr = false;
-    if (!attr) {
+    static Db1PerDeviceOnce attr_once;
+    attr_once.run([] {
         hipFuncSetAttribute((const void*)conv_implicit_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CI_STAGE_BYTES);
         hipFuncSetAttribute((const void*)conv_implicit_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CI_STAGE_BYTES);
-        attr = true;
-    }
+    });
     hipStream_t st = (hipStream_t)stream;
     if (bias && dtBias == DB1_BF16) conv_implicit_kernel<bf16_t><<<(unsigned)n_patches, 256, 2 * CI_STAGE_BYTES, st>>>(a);
     else conv_implicit_kernel<float><<<(unsigned)n_patches, 256, 2 * CI_STAGE_BYTES, st>>>(a);
@@ -215,14 +205,12 @@ extern "C" int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* 
     if (!dy || !x || !gp_acc || !db1_aligned16(dy) || !db1_aligned16(x)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "conv3x3_implicit_wgrad: operands must be 16-byte aligned");
     ConvArgs a;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)dy; a.y = gp_acc; a.bias = nullptr; a.n_patches = n_patches; a.sign = 1;
-    a.zeros = ci_zero_page();
-    if (!a.zeros) DB1_FAIL(DB1_ERR_HIP, "conv3x3_implicit_wgrad: cannot allocate the zero page");
     const int64_t nk = n_patches * (CI_HW / TBK);
     int ks = 128;                                        // 5 column tiles x 128 pixel ranges = 640 workgroups
     while (ks > 1 && nk / ks < 8) ks >>= 1;
     a.ksplit = ks;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)conv_wgrad_implicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); attr = true; }
+    static Db1PerDeviceOnce attr_once;
+    attr_once.run([] { hipFuncSetAttribute((const void*)conv_wgrad_implicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); });
     conv_wgrad_implicit_kernel<<<dim3(5, 1, (unsigned)ks), 256, 4 * TILE_BYTES, (hipStream_t)stream>>>(a);
     DB1_CHECK_LAUNCH("conv3x3_implicit_wgrad");
     return DB1_OK;

@@ -3,7 +3,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include "../../include/db1_hip.h"
+#include "../../include/db1_hip_test.h"
+
+// The only process-level state of the library: "this kernel's dynamic-LDS attribute has been set on this device" -- an immutable
+// per-device cache, set once under std::call_once (kernel attributes are per device: a process that drives several GPUs sets
+// them on each).
+struct Db1PerDeviceOnce {
+    std::once_flag flags[64];
+    template <class F> void run(F&& fn) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::call_once(flags[dev & 63], fn);
+    }
+};
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 
@@ -19,6 +33,15 @@ void db1_set_error(const char* fmt, ...);
     do {                                                                              \
         hipError_t e__ = hipGetLastError();                                           \
         if (e__ != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// Scratch memory comes from the CALLER (include/db1_hip.h, "Conventions"): an entry point that needs scratch takes (ws, ws_bytes) and has a
+// db1_<op>_workspace_bytes(...) query; the library never calls hipMalloc / hipFree / hipDeviceSynchronize.
+#define DB1_NEED_WS(ws, ws_bytes, need, name)                                                                      \
+    do {                                                                                                           \
+        if ((need) > 0 && (!(ws) || (int64_t)(ws_bytes) < (int64_t)(need) || (((uintptr_t)(ws)) & 15)))             \
+            DB1_FAIL(DB1_ERR_WORKSPACE_TOO_SMALL, "%s: needs %lld bytes of 16-byte aligned workspace, got %lld",  \
+                     name, (long long)(need), (long long)((ws) ? (ws_bytes) : 0));                               \
     } while (0)
 
 static inline int db1_elt_size(int dt) { return dt == DB1_F32 ? 4 : 2; }

@@ -260,18 +260,6 @@ __global__ __launch_bounds__(64 * LNR_WAVES) void ln_param_reduce_kernel(const f
         if (c < d) dgamma[c] += t; else dbeta[c - d] += t;
     }
 }
-static float* g_ln_ws = nullptr;  // grow-only partial-sum workspace (single compute stream, like the split-K workspace in gemm.hip)
-static size_t g_ln_ws_bytes = 0;
-static float* ln_workspace(size_t bytes) {
-    if (bytes > g_ln_ws_bytes) {
-        if (g_ln_ws) { hipDeviceSynchronize(); hipFree(g_ln_ws); }
-        g_ln_ws = nullptr;
-        g_ln_ws_bytes = 0;
-        if (hipMalloc((void**)&g_ln_ws, bytes) != hipSuccess) return nullptr;
-        g_ln_ws_bytes = bytes;
-    }
-    return g_ln_ws;
-}
 template <typename T> static int ln_reg_nv(int d) {  // NV such that d == 64 * V * NV, or 0
     const int V = Vec16<T>::N;
     for (int nv = 1; nv <= 4; nv <<= 1) if (d == 64 * V * nv) return nv;
@@ -308,22 +296,27 @@ extern "C" int db1_layernorm_residual_fwd(const void* x, const void* r, float al
     return DB1_OK;
 }
 
+static const int LN_BWD_RPB = 32;  // rows per block of the fused backward = rows per partial-sum slot
+extern "C" int64_t db1_layernorm_residual_bwd_workspace_bytes(int64_t rows, int d, int dt) {
+    if (dt != DB1_BF16 || !ln_reg_nv<bf16_t>(d)) return 0;  // the generic kernels accumulate the parameter gradients directly
+    return ((rows + LN_BWD_RPB - 1) / LN_BWD_RPB) * 2 * (int64_t)d * (int64_t)sizeof(float);
+}
 extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                                           void* ds, float* dgamma_acc, float* dbeta_acc, int64_t rows, int d, int dt,
-                                          int dtParam, void* stream) {
+                                          int dtParam, void* ws_, int64_t ws_bytes, void* stream) {
     if (!db1_dt_ok(dt) || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "layernorm bwd: dtype");
     const int V = dt == DB1_F32 ? 4 : 8;
     if (rows <= 0 || d <= 0 || d % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd: d=%d must be a multiple of %d", d, V);
     if (!db1_aligned16(dy) || !db1_aligned16(s) || !db1_aligned16(ds)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "layernorm bwd: alignment");
     hipStream_t st = (hipStream_t)stream;
     if (dt == DB1_BF16 && ln_reg_nv<bf16_t>(d)) {  // fused one-pass backward (ds + parameter partials)
-        const int nv = ln_reg_nv<bf16_t>(d), rpb = 32;
+        const int nv = ln_reg_nv<bf16_t>(d), rpb = LN_BWD_RPB;
         const int nblocks = (int)((rows + rpb - 1) / rpb);
         const bool params = dgamma_acc && dbeta_acc;
         float* ws = nullptr;
         if (params) {
-            ws = ln_workspace((size_t)nblocks * 2 * d * sizeof(float));
-            if (!ws) DB1_FAIL(DB1_ERR_HIP, "layernorm bwd: cannot allocate the partial-sum workspace");
+            DB1_NEED_WS(ws_, ws_bytes, db1_layernorm_residual_bwd_workspace_bytes(rows, d, dt), "layernorm bwd");
+            ws = (float*)ws_;
         }
 #define LN_BWD_F(TP, NV) ln_bwd_fused_kernel<bf16_t, TP, NV><<<nblocks, 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)s, (const TP*)gamma, mean, rstd, (bf16_t*)ds, ws, rows, d, rpb)
 #define LN_BWD_NV(TP) do { if (nv == 1) LN_BWD_F(TP, 1); else if (nv == 2) LN_BWD_F(TP, 2); else LN_BWD_F(TP, 4); } while (0)
@@ -540,8 +533,13 @@ extern "C" int db1_ffn_act_bwd(const void* z, const void* dout, void* dz, int64_
     return DB1_OK;
 }
 
+static inline int act_bias_rpc(int64_t rows) { return rows >= 32768 ? 64 : 32; }  // (8 workgroups per CU are enough to stream)
+extern "C" int64_t db1_ffn_act_bwd_bias_workspace_bytes(int64_t rows, int n, int act) {
+    const int rpc = act_bias_rpc(rows);
+    return ((rows + rpc - 1) / rpc) * (int64_t)(act == DB1_ACT_GEGLU ? 2 * n : n) * (int64_t)sizeof(float);
+}
 extern "C" int db1_ffn_act_bwd_bias(const void* z, const void* dout, void* dz, float* dbias_acc, int64_t rows, int n, int act, int dt,
-                                    void* stream) {
+                                    void* ws_, int64_t ws_bytes, void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "ffn_act_bwd_bias: dtype");
     const int V = dt == DB1_F32 ? 4 : 8;
     if (rows <= 0 || n <= 0 || n % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "ffn_act_bwd_bias: n=%d must be a multiple of %d", n, V);
@@ -549,9 +547,9 @@ extern "C" int db1_ffn_act_bwd_bias(const void* z, const void* dout, void* dz, f
     if (!dbias_acc) DB1_FAIL(DB1_ERR_BAD_SHAPE, "ffn_act_bwd_bias: null accumulator");
     hipStream_t st = (hipStream_t)stream;
     const int ld = act == DB1_ACT_GEGLU ? 2 * n : n;
-    const int rpc = rows >= 32768 ? 64 : 32, nchunks = (int)((rows + rpc - 1) / rpc);  // (8 workgroups per CU are enough to stream)
-    float* ws = ln_workspace((size_t)nchunks * ld * sizeof(float));
-    if (!ws) DB1_FAIL(DB1_ERR_HIP, "ffn_act_bwd_bias: cannot allocate the partial-sum workspace");
+    const int rpc = act_bias_rpc(rows), nchunks = (int)((rows + rpc - 1) / rpc);
+    DB1_NEED_WS(ws_, ws_bytes, db1_ffn_act_bwd_bias_workspace_bytes(rows, n, act), "ffn_act_bwd_bias");
+    float* ws = (float*)ws_;
     dim3 g((unsigned)((n / V + 255) / 256), (unsigned)nchunks);
 #define L(T, A) act_bwd_bias_kernel<T, A><<<g, 256, 0, st>>>((const T*)z, (const T*)dout, (T*)dz, ws, rows, n, rpc)
     DB1_DISPATCH_DT(dt, T, { if (act == 0) L(T, 0); else if (act == 1) L(T, 1); else L(T, 2); });
@@ -636,17 +634,27 @@ __global__ __launch_bounds__(256) void colsum_chunk_kernel(const T* __restrict__
     }
 }
 
-extern "C" int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int cols, int64_t ldx, int dt, void* stream) {
+static inline int colsum_rpc(int64_t rows) {  // the ordered reduce walks the chunks serially: keep them few (conv bias sums: 3.9 M rows)
+    int rpc = 32;
+    while (rows / rpc > 1024) rpc *= 2;
+    return rpc;
+}
+extern "C" int64_t db1_colsum_acc_workspace_bytes(int64_t rows, int cols) {
+    if (rows < 1024) return 0;  // short inputs add straight into the accumulator
+    const int rpc = colsum_rpc(rows);
+    return ((rows + rpc - 1) / rpc) * (int64_t)cols * (int64_t)sizeof(float);
+}
+extern "C" int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int cols, int64_t ldx, int dt, void* ws_, int64_t ws_bytes,
+                              void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "colsum: dtype");
     if (rows <= 0 || cols <= 0 || ldx < cols) DB1_FAIL(DB1_ERR_BAD_SHAPE, "colsum: shape");
     const int V = dt == DB1_F32 ? 4 : 8;
     if (cols % V == 0 && ldx % V == 0 && db1_aligned16(x)) {
         if (rows >= 1024) {  // long inputs: chunk partials + ordered reduce (deterministic, ~16 resident waves per CU)
-            int rpc = 32;
-            while (rows / rpc > 1024) rpc *= 2;  // the ordered reduce walks the chunks serially: keep them few (conv bias sums: 3.9 M rows)
+            const int rpc = colsum_rpc(rows);
             const int nchunks = (int)((rows + rpc - 1) / rpc);
-            float* ws = ln_workspace((size_t)nchunks * cols * sizeof(float));
-            if (!ws) DB1_FAIL(DB1_ERR_HIP, "colsum: cannot allocate the partial-sum workspace");
+            DB1_NEED_WS(ws_, ws_bytes, db1_colsum_acc_workspace_bytes(rows, cols), "colsum");
+            float* ws = (float*)ws_;
             dim3 gc((unsigned)((cols / V + 63) / 64), (unsigned)nchunks);
             DB1_DISPATCH_DT(dt, T, (colsum_chunk_kernel<T><<<gc, 256, 0, (hipStream_t)stream>>>((const T*)x, ws, rows, cols, ldx, rpc)));
             DB1_CHECK_LAUNCH("colsum_chunk");
@@ -764,8 +772,12 @@ __global__ __launch_bounds__(256) void add2d_colsums_kernel(const T* __restrict_
     }
 }
 // y may alias b.  sum_a_acc[c] += sum_r a[r, c], sum_b_acc[c] += sum_r b[r, c] (float32, fixed summation order).
+extern "C" int64_t db1_add2d_colsums_workspace_bytes(int64_t rows, int cols) {
+    const int rpc = colsum_rpc(rows);
+    return ((rows + rpc - 1) / rpc) * 2 * (int64_t)cols * (int64_t)sizeof(float);
+}
 extern "C" int db1_add2d_colsums(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, float* sum_a_acc,
-                                 float* sum_b_acc, int64_t rows, int cols, int dt, void* stream) {
+                                 float* sum_b_acc, int64_t rows, int cols, int dt, void* ws_, int64_t ws_bytes, void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "add2d_colsums: dtype");
     const int V = dt == DB1_F32 ? 4 : 8;
     if (rows <= 0 || cols <= 0 || lda < cols || ldb < cols || ldy < cols) DB1_FAIL(DB1_ERR_BAD_SHAPE, "add2d_colsums: shape");
@@ -773,11 +785,10 @@ extern "C" int db1_add2d_colsums(const void* a, int64_t lda, const void* b, int6
         DB1_FAIL(DB1_ERR_BAD_ALIGN, "add2d_colsums: needs 16-byte aligned rows (cols, strides multiples of %d)", V);
     if (!sum_a_acc || !sum_b_acc) DB1_FAIL(DB1_ERR_BAD_SHAPE, "add2d_colsums: null accumulator");
     hipStream_t st = (hipStream_t)stream;
-    int rpc = 32;
-    while (rows / rpc > 1024) rpc *= 2;
+    const int rpc = colsum_rpc(rows);
     const int nchunks = (int)((rows + rpc - 1) / rpc);
-    float* ws = ln_workspace((size_t)nchunks * 2 * cols * sizeof(float));
-    if (!ws) DB1_FAIL(DB1_ERR_HIP, "add2d_colsums: cannot allocate the partial-sum workspace");
+    DB1_NEED_WS(ws_, ws_bytes, db1_add2d_colsums_workspace_bytes(rows, cols), "add2d_colsums");
+    float* ws = (float*)ws_;
     dim3 g((unsigned)((cols / V + 63) / 64), (unsigned)nchunks);
     DB1_DISPATCH_DT(dt, T, (add2d_colsums_kernel<T><<<g, 256, 0, st>>>((const T*)a, lda, (const T*)b, ldb, (T*)y, ldy, ws, rows, cols, rpc)));
     DB1_CHECK_LAUNCH("add2d_colsums");
@@ -809,20 +820,21 @@ extern "C" int db1_cast(const void* x, void* y, int64_t n, int dtIn, int dtOut, 
 // =====================================================================================
 template <typename TT, typename TO>
 __global__ __launch_bounds__(256) void gather_kernel(const TT* __restrict__ table, const int64_t* __restrict__ ids, TO* __restrict__ out,
-                                                     int64_t n_tokens, int d, int64_t ld_out) {
+                                                     int64_t n_tokens, int d, int64_t ld_out, int64_t n_rows) {
     int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n_tokens) return;
     const int lane = threadIdx.x & 63;
     const int64_t id = ids[t];
-    for (int i = lane; i < d; i += 64) stf(out + t * ld_out + i, id >= 0 ? ldf(table + id * d + i) : 0.f);
+    const bool ok = id >= 0 && id < n_rows;   // ids outside the table read nothing (zeros), they never touch memory
+    for (int i = lane; i < d; i += 64) stf(out + t * ld_out + i, ok ? ldf(table + id * d + i) : 0.f);
 }
 extern "C" int db1_embed_gather_fwd(const void* table, const int64_t* ids, void* out, int64_t n_tokens, int d, int64_t ld_out,
-                                    int dtTable, int dtOut, void* stream) {
+                                    int64_t n_table_rows, int dtTable, int dtOut, void* stream) {
     if (!db1_dt_ok(dtTable) || !db1_dt_ok(dtOut)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "embed_gather: dtype");
-    if (n_tokens <= 0 || d <= 0 || ld_out < d) DB1_FAIL(DB1_ERR_BAD_SHAPE, "embed_gather: shape");
+    if (n_tokens <= 0 || d <= 0 || ld_out < d || n_table_rows <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "embed_gather: shape");
     hipStream_t st = (hipStream_t)stream;
     dim3 g((unsigned)((n_tokens + 3) / 4));
-#define L(A, B) gather_kernel<A, B><<<g, 256, 0, st>>>((const A*)table, ids, (B*)out, n_tokens, d, ld_out)
+#define L(A, B) gather_kernel<A, B><<<g, 256, 0, st>>>((const A*)table, ids, (B*)out, n_tokens, d, ld_out, n_table_rows)
     if (dtTable == DB1_F32 && dtOut == DB1_F32) L(float, float);
     else if (dtTable == DB1_BF16 && dtOut == DB1_BF16) L(bf16_t, bf16_t);
     else if (dtTable == DB1_F32) L(float, bf16_t);
@@ -834,20 +846,20 @@ extern "C" int db1_embed_gather_fwd(const void* table, const int64_t* ids, void*
 
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_add_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids, float* dtable,
-                                                          int64_t n_tokens, int d, int64_t ld) {
+                                                          int64_t n_tokens, int d, int64_t ld, int64_t n_rows) {
     int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n_tokens) return;
     const int lane = threadIdx.x & 63;
     const int64_t id = ids[t];
-    if (id < 0) return;
+    if (id < 0 || id >= n_rows) return;
     for (int i = lane; i < d; i += 64) atomicAdd(dtable + id * d + i, ldf(dout + t * ld + i));
 }
 extern "C" int db1_embed_scatter_add_bwd(const void* dout, const int64_t* ids, float* dtable_acc, int64_t n_tokens, int d,
-                                         int64_t ld_dout, int dt, void* stream) {
+                                         int64_t ld_dout, int64_t n_table_rows, int dt, void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "embed_scatter: dtype");
-    if (n_tokens <= 0 || d <= 0 || ld_dout < d) DB1_FAIL(DB1_ERR_BAD_SHAPE, "embed_scatter: shape");
+    if (n_tokens <= 0 || d <= 0 || ld_dout < d || n_table_rows <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "embed_scatter: shape");
     dim3 g((unsigned)((n_tokens + 3) / 4));
-    DB1_DISPATCH_DT(dt, T, (scatter_add_kernel<T><<<g, 256, 0, (hipStream_t)stream>>>((const T*)dout, ids, dtable_acc, n_tokens, d, ld_dout)));
+    DB1_DISPATCH_DT(dt, T, (scatter_add_kernel<T><<<g, 256, 0, (hipStream_t)stream>>>((const T*)dout, ids, dtable_acc, n_tokens, d, ld_dout, n_table_rows)));
     DB1_CHECK_LAUNCH("embed_scatter");
     return DB1_OK;
 }
@@ -860,7 +872,8 @@ template <typename TT, typename T, bool BWD>
 __global__ __launch_bounds__(256) void rl_assemble_kernel(const TT* __restrict__ word_table, const TT* __restrict__ pos_table,
                                                           const T* vis, const int64_t* __restrict__ ids,
                                                           const int64_t* __restrict__ position_id, int64_t* labels, T* out,
-                                                          float* dword, float* dpos, T* dvis, int L, int d, int nvis) {
+                                                          float* dword, float* dpos, T* dvis, int L, int d, int nvis, int64_t n_word,
+                                                          int64_t n_pos) {
     __shared__ int cnt_sm[4];
     __shared__ int rank_sm[RLA_TPB];
     const int b = blockIdx.y, c0 = blockIdx.x * RLA_TPB, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -888,19 +901,20 @@ __global__ __launch_bounds__(256) void rl_assemble_kernel(const TT* __restrict__
         const int64_t id = row[t];
         const int rk = rank_sm[tt];
         const int64_t pid = position_id[(int64_t)b * L + t];
+        const bool id_ok = id >= 0 && id < n_word, pid_ok = pid >= 0 && pid < n_pos;   // out-of-table ids contribute nothing
         const int64_t o = ((int64_t)b * L + t) * d;
         for (int i = lane; i < d; i += 64) {
             if (!BWD) {
                 float v = 0.f;
-                if (id >= 0) v = ldf(word_table + id * d + i);
+                if (id_ok) v = ldf(word_table + id * d + i);
                 else if (rk >= 0 && rk < nvis && vis) v = ldf(vis + ((int64_t)b * nvis + rk) * d + i);
-                v += ldf(pos_table + pid * d + i);
+                if (pid_ok) v += ldf(pos_table + pid * d + i);
                 stf(out + o + i, v);
             } else {
                 const float g = ldf(out + o + i);  // 'out' carries dout in the backward
-                if (id >= 0) atomicAdd(dword + id * d + i, g);
+                if (id_ok) atomicAdd(dword + id * d + i, g);
                 else if (rk >= 0 && rk < nvis && dvis) stf(dvis + ((int64_t)b * nvis + rk) * d + i, g);
-                atomicAdd(dpos + pid * d + i, g);
+                if (pid_ok) atomicAdd(dpos + pid * d + i, g);
             }
         }
     }
@@ -908,12 +922,12 @@ __global__ __launch_bounds__(256) void rl_assemble_kernel(const TT* __restrict__
 
 extern "C" int db1_rl_assemble_fwd(const void* word_table, const void* pos_table, const void* vis, const int64_t* ids,
                                    const int64_t* position_id, int64_t* labels, void* out, int B, int L, int d,
-                                   int n_vis_per_row, int dtTable, int dt, void* stream) {
+                                   int n_vis_per_row, int64_t n_word_rows, int64_t n_pos_rows, int dtTable, int dt, void* stream) {
     if (!db1_dt_ok(dt) || !db1_dt_ok(dtTable)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "rl_assemble_fwd: dtype");
     if (B <= 0 || L <= 0 || d <= 0 || L > 12288) DB1_FAIL(DB1_ERR_BAD_SHAPE, "rl_assemble_fwd: shape");
     hipStream_t st = (hipStream_t)stream;
     const dim3 g((unsigned)((L + RLA_TPB - 1) / RLA_TPB), (unsigned)B);
-#define L_(TT, T) rl_assemble_kernel<TT, T, false><<<g, 256, 0, st>>>((const TT*)word_table, (const TT*)pos_table, (const T*)vis, ids, position_id, labels, (T*)out, nullptr, nullptr, nullptr, L, d, n_vis_per_row)
+#define L_(TT, T) rl_assemble_kernel<TT, T, false><<<g, 256, 0, st>>>((const TT*)word_table, (const TT*)pos_table, (const T*)vis, ids, position_id, labels, (T*)out, nullptr, nullptr, nullptr, L, d, n_vis_per_row, n_word_rows, n_pos_rows)
     if (dtTable == DB1_F32 && dt == DB1_F32) L_(float, float);
     else if (dtTable == DB1_BF16 && dt == DB1_BF16) L_(bf16_t, bf16_t);
     else if (dtTable == DB1_F32) L_(float, bf16_t);
@@ -924,14 +938,15 @@ extern "C" int db1_rl_assemble_fwd(const void* word_table, const void* pos_table
 }
 
 extern "C" int db1_rl_assemble_bwd(const void* dout, const int64_t* ids, const int64_t* position_id, float* dword_acc,
-                                   float* dpos_acc, void* dvis, int B, int L, int d, int n_vis_per_row, int dt, void* stream) {
+                                   float* dpos_acc, void* dvis, int B, int L, int d, int n_vis_per_row, int64_t n_word_rows, int64_t n_pos_rows,
+                                   int dt, void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "rl_assemble_bwd: dtype");
     if (B <= 0 || L <= 0 || d <= 0 || L > 12288) DB1_FAIL(DB1_ERR_BAD_SHAPE, "rl_assemble_bwd: shape");
     hipStream_t st = (hipStream_t)stream;
     const dim3 g((unsigned)((L + RLA_TPB - 1) / RLA_TPB), (unsigned)B);
     if (dvis && n_vis_per_row > 0) hipMemsetAsync(dvis, 0, (size_t)B * n_vis_per_row * d * (dt == DB1_F32 ? 4 : 2), st);
     DB1_DISPATCH_DT(dt, T, (rl_assemble_kernel<float, T, true><<<g, 256, 0, st>>>(nullptr, nullptr, nullptr, ids, position_id, nullptr,
-                                                                                  (T*)const_cast<void*>(dout), dword_acc, dpos_acc, (T*)dvis, L, d, n_vis_per_row)));
+                                                                                  (T*)const_cast<void*>(dout), dword_acc, dpos_acc, (T*)dvis, L, d, n_vis_per_row, n_word_rows, n_pos_rows)));
     DB1_CHECK_LAUNCH("rl_assemble_bwd");
     return DB1_OK;
 }
@@ -974,9 +989,12 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
     if (tid == 0) {
         const float l = M + logf(S);
         lse[t] = l;
-        const float mk = mask[t];
         int64_t y = labels[t];
-        const float nll = l - ldf(row + y);
+        // a label outside [0, V) (e.g. torch's ignore_index -100, which the reference's CrossEntropyLoss skips) reads nothing and
+        // adds no loss; the backward gives such a row no gradient
+        const bool y_ok = y >= 0 && y < V;
+        const float mk = y_ok ? mask[t] : 0.f;
+        const float nll = y_ok ? l - ldf(row + y) : 0.f;
         if (tok_loss) tok_loss[t] = mk * nll;  // summed in a fixed order by ce_sum_kernel (65 536 same-address atomics took ~1 ms)
         else { atomicAdd(sums + 0, mk * nll); atomicAdd(sums + 1, mk); }
     }
@@ -1005,8 +1023,9 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, const int6
     T* drow = dlogits + t * ld;
     const int tid = threadIdx.x;
     const float l = lse[t];
-    const float w = mask[t] / sums[1] * gscale;
-    const int y = (int)labels[t];
+    const int64_t yl = labels[t];
+    const int y = (yl >= 0 && yl < V) ? (int)yl : -1;
+    const float w = (y >= 0 ? mask[t] : 0.f) / sums[1] * gscale;
     constexpr int VN = Vec16<T>::N;
     if (vec_ok) {
         for (int c = tid * VN; c < ld; c += 256 * VN) {
@@ -1021,14 +1040,15 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, const int6
     }
 }
 
+extern "C" int64_t db1_masked_ce_fwd_workspace_bytes(int64_t T_) { return T_ * (int64_t)sizeof(float); }  // per-token losses
 extern "C" int db1_masked_ce_fwd(const void* logits, const int64_t* labels, const float* mask, float* lse, float* sums,
-                                 int64_t T_, int V, int64_t ld, int dt, void* stream) {
+                                 int64_t T_, int V, int64_t ld, int dt, void* ws_, int64_t ws_bytes, void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "masked_ce_fwd: dtype");
     if (T_ <= 0 || V <= 0 || ld < V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "masked_ce_fwd: shape");
     const int VN = dt == DB1_F32 ? 4 : 8;
     const int vec_ok = (ld % VN == 0) && db1_aligned16(logits);
-    float* tok_loss = ln_workspace((size_t)T_ * sizeof(float));
-    if (!tok_loss) DB1_FAIL(DB1_ERR_HIP, "masked_ce_fwd: cannot allocate the per-token loss workspace");
+    DB1_NEED_WS(ws_, ws_bytes, db1_masked_ce_fwd_workspace_bytes(T_), "masked_ce_fwd");
+    float* tok_loss = (float*)ws_;
     DB1_DISPATCH_DT(dt, T, (ce_fwd_kernel<T><<<(unsigned)T_, 256, 0, (hipStream_t)stream>>>((const T*)logits, labels, mask, lse, sums, tok_loss, V, ld, vec_ok)));
     DB1_CHECK_LAUNCH("masked_ce_fwd");
     ce_sum_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(tok_loss, mask, sums, T_);

@@ -162,21 +162,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         *reinterpret_cast<uint2*>(c) = o;
     }
 }
-// grow-only partial-sum workspace.  One per process: the library serialises its GEMMs on the caller's stream (the model
-// and the engine use a single compute stream), which is what makes reuse across calls safe.
-static float* g_splitk_ws = nullptr;
-static size_t g_splitk_ws_bytes = 0;
-static float* splitk_workspace(size_t bytes) {
-    if (bytes > g_splitk_ws_bytes) {
-        if (g_splitk_ws) { hipDeviceSynchronize(); hipFree(g_splitk_ws); }
-        g_splitk_ws = nullptr;
-        g_splitk_ws_bytes = 0;
-        if (hipMalloc((void**)&g_splitk_ws, bytes) != hipSuccess) return nullptr;
-        g_splitk_ws_bytes = bytes;
-    }
-    return g_splitk_ws;
-}
-
 // storage form of an operand from its strides: returns 0 = K-major, 1 = M-major, -1 = neither
 static int operand_form(int64_t row_stride, int64_t k_stride, int64_t* ld) {
     if (k_stride == 1 && row_stride >= 1) { *ld = row_stride; return 0; }
@@ -219,162 +204,263 @@ static void launch_tile(const GemmTileArgs& t, int dtC, int dtBias, dim3 grid, h
 }
 
 static thread_local int g_tri_mode = 0, g_tri_period = 0;  // structural-zero hint of the current call (db1_gemm_strided_tri)
-static int g_force_generic = 0;
-extern "C" void db1_gemm_force_generic(int on) { g_force_generic = on; }
-static int g_splitk = 1;      // DB1_GEMM_SPLITK=0 disables the workspace split-K (A/B measurements)
-static int g_tile_pref = -1;  // -1: read DB1_GEMM_TILE on first use; 0: measured heuristics; 128 / 256 / 512: pin that tile kernel
-extern "C" void db1_gemm_tile_override(int tile) { g_tile_pref = tile; }
+// test-only steering (include/db1_hip_test.h), thread-local: never set by product code
+static thread_local int g_force_generic = 0;
+static thread_local int g_tile_pref = 0;      // 0: measured heuristics; 128 / 256 / 512 / 1024: pin that tile kernel
+extern "C" void db1_test_gemm_force_generic(int on) { g_force_generic = on; }
+extern "C" void db1_test_gemm_tile_override(int tile) { g_tile_pref = tile; }
+// read-once process configuration for A/B measurements (immutable after the first GEMM call)
+struct GemmEnv {
+    int tile, splitk;
+    GemmEnv() {
+        const char* e = getenv("DB1_GEMM_TILE"); tile = e ? atoi(e) : 0;
+        const char* k = getenv("DB1_GEMM_SPLITK"); splitk = k ? atoi(k) : 1;   // DB1_GEMM_SPLITK=0 disables the workspace split-K
+    }
+};
+static const GemmEnv& gemm_env() { static const GemmEnv e; return e; }
+
+// ---- the dispatcher's decision, separated from the launch so that the workspace query, the kernel-choice query and the call agree
+enum { GK_GENERIC = 0, GK_TILE128 = 1, GK_TILE256 = 2, GK_PP = 3, GK_PP32 = 4, GK_W4 = 5, GK_SKINNY = 6, GK_SPLITK = 16, GK_TAIL = 32 };
+struct GemmPlan {
+    int kind = GK_GENERIC;   // GK_* of the kernel that runs the contraction (for GK_TAIL: of the main part)
+    int fa = 0, fb = 0;
+    int64_t lda = 0, ldb = 0;
+    int S = 0;               // GK_SPLITK: slices of k
+    int m_tail = 0;          // GK_TAIL: rows of the second call
+    int ksplit = 1;          // GK_TILE128 with atomic split-K (conv weight gradients)
+};
+struct GemmShape {
+    int M, N, K, dtA, dtB, dtC, batch0, batch1;
+    int64_t a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
+    float beta;
+};
+static GemmTileArgs tile_args(const GemmShape& g, const GemmPlan& pl) {
+    GemmTileArgs t;
+    t.A = nullptr; t.B = nullptr; t.C = nullptr; t.bias = nullptr;
+    t.M = g.M; t.N = g.N; t.K = g.K; t.lda = pl.lda; t.ldb = pl.ldb; t.ldc = g.c_rs;
+    t.batch1 = g.batch1; t.a_bs0 = g.a_bs0; t.a_bs1 = g.a_bs1; t.b_bs0 = g.b_bs0; t.b_bs1 = g.b_bs1; t.c_bs0 = g.c_bs0; t.c_bs1 = g.c_bs1;
+    t.alpha = 1.f; t.beta = g.beta; t.tiles_m = (g.M + TBM - 1) / TBM; t.tiles_n = (g.N + TBN - 1) / TBN; t.ksplit = 1;
+    t.tri_mode = g_tri_mode; t.tri_period = g_tri_period;
+    t.split_n = 0; t.Cu = nullptr; t.Cv = nullptr; t.bias_u = nullptr; t.bias_v = nullptr; t.ld_uv = 0;
+    if (t.tri_mode == 2 && (t.tri_period <= 0 || (t.tri_period % TBK) || (g.K % t.tri_period))) t.tri_mode = 0;
+    return t;
+}
+static int64_t splitk_bytes(const GemmShape& g, int S, int M) { return (int64_t)g.batch0 * g.batch1 * S * M * g.N * (int64_t)sizeof(float); }
+
+// `aligned`: the operand pointers are 16-byte aligned (the queries assume so); `ws_bytes`: workspace the caller offers (< 0: "whatever
+// the plan needs", used by the queries).  A split-K plan is only made when its partial sums fit the offered workspace.
+static GemmPlan gemm_plan(const GemmShape& g, bool aligned, int64_t ws_bytes) {
+    GemmPlan pl;
+    const int M = g.M, N = g.N, K = g.K;
+    const int64_t batch = (int64_t)g.batch0 * g.batch1;
+    aligned = aligned && !(g.a_bs0 % 8) && !(g.a_bs1 % 8) && !(g.b_bs0 % 8) && !(g.b_bs1 % 8) && !(g.c_bs0 % 4) && !(g.c_bs1 % 4);
+    const int tile_pref = g_tile_pref ? g_tile_pref : gemm_env().tile;
+    if (g_force_generic || !aligned) return pl;
+    // few rows (inference with memory: 1 .. ~50 new tokens): stream W once, see gemm_skinny.hip
+    if (batch == 1 && g.dtA == DB1_BF16 && g.dtB == DB1_BF16 && M <= 64 && g.a_cs == 1 && g.b_rs == 1 && g.c_cs == 1 && (N % 16) == 0 &&
+        (K % 64) == 0 && (g.a_rs % 8) == 0 && (g.b_cs % 8) == 0 && (g.c_rs % 4) == 0 && tile_pref <= 0) {
+        pl.kind = GK_SKINNY;
+        return pl;
+    }
+    if (batch > 65535 || !fast_ok(M, N, K, g.dtA, g.dtB, g.a_rs, g.a_cs, g.b_rs, g.b_cs, g.c_rs, g.c_cs, &pl.fa, &pl.fb, &pl.lda, &pl.ldb)) return pl;
+    const int fa = pl.fa, fb = pl.fb;
+    const bool splitk_on = gemm_env().splitk != 0;
+    // measured on MI355X at the DB1-1.3B shapes (tools/bench_kernels.py gemm; table in DESIGN.md): the 256x256 kernels win by 15-35 %
+    // wherever they have >= ~160 output tiles to spread over the 256 CUs; below that the 3-stage 256x128 kernel wins for the
+    // transposed-operand forms and the 2-stage 128x128 kernel for NT / small outputs.
+    const bool pp_shape = (M % 256) == 0 && (N % 256) == 0, t256_shape = (M % 256) == 0 && (N % TBN) == 0;
+    const GemmTileArgs t = tile_args(g, pl);
+    auto big = [&](const GemmTileArgs& u, int nbatch, bool k32) {   // which 256x256 kernel db1_gemm_pp(32)_launch ends up running
+        return db1_gemm_w4_supported(u, fa, fb, u.C == (void*)1 ? DB1_F32 : g.dtC, nbatch) ? GK_W4 : (k32 ? GK_PP32 : GK_PP);
+    };
+    // a short last wave of 256x256 tiles (head dW: 1040 tiles = 4 waves + 16 tiles, i.e. a fifth wave on 6 % of the CUs): the tile
+    // rows of that remainder become a second call (9.3 -> 7.9 ms at T = 65 536)
+    if (tile_pref == 0 && splitk_on && pp_shape && batch == 1 && g.c_cs == 1 && g_tri_mode == 0) {
+        const int64_t tn_ = N / 256, wg_ = (int64_t)(M / 256) * tn_, rem = wg_ % 256;
+        if (wg_ > 256 && rem > 0 && rem <= 48 && rem % tn_ == 0 && (K / TBK) >= 256) {
+            GemmShape mainp = g;                      // (the second call plans itself: split-K or the 256x128 kernel, as its size says)
+            mainp.M = M - (int)(rem / tn_) * 256;
+            pl = gemm_plan(mainp, true, ws_bytes);
+            pl.kind |= GK_TAIL;
+            pl.m_tail = (int)(rem / tn_) * 256;
+            return pl;
+        }
+    }
+    // deterministic split-K (see splitk_reduce_kernel): only when the big-tile kernels would leave most CUs idle
+    if (tile_pref == 0 && splitk_on && g.batch1 == 1 && (pp_shape || (t256_shape && fb == 1)) && g.c_cs == 1) {
+        const int64_t wg = pp_shape ? (int64_t)(M / 256) * (N / 256) * batch : (int64_t)(M / 256) * (N / TBN) * batch;
+        int S = 0;
+        for (int cand = 8; cand >= 2; cand >>= 1)
+            if (wg * cand <= 288 && (K / TBK) % cand == 0 && (K / TBK) / cand >= 32) { S = cand; break; }
+        // half a wave of 256x256 tiles (ff2 dW: 128) in two slices: nothing at K = 16 384, but 1184 -> 978 us at K = 65 536 (the 256x128
+        // kernel it would otherwise take runs at 930 TFLOP/s, the ping-pong kernel at 1120 incl. the reduce)
+        const bool half_wave = pp_shape && fb == 1 && wg > 96 && wg <= 128 && S == 2 && (K / TBK) / S >= 256;
+        // three quarters of a wave (qkv dW: 192 tiles) in four slices = three whole waves: 1310-1324 -> 1196-1221 us at K = 65 536 with
+        // the 4-wave kernel (with the 8-wave kernels this gained 2 %)
+        const bool three_quarters = pp_shape && fb == 1 && wg == 192 && (K / TBK) % 4 == 0 && (K / TBK) / 4 >= 128;
+        if (three_quarters) S = 4;
+        if (S && (wg <= 96 || half_wave || three_quarters) && (!pp_shape || wg * S >= 160) && (ws_bytes < 0 || splitk_bytes(g, S, M) <= ws_bytes)) {
+            GemmTileArgs u = t;
+            u.K = K / S; u.ldc = N; u.C = (void*)1;   // (marker: fp32 partials)
+            if (u.tri_mode == 1 || (u.tri_mode == 2 && (u.K % u.tri_period))) u.tri_mode = 0;
+            u.batch1 = S;
+            pl.S = S;
+            pl.kind = (pp_shape ? big(u, (int)batch * S, fb == 1) : GK_TILE256) | GK_SPLITK;
+            return pl;
+        }
+    }
+    if (pp_shape && tile_pref == 1024) { pl.kind = big(t, (int)batch, true); return pl; }
+    if (pp_shape && (tile_pref == 512 || (tile_pref == 0 && (int64_t)(M / 256) * (N / 256) * batch >= 160))) {
+        // measured: the 4-stage k32 ring is 3-9 % faster when B is M-major (NN, TN); with both operands K-major
+        // (NT) its 64-byte rows fetch half cache lines and the 2-stage k64 kernel is 4-9 % faster
+        pl.kind = big(t, (int)batch, tile_pref == 0 && fb == 1);
+        return pl;
+    }
+    // (measured: routing the under-filled transposed-operand cases -- o_net dW on 128 workgroups, the per-head dR on 64 --
+    // to the 128x128 kernel for more workgroups made them 15-20 % slower, so form alone decides)
+    const bool want256 = tile_pref == 256 || (tile_pref == 0 && fb == 1);
+    if (want256 && t256_shape) { pl.kind = GK_TILE256; return pl; }
+    // atomic split-K for small outputs with a very long contraction (weight gradients of the 64-channel patch convolutions:
+    // 64 x 576 outputs over 1.9 M rows would otherwise occupy 5 of 256 CUs)
+    pl.kind = GK_TILE128;
+    const int ntiles = t.tiles_m * t.tiles_n * (int)batch;
+    if (g.dtC == DB1_F32 && g.beta == 1.0f && ntiles < 128 && K >= 64 * TBK) {
+        int ks = 512 / ntiles;
+        while (ks > 1 && ((K / TBK) % ks || (K / TBK) / ks < 8)) ks--;
+        pl.ksplit = ks;
+    }
+    return pl;
+}
+
+static GemmShape gemm_shape(int M, int N, int K, int dtA, int dtB, int dtC, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs,
+                            int64_t c_cs, int batch0, int batch1, int64_t a_bs0, int64_t a_bs1, int64_t b_bs0, int64_t b_bs1, int64_t c_bs0,
+                            int64_t c_bs1, float beta) {
+    GemmShape g;
+    g.M = M; g.N = N; g.K = K; g.dtA = dtA; g.dtB = dtB; g.dtC = dtC; g.batch0 = batch0; g.batch1 = batch1;
+    g.a_rs = a_rs; g.a_cs = a_cs; g.b_rs = b_rs; g.b_cs = b_cs; g.c_rs = c_rs; g.c_cs = c_cs;
+    g.a_bs0 = a_bs0; g.a_bs1 = a_bs1; g.b_bs0 = b_bs0; g.b_bs1 = b_bs1; g.c_bs0 = c_bs0; g.c_bs1 = c_bs1; g.beta = beta;
+    return g;
+}
+
+extern "C" int64_t db1_gemm_workspace_bytes(int M, int N, int K, int dtA, int dtB, int dtC, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs,
+                                            int64_t c_rs, int64_t c_cs, int batch0, int batch1) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch0 <= 0 || batch1 <= 0) return 0;
+    // (batch strides only enter through their alignment, which the model's operands satisfy; beta does not change a split-K decision)
+    GemmShape g = gemm_shape(M, N, K, dtA, dtB, dtC, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, batch0, batch1, 0, 0, 0, 0, 0, 0, 0.f);
+    const GemmPlan pl = gemm_plan(g, true, -1);
+    if (pl.kind & GK_TAIL) {
+        GemmShape tail = g;
+        tail.M = pl.m_tail;
+        const GemmPlan tp = gemm_plan(tail, true, -1);
+        return (tp.kind & GK_SPLITK) ? splitk_bytes(tail, tp.S, tail.M) : 0;
+    }
+    return (pl.kind & GK_SPLITK) ? splitk_bytes(g, pl.S, M) : 0;
+}
+
+extern "C" int db1_gemm_kernel_choice(int M, int N, int K, int dtA, int dtB, int dtC, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs,
+                                      int64_t c_rs, int64_t c_cs, int batch0, int batch1, float beta, int64_t ws_bytes) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch0 <= 0 || batch1 <= 0) return -1;
+    return gemm_plan(gemm_shape(M, N, K, dtA, dtB, dtC, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, batch0, batch1, 0, 0, 0, 0, 0, 0, beta), true, ws_bytes).kind;
+}
 
 extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int dtA, int dtB,
                                 int dtC, int dtBias, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs,
                                 int64_t c_cs, int batch0, int batch1, int64_t a_bs0, int64_t a_bs1, int64_t b_bs0,
-                                int64_t b_bs1, int64_t c_bs0, int64_t c_bs1, float alpha, float beta, void* stream) {
+                                int64_t b_bs1, int64_t c_bs0, int64_t c_bs1, float alpha, float beta, void* ws, int64_t ws_bytes, void* stream) {
     if (!db1_dt_ok(dtA) || !db1_dt_ok(dtB) || !db1_dt_ok(dtC) || (bias && !db1_dt_ok(dtBias)))
         DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "gemm: dtype codes %d %d %d", dtA, dtB, dtC);
     if (M <= 0 || N <= 0 || K <= 0 || batch0 <= 0 || batch1 <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "gemm: M=%d N=%d K=%d batch=%dx%d", M, N, K, batch0, batch1);
     if (!A || !B || !C) DB1_FAIL(DB1_ERR_BAD_SHAPE, "gemm: null operand");
     hipStream_t st = (hipStream_t)stream;
-    int fa, fb;
-    int64_t lda, ldb;
     const int64_t batch = (int64_t)batch0 * batch1;
-    const bool aligned = db1_aligned16(A) && db1_aligned16(B) && db1_aligned16(C) && !(a_bs0 % 8) && !(a_bs1 % 8) && !(b_bs0 % 8) &&
-                         !(b_bs1 % 8) && !(c_bs0 % 4) && !(c_bs1 % 4);
-    // few rows (inference with memory: 1 .. ~50 new tokens): stream W once, see gemm_skinny.hip
-    if (!g_force_generic && aligned && batch == 1 && dtA == DB1_BF16 && dtB == DB1_BF16 && M <= 64 && a_cs == 1 && b_rs == 1 && c_cs == 1 &&
-        (N % 16) == 0 && (K % 64) == 0 && (a_rs % 8) == 0 && (b_cs % 8) == 0 && (c_rs % 4) == 0 && (g_tile_pref <= 0))
+    const GemmShape g = gemm_shape(M, N, K, dtA, dtB, dtC, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, batch0, batch1, a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1, beta);
+    if (ws && (((uintptr_t)ws) & 15)) ws_bytes = 0;   // an unusable workspace is no workspace: the plan then avoids the split-K paths
+    const GemmPlan pl = gemm_plan(g, db1_aligned16(A) && db1_aligned16(B) && db1_aligned16(C), ws ? ws_bytes : 0);
+    const int base = pl.kind & 15, fa = pl.fa, fb = pl.fb;
+    if (base == GK_SKINNY)
         return db1_gemm_skinny_launch((const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, a_rs, b_cs, c_rs, alpha, beta, dtC, dtBias, st);
-    if (!g_force_generic && aligned && batch <= 65535 &&
-        fast_ok(M, N, K, dtA, dtB, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, &fa, &fb, &lda, &ldb)) {
-        GemmTileArgs t;
-        t.A = (const bf16_t*)A; t.B = (const bf16_t*)B; t.C = C; t.bias = bias;
-        t.M = M; t.N = N; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = c_rs;
-        t.batch1 = batch1; t.a_bs0 = a_bs0; t.a_bs1 = a_bs1; t.b_bs0 = b_bs0; t.b_bs1 = b_bs1; t.c_bs0 = c_bs0; t.c_bs1 = c_bs1;
-        t.alpha = alpha; t.beta = beta; t.tiles_m = (M + TBM - 1) / TBM; t.tiles_n = (N + TBN - 1) / TBN;
-        t.tri_mode = g_tri_mode; t.tri_period = g_tri_period;
-        t.split_n = 0; t.Cu = nullptr; t.Cv = nullptr; t.bias_u = nullptr; t.bias_v = nullptr; t.ld_uv = 0;
-        if (t.tri_mode == 2 && (t.tri_period <= 0 || (t.tri_period % TBK) || (K % t.tri_period))) t.tri_mode = 0;
-        // measured on MI355X at the DB1-1.3B shapes (tools/bench_kernels.py gemm; table in DESIGN.md): the 256x256 ping-pong
-        // kernel wins by 15-35 % wherever it has >= ~160 output tiles to spread over the 256 CUs; below that the 3-stage
-        // 256x128 kernel wins for the transposed-operand forms and the 2-stage 128x128 kernel for NT / small outputs.
-        // DB1_GEMM_TILE=128|256|512 pins one.
-        if (g_tile_pref < 0) {
-            const char* e = getenv("DB1_GEMM_TILE"); g_tile_pref = e ? atoi(e) : 0;
-            const char* k = getenv("DB1_GEMM_SPLITK"); if (k) g_splitk = atoi(k);
-        }
-        const int tile_pref = g_tile_pref;
-        const bool pp_shape = (M % 256) == 0 && (N % 256) == 0, t256_shape = (M % 256) == 0 && (N % TBN) == 0;
-        // a short last wave of 256x256 tiles (head dW: 1040 tiles = 4 waves + 16 tiles, i.e. a fifth wave on 6 % of the CUs): the tile
-        // rows of that remainder become a second call, which takes the split-K path below (9.3 -> 7.9 ms at T = 65 536)
-        if (tile_pref == 0 && g_splitk && pp_shape && batch == 1 && c_cs == 1 && g_tri_mode == 0) {
-            const int64_t tn_ = N / 256, wg_ = (int64_t)(M / 256) * tn_, rem = wg_ % 256;
-            if (wg_ > 256 && rem > 0 && rem <= 48 && rem % tn_ == 0 && (K / TBK) >= 256) {
-                const int m_tail = (int)(rem / tn_) * 256, m_main = M - m_tail;
-                const size_t esA = dtA == DB1_F32 ? 4 : 2, esC = dtC == DB1_F32 ? 4 : 2;
-                int rc = db1_gemm_strided(A, B, C, bias, m_main, N, K, dtA, dtB, dtC, dtBias, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, 1, 1, 0, 0, 0, 0, 0,
-                                          0, alpha, beta, stream);
-                if (rc) return rc;
-                return db1_gemm_strided((const char*)A + (size_t)m_main * a_rs * esA, B, (char*)C + (size_t)m_main * c_rs * esC, bias, m_tail, N, K, dtA,
-                                        dtB, dtC, dtBias, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, stream);
-            }
-        }
-        // deterministic split-K (see splitk_reduce_kernel): only when the big-tile kernels would leave most CUs idle
-        if (tile_pref == 0 && g_splitk && batch1 == 1 && (pp_shape || (t256_shape && fb == 1)) && c_cs == 1) {
-            const int64_t wg = pp_shape ? (int64_t)(M / 256) * (N / 256) * batch : (int64_t)(M / 256) * (N / TBN) * batch;
-            int S = 0;
-            for (int cand = 8; cand >= 2; cand >>= 1)
-                if (wg * cand <= 288 && (K / TBK) % cand == 0 && (K / TBK) / cand >= 32) { S = cand; break; }
-            // half a wave of 256x256 tiles (ff2 dW: 128) in two slices: nothing at K = 16 384, but 1184 -> 978 us at K = 65 536 (the 256x128
-            // kernel it would otherwise take runs at 930 TFLOP/s, the ping-pong kernel at 1120 incl. the reduce)
-            const bool half_wave = pp_shape && fb == 1 && wg > 96 && wg <= 128 && S == 2 && (K / TBK) / S >= 256;
-            // three quarters of a wave (qkv dW: 192 tiles) in four slices = three whole waves: 1310-1324 -> 1196-1221 us at K = 65 536 with
-            // the 4-wave kernel (with the 8-wave kernels this gained 2 %)
-            const bool three_quarters = pp_shape && fb == 1 && wg == 192 && (K / TBK) % 4 == 0 && (K / TBK) / 4 >= 128;
-            if (three_quarters) S = 4;
-            if (S && (wg <= 96 || half_wave || three_quarters) && (!pp_shape || wg * S >= 160)) {
-                float* ws = splitk_workspace((size_t)batch * S * M * N * sizeof(float));
-                if (!ws) DB1_FAIL(DB1_ERR_HIP, "gemm: cannot allocate %zu bytes of split-K workspace", (size_t)batch * S * M * N * sizeof(float));
-                GemmTileArgs u = t;
-                const int64_t kc = K / S;
-                u.K = (int)kc; u.C = ws; u.bias = nullptr; u.beta = 0.f; u.ldc = N;
-                if (u.tri_mode == 1 || (u.tri_mode == 2 && (kc % u.tri_period))) u.tri_mode = 0;  // a slice of k no longer starts at k = 0 / on a period
-                u.batch1 = S; u.a_bs1 = fa == 0 ? kc : kc * lda; u.b_bs1 = fb == 0 ? kc : kc * ldb;
-                u.c_bs0 = (int64_t)S * M * N; u.c_bs1 = (int64_t)M * N;
-                int rc = pp_shape ? (fb == 1 ? db1_gemm_pp32_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st)
-                                             : db1_gemm_pp_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st))
-                                  : db1_gemm_tile256_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st);
-                if (rc) return rc;
-                dim3 rg((unsigned)(((int64_t)M * (N / 4) + 255) / 256), (unsigned)batch);
-#define RED(TC, TB) splitk_reduce_kernel<TC, TB><<<rg, 256, 0, st>>>(ws, (TC*)C, (const TB*)bias, M, N, S, c_rs, c_bs0, beta)
-                if (dtC == DB1_F32) { if (dtBias == DB1_BF16) RED(float, bf16_t); else RED(float, float); }
-                else { if (dtBias == DB1_BF16) RED(bf16_t, bf16_t); else RED(bf16_t, float); }
+    if (base == GK_GENERIC) {
+        GemmStridedArgs a;
+        a.A = A; a.B = B; a.C = C; a.bias = bias; a.M = M; a.N = N; a.K = K;
+        a.a_rs = a_rs; a.a_cs = a_cs; a.b_rs = b_rs; a.b_cs = b_cs; a.c_rs = c_rs; a.c_cs = c_cs;
+        a.batch1 = batch1; a.a_bs0 = a_bs0; a.a_bs1 = a_bs1; a.b_bs0 = b_bs0; a.b_bs1 = b_bs1; a.c_bs0 = c_bs0; a.c_bs1 = c_bs1;
+        a.alpha = alpha; a.beta = beta;
+        return db1_gemm_strided_generic(a, dtA, dtB, dtC, dtBias, (int)batch, st);
+    }
+    if (pl.kind & GK_TAIL) {   // the last, short wave of tile rows as a second call (it takes the split-K path)
+        const int m_main = M - pl.m_tail;
+        const size_t esA = dtA == DB1_F32 ? 4 : 2, esC = dtC == DB1_F32 ? 4 : 2;
+        int rc = db1_gemm_strided(A, B, C, bias, m_main, N, K, dtA, dtB, dtC, dtBias, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, 1, 1, 0, 0, 0, 0, 0,
+                                  0, alpha, beta, ws, ws_bytes, stream);
+        if (rc) return rc;
+        return db1_gemm_strided((const char*)A + (size_t)m_main * a_rs * esA, B, (char*)C + (size_t)m_main * c_rs * esC, bias, pl.m_tail, N, K, dtA,
+                                dtB, dtC, dtBias, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, ws, ws_bytes, stream);
+    }
+    GemmTileArgs t = tile_args(g, pl);
+    t.A = (const bf16_t*)A; t.B = (const bf16_t*)B; t.C = C; t.bias = bias; t.alpha = alpha;
+    if (pl.kind & GK_SPLITK) {
+        const int S = pl.S;
+        float* wsf = (float*)ws;
+        GemmTileArgs u = t;
+        const int64_t kc = K / S;
+        u.K = (int)kc; u.C = wsf; u.bias = nullptr; u.beta = 0.f; u.ldc = N;
+        if (u.tri_mode == 1 || (u.tri_mode == 2 && (kc % u.tri_period))) u.tri_mode = 0;  // a slice of k no longer starts at k = 0 / on a period
+        u.batch1 = S; u.a_bs1 = fa == 0 ? kc : kc * pl.lda; u.b_bs1 = fb == 0 ? kc : kc * pl.ldb;
+        u.c_bs0 = (int64_t)S * M * N; u.c_bs1 = (int64_t)M * N;
+        const bool pp_shape = (M % 256) == 0 && (N % 256) == 0;
+        int rc = pp_shape ? (fb == 1 ? db1_gemm_pp32_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st)
+                                     : db1_gemm_pp_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st))
+                          : db1_gemm_tile256_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st);
+        if (rc) return rc;
+        dim3 rg((unsigned)(((int64_t)M * (N / 4) + 255) / 256), (unsigned)batch);
+#define RED(TC, TB) splitk_reduce_kernel<TC, TB><<<rg, 256, 0, st>>>(wsf, (TC*)C, (const TB*)bias, M, N, S, c_rs, c_bs0, beta)
+        if (dtC == DB1_F32) { if (dtBias == DB1_BF16) RED(float, bf16_t); else RED(float, float); }
+        else { if (dtBias == DB1_BF16) RED(bf16_t, bf16_t); else RED(bf16_t, float); }
 #undef RED
-                DB1_CHECK_LAUNCH("splitk_reduce");
-                return DB1_OK;
-            }
-        }
-        if (pp_shape && tile_pref == 1024) return db1_gemm_pp32_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
-        if (pp_shape && (tile_pref == 512 || (tile_pref == 0 && (int64_t)(M / 256) * (N / 256) * batch >= 160))) {
-            // measured: the 4-stage k32 ring is 3-9 % faster when B is M-major (NN, TN); with both operands K-major
-            // (NT) its 64-byte rows fetch half cache lines and the 2-stage k64 kernel is 4-9 % faster
-            if (tile_pref == 0 && fb == 1) return db1_gemm_pp32_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
-            return db1_gemm_pp_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
-        }
-        // (measured: routing the under-filled transposed-operand cases -- o_net dW on 128 workgroups, the per-head dR on 64 --
-        // to the 128x128 kernel for more workgroups made them 15-20 % slower, so form alone decides)
-        const bool want256 = tile_pref == 256 || (tile_pref == 0 && fb == 1);
-        if (want256 && t256_shape) return db1_gemm_tile256_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
-        // split-K for small outputs with a very long contraction (weight gradients of the 64-channel patch convolutions:
-        // 64 x 576 outputs over 1.9 M rows would otherwise occupy 5 of 256 CUs)
-        t.ksplit = 1;
-        const int ntiles = t.tiles_m * t.tiles_n * (int)batch;
-        if (dtC == DB1_F32 && beta == 1.0f && ntiles < 128 && K >= 64 * TBK) {
-            int ks = 512 / ntiles;
-            while (ks > 1 && ((K / TBK) % ks || (K / TBK) / ks < 8)) ks--;
-            t.ksplit = ks;
-        }
-        dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch, (unsigned)t.ksplit);
-        static bool attr_set = false;
-        if (!attr_set) {
-            // 64 KiB of dynamic LDS needs the opt-in attribute on every instantiation
-#define SET_ATTR(AK, BK_, TC, TB) hipFuncSetAttribute((const void*)gemm_bf16_tile_kernel<AK, BK_, TC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES)
-#define SET_ALL(AK, BK_) SET_ATTR(AK, BK_, float, float); SET_ATTR(AK, BK_, float, bf16_t); SET_ATTR(AK, BK_, bf16_t, float); SET_ATTR(AK, BK_, bf16_t, bf16_t)
-            SET_ALL(true, true); SET_ALL(true, false); SET_ALL(false, false);
-#undef SET_ALL
-#undef SET_ATTR
-            attr_set = true;
-        }
-        if (fa == 0 && fb == 0) launch_tile<true, true>(t, dtC, dtBias, grid, st);
-        else if (fa == 0 && fb == 1) launch_tile<true, false>(t, dtC, dtBias, grid, st);
-        else launch_tile<false, false>(t, dtC, dtBias, grid, st);
-        DB1_CHECK_LAUNCH("gemm_bf16_tile");
+        DB1_CHECK_LAUNCH("splitk_reduce");
         return DB1_OK;
     }
-    GemmStridedArgs a;
-    a.A = A; a.B = B; a.C = C; a.bias = bias; a.M = M; a.N = N; a.K = K;
-    a.a_rs = a_rs; a.a_cs = a_cs; a.b_rs = b_rs; a.b_cs = b_cs; a.c_rs = c_rs; a.c_cs = c_cs;
-    a.batch1 = batch1; a.a_bs0 = a_bs0; a.a_bs1 = a_bs1; a.b_bs0 = b_bs0; a.b_bs1 = b_bs1; a.c_bs0 = c_bs0; a.c_bs1 = c_bs1;
-    a.alpha = alpha; a.beta = beta;
-    return db1_gemm_strided_generic(a, dtA, dtB, dtC, dtBias, (int)batch, st);
+    if (base == GK_W4 || base == GK_PP || base == GK_PP32) {
+        const int tile_pref = g_tile_pref ? g_tile_pref : gemm_env().tile;
+        const bool k32 = tile_pref == 1024 || (tile_pref == 0 && fb == 1);
+        return k32 ? db1_gemm_pp32_launch(t, fa, fb, dtC, dtBias, (int)batch, st) : db1_gemm_pp_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
+    }
+    if (base == GK_TILE256) return db1_gemm_tile256_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
+    t.ksplit = pl.ksplit;
+    dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch, (unsigned)t.ksplit);
+    static Db1PerDeviceOnce attr_once;   // 64 KiB of dynamic LDS needs the opt-in attribute: once per device, every instantiation
+    attr_once.run([] {
+#define SET_ATTR(AK, BK_, TC, TB) hipFuncSetAttribute((const void*)gemm_bf16_tile_kernel<AK, BK_, TC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES)
+#define SET_ALL(AK, BK_) SET_ATTR(AK, BK_, float, float); SET_ATTR(AK, BK_, float, bf16_t); SET_ATTR(AK, BK_, bf16_t, float); SET_ATTR(AK, BK_, bf16_t, bf16_t)
+        SET_ALL(true, true); SET_ALL(true, false); SET_ALL(false, false);
+#undef SET_ALL
+#undef SET_ATTR
+    });
+    if (fa == 0 && fb == 0) launch_tile<true, true>(t, dtC, dtBias, grid, st);
+    else if (fa == 0 && fb == 1) launch_tile<true, false>(t, dtC, dtBias, grid, st);
+    else launch_tile<false, false>(t, dtC, dtBias, grid, st);
+    DB1_CHECK_LAUNCH("gemm_bf16_tile");
+    return DB1_OK;
 }
 
 extern "C" int db1_gemm_strided_tri(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int dtA, int dtB,
                                     int dtC, int dtBias, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs,
                                     int64_t c_cs, int batch0, int batch1, int64_t a_bs0, int64_t a_bs1, int64_t b_bs0,
                                     int64_t b_bs1, int64_t c_bs0, int64_t c_bs1, float alpha, float beta, int tri_mode, int tri_period,
-                                    void* stream) {
+                                    void* ws, int64_t ws_bytes, void* stream) {
     if (tri_mode < 0 || tri_mode > 2) DB1_FAIL(DB1_ERR_UNSUPPORTED, "gemm_strided_tri: mode %d", tri_mode);
     g_tri_mode = tri_mode;
     g_tri_period = tri_period;
     const int rc = db1_gemm_strided(A, B, C, bias, M, N, K, dtA, dtB, dtC, dtBias, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, batch0, batch1, a_bs0,
-                                    a_bs1, b_bs0, b_bs1, c_bs0, c_bs1, alpha, beta, stream);
+                                    a_bs1, b_bs0, b_bs1, c_bs0, c_bs1, alpha, beta, ws, ws_bytes, stream);
     g_tri_mode = 0;
     g_tri_period = 0;
     return rc;
 }
 
 extern "C" int db1_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
-                           int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream) {
-    return db1_gemm_strided(A, B, C, bias, M, N, K, dtAB, dtAB, dtC, dtAB, lda, 1, 1, ldb, ldc, 1, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, stream);
+                           int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* ws, int64_t ws_bytes, void* stream) {
+    return db1_gemm_strided(A, B, C, bias, M, N, K, dtAB, dtAB, dtC, dtAB, lda, 1, 1, ldb, ldc, 1, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, ws, ws_bytes, stream);
 }
 // y = x W^T for the attention input projection with the two head biases folded into the epilogue (see GemmTileArgs::split_n)
 extern "C" int db1_gemm_nt_headbias_supported(int M, int N, int K, int split_n) {
@@ -398,10 +484,10 @@ extern "C" int db1_gemm_nt_headbias(const void* A, const void* W, void* C, void*
     return db1_gemm_pp_launch(t, 0, 0, DB1_BF16, DB1_BF16, 1, (hipStream_t)stream);
 }
 extern "C" int db1_gemm_nn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
-                           int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream) {
-    return db1_gemm_strided(A, B, C, bias, M, N, K, dtAB, dtAB, dtC, dtAB, lda, 1, ldb, 1, ldc, 1, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, stream);
+                           int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* ws, int64_t ws_bytes, void* stream) {
+    return db1_gemm_strided(A, B, C, bias, M, N, K, dtAB, dtAB, dtC, dtAB, lda, 1, ldb, 1, ldc, 1, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, ws, ws_bytes, stream);
 }
 extern "C" int db1_gemm_tn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
-                           int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream) {
-    return db1_gemm_strided(A, B, C, bias, M, N, K, dtAB, dtAB, dtC, dtAB, 1, lda, ldb, 1, ldc, 1, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, stream);
+                           int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* ws, int64_t ws_bytes, void* stream) {
+    return db1_gemm_strided(A, B, C, bias, M, N, K, dtAB, dtAB, dtC, dtAB, 1, lda, ldb, 1, ldc, 1, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, ws, ws_bytes, stream);
 }

@@ -210,13 +210,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp_kernel(GemmTileArgs p) {
 
 template <bool AK, bool BK_>
 static void launch_pp(const GemmTileArgs& t, int dtC, int dtBias, dim3 grid, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static Db1PerDeviceOnce attr_once;   // dynamic LDS above 64 KiB needs the opt-in attribute: once per device, every instantiation
+    attr_once.run([] {
 #define SET_ATTR(TC, TB) hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<AK, BK_, TC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES)
         SET_ATTR(float, float); SET_ATTR(float, bf16_t); SET_ATTR(bf16_t, float); SET_ATTR(bf16_t, bf16_t);
 #undef SET_ATTR
-        attr_set = true;
-    }
+    });
     if (dtC == DB1_F32) {
         if (dtBias == DB1_BF16) gemm_bf16_pp_kernel<AK, BK_, float, bf16_t><<<grid, 512, PP_LDS_BYTES, st>>>(t);
         else gemm_bf16_pp_kernel<AK, BK_, float, float><<<grid, 512, PP_LDS_BYTES, st>>>(t);

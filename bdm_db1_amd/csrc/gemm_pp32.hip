@@ -189,13 +189,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp32_kernel(GemmTileArgs p) 
 template <bool AK, bool BK_, int NS>
 static void launch_pp32(const GemmTileArgs& t, int dtC, int dtBias, dim3 grid, hipStream_t st) {
     constexpr int LDS = NS * P32_STAGE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static Db1PerDeviceOnce attr_once;   // dynamic LDS above 64 KiB needs the opt-in attribute: once per device, every instantiation
+    attr_once.run([] {
 #define SET_ATTR(TC, TB) hipFuncSetAttribute((const void*)gemm_bf16_pp32_kernel<AK, BK_, TC, TB, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
         SET_ATTR(float, float); SET_ATTR(float, bf16_t); SET_ATTR(bf16_t, float); SET_ATTR(bf16_t, bf16_t);
 #undef SET_ATTR
-        attr_set = true;
-    }
+    });
     if (dtC == DB1_F32) {
         if (dtBias == DB1_BF16) gemm_bf16_pp32_kernel<AK, BK_, float, bf16_t, NS><<<grid, 512, LDS, st>>>(t);
         else gemm_bf16_pp32_kernel<AK, BK_, float, float, NS><<<grid, 512, LDS, st>>>(t);
@@ -213,7 +212,7 @@ int db1_gemm_pp32_launch(const GemmTileArgs& t_in, int fa, int fb, int dtC, int 
     t.ksplit = 1;
     dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch);
     static int ns = -1;  // DB1_GEMM_PP32_STAGES=4|5 (A/B measurements)
-    if (ns < 0) { const char* e = getenv("DB1_GEMM_PP32_STAGES"); ns = e ? atoi(e) : 4; }  // measured: 4 stages (128 KiB) beat 5 (160 KiB) on every shape
+    if (ns < 0) { const char* e = getenv("DB1_GEMM_PP32_STAGES"); ns = e ? atoi(e) : 4; }   /* read once */  // measured: 4 stages (128 KiB) beat 5 (160 KiB) on every shape
 #define FORMS(NS_)                                                                            \
     if (fa == 0 && fb == 0) launch_pp32<true, true, NS_>(t, dtC, dtBias, grid, st);           \
     else if (fa == 0 && fb == 1) launch_pp32<true, false, NS_>(t, dtC, dtBias, grid, st);     \

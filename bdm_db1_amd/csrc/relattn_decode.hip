@@ -177,16 +177,18 @@ __global__ __launch_bounds__(128) void relattn_decode_merge_kernel(DecodeArgs p)
     p.out[((int64_t)b * p.q + i) * p.H * DEC_D + h * DEC_D + d] = f2bf(l > 0.f ? o / l : 0.f);
 }
 
-static float* g_dec_ws = nullptr;  // grow-only workspace (single compute stream, like the others)
-static size_t g_dec_ws_bytes = 0;
-
 extern "C" int db1_relattn_decode_supported(int B, int q, int klen, int H, int D, int dt) {
     return (dt == DB1_BF16 && D == DEC_D && B > 0 && H > 0 && q >= 1 && q <= 64 && klen >= q && B <= 65535 && H <= 65535) ? 1 : 0;
 }
 
+extern "C" int64_t db1_relattn_decode_workspace_bytes(int B, int q, int klen, int H) {  // per (b, h, key chunk): 64 rows x (out, max, sum)
+    (void)q;
+    return (int64_t)B * H * ((klen + DEC_KC - 1) / DEC_KC) * 64 * (DEC_D + 2) * (int64_t)sizeof(float);
+}
+
 extern "C" int db1_relattn_decode_fwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
                                       int64_t kv_batch_stride, const void* R, int nd, void* out, int B, int q, int klen, int mlen, int H,
-                                      int D, int shift, float scale, void* stream) {
+                                      int D, int shift, float scale, void* ws, int64_t ws_bytes, void* stream) {
     if (!db1_relattn_decode_supported(B, q, klen, H, D, DB1_BF16))
         DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_decode: needs bf16, d_head = 128, 1 <= q <= 64 (got q=%d klen=%d D=%d)", q, klen, D);
     if (mlen != klen - q) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_decode: klen (%d) must be mlen (%d) + q (%d)", klen, mlen, q);
@@ -199,14 +201,8 @@ extern "C" int db1_relattn_decode_fwd(const void* qu, const void* qv, const void
     a.out = (bf16_t*)out; a.kv_rs = kv_row_stride; a.kv_bs = kv_batch_stride;
     a.B = B; a.q = q; a.klen = klen; a.mlen = mlen; a.H = H; a.shift = shift; a.nd = nd; a.scale = scale;
     a.nchunk = (klen + DEC_KC - 1) / DEC_KC;
-    const size_t need = (size_t)B * H * a.nchunk * 64 * (DEC_D + 2) * sizeof(float);
-    if (need > g_dec_ws_bytes) {
-        if (g_dec_ws) { hipDeviceSynchronize(); hipFree(g_dec_ws); }
-        g_dec_ws = nullptr; g_dec_ws_bytes = 0;
-        if (hipMalloc((void**)&g_dec_ws, need) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "relattn_decode: cannot allocate %zu bytes of workspace", need);
-        g_dec_ws_bytes = need;
-    }
-    a.part = g_dec_ws;
+    DB1_NEED_WS(ws, ws_bytes, db1_relattn_decode_workspace_bytes(B, q, klen, H), "relattn_decode");
+    a.part = (float*)ws;
     hipStream_t st = (hipStream_t)stream;
     relattn_decode_kernel<<<dim3((unsigned)a.nchunk, (unsigned)H, (unsigned)B), 256, 4 * DEC_WAVE_LDS, st>>>(a);
     DB1_CHECK_LAUNCH("relattn_decode");

@@ -137,36 +137,30 @@ __global__ __launch_bounds__(256) void relattn_dqr_transpose_kernel(const bf16_t
         if (c0 + r < HD && r0 + tx < nd) Rt[(int64_t)(c0 + r) * nd + r0 + tx] = tile[tx][r];
 }
 
-static bf16_t* g_dqr_rt = nullptr;  // grow-only transposed copy of R (single compute stream, like the other workspaces)
-static size_t g_dqr_rt_bytes = 0;
-
 extern "C" int db1_relattn_dqr_supported(int B, int L, int H, int D, int dt) {
     return (dt == DB1_BF16 && D == 128 && B > 0 && H > 0 && H <= 256 && L >= 128 && (L % 128) == 0 && L <= DQR_MAX_L) ? 1 : 0;
 }
 
+extern "C" int64_t db1_relattn_dqr_workspace_bytes(int L, int H) { return (int64_t)H * 128 * L * (int64_t)sizeof(bf16_t); }  // R^T
+
 /* dq_r[b, i, h, :] = sum_dist dT[h, b, i, dist] * R[dist, h, :]; dT [H, B, L, L] bf16 (zero for dist > i), R [L, H, 128] with row stride r_rs,
  * out [B, L, H, 128] with row / batch strides (elements) */
 extern "C" int db1_relattn_dqr(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride,
-                               int B, int L, int H, int D, void* stream) {
+                               int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream) {
     if (!db1_relattn_dqr_supported(B, L, H, D, DB1_BF16)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_dqr: needs bf16, d_head = 128, L %% 128 == 0, L <= 1024 (got L=%d D=%d)", L, D);
     if (!dT || !R || !out) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_dqr: null buffer");
     if (!db1_aligned16(dT) || !db1_aligned16(out) || (out_row_stride % 4) || (out_batch_stride % 4)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_dqr: alignment");
     hipStream_t st = (hipStream_t)stream;
-    const size_t need = (size_t)H * 128 * L * sizeof(bf16_t);
-    if (need > g_dqr_rt_bytes) {
-        if (g_dqr_rt) { hipDeviceSynchronize(); hipFree(g_dqr_rt); }
-        g_dqr_rt = nullptr; g_dqr_rt_bytes = 0;
-        if (hipMalloc((void**)&g_dqr_rt, need) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "relattn_dqr: cannot allocate %zu bytes", need);
-        g_dqr_rt_bytes = need;
-    }
-    relattn_dqr_transpose_kernel<<<dim3((unsigned)((H * 128 + 31) / 32), (unsigned)((L + 31) / 32)), 256, 0, st>>>((const bf16_t*)R, g_dqr_rt, L, H * 128, r_row_stride);
+    DB1_NEED_WS(ws, ws_bytes, db1_relattn_dqr_workspace_bytes(L, H), "relattn_dqr");
+    bf16_t* Rt = (bf16_t*)ws;
+    relattn_dqr_transpose_kernel<<<dim3((unsigned)((H * 128 + 31) / 32), (unsigned)((L + 31) / 32)), 256, 0, st>>>((const bf16_t*)R, Rt, L, H * 128, r_row_stride);
     DB1_CHECK_LAUNCH("relattn_dqr transpose");
     DqrArgs a;
-    a.dT = (const bf16_t*)dT; a.Rt = g_dqr_rt; a.out = (bf16_t*)out; a.B = B; a.L = L; a.H = H;
+    a.dT = (const bf16_t*)dT; a.Rt = Rt; a.out = (bf16_t*)out; a.B = B; a.L = L; a.H = H;
     a.wph = 256 / H > 0 ? 256 / H : 1;
     a.o_rs = out_row_stride; a.o_bs = out_batch_stride;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)relattn_dqr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQR_STAGES * DQR_TILE_BYTES); attr = true; }
+    static Db1PerDeviceOnce attr_once;
+    attr_once.run([] { hipFuncSetAttribute((const void*)relattn_dqr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQR_STAGES * DQR_TILE_BYTES); });
     relattn_dqr_kernel<<<dim3((unsigned)(H * a.wph)), 512, DQR_STAGES * DQR_TILE_BYTES, st>>>(a);
     DB1_CHECK_LAUNCH("relattn_dqr");
     return DB1_OK;

@@ -773,8 +773,8 @@ extern "C" int db1_relattn_flash_fwd(const void* qu, const void* qv, const void*
     int st = flash_check(a, D, "relattn_flash_fwd");
     if (st) return st;
     if (!db1_aligned16(out)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_flash_fwd: out alignment");
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)relattn_flash_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W16_FWD_LDS); attr = true; }
+    static Db1PerDeviceOnce attr_once;
+    attr_once.run([] { hipFuncSetAttribute((const void*)relattn_flash_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W16_FWD_LDS); });
     relattn_flash_fwd_kernel<<<dim3(flash_grid(L / FA_BQ, H, B)), 512, W16_FWD_LDS, (hipStream_t)stream>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_fwd");
     return DB1_OK;
@@ -796,12 +796,11 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
         DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_flash_bwd: alignment");
     if (!delta || !dT || !lse) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_flash_bwd: null buffer");
     hipStream_t s = (hipStream_t)stream;
-    static bool attr = false;
-    if (!attr) {
+    static Db1PerDeviceOnce attr_once;
+    attr_once.run([] {
         hipFuncSetAttribute((const void*)relattn_flash_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W16_BQ_LDS);
         hipFuncSetAttribute((const void*)relattn_flash_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV16_LDS);
-        attr = true;
-    }
+    });
     const dim3 grid(flash_grid(L / FA_BQ, H, B));
     relattn_flash_bwd_q_kernel<<<grid, 512, W16_BQ_LDS, s>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_bwd_q");

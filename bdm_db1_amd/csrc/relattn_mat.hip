@@ -82,6 +82,15 @@ __global__ __launch_bounds__(256) void relattn_softmax_fwd_kernel(float* AC, con
     const float* t = T + row * nd;
     const int jlo = i - shift + 1 > 0 ? i - shift + 1 : 0;         // visible: i - shift < j <= i + mlen
     const int jhi = i + mlen < Lk - 1 ? i + mlen : Lk - 1;
+    if (jlo > jhi) {
+        // no visible key: the reference fills EVERY score of the row with -1e30 (masked_fill, transformer_xl.py:181-204) and the softmax of
+        // a constant row is uniform over all Lk keys (e.g. same_length with the default mem_len = 0).  masked_fill passes no gradient,
+        // which is what the backward kernel produces for such a row (dS = dT = 0).
+        const float u = 1.f / (float)Lk;
+        for (int j = threadIdx.x; j < Lk; j += 256) s[j] = u;
+        if (lse && threadIdx.x == 0) lse[row] = -1e30f + logf((float)Lk);
+        return;
+    }
     float m = -3.0e38f;
     for (int j = jlo + threadIdx.x; j <= jhi; j += 256) {
         const float v = (s[j] + t[mlen + i - j]) * scale;
@@ -104,7 +113,6 @@ __global__ __launch_bounds__(256) void relattn_softmax_fwd_kernel(float* AC, con
 extern "C" int db1_relattn_softmax_fwd(float* AC, const float* T, float* lse, int H, int B, int Lq, int Lk, int nd, int mlen, int shift,
                                        float scale, void* stream) {
     if (H <= 0 || B <= 0 || Lq <= 0 || Lk <= 0 || nd < mlen + Lq) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_softmax_fwd: shape (nd=%d must be >= mlen+Lq)", nd);
-    if (shift < 1 && mlen < 1) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_softmax_fwd: empty attention window (transformer_xl.py:205-206 raises ValueError)");
     const int64_t rows = (int64_t)H * B * Lq;
     relattn_softmax_fwd_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(AC, T, lse, Lq, Lk, nd, mlen, shift, scale);
     DB1_CHECK_LAUNCH("relattn_softmax_fwd");

@@ -38,7 +38,7 @@ class GraphedMemoryStep:
                 for dst, src in zip(self.mems, m):
                     dst.copy_(src)
                 self.kv = [k.contiguous().clone() for k in st.kv]
-                model._dec_state = SimpleNamespace(mems=self.mems, kv=self.kv, version=model._wversion)
+                model._dec_state = model._dec_pack(self.mems, self.kv)
         self._version = model._wversion
         torch.cuda.synchronize()
         self._capture()
@@ -55,7 +55,7 @@ class GraphedMemoryStep:
             for dst, src in zip(self.kv, new_kv):
                 dst.copy_(src)
         self.graph, self.logits = g, logits
-        model._dec_state = SimpleNamespace(mems=self.mems, kv=self.kv, version=model._wversion)
+        model._dec_state = model._dec_pack(self.mems, self.kv)
 
     def reset_memory(self):
         """start a new episode: zero memory (init_mem) and the matching K/V cache (rebuilt from the zero hidden states)"""
@@ -67,7 +67,7 @@ class GraphedMemoryStep:
             dec = model._decode_begin(self.mems, self.B, self.q, self.mems[0].shape[1])
             for dst, src in zip(self.kv, dec.kv):
                 dst.copy_(src)
-            model._dec_state = SimpleNamespace(mems=self.mems, kv=self.kv, version=model._wversion)
+            model._dec_state = model._dec_pack(self.mems, self.kv)
 
     def __call__(self, ids: torch.Tensor):
         """ids [batch, n_new] -> (logits [batch, n_new, vocab] (static buffer, overwritten by the next call), memory list)"""

@@ -107,7 +107,9 @@ class DB1Engine:
         self.optimizer = _Optimizer(float(lr) if lr is not None else 1e-4, float(g("weight_decay", 0.01)))
         self.lr_scheduler = lr_scheduler
         self.overlap_comm = bool(g("overlap_grad_reduce", True))
-        model.keep_logits = bool(g("keep_logits", False))
+        # DeepSpeed's engine hands back logits the caller may keep; `keep_logits=False` (bench.py, memory-tight training) lets the CE backward
+        # overwrite the logits buffer with dlogits in place (4.4 GB at 64 x 1024 tokens)
+        model.keep_logits = bool(g("keep_logits", True))
         ar = model.arena
         if ar.exp_avg is None:
             ar.exp_avg = torch.zeros_like(ar.master)
@@ -160,6 +162,10 @@ class DB1Engine:
         return loss
 
     def step(self):
+        with torch.cuda.device(self.module.device):
+            return self._step()
+
+    def _step(self):
         boundary = self.is_gradient_accumulation_boundary()
         self.micro_steps += 1
         if not boundary:
@@ -219,7 +225,8 @@ class DB1Engine:
             self.global_steps = int(state["optimizer"].get("step", 0))
         if self.lr_scheduler is not None and state.get("lr_scheduler"):
             self.lr_scheduler.load_state_dict(state["lr_scheduler"])
-        self.micro_steps = int(state.get("micro_steps", 0))
+        # partially accumulated gradients are not part of a checkpoint: resume at the last accumulation boundary
+        self.micro_steps = int(state.get("micro_steps", 0)) // self._ga * self._ga
         client = {k: v for k, v in state.items() if k not in ("module", "optimizer", "lr_scheduler")}
         return path, client
 

@@ -11,6 +11,7 @@ from typing import Dict, List, Tuple
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "db1_hip.h")
+TEST_HEADER = os.path.join(HERE, "..", "include", "db1_hip_test.h")   # thread-local kernel-steering hooks of the tests / tuning tools
 LIB_PATH = os.path.join(HERE, "libdb1_hip.so")
 
 DB1_F32, DB1_BF16 = 0, 1
@@ -26,15 +27,17 @@ class Db1Error(RuntimeError):
     pass
 
 
-def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
-    """Returns {name: (restype, [argtypes])} for every function declared in the header."""
+def parse_header(path: str = HEADER, with_test_hooks: bool = False) -> Dict[str, Tuple[object, List[object]]]:
+    """Returns {name: (restype, [argtypes])} for every function declared in the header (``with_test_hooks``: and in db1_hip_test.h)."""
     src = open(path).read()
+    if with_test_hooks:
+        src += open(TEST_HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
     protos = {}
-    for m in re.finditer(r"(?:^|\n)\s*(const\s+char\s*\*|int|void)\s+(db1_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"(?:^|\n)\s*(const\s+char\s*\*|int64_t|int|void)\s+(db1_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
-        restype = ctypes.c_char_p if "char" in ret else (None if ret == "void" else ctypes.c_int)
+        restype = ctypes.c_char_p if "char" in ret else (None if ret == "void" else (ctypes.c_int64 if ret == "int64_t" else ctypes.c_int))
         argtypes = []
         if args and args != "void":
             for a in args.split(","):
@@ -64,7 +67,7 @@ def load():
         raise Db1Error(f"{LIB_PATH} is missing: run `python -m bdm_db1_amd.build` (or __graft_entry__.build()). "
                        "There is no CPU fallback for the DB1 hot path.")
     lib = ctypes.CDLL(LIB_PATH)
-    _protos = parse_header()
+    _protos = parse_header(with_test_hooks=True)
     for name, (restype, argtypes) in _protos.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = restype

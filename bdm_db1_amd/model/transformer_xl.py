@@ -561,7 +561,8 @@ class TransformerXL(nn.Module):
             if compute_loss and task.label is not None:
                 rl_label = self._dev_ids(task.label).clone()  # "-1 -> 0" (:644-645) is applied to a private copy by the kernel
             emb = self._new(B, L, d)
-            ops.rl_assemble_fwd(E, self.W("rl_local_timestep_embedding.weight"), vis, ids, pos, rl_label, emb)
+            # "-1 -> 0" on the labels only when there are image placeholders to point at (transformer_xl.py:630-645)
+            ops.rl_assemble_fwd(E, self.W("rl_local_timestep_embedding.weight"), vis, ids, pos, rl_label if vis is not None else None, emb)
             c.ids, c.pos = ids, pos
         elif kind in ("ICTaskInput", "VQATaskInput"):
             prompt, text = self._dev_ids(task.prompt_seq), self._dev_ids(task.text_seq)
@@ -587,7 +588,7 @@ class TransformerXL(nn.Module):
 
     def _embed_bwd(self, dh: torch.Tensor, ecs: List[_Ctx], shapes):
         d = self.d_model
-        gE = self.arena.view(self.arena.grad, "word_embedding.weight", full=True).view(self.vocab_pad, d)
+        gE = self.arena.view(self.arena.grad, "word_embedding.weight")   # [total_vocab_size, d]: ids beyond it read / write nothing
         b0 = 0
         for c, (B, L) in zip(ecs, shapes):
             de = dh[b0:b0 + B]
@@ -631,7 +632,7 @@ class TransformerXL(nn.Module):
         H, D = self.n_head, self.d_head
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
         av = self._new(B, Lq, H, D)
-        flash = (self.use_flash and mlen == 0 and Lq == Lk and ops.relattn_flash_supported(B, Lq, H, D, self.compute_dtype))
+        flash = (self.use_flash and mlen == 0 and Lq == Lk and shift >= 1 and ops.relattn_flash_supported(B, Lq, H, D, self.compute_dtype))
         assert quv is None or flash
         if flash:
             if quv is not None:  # written by the projection's epilogue (db1_gemm_nt_headbias)
@@ -667,6 +668,10 @@ class TransformerXL(nn.Module):
             self._dec_R = (self._wversion, Rs)
         return self._dec_R[1]
 
+    def _dec_pack(self, mems, kv):
+        """cache record: the memory tensors, their version counters at this moment, and the projected keys / values that belong to them"""
+        return SimpleNamespace(mems=mems, mem_versions=[m._version for m in mems], kv=kv, version=self._wversion)
+
     def _decode_begin(self, mems, B, L, mlen):
         """decode context for this call, or None when the fused path does not apply (then the materialised path runs)"""
         if not (self.use_decode and self.compute_dtype == torch.bfloat16 and mlen + L <= self.mem_len + 64 and
@@ -674,8 +679,11 @@ class TransformerXL(nn.Module):
             return None
         st = self._dec_state
         H, D, d = self.n_head, self.d_head, self.d_model
+        # the cache belongs to exactly the tensors the previous call returned, UNMODIFIED: same objects and same torch version counters
+        # (an in-place edit such as `mems[i][done_env] = 0` on an episode reset keeps the identity but bumps `_version` -> rebuild)
         valid = (st is not None and st.version == self._wversion and len(st.mems) == len(mems) and
-                 all(a is b for a, b in zip(st.mems, mems)) and st.kv[0].shape[0] == B and st.kv[0].shape[1] >= mlen)
+                 all(a is b and a._version == v for a, b, v in zip(st.mems, mems, st.mem_versions)) and
+                 st.kv[0].shape[0] == B and st.kv[0].shape[1] >= mlen)
         if valid:
             kv = st.kv
         else:  # rebuild from the hidden states (first call after init_mem, or a caller that edited the memory)
@@ -779,8 +787,8 @@ class TransformerXL(nn.Module):
             qkv = self._new(B * Lk, 3 * d)
             quv = None
             Wqkv = self.W(p + "dec_attn.qkv_net.weight")
-            if (mem is None and self.use_flash and self.use_flash_bwd and self.compute_dtype == torch.bfloat16 and self.use_headbias_epilogue and
-                    ops.relattn_flash_supported(B, L, self.n_head, self.d_head, self.compute_dtype) and
+            if (mem is None and shift >= 1 and self.use_flash and self.use_flash_bwd and self.compute_dtype == torch.bfloat16 and
+                    self.use_headbias_epilogue and ops.relattn_flash_supported(B, L, self.n_head, self.d_head, self.compute_dtype) and
                     ops.gemm_nt_headbias_supported(T, 3 * d, d, d)):
                 # q + r_w_bias and q + r_r_bias leave the projection's accumulators directly (the q columns of qkv stay unwritten)
                 quv = (self._new(B, L, self.n_head, self.d_head), self._new(B, L, self.n_head, self.d_head))
@@ -928,6 +936,12 @@ class TransformerXL(nn.Module):
         return None
 
     def forward(self, tasks_input: Sequence, compute_loss: bool = True, mems=None):
+        """transformer_xl.py:506-619.  Runs on ``self.dev`` whatever the caller's current device is (streams, workspaces and the
+        per-device kernel attributes all follow the current device)."""
+        with torch.cuda.device(self.dev):
+            return self._forward(tasks_input, compute_loss, mems)
+
+    def _forward(self, tasks_input: Sequence, compute_loss: bool = True, mems=None):
         assert not (compute_loss and mems is not None), "During training, Gato does not use memory mechanism."
         keep = compute_loss and torch.is_grad_enabled()
         d = self.d_model
@@ -942,8 +956,13 @@ class TransformerXL(nn.Module):
         mlen = mems[0].size(1) if mems is not None else 0
         klen = L + mlen
         shift = self._window(L, mlen)
-        if shift < 1 and mlen < 1:
-            raise ValueError("empty attention mask")  # transformer_xl.py:177,205-206
+        # The reference builds a uint8 mask (1 = hidden, transformer_xl.py:551-567) and raises ValueError when NOTHING is hidden
+        # (`torch.sum(attention_mask).item()` is 0, :177,205-206): the causal part triu(1 + mlen) hides something iff qlen > 1, the
+        # same_length part tril(-shift) iff shift <= qlen - 1.  (So a 1-token call without a full memory raises there, and here.)
+        # The opposite extreme -- every key of a row hidden, e.g. same_length with mem_len = 0 -- does NOT raise in the reference:
+        # such rows attend uniformly to all keys; the materialised kernels reproduce that (db1_relattn_softmax_fwd).
+        if not (L > 1 or (self.same_length and shift <= L - 1)):
+            raise ValueError("attention mask hides nothing (transformer_xl.py:177,205-206)")
         dec = self._decode_begin(mems, B, L, mlen) if (mems is not None and mlen > 0) else None
         R_in = self._sinusoid(klen) if dec is None else None
         x = h.view(B * L, d)
@@ -981,7 +1000,7 @@ class TransformerXL(nn.Module):
             new_mems = [torch.cat([mems[i].to(self.compute_dtype), hids[i].view(B, L, d)], dim=1)[:, beg_idx:end_idx].detach()
                         for i in range(self.n_layer)]
             # the K/V cache belongs to exactly these tensors (checked by identity on the next call)
-            self._dec_state = None if dec is None else SimpleNamespace(mems=new_mems, kv=dec.new_kv, version=self._wversion)
+            self._dec_state = None if dec is None else self._dec_pack(new_mems, dec.new_kv)
             res = res + (new_mems,)
         return res
 
@@ -989,6 +1008,10 @@ class TransformerXL(nn.Module):
         """Accumulate d(loss * grad_scale)/d(params) of the last forward into the gradient arena.
         ``layer_done_hook(name)`` fires as soon as a layer's gradients are final (used by the data-parallel
         engine to start that layer's bucket all-reduce while earlier layers are still in backward)."""
+        with torch.cuda.device(self.dev):
+            return self._backward(grad_scale, layer_done_hook)
+
+    def _backward(self, grad_scale, layer_done_hook):
         ctx = self._ctx
         if ctx is None:
             raise RuntimeError("backward() without a preceding forward(compute_loss=True)")

@@ -35,6 +35,47 @@ def stream():
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
+class _Workspace:
+    """The scratch the C ABI asks its caller for (include/db1_hip.h: ``db1_<op>_workspace_bytes``): one torch buffer per (device,
+    stream), grown on demand by the caching allocator (stream-ordered: no device synchronisation, no hipMalloc inside an entry
+    point).  Every op that needs scratch is finished with it when its work on the stream is done, and ops of one stream run in
+    order, so one buffer of the largest size requested so far serves them all.  Under hipGraph capture the capturing stream gets its
+    own buffer from the graph's private pool (torch allows allocation there), which lives as long as this cache references it."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, nbytes: int, device):
+        if nbytes <= 0:
+            return _vp(0), 0
+        key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return _vp(buf.data_ptr()), buf.numel()
+
+
+_workspace = _Workspace()
+_ws_query_cache = {}
+
+
+def reserve_workspace(nbytes: int, device=None):
+    """pre-size the current stream's scratch buffer (so that a timed region never contains its first allocation)"""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    _workspace.get(int(nbytes), device)
+
+
+def _ws(query: str, args: tuple, device):
+    """(ws pointer, ws_bytes) for one call: size from the library's own query (memoised per shape)"""
+    key = (query, args)
+    n = _ws_query_cache.get(key)
+    if n is None:
+        n = int(getattr(lib.load(), query)(*args))
+        _ws_query_cache[key] = n
+    return _workspace.get(n, device)
+
+
 def _strides2(t: torch.Tensor):
     assert t.dim() == 2
     return t.stride(0), t.stride(1)
@@ -84,9 +125,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias: Optional[tor
     assert K == K2 and out.shape == (M, N), (a.shape, b.shape, out.shape)
 
     def run():
+        ws, wsn = _ws("db1_gemm_workspace_bytes", (M, N, K, dt_code(a), dt_code(b), dt_code(out), a.stride(0), a.stride(1), b.stride(0), b.stride(1),
+                                                    out.stride(0), out.stride(1), 1, 1), out.device)
         lib.call("db1_gemm_strided", P(a), P(b), P(out), P(bias), M, N, K, dt_code(a), dt_code(b), dt_code(out),
                  dt_code(bias) if bias is not None else 0, a.stride(0), a.stride(1), b.stride(0), b.stride(1),
-                 out.stride(0), out.stride(1), 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, stream())
+                 out.stride(0), out.stride(1), 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, ws, wsn, stream())
 
     if _gemm_timer is not None and _is_tile_gemm(M, N, K, a, b, out, a.stride(), b.stride(), out.stride()):
         _gemm_timer.wrap(2.0 * M * N * K, run)
@@ -124,10 +167,12 @@ def gemm_batched(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: flo
     assert K == K2 and out.shape == (Z0, Z1, M, N) and b.shape[:2] == (Z0, Z1), (a.shape, b.shape, out.shape)
 
     def run():
+        ws, wsn = _ws("db1_gemm_workspace_bytes", (M, N, K, dt_code(a), dt_code(b), dt_code(out), a.stride(2), a.stride(3), b.stride(2), b.stride(3),
+                                                    out.stride(2), out.stride(3), Z0, Z1), out.device)
         lib.call("db1_gemm_strided_tri", P(a), P(b), P(out), _vp(0), M, N, K, dt_code(a), dt_code(b), dt_code(out), 0,
                  a.stride(2), a.stride(3), b.stride(2), b.stride(3), out.stride(2), out.stride(3), Z0, Z1,
                  a.stride(0), a.stride(1), b.stride(0), b.stride(1), out.stride(0), out.stride(1), alpha, beta, int(tri[0]), int(tri[1]),
-                 stream())
+                 ws, wsn, stream())
 
     # the batched contractions of the attention backward (dq_r, dR) run on the same tile kernels: timed with the dense 2MNK they execute
     if _gemm_timer is not None and _is_tile_gemm(M, N, K, a, b, out, a.stride()[2:], b.stride()[2:], out.stride()[2:]):
@@ -146,7 +191,8 @@ def relattn_dqr(dT, R, dqv):
     H, B, L, _ = dT.shape
     D = dqv.shape[-1]
     assert dT.is_contiguous() and R.stride(1) == 1 and dqv.stride(3) == 1 and dqv.stride(2) == D
-    lib.call("db1_relattn_dqr", P(dT), P(R), R.stride(0), P(dqv), dqv.stride(1), dqv.stride(0), B, L, H, D, stream())
+    ws, wsn = _ws("db1_relattn_dqr_workspace_bytes", (L, H), dT.device)
+    lib.call("db1_relattn_dqr", P(dT), P(R), R.stride(0), P(dqv), dqv.stride(1), dqv.stride(0), B, L, H, D, ws, wsn, stream())
 
 
 def layernorm_residual_fwd(x, r, alpha, gamma, beta, y, s_out, mean, rstd, eps):
@@ -157,8 +203,9 @@ def layernorm_residual_fwd(x, r, alpha, gamma, beta, y, s_out, mean, rstd, eps):
 
 def layernorm_residual_bwd(dy, s, gamma, mean, rstd, ds, dgamma_acc, dbeta_acc):
     rows, d = dy.numel() // dy.shape[-1], dy.shape[-1]
+    ws, wsn = _ws("db1_layernorm_residual_bwd_workspace_bytes", (rows, d, dt_code(dy)), dy.device)
     lib.call("db1_layernorm_residual_bwd", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dgamma_acc), P(dbeta_acc),
-             rows, d, dt_code(dy), dt_code(gamma), stream())
+             rows, d, dt_code(dy), dt_code(gamma), ws, wsn, stream())
 
 
 def ffn_act_fwd(z, out, act: str):
@@ -175,13 +222,15 @@ def ffn_act_bwd_bias(z, dout, dz, dbias_acc, act: str):
     """activation backward + dbias_acc += column sums of dz, one pass"""
     rows, n = dout.numel() // dout.shape[-1], dout.shape[-1]
     assert dbias_acc.dtype == torch.float32 and dbias_acc.numel() == dz.shape[-1]
-    lib.call("db1_ffn_act_bwd_bias", P(z), P(dout), P(dz), P(dbias_acc), rows, n, ACT_CODES[act], dt_code(z), stream())
+    ws, wsn = _ws("db1_ffn_act_bwd_bias_workspace_bytes", (rows, n, ACT_CODES[act]), z.device)
+    lib.call("db1_ffn_act_bwd_bias", P(z), P(dout), P(dz), P(dbias_acc), rows, n, ACT_CODES[act], dt_code(z), ws, wsn, stream())
 
 
 def colsum_acc(x2d, out_acc):
     rows, cols = x2d.shape
     assert x2d.stride(1) == 1 and out_acc.dtype == torch.float32
-    lib.call("db1_colsum_acc", P(x2d), P(out_acc), rows, cols, x2d.stride(0), dt_code(x2d), stream())
+    ws, wsn = _ws("db1_colsum_acc_workspace_bytes", (rows, cols), x2d.device)
+    lib.call("db1_colsum_acc", P(x2d), P(out_acc), rows, cols, x2d.stride(0), dt_code(x2d), ws, wsn, stream())
 
 
 def add(a, b, y):
@@ -201,8 +250,9 @@ def add2d_colsums(a2d, b2d, y2d, sum_a_acc, sum_b_acc):
     rows, cols = y2d.shape
     assert a2d.stride(1) == 1 and b2d.stride(1) == 1 and y2d.stride(1) == 1 and a2d.dtype == y2d.dtype == b2d.dtype
     assert sum_a_acc.dtype == torch.float32 and sum_b_acc.dtype == torch.float32
+    ws, wsn = _ws("db1_add2d_colsums_workspace_bytes", (rows, cols), y2d.device)
     lib.call("db1_add2d_colsums", P(a2d), a2d.stride(0), P(b2d), b2d.stride(0), P(y2d), y2d.stride(0), P(sum_a_acc), P(sum_b_acc),
-             rows, cols, dt_code(y2d), stream())
+             rows, cols, dt_code(y2d), ws, wsn, stream())
 
 
 def cast(x, y):
@@ -212,32 +262,33 @@ def cast(x, y):
 def embed_gather(table, ids, out2d):
     n, d = out2d.shape
     assert ids.dtype == torch.int64 and ids.numel() == n and out2d.stride(1) == 1
-    lib.call("db1_embed_gather_fwd", P(table), P(ids), P(out2d), n, d, out2d.stride(0), dt_code(table), dt_code(out2d), stream())
+    lib.call("db1_embed_gather_fwd", P(table), P(ids), P(out2d), n, d, out2d.stride(0), table.shape[0], dt_code(table), dt_code(out2d), stream())
 
 
 def embed_scatter_add(dout2d, ids, dtable_acc):
     n, d = dout2d.shape
     assert ids.dtype == torch.int64 and dtable_acc.dtype == torch.float32 and dout2d.stride(1) == 1
-    lib.call("db1_embed_scatter_add_bwd", P(dout2d), P(ids), P(dtable_acc), n, d, dout2d.stride(0), dt_code(dout2d), stream())
+    lib.call("db1_embed_scatter_add_bwd", P(dout2d), P(ids), P(dtable_acc), n, d, dout2d.stride(0), dtable_acc.shape[0], dt_code(dout2d), stream())
 
 
 def rl_assemble_fwd(word_table, pos_table, vis, ids, position_id, labels, out):
     B, L, d = out.shape
     nvis = 0 if vis is None else vis.shape[1]
     lib.call("db1_rl_assemble_fwd", P(word_table), P(pos_table), P(vis), P(ids), P(position_id), P(labels), P(out),
-             B, L, d, nvis, dt_code(word_table), dt_code(out), stream())
+             B, L, d, nvis, word_table.shape[0], pos_table.shape[0], dt_code(word_table), dt_code(out), stream())
 
 
 def rl_assemble_bwd(dout, ids, position_id, dword_acc, dpos_acc, dvis):
     B, L, d = dout.shape
     nvis = 0 if dvis is None else dvis.shape[1]
     lib.call("db1_rl_assemble_bwd", P(dout), P(ids), P(position_id), P(dword_acc), P(dpos_acc), P(dvis), B, L, d, nvis,
-             dt_code(dout), stream())
+             dword_acc.shape[0], dpos_acc.shape[0], dt_code(dout), stream())
 
 
 def masked_ce_fwd(logits2d, labels, mask, lse, sums, V):
     T, ld = logits2d.shape[0], logits2d.stride(0)
-    lib.call("db1_masked_ce_fwd", P(logits2d), P(labels), P(mask), P(lse), P(sums), T, V, ld, dt_code(logits2d), stream())
+    ws, wsn = _ws("db1_masked_ce_fwd_workspace_bytes", (T,), logits2d.device)
+    lib.call("db1_masked_ce_fwd", P(logits2d), P(labels), P(mask), P(lse), P(sums), T, V, ld, dt_code(logits2d), ws, wsn, stream())
 
 
 def masked_ce_bwd(logits2d, labels, mask, lse, sums, dlogits2d, V, gscale=1.0):
@@ -266,8 +317,9 @@ def relattn_decode_supported(B, q, klen, H, D, dtype) -> bool:
 def relattn_decode_fwd(qu, qv, k, v, R, out, B, q, klen, mlen, H, D, shift, scale):
     """k, v: views [B, klen, H, D] (any row / batch stride, unit stride inside a head row)"""
     assert k.stride(3) == 1 and k.stride(2) == D and v.stride() == k.stride()
+    ws, wsn = _ws("db1_relattn_decode_workspace_bytes", (B, q, klen, H), out.device)
     lib.call("db1_relattn_decode_fwd", P(qu), P(qv), P(k), P(v), k.stride(1), k.stride(0), P(R), R.shape[0], P(out),
-             B, q, klen, mlen, H, D, shift, float(scale), stream())
+             B, q, klen, mlen, H, D, shift, float(scale), ws, wsn, stream())
 
 
 def relattn_flash_supported(B, L, H, D, dtype) -> bool:
@@ -388,10 +440,23 @@ def mulaw_decode(ids, out, is_action, num_bins=1024, mu=100.0, M=256.0, oob_flag
              float(M), P(oob_flag), stream())
 
 
+GEMM_KERNELS = {0: "strided-fp32", 1: "tile128", 2: "tile256", 3: "pp-k64", 4: "pp-k32", 5: "w4", 6: "skinny"}
+
+
+def gemm_kernel_choice(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, beta: float = 0.0, ws_bytes: int = -1):
+    """(kernel name, split-K?, tail-call?) that ``gemm(a, b, out)`` would take (db1_gemm_kernel_choice)"""
+    M, K = a.shape
+    N = b.shape[1]
+    code = lib.load().db1_gemm_kernel_choice(M, N, K, dt_code(a), dt_code(b), dt_code(out), a.stride(0), a.stride(1), b.stride(0), b.stride(1),
+                                             out.stride(0), out.stride(1), 1, 1, float(beta), int(ws_bytes))
+    return GEMM_KERNELS[code & 15], bool(code & 16), bool(code & 32)
+
+
 def gemm_force_generic(on: bool):
-    lib.load().db1_gemm_force_generic(1 if on else 0)
+    """test hook (include/db1_hip_test.h), thread-local"""
+    lib.load().db1_test_gemm_force_generic(1 if on else 0)
 
 
 def gemm_tile_override(tile: int):
-    """0 = measured heuristics; 128 / 256 / 512 pin one bf16 tile kernel (tests, tuning)."""
-    lib.load().db1_gemm_tile_override(int(tile))
+    """test / tuning hook (include/db1_hip_test.h), thread-local: 0 = measured heuristics; 128 / 256 / 512 / 1024 pin one bf16 tile kernel"""
+    lib.load().db1_test_gemm_tile_override(int(tile))

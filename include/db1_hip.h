@@ -11,13 +11,24 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm tensors are
- *     only containers); the library never allocates or frees memory;
- *   - every call is asynchronous on the given hipStream_t (passed as void*);
+ *     only containers).  The library never allocates, frees or synchronises: there is no
+ *     hipMalloc / hipFree / hipDeviceSynchronize behind any entry point.  An entry point
+ *     that needs scratch takes (void* ws, int64_t ws_bytes) -- 16-byte aligned device memory
+ *     the caller owns -- and has a query  int64_t db1_<op>_workspace_bytes(shape...)  that
+ *     returns what that call needs (0 = none, ws may then be NULL); too little workspace is
+ *     DB1_ERR_WORKSPACE_TOO_SMALL, except for the GEMMs, which then take a kernel that needs
+ *     none.  The scratch is dead when the call's work on the stream is done: one buffer of the
+ *     largest size serves every call of a stream;
+ *   - every call is asynchronous on the given hipStream_t (passed as void*) and may be
+ *     captured into a hipGraph;
  *   - return value: 0 = ok, negative = DB1_ERR_*; db1_last_error() gives a
  *     thread-local message; no C++ exception crosses the boundary;
  *   - dtype codes: DB1_F32 / DB1_BF16; "acc" outputs are float32 and are
  *     ACCUMULATED into (+=), so gradient accumulation and tied parameters are free;
- *   - one host thread per GPU (one process per rank), no global mutable state.
+ *   - no global mutable state: the library keeps one immutable per-device cache ("this kernel's
+ *     dynamic-LDS attribute is set", std::call_once) and reads its A/B environment switches
+ *     once; the kernel-steering hooks of the tests are thread-local and live in db1_hip_test.h.
+ *     Any number of host threads / devices / streams may call concurrently.
  */
 #ifndef DB1_HIP_H
 #define DB1_HIP_H
@@ -60,7 +71,19 @@ int db1_gemm_strided(const void* A, const void* B, void* C, const void* bias,
                      int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs, int64_t c_cs,
                      int batch0, int batch1,
                      int64_t a_bs0, int64_t a_bs1, int64_t b_bs0, int64_t b_bs1, int64_t c_bs0, int64_t c_bs1,
-                     float alpha, float beta, void* stream);
+                     float alpha, float beta, void* ws, int64_t ws_bytes, void* stream);
+/* Scratch of the deterministic split-K path (fp32 partial sums of outputs too small to fill the chip, added in a fixed order).
+ * Without it (ws NULL / smaller) the same product runs on a kernel that needs none: results are equally valid, large-K weight
+ * gradients are slower. */
+int64_t db1_gemm_workspace_bytes(int M, int N, int K, int dtA, int dtB, int dtC,
+                                 int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs, int64_t c_cs,
+                                 int batch0, int batch1);
+/* which kernel db1_gemm_strided takes for this product given ws_bytes of workspace (-1: as much as it wants):
+ * 0 strided fp32-MFMA, 1 128x128 tile, 2 256x128 tile, 3 / 4 256x256 8-wave (k64 x 2 / k32 x 4), 5 256x256 4-wave hand-scheduled,
+ * 6 skinny W-streaming; +16 split-K through the workspace; +32 the last partial wave of tile rows runs as a second call */
+int db1_gemm_kernel_choice(int M, int N, int K, int dtA, int dtB, int dtC,
+                           int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs, int64_t c_cs,
+                           int batch0, int batch1, float beta, int64_t ws_bytes);
 /* Row-major 2-D conveniences.  nt: C = A[M,K] * B[N,K]^T (y = x W^T);
  * nn: C = A[M,K] * B[K,N] (dx = dy W);  tn: C = A[K,M]^T * B[K,N] (dW = dy^T x). */
 /* db1_gemm_strided with a structural-zero hint for A (an optimisation only: results are those of the plain call):
@@ -70,9 +93,9 @@ int db1_gemm_strided(const void* A, const void* B, void* C, const void* bias,
 int db1_gemm_strided_tri(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int dtA, int dtB, int dtC, int dtBias,
                          int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs, int64_t c_cs, int batch0, int batch1,
                          int64_t a_bs0, int64_t a_bs1, int64_t b_bs0, int64_t b_bs1, int64_t c_bs0, int64_t c_bs1, float alpha, float beta,
-                         int tri_mode, int tri_period, void* stream);
+                         int tri_mode, int tri_period, void* ws, int64_t ws_bytes, void* stream);
 int db1_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
-                int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream);
+                int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* ws, int64_t ws_bytes, void* stream);
 /* The attention input projection (transformer_xl.py:136-141,160-175): C[M,N] = A[M,K] * W[N,K]^T in bf16, except that the columns n < split_n
  * (the query block) are written as acc + bias_u[n] to Cu and acc + bias_v[n] to Cv (row stride ld_uv) instead of to C: q + r_w_bias and
  * q + r_r_bias leave the GEMM's accumulators directly (no separate pass, one rounding).  Large shapes only (see _supported). */
@@ -80,14 +103,9 @@ int db1_gemm_nt_headbias_supported(int M, int N, int K, int split_n);
 int db1_gemm_nt_headbias(const void* A, const void* W, void* C, void* Cu, void* Cv, const void* bias_u, const void* bias_v, int M, int N, int K,
                          int split_n, int64_t lda, int64_t ldw, int64_t ldc, int64_t ld_uv, void* stream);
 int db1_gemm_nn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
-                int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream);
+                int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* ws, int64_t ws_bytes, void* stream);
 int db1_gemm_tn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
-                int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* stream);
-/* test hook: route every GEMM to the strided fp32-MFMA kernel (cross-checks the tile kernels at full size) */
-void db1_gemm_force_generic(int on);
-/* test / tuning hook: pin one bf16 tile kernel where its shape constraints hold (128 = 128x128, 256 = 256x128 3-stage,
-   512 = 256x256 ping-pong with 2 stages of k64, 1024 = the same with a 4-stage ring of k32; 0 = the measured heuristics, the default unless DB1_GEMM_TILE is set in the environment) */
-void db1_gemm_tile_override(int tile);
+                int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* ws, int64_t ws_bytes, void* stream);
 /* which kernel db1_gemm_strided would pick: 0 = strided fp32-MFMA, 1 = bf16 MFMA tile kernel */
 int db1_gemm_would_use_fast(int M, int N, int K, int dtA, int dtB, int dtC,
                             int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs, int64_t c_cs);
@@ -100,9 +118,10 @@ int db1_layernorm_residual_fwd(const void* x, const void* r, float alpha, const 
                                void* y, void* s_out, float* mean, float* rstd,
                                int64_t rows, int d, float eps, int dt, int dtParam, void* stream);
 /* ds = dL/ds (dtype dt); dgamma_acc / dbeta_acc: float32 [d], accumulated. */
+int64_t db1_layernorm_residual_bwd_workspace_bytes(int64_t rows, int d, int dt);   /* per-block parameter-gradient partials */
 int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                                void* ds, float* dgamma_acc, float* dbeta_acc,
-                               int64_t rows, int d, int dt, int dtParam, void* stream);
+                               int64_t rows, int d, int dt, int dtParam, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ feed-forward activation
  * GEGLU: out[r, j] = z[r, j] * gelu_erf(z[r, n + j]) (activations.py:19-32); GELU/RELU: elementwise. */
@@ -110,17 +129,20 @@ int db1_ffn_act_fwd(const void* z, void* out, int64_t rows, int n_out, int act, 
 int db1_ffn_act_bwd(const void* z, const void* dout, void* dz, int64_t rows, int n_out, int act, int dt, void* stream);
 /* same, and dbias_acc[c] += sum_r dz[r, c] over all columns of dz (float32 [2*n_out] for GEGLU, [n_out] otherwise): the
  * gradient of the first feed-forward bias (transformer_xl.py:264) from the same pass; fixed summation order. */
+int64_t db1_ffn_act_bwd_bias_workspace_bytes(int64_t rows, int n_out, int act);
 int db1_ffn_act_bwd_bias(const void* z, const void* dout, void* dz, float* dbias_acc, int64_t rows, int n_out, int act, int dt,
-                         void* stream);
+                         void* ws, int64_t ws_bytes, void* stream);
 
 /* out_acc[c] += sum_r x[r, c]  (bias / u / v gradients). ldx = row stride in elements. */
-int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int cols, int64_t ldx, int dt, void* stream);
+int64_t db1_colsum_acc_workspace_bytes(int64_t rows, int cols);   /* per-chunk partials, added in a fixed order */
+int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int cols, int64_t ldx, int dt, void* ws, int64_t ws_bytes, void* stream);
 /* y = a + b (elementwise), used by pre-LN residuals and dq = dq_k + dq_r */
 int db1_add(const void* a, const void* b, void* y, int64_t n, int dt, void* stream);
 /* y = a + b and, from the same pass, sum_a_acc[c] += sum_r a[r, c], sum_b_acc[c] += sum_r b[r, c] (float32, fixed order; y may alias b).
  * The attention backward's dq = dq_k + dq_r with the r_w_bias / r_r_bias gradients (transformer_xl.py:160-209): one pass instead of three. */
+int64_t db1_add2d_colsums_workspace_bytes(int64_t rows, int cols);
 int db1_add2d_colsums(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, float* sum_a_acc, float* sum_b_acc,
-                      int64_t rows, int cols, int dt, void* stream);
+                      int64_t rows, int cols, int dt, void* ws, int64_t ws_bytes, void* stream);
 /* y[r, c] = a[r, c] + b[r, c] with row strides (a may have a different dtype; y may alias b) */
 int db1_add2d(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows, int cols,
               int dtA, int dt, void* stream);
@@ -130,26 +152,29 @@ int db1_cast(const void* x, void* y, int64_t n, int dtIn, int dtOut, void* strea
 /* ------------------------------------------------------------------ embeddings
  * out[t, :] = table[ids[t], :] (zeros where ids[t] < 0)   (transformer_xl.py:627-629, 665, 677, 686) */
 int db1_embed_gather_fwd(const void* table, const int64_t* ids, void* out, int64_t n_tokens, int d,
-                         int64_t ld_out, int dtTable, int dtOut, void* stream);
-/* dtable_acc[ids[t], :] += dout[t, :] (float32 atomics; ids < 0 skipped) */
+                         int64_t ld_out, int64_t n_table_rows, int dtTable, int dtOut, void* stream);
+/* dtable_acc[ids[t], :] += dout[t, :] (float32 atomics; ids outside [0, n_table_rows) are skipped, as they read zeros in the forward) */
 int db1_embed_scatter_add_bwd(const void* dout, const int64_t* ids, float* dtable_acc, int64_t n_tokens, int d,
-                              int64_t ld_dout, int dt, void* stream);
+                              int64_t ld_dout, int64_t n_table_rows, int dt, void* stream);
 /* RL sequence assembly (transformer_xl.py:621-660): rows with ids >= 0 take word_table[ids];
  * the k-th "-1" placeholder of row b takes vis[b, k, :]; then + pos_table[position_id].
- * labels (may be NULL): label == -1 -> 0 in place (:644-645). */
+ * labels (may be NULL): label == -1 -> 0 in place (:644-645).  Token ids >= n_word_rows / position ids outside [0, n_pos_rows)
+ * contribute nothing (no out-of-table access). */
 int db1_rl_assemble_fwd(const void* word_table, const void* pos_table, const void* vis, const int64_t* ids,
                         const int64_t* position_id, int64_t* labels, void* out,
-                        int B, int L, int d, int n_vis_per_row, int dtTable, int dt, void* stream);
+                        int B, int L, int d, int n_vis_per_row, int64_t n_word_rows, int64_t n_pos_rows, int dtTable, int dt, void* stream);
 int db1_rl_assemble_bwd(const void* dout, const int64_t* ids, const int64_t* position_id,
                         float* dword_acc, float* dpos_acc, void* dvis,
-                        int B, int L, int d, int n_vis_per_row, int dt, void* stream);
+                        int B, int L, int d, int n_vis_per_row, int64_t n_word_rows, int64_t n_pos_rows, int dt, void* stream);
 
 /* ------------------------------------------------------------------ masked cross-entropy on materialised logits
- * (transformer_xl.py:602-609). logits [T, ld] (columns >= V are padding).  fwd: lse[t], and
+ * (transformer_xl.py:602-609). logits [T, ld] (columns >= V are padding); a label outside [0, V) adds no loss and gets no gradient
+ * (torch's ignore_index).  fwd: lse[t], and
  * sums[0] += sum_t mask*nll, sums[1] += sum_t mask.  bwd: dlogits = mask/sums[1] * gscale * (softmax - onehot)
  * (zeros in the padding), may be in place. */
+int64_t db1_masked_ce_fwd_workspace_bytes(int64_t T);   /* per-token losses, summed in a fixed order */
 int db1_masked_ce_fwd(const void* logits, const int64_t* labels, const float* mask, float* lse, float* sums,
-                      int64_t T, int V, int64_t ld, int dt, void* stream);
+                      int64_t T, int V, int64_t ld, int dt, void* ws, int64_t ws_bytes, void* stream);
 int db1_masked_ce_bwd(const void* logits, const int64_t* labels, const float* mask, const float* lse, const float* sums,
                       void* dlogits, int64_t T, int V, int64_t ld, float gscale, int dt, void* stream);
 
@@ -159,9 +184,10 @@ int db1_masked_ce_bwd(const void* logits, const int64_t* labels, const float* ma
  * (+ h*D); R: [nd, H*D] rows indexed by distance mlen + i - j; out: [B, q, H, D].  Same visibility predicate as the
  * materialised path: i - shift < j <= i + mlen. */
 int db1_relattn_decode_supported(int B, int q, int klen, int H, int D, int dt);
+int64_t db1_relattn_decode_workspace_bytes(int B, int q, int klen, int H);   /* per-key-chunk partial outputs of the flash-decoding merge */
 int db1_relattn_decode_fwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
                            int64_t kv_batch_stride, const void* R, int nd, void* out, int B, int q, int klen, int mlen, int H,
-                           int D, int shift, float scale, void* stream);
+                           int D, int shift, float scale, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ relative-position attention, materialised path
  * (fp32 parity gate, any head size).  Buffers S,T are float32 in [H][B][Lq][*] layout.
@@ -170,7 +196,8 @@ int db1_relattn_add_head_bias(const void* qkv, const void* u, const void* vb, vo
                               int B, int Lq, int Lk, int H, int D, int dt, int dtParam, void* stream);
 /* P[h,b,i,j] = softmax_j( (AC[h,b,i,j] + T[h,b,i, mlen+i-j]) * scale ) over visible keys
  * i - shift < j <= i + mlen  (closed form of _rel_shift + mask, transformer_xl.py:98-110,171-209,551-567);
- * written in place over AC.  lse (nullable) [H,B,Lq]. */
+ * written in place over AC.  lse (nullable) [H,B,Lq].  A row with NO visible key gets the uniform distribution over all Lk keys,
+ * as the reference's masked_fill(-1e30) + softmax does (and no gradient flows into its scores). */
 int db1_relattn_softmax_fwd(float* AC, const float* T, float* lse, int H, int B, int Lq, int Lk, int nd,
                             int mlen, int shift, float scale, void* stream);
 /* dS = P * (dP - rowsum(P*dP)) * scale, in place over dP; dT[h,b,i,mlen+i-j] = dS[h,b,i,j] (zero elsewhere). */
@@ -199,8 +226,9 @@ int db1_relattn_flash_bwd(const void* qu, const void* qv, const void* k, const v
  * stream over dT with R stationary in registers: dT [H,B,L,L] bf16 (zero for dist > i), R [L, H*128] bf16 with row stride r_row_stride,
  * out [B,L,H,128] bf16 with row / batch strides in elements.  Same result as db1_gemm_strided_tri on the same operands. */
 int db1_relattn_dqr_supported(int B, int L, int H, int D, int dt);
+int64_t db1_relattn_dqr_workspace_bytes(int L, int H);   /* the transposed copy of R the stream kernel keeps in registers */
 int db1_relattn_dqr(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride,
-                    int B, int L, int H, int D, void* stream);
+                    int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ image-patch embedder pieces
  * (src/tokenizer/vision_embedding.py:65-86).  pixels [N_img, C, Himg, Wimg] -> normalised patches

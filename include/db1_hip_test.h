@@ -1,0 +1,23 @@
+/*
+ * db1_hip_test.h -- TEST-ONLY symbols of libdb1_hip.so.  Not part of the product ABI (include/db1_hip.h): production callers never
+ * use them.  They steer which GEMM kernel the dispatcher takes so that the parity tests can cross-check every tile kernel at full
+ * size against the strided fp32-MFMA kernel, and so that tuning scripts can time one kernel.  The state they set is THREAD-LOCAL
+ * (it affects only GEMM calls made afterwards by the same host thread).
+ */
+#ifndef DB1_HIP_TEST_H
+#define DB1_HIP_TEST_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* route every GEMM of this thread to the strided fp32-MFMA kernel (on != 0) */
+void db1_test_gemm_force_generic(int on);
+/* pin one bf16 tile kernel where its shape constraints hold: 128 = 128x128, 256 = 256x128 3-stage, 512 = 256x256 8-wave ping-pong
+ * (2 stages of k64), 1024 = the same with a 4-stage ring of k32; 0 = the measured heuristics (the default) */
+void db1_test_gemm_tile_override(int tile);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DB1_HIP_TEST_H */

@@ -184,17 +184,20 @@ def relattn_core_fwd(q, k, v, R, u, vb, masked, scale, mlen=0):
     P = np.exp(S)
     P = P / P.sum(-1, keepdims=True)
     out = (P @ v.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3)
-    return out, (P, dist, mlen)
+    return out, (P, dist, mlen, masked)
 
 
 def relattn_core_bwd(dout, q, k, v, R, u, vb, scale, cache):
-    P, dist, mlen = cache
+    P, dist, mlen, masked = cache
     B, Lq, H, D = q.shape
     Lk = k.shape[1]
     do = dout.transpose(0, 2, 1, 3)                # (B,H,Lq,D)
     dP = do @ v.transpose(0, 2, 3, 1)
     dv = (P.transpose(0, 1, 3, 2) @ do).transpose(0, 2, 1, 3)
     dS = P * (dP - (P * dP).sum(-1, keepdims=True)) * scale
+    # masked_fill passes no gradient to the scores it overwrites: only matters for a row whose keys are ALL hidden (its P is
+    # uniform, not zero -- e.g. same_length with mem_len = 0); elsewhere P, hence dS, is already exactly zero there
+    dS = np.where(masked[None, None].astype(bool), 0.0, dS)
     dqk = (dS @ k.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3)      # gradient w.r.t. (q+u)
     dk = (dS.transpose(0, 1, 3, 2) @ (q + u).transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3)
     # re-index dS by distance: dT[b,n,i,r] = dS[b,n,i,j] with j = mlen + i - r (each (i,r) has at most one j;
@@ -207,7 +210,11 @@ def relattn_core_bwd(dout, q, k, v, R, u, vb, scale, cache):
     dT = np.take_along_axis(dS, np.broadcast_to(np.clip(jj, 0, Lk - 1)[None, None], (B, H, Lq, nd)), axis=3) * ok[None, None]
     dqr = (dT @ R.transpose(1, 0, 2)[None]).transpose(0, 2, 1, 3)   # gradient w.r.t. (q+vb)
     qv = (q + vb).transpose(0, 2, 1, 3)
-    dR = np.einsum("bnri,bnid->rnd", dT.transpose(0, 1, 3, 2), qv, optimize=True)
+    # dR[r,n,:] = sum_{b,i} dT[b,n,i,r] qv[b,n,i,:]: one BLAS product per head over the (batch, query) rows (np.einsum ran this
+    # contraction in its scalar C loop: half of the whole backward's time)
+    dTn = dT.transpose(1, 0, 2, 3).reshape(H, B * Lq, nd)
+    qvn = qv.transpose(1, 0, 2, 3).reshape(H, B * Lq, D)
+    dR = (dTn.transpose(0, 2, 1) @ qvn).transpose(1, 0, 2)
     dq = dqk + dqr
     du = dqk.sum((0, 1))
     dvb = dqr.sum((0, 1))
@@ -509,6 +516,7 @@ class TaskBatch:
     vision_seq: Optional[Array] = None
     prompt_seq: Optional[Array] = None
     img_seq: Optional[Array] = None
+    ques_len: Optional[Array] = None        # VQA only; the reference reads it for a debug offset, it does not enter the maths (:721)
     vision_row_ids: Optional[Array] = None  # injected (train-mode) position picks; None = eval rule
     vision_col_ids: Optional[Array] = None
 

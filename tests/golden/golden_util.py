@@ -37,7 +37,17 @@ CASES = {
     # inference with Transformer-XL memory (evaluate_rl.py:157-266 call pattern)
     "small_mems": dict(n_embed=64, n_head=2, n_position=24, mem_len=24, text_vocab_size=300,
                        num_continuous_bin=64, num_discrete_values=64, n_layer=3),
+    # VQA input path (_forward_vqa, transformer_xl.py:705-748) next to a text task
+    "small_vqa": dict(n_embed=64, n_head=2, n_position=40, mem_len=40, text_vocab_size=300,
+                      num_continuous_bin=64, num_discrete_values=64),
+    # memory inference at d_head = 128, the head size of DB1-1.3B: what the bf16 K/V-cached decode kernels need
+    "mems_d128": dict(n_embed=256, n_head=2, n_position=32, mem_len=32, text_vocab_size=300,
+                      num_continuous_bin=64, num_discrete_values=64, n_layer=2),
+    # the default mem_len = 0 under same_length: EVERY key hidden -> the reference attends uniformly to all keys (no error)
+    "small_memlen0": dict(n_embed=64, n_head=2, n_position=24, mem_len=0, text_vocab_size=300,
+                          num_continuous_bin=64, num_discrete_values=64),
 }
+MEM_CASES = {"small_mems": (5, 1, 7), "mems_d128": (6, 1, 1, 9, 1)}   # query lengths of the consecutive calls with memory
 
 
 def case_cfg(name: str) -> dict:
@@ -160,9 +170,25 @@ def make_batch(name: str, cfg: dict, seed: int):
         lm[:, P + nv - 1:] = (rng.random((Bc, T + 1)) > 0.3)
         lm[:, P + nv - 1] = 1.0
         tasks.append(dict(kind="ic", prompt_seq=prompt, img_seq=img, text_seq=text, label=label, loss_mask=lm))
-    elif name in ("small_window", "small_flags", "small_prelnorm"):
+    elif name in ("small_window", "small_flags", "small_prelnorm", "small_memlen0"):
         tasks.append(nlp(3))
-    elif name == "small_mems":
+    elif name == "small_vqa":
+        # prompt 3 + image 32x32 (4 patches) + text (question 9 ++ answer): _forward_vqa concatenates exactly like _forward_ic
+        Bq, P, nv, ql = 2, 3, 4, 9
+        T = L - P - nv
+        prompt = rng.integers(0, V_text, size=(Bq, P))
+        text = rng.integers(1, V_text, size=(Bq, T))
+        img = rng.standard_normal((Bq, 3, 32, 32)).astype(np.float32)
+        label = np.zeros((Bq, L), np.int64)
+        al = T - ql + 1                                           # answer tokens: right-aligned labels (coco_token_dataset.py:183-192)
+        label[:, L - al:] = rng.integers(0, V_text, size=(Bq, al))
+        lm = np.zeros((Bq, L), np.float32)
+        lm[:, L - al:] = 1.0
+        lm[1, L - 3] = 0.0
+        tasks.append(dict(kind="vqa", prompt_seq=prompt, img_seq=img, text_seq=text, label=label, loss_mask=lm,
+                          ques_len=np.full((Bq,), ql, np.int64)))
+        tasks.append(nlp(1))
+    elif name in MEM_CASES:
         pass
     return tasks
 

@@ -23,7 +23,7 @@ sys.path.insert(0, HERE)
 sys.dont_write_bytecode = True
 
 import torch  # noqa: E402
-from golden_util import CASES, case_cfg, make_params, make_batch, sample_idx  # noqa: E402
+from golden_util import CASES, MEM_CASES, case_cfg, make_params, make_batch, sample_idx  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -48,7 +48,7 @@ def build_ref_model(cfg, params):
 
 
 def to_ref_inputs(tasks):
-    from src.data.input_specs import NLPTaskInput, RLTaskInput, ICTaskInput
+    from src.data.input_specs import NLPTaskInput, RLTaskInput, ICTaskInput, VQATaskInput
     T = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
     out = []
     for t in tasks:
@@ -59,6 +59,9 @@ def to_ref_inputs(tasks):
             out.append(RLTaskInput(text_seq=None, vision_seq=T(t["vision_seq"]), tensor_seq=T(t["tensor_seq"]), **base))
         elif t["kind"] == "ic":
             out.append(ICTaskInput(prompt_seq=T(t["prompt_seq"]), img_seq=T(t["img_seq"]), text_seq=T(t["text_seq"]), img_id_seq=None, **base))
+        elif t["kind"] == "vqa":
+            out.append(VQATaskInput(prompt_seq=T(t["prompt_seq"]), img_seq=T(t["img_seq"]), text_seq=T(t["text_seq"]), img_id_seq=None,
+                                    ques_id_seq=None, ques_len=T(t["ques_len"]), **base))
     return out
 
 
@@ -67,11 +70,11 @@ def gen_model_case(name, seed):
     params = make_params(cfg, seed)
     m = build_ref_model(cfg, params)
     out = {"inv_freq": m.pos_emb.inv_freq.numpy().copy()}
-    if name == "small_mems":
-        # 3 consecutive calls with memory, qlen 5 / 1 / 7
+    if name in MEM_CASES:
+        # consecutive calls with memory (small_mems: qlen 5 / 1 / 7)
         rng = np.random.default_rng(seed + 7)
         mems = m.init_mem(2)
-        for step, q in enumerate((5, 1, 7)):
+        for step, q in enumerate(MEM_CASES[name]):
             ids = rng.integers(0, cfg["text_vocab_size"], size=(2, q))
             from src.data.input_specs import NLPTaskInput
             x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None,
@@ -433,10 +436,15 @@ def main():
         print("wrote samplers")
         return
     torch.manual_seed(0)
+    only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "model" else None
     for i, name in enumerate(CASES):
+        if only is not None and name not in only:
+            continue
         d = gen_model_case(name, seed=100 + i)
         np.savez_compressed(os.path.join(HERE, f"model_{name}.npz"), **d)
         print("wrote", name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in list(d.items())[:4]})
+    if only is not None:
+        return
     np.savez_compressed(os.path.join(HERE, "patch_embed.npz"), **gen_patch_embed(7))
     np.savez_compressed(os.path.join(HERE, "scalar_tokenizer.npz"), **gen_scalar_tokenizer(11))
     np.savez_compressed(os.path.join(HERE, "adam.npz"), **gen_adam(13))

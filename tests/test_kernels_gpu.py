@@ -494,6 +494,46 @@ def test_embedding_gather_scatter(ops, dtype):
     close(acc, g, 1e-6, name="scatter")
 
 
+def test_out_of_table_ids_and_labels_touch_nothing(ops):
+    """ids beyond the table / position ids beyond 513 rows / labels outside [0, V) (torch's ignore_index -100): zeros in, nothing out,
+    no out-of-bounds access (the reference raises an IndexError there; a device kernel must not read past its tables)"""
+    rng = np.random.default_rng(81)
+    V, d, n = 20, 32, 12
+    table = rng.standard_normal((V, d))
+    ids = np.array([0, 19, 20, 1 << 40, -1, -100, 5, 7, 19, 3, 25, 2], np.int64)
+    out = torch.full((n, d), 7.0, device=DEV)
+    ops.embed_gather(dev(table), torch.from_numpy(ids).to(DEV), out)
+    ok = (ids >= 0) & (ids < V)
+    close(out, np.where(ok[:, None], table[np.where(ok, ids, 0)], 0.0), 1e-7, name="gather oob")
+    acc = torch.zeros(V + 4, d, device=DEV)
+    ops.embed_scatter_add(dev(rng.standard_normal((n, d))), torch.from_numpy(ids).to(DEV), acc[:V])
+    assert float(acc[V:].abs().max()) == 0.0
+    # RL assembly with a position id of 513 (table has 513 rows) and a word id == V
+    B, L = 1, 40
+    rid = rng.integers(0, V, (B, L)); rid[0, 3] = V
+    pos = rng.integers(0, 513, (B, L)); pos[0, 5] = 513; pos[0, 6] = -2
+    word, post = rng.standard_normal((V, d)), rng.standard_normal((513, d))
+    o = torch.empty(B, L, d, device=DEV)
+    ops.rl_assemble_fwd(dev(word), dev(post), None, torch.from_numpy(rid).to(DEV), torch.from_numpy(pos).to(DEV), None, o)
+    ref = np.where((rid < V)[..., None], word[np.minimum(rid, V - 1)], 0.0) + np.where(((pos >= 0) & (pos < 513))[..., None], post[np.clip(pos, 0, 512)], 0.0)
+    close(o, ref, 1e-6, name="rl oob")
+    # masked CE: labels -100 / V are skipped like mask = 0
+    T, ld = 6, 24
+    logits = rng.standard_normal((T, ld)).astype(np.float32)
+    lab = np.array([1, -100, V - 1, V, 0, 3], np.int64)
+    msk = np.ones(T, np.float32)
+    lse, sums = torch.zeros(T, device=DEV), torch.zeros(2, device=DEV)
+    ops.masked_ce_fwd(dev(logits), torch.from_numpy(lab).to(DEV), dev(msk), lse, sums, V)
+    good = (lab >= 0) & (lab < V)
+    lz = logits[:, :V].astype(np.float64)
+    ref_lse = np.log(np.exp(lz - lz.max(1, keepdims=True)).sum(1)) + lz.max(1)
+    nll = np.where(good, ref_lse - lz[np.arange(T), np.where(good, lab, 0)], 0.0)
+    assert abs(float(sums[0]) - nll.sum()) < 1e-4 and float(sums[1]) == good.sum()
+    dl = torch.empty(T, ld, device=DEV)
+    ops.masked_ce_bwd(dev(logits), torch.from_numpy(lab).to(DEV), dev(msk), lse, sums, dl, V)
+    assert float(dl[~torch.from_numpy(good).to(DEV)].abs().max()) == 0.0 and float(dl[0].abs().max()) > 0
+
+
 def test_rl_assemble(ops):
     rng = np.random.default_rng(9)
     B, L, d, V, nvis = 3, 300, 40, 60, 9

@@ -17,7 +17,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 from oracle import db1_oracle as O  # noqa: E402
-from golden_util import CASES, case_cfg, make_params, make_batch, sample_idx  # noqa: E402
+from golden_util import CASES, MEM_CASES, case_cfg, make_params, make_batch, sample_idx  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
 DEV = "cuda"
@@ -46,7 +46,7 @@ def build(name, compute_dtype=torch.float32):
 
 
 def to_inputs(tasks):
-    from bdm_db1_amd.data import NLPTaskInput, RLTaskInput, ICTaskInput
+    from bdm_db1_amd.data import NLPTaskInput, RLTaskInput, ICTaskInput, VQATaskInput
     T = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
     out = []
     for t in tasks:
@@ -55,6 +55,9 @@ def to_inputs(tasks):
             out.append(NLPTaskInput(text_seq=T(t["text_seq"]), text_len=None, **base))
         elif t["kind"] == "rl":
             out.append(RLTaskInput(text_seq=None, vision_seq=T(t["vision_seq"]), tensor_seq=T(t["tensor_seq"]), **base))
+        elif t["kind"] == "vqa":   # _forward_vqa (transformer_xl.py:705-748)
+            out.append(VQATaskInput(prompt_seq=T(t["prompt_seq"]), img_seq=T(t["img_seq"]), text_seq=T(t["text_seq"]), img_id_seq=None,
+                                    ques_id_seq=None, ques_len=T(t["ques_len"]), **base))
         else:
             out.append(ICTaskInput(prompt_seq=T(t["prompt_seq"]), img_seq=T(t["img_seq"]), text_seq=T(t["text_seq"]), img_id_seq=None, **base))
     return out
@@ -66,7 +69,7 @@ def rel_err(got, ref):
     return np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
 
 
-TRAIN_CASES = [n for n in CASES if n != "small_mems"]
+TRAIN_CASES = [n for n in CASES if n not in MEM_CASES]
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
@@ -146,19 +149,75 @@ def test_engine_three_adam_steps_match_oracle(adamw):
     assert float(model.arena.grad.abs().max()) == 0.0  # zeroed after the step
 
 
-def test_inference_with_memory_matches_reference_golden():
-    cfg, params, gold, model, oracle, seed = build("small_mems")
+@pytest.mark.parametrize("name", list(MEM_CASES))
+def test_inference_with_memory_matches_reference_golden(name):
+    cfg, params, gold, model, oracle, seed = build(name)
     from bdm_db1_amd.data import NLPTaskInput
     mems = model.init_mem(2)
     assert len(mems) == cfg["n_layer"] and tuple(mems[0].shape) == (2, cfg["mem_len"], cfg["n_embed"])
     with torch.no_grad():
-        for step in range(3):
+        for step in range(len(MEM_CASES[name])):
             ids = torch.from_numpy(gold[f"ids{step}"]).to(DEV)
             x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
             logits, loss, mems = model([x], compute_loss=False, mems=mems)
             assert loss is None
             assert rel_err(logits, gold[f"logits{step}"]) < 1e-4
             assert rel_err(mems[-1], gold[f"mem_last{step}"]) < 1e-4
+
+
+@pytest.mark.parametrize("edit_mems_in_place", [False, True])
+def test_bf16_kv_cached_decode_matches_reference_golden(edit_mems_in_place):
+    """The bf16 K/V-cached decode path (skinny projections, fused decode attention, cached keys / values; d_head = 128 like DB1-1.3B)
+    against the REFERENCE's own memory run (model_mems_d128.npz: calls of 6 / 1 / 1 / 9 / 1 tokens), not against another HIP path.
+    Stated tolerance: logits 3e-2 of max |logit|, memory 3e-2 (bf16 storage of activations and weights).
+    With ``edit_mems_in_place`` the caller touches the returned memory between calls (`mems[i] *= 1`: same values, same tensor
+    identity, new version counter): the cache must notice and rebuild itself from the hidden states instead of trusting identity."""
+    name = "mems_d128"
+    cfg, params, gold, model, oracle, seed = build(name, compute_dtype=torch.bfloat16)
+    from bdm_db1_amd.data import NLPTaskInput
+    assert model.d_head == 128 and model.use_decode
+    mems = model.init_mem(2)
+    rebuilt = 0
+    with torch.no_grad():
+        for step in range(len(MEM_CASES[name])):
+            ids = torch.from_numpy(gold[f"ids{step}"]).to(DEV)
+            x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
+            st_before = model._dec_state
+            logits, loss, mems = model([x], compute_loss=False, mems=mems)
+            assert model._dec_state is not None, "the fused decode path did not run"
+            if step > 0 and edit_mems_in_place:
+                assert st_before is not None and any(m._version != v for m, v in zip(st_before.mems, st_before.mem_versions))
+                rebuilt += 1
+            assert rel_err(logits, gold[f"logits{step}"]) < 3e-2, step
+            assert rel_err(mems[-1], gold[f"mem_last{step}"]) < 3e-2, step
+            if edit_mems_in_place:
+                for m in mems:
+                    m.mul_(1.0)
+    assert rebuilt == (len(MEM_CASES[name]) - 1 if edit_mems_in_place else 0)
+
+
+def test_mask_edge_cases_follow_the_reference():
+    """transformer_xl.py:177,205-206,551-567.  (a) `mem_len = 0` under same_length hides EVERY key: the reference does not raise, it
+    attends uniformly (the golden case small_memlen0 pins forward and backward; here: no exception, finite loss).  (b) a call whose
+    mask hides NOTHING raises ValueError in the reference: one query token without a full memory."""
+    from bdm_db1_amd.data import NLPTaskInput
+    cfg, params, gold, model, oracle, seed = build("small_memlen0")
+    tasks = make_batch("small_memlen0", cfg, seed)
+    logits, loss = model(to_inputs(tasks))
+    assert np.isfinite(float(loss)) and abs(float(loss) - float(gold["loss"])) < 2e-5 * abs(float(gold["loss"]))
+    cfg, params, gold, model, oracle, seed = build("small_window")
+    one = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=torch.ones(1, 1, device=DEV), label=torch.zeros(1, 1, dtype=torch.long, device=DEV),
+                       text_seq=torch.zeros(1, 1, dtype=torch.long, device=DEV), text_len=None)
+    with pytest.raises(ValueError):
+        model([one])
+    with pytest.raises(ValueError):
+        oracle.forward([O.TaskBatch(kind="nlp", text_seq=np.zeros((1, 1), np.int64), label=np.zeros((1, 1), np.int64), loss_mask=np.ones((1, 1), np.float32))])
+    # ... but with a full memory the same_length window hides key 0, and the call goes through (evaluate_rl's 1-token calls)
+    cfg, params, gold, model, oracle, seed = build("small_mems")
+    with torch.no_grad():
+        x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=torch.zeros(2, 1, dtype=torch.long, device=DEV), text_len=None)
+        logits, _, mems = model([x], compute_loss=False, mems=model.init_mem(2))
+    assert tuple(logits.shape) == (2, 1, model.total_vocab_size)
 
 
 def test_state_dict_names_match_reference():

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 from oracle import db1_oracle as O  # noqa: E402
-from golden_util import CASES, case_cfg, make_params, make_batch, sample_idx  # noqa: E402
+from golden_util import CASES, MEM_CASES, case_cfg, make_params, make_batch, sample_idx  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
 
@@ -33,7 +33,7 @@ def to_tasks(tasks):
     return [O.TaskBatch(**t) for t in tasks]
 
 
-TRAIN_CASES = [n for n in CASES if n != "small_mems"]
+TRAIN_CASES = [n for n in CASES if n not in MEM_CASES]
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
@@ -66,11 +66,12 @@ def test_model_forward_backward_matches_reference(name):
     assert checked >= 10
 
 
-def test_model_with_memory_matches_reference():
-    cfg, params, gold, model = build("small_mems", 100 + list(CASES).index("small_mems"))
+@pytest.mark.parametrize("name", list(MEM_CASES))
+def test_model_with_memory_matches_reference(name):
+    cfg, params, gold, model = build(name, 100 + list(CASES).index(name))
     B, ml, d = 2, cfg["mem_len"], cfg["n_embed"]
     mems = [np.zeros((B, ml, d)) for _ in range(cfg["n_layer"])]
-    for step in range(3):
+    for step in range(len(MEM_CASES[name])):
         ids = gold[f"ids{step}"]
         logits, loss, mems = model.forward([O.TaskBatch(kind="nlp", text_seq=ids)], compute_loss=False, mems=mems)
         assert loss is None
