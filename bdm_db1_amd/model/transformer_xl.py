@@ -976,8 +976,8 @@ class TransformerXL(nn.Module):
                                full=True).view(self.vocab_pad, d)
         T = B * L
         logits_pad = self._new(T, self.vocab_pad)
-        ops.gemm(x, Wout.t(), logits_pad)
         V = self.total_vocab_size
+        ops.gemm(x, Wout.t(), logits_pad, useful_flops=2.0 * T * V * d)   # (the padded vocabulary columns are not counted as work)
         lm_logits = logits_pad.view(B, L, self.vocab_pad)[:, :, :V]
         loss = None
         if compute_loss:
@@ -1024,9 +1024,9 @@ class TransformerXL(nn.Module):
         wname = "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight"
         Wout = self.arena.view(self.arena.work, wname, full=True).view(self.vocab_pad, d)
         gW = self.arena.view(self.arena.grad, wname, full=True).view(self.vocab_pad, d)
-        ops.gemm(dlogits.t(), ctx.hfin, gW, beta=1.0)
+        ops.gemm(dlogits.t(), ctx.hfin, gW, beta=1.0, useful_flops=2.0 * T * V * d)
         dh = self._new(T, d)
-        ops.gemm(dlogits, Wout, dh)
+        ops.gemm(dlogits, Wout, dh, useful_flops=2.0 * T * V * d)
         del dlogits
         for i in reversed(range(self.n_layer)):
             dh = (self._layer_bwd_prelnorm if self.pre_lnorm else self._layer_bwd)(i, dh, ctx.lcs[i], ctx.R_in, B, L, ctx.shift)

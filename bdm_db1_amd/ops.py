@@ -82,26 +82,27 @@ def _strides2(t: torch.Tensor):
 
 
 class KernelTimer:
-    """HIP-event timing of the bf16 tile-GEMM launches (bench.py's roofline leg): one event pair per launch,
-    recorded on the stream the kernel is launched on; nothing is synchronised until ``total()``."""
+    """HIP-event timing of individual launches for bench.py's roofline legs: one event pair per launch, recorded on the stream the
+    kernel is launched on; nothing is synchronised until ``summary()``.  ``work`` is the ALGORITHMIC work of the launch: FLOPs actually
+    executed for the MFMA-bound families ("gemm", "flash_fwd", "flash_bwd"), bytes for the HBM-bound kernels."""
 
     def __init__(self):
-        self.pairs = []
-        self.flops = 0.0
-        self.launches = 0
+        self.rec = {}   # family -> [event pairs, summed work, launches]
 
-    def wrap(self, flops: float, fn):
+    def wrap(self, family: str, work: float, fn):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        self.pairs.append((e0, e1))
-        self.flops += flops
-        self.launches += 1
+        r = self.rec.setdefault(family, [[], 0.0, 0])
+        r[0].append((e0, e1))
+        r[1] += work
+        r[2] += 1
 
-    def total_ms(self) -> float:
+    def summary(self):
+        """{family: (total ms, work, launches)}"""
         torch.cuda.synchronize()
-        return float(sum(a.elapsed_time(b) for a, b in self.pairs))
+        return {k: (float(sum(a.elapsed_time(b) for a, b in v[0])), v[1], v[2]) for k, v in self.rec.items()}
 
 
 _gemm_timer: Optional[KernelTimer] = None
@@ -112,14 +113,39 @@ def set_gemm_timer(t: Optional[KernelTimer]):
     _gemm_timer = t
 
 
+def _timed(family: str, work: float, run):
+    if _gemm_timer is not None:
+        _gemm_timer.wrap(family, work, run)
+    else:
+        run()
+
+
+def _tri_fraction(M: int, K: int, mode: int, period: int, tm: int = 256, tk: int = 64) -> float:
+    """share of the k-tiles a tile GEMM executes under a structural-zero hint for A (db1_gemm_strided_tri): a k-tile is skipped when
+    it is zero for EVERY row of the m-tile (mode 1: k > m; mode 2: (k mod period) < m)"""
+    if mode == 0:
+        return 1.0
+    done = total = 0
+    for m0 in range(0, M, tm):
+        m1 = min(m0 + tm, M) - 1
+        for k0 in range(0, K, tk):
+            total += 1
+            if mode == 1:
+                done += 0 if k0 > m1 else 1
+            else:
+                done += 0 if (k0 % period) + tk - 1 < m0 else 1
+    return done / max(total, 1)
+
+
 def _is_tile_gemm(M, N, K, a, b, out, sa, sb, so) -> bool:
     return bool(lib.load().db1_gemm_would_use_fast(M, N, K, dt_code(a), dt_code(b), dt_code(out), sa[0], sa[1], sb[0], sb[1], so[0], so[1]))
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias: Optional[torch.Tensor] = None,
-         alpha: float = 1.0, beta: float = 0.0):
+         alpha: float = 1.0, beta: float = 0.0, useful_flops: Optional[float] = None):
     """out[m,n] = alpha * a[m,k] @ b[k,n] + beta*out + bias[n]; a, b, out are 2-D VIEWS with any strides
-    (pass ``w.t()`` for y = x W^T).  Optional leading batch dims are not handled here (see gemm_batched)."""
+    (pass ``w.t()`` for y = x W^T).  Optional leading batch dims are not handled here (see gemm_batched).
+    ``useful_flops``: what the timer counts when part of the product is padding (the vocabulary pad of the tied head)."""
     M, K = a.shape
     K2, N = b.shape
     assert K == K2 and out.shape == (M, N), (a.shape, b.shape, out.shape)
@@ -132,7 +158,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, bias: Optional[tor
                  out.stride(0), out.stride(1), 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, ws, wsn, stream())
 
     if _gemm_timer is not None and _is_tile_gemm(M, N, K, a, b, out, a.stride(), b.stride(), out.stride()):
-        _gemm_timer.wrap(2.0 * M * N * K, run)
+        _gemm_timer.wrap("gemm", 2.0 * M * N * K if useful_flops is None else useful_flops, run)
     else:
         run()
     return out
@@ -153,10 +179,7 @@ def gemm_nt_headbias(x, w, out, qu, qv, bias_u, bias_v, split_n):
         lib.call("db1_gemm_nt_headbias", P(x), P(w), P(out), P(qu), P(qv), P(bias_u), P(bias_v), M, N, K, split_n, x.stride(0), w.stride(0),
                  out.stride(0), split_n, stream())
 
-    if _gemm_timer is not None:
-        _gemm_timer.wrap(2.0 * M * N * K, run)
-    else:
-        run()
+    _timed("gemm", 2.0 * M * N * K, run)
 
 
 def gemm_batched(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, beta: float = 0.0, tri=(0, 0)):
@@ -174,9 +197,10 @@ def gemm_batched(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: flo
                  a.stride(0), a.stride(1), b.stride(0), b.stride(1), out.stride(0), out.stride(1), alpha, beta, int(tri[0]), int(tri[1]),
                  ws, wsn, stream())
 
-    # the batched contractions of the attention backward (dq_r, dR) run on the same tile kernels: timed with the dense 2MNK they execute
+    # the batched contractions of the attention backward (dq_r, dR) run on the same tile kernels: timed with the FLOPs they execute
+    # (k-tiles skipped under the structural-zero hint are not counted)
     if _gemm_timer is not None and _is_tile_gemm(M, N, K, a, b, out, a.stride()[2:], b.stride()[2:], out.stride()[2:]):
-        _gemm_timer.wrap(2.0 * M * N * K * Z0 * Z1, run)
+        _gemm_timer.wrap("gemm", 2.0 * M * N * K * Z0 * Z1 * _tri_fraction(M, K, int(tri[0]), int(tri[1])), run)
     else:
         run()
     return out
@@ -192,25 +216,31 @@ def relattn_dqr(dT, R, dqv):
     D = dqv.shape[-1]
     assert dT.is_contiguous() and R.stride(1) == 1 and dqv.stride(3) == 1 and dqv.stride(2) == D
     ws, wsn = _ws("db1_relattn_dqr_workspace_bytes", (L, H), dT.device)
-    lib.call("db1_relattn_dqr", P(dT), P(R), R.stride(0), P(dqv), dqv.stride(1), dqv.stride(0), B, L, H, D, ws, wsn, stream())
+    # algorithmic bytes: the causal half of dT read once + the output written
+    _timed("relattn_dqr", 2.0 * (H * B * L * (L + 1) / 2 + dqv.numel()),
+           lambda: lib.call("db1_relattn_dqr", P(dT), P(R), R.stride(0), P(dqv), dqv.stride(1), dqv.stride(0), B, L, H, D, ws, wsn, stream()))
 
 
 def layernorm_residual_fwd(x, r, alpha, gamma, beta, y, s_out, mean, rstd, eps):
     rows, d = x.numel() // x.shape[-1], x.shape[-1]
-    lib.call("db1_layernorm_residual_fwd", P(x), P(r), float(alpha), P(gamma), P(beta), P(y), P(s_out), P(mean), P(rstd),
-             rows, d, float(eps), dt_code(x), dt_code(gamma), stream())
+    nstreams = 2 + (r is not None) + (s_out is not None)   # x [, r] in; y [, s] out
+    _timed("layernorm_fwd", float(rows * d * x.element_size() * nstreams),
+           lambda: lib.call("db1_layernorm_residual_fwd", P(x), P(r), float(alpha), P(gamma), P(beta), P(y), P(s_out), P(mean), P(rstd),
+                            rows, d, float(eps), dt_code(x), dt_code(gamma), stream()))
 
 
 def layernorm_residual_bwd(dy, s, gamma, mean, rstd, ds, dgamma_acc, dbeta_acc):
     rows, d = dy.numel() // dy.shape[-1], dy.shape[-1]
     ws, wsn = _ws("db1_layernorm_residual_bwd_workspace_bytes", (rows, d, dt_code(dy)), dy.device)
-    lib.call("db1_layernorm_residual_bwd", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dgamma_acc), P(dbeta_acc),
-             rows, d, dt_code(dy), dt_code(gamma), ws, wsn, stream())
+    _timed("layernorm_bwd", float(rows * d * dy.element_size() * 3),   # dy, s in; ds out
+           lambda: lib.call("db1_layernorm_residual_bwd", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dgamma_acc), P(dbeta_acc),
+                            rows, d, dt_code(dy), dt_code(gamma), ws, wsn, stream()))
 
 
 def ffn_act_fwd(z, out, act: str):
     rows, n = out.numel() // out.shape[-1], out.shape[-1]
-    lib.call("db1_ffn_act_fwd", P(z), P(out), rows, n, ACT_CODES[act], dt_code(z), stream())
+    _timed("ffn_act_fwd", float((z.numel() + out.numel()) * z.element_size()),
+           lambda: lib.call("db1_ffn_act_fwd", P(z), P(out), rows, n, ACT_CODES[act], dt_code(z), stream()))
 
 
 def ffn_act_bwd(z, dout, dz, act: str):
@@ -223,7 +253,8 @@ def ffn_act_bwd_bias(z, dout, dz, dbias_acc, act: str):
     rows, n = dout.numel() // dout.shape[-1], dout.shape[-1]
     assert dbias_acc.dtype == torch.float32 and dbias_acc.numel() == dz.shape[-1]
     ws, wsn = _ws("db1_ffn_act_bwd_bias_workspace_bytes", (rows, n, ACT_CODES[act]), z.device)
-    lib.call("db1_ffn_act_bwd_bias", P(z), P(dout), P(dz), P(dbias_acc), rows, n, ACT_CODES[act], dt_code(z), ws, wsn, stream())
+    _timed("ffn_act_bwd", float((z.numel() + dout.numel() + dz.numel()) * z.element_size()),
+           lambda: lib.call("db1_ffn_act_bwd_bias", P(z), P(dout), P(dz), P(dbias_acc), rows, n, ACT_CODES[act], dt_code(z), ws, wsn, stream()))
 
 
 def colsum_acc(x2d, out_acc):
@@ -251,8 +282,9 @@ def add2d_colsums(a2d, b2d, y2d, sum_a_acc, sum_b_acc):
     assert a2d.stride(1) == 1 and b2d.stride(1) == 1 and y2d.stride(1) == 1 and a2d.dtype == y2d.dtype == b2d.dtype
     assert sum_a_acc.dtype == torch.float32 and sum_b_acc.dtype == torch.float32
     ws, wsn = _ws("db1_add2d_colsums_workspace_bytes", (rows, cols), y2d.device)
-    lib.call("db1_add2d_colsums", P(a2d), a2d.stride(0), P(b2d), b2d.stride(0), P(y2d), y2d.stride(0), P(sum_a_acc), P(sum_b_acc),
-             rows, cols, dt_code(y2d), ws, wsn, stream())
+    _timed("add2d_colsums", float(3 * rows * cols * y2d.element_size()),
+           lambda: lib.call("db1_add2d_colsums", P(a2d), a2d.stride(0), P(b2d), b2d.stride(0), P(y2d), y2d.stride(0), P(sum_a_acc), P(sum_b_acc),
+                            rows, cols, dt_code(y2d), ws, wsn, stream()))
 
 
 def cast(x, y):
@@ -288,14 +320,16 @@ def rl_assemble_bwd(dout, ids, position_id, dword_acc, dpos_acc, dvis):
 def masked_ce_fwd(logits2d, labels, mask, lse, sums, V):
     T, ld = logits2d.shape[0], logits2d.stride(0)
     ws, wsn = _ws("db1_masked_ce_fwd_workspace_bytes", (T,), logits2d.device)
-    lib.call("db1_masked_ce_fwd", P(logits2d), P(labels), P(mask), P(lse), P(sums), T, V, ld, dt_code(logits2d), ws, wsn, stream())
+    _timed("masked_ce_fwd", float(T * V * logits2d.element_size()),
+           lambda: lib.call("db1_masked_ce_fwd", P(logits2d), P(labels), P(mask), P(lse), P(sums), T, V, ld, dt_code(logits2d), ws, wsn, stream()))
 
 
 def masked_ce_bwd(logits2d, labels, mask, lse, sums, dlogits2d, V, gscale=1.0):
     T, ld = logits2d.shape[0], logits2d.stride(0)
     assert dlogits2d.stride(0) == ld
-    lib.call("db1_masked_ce_bwd", P(logits2d), P(labels), P(mask), P(lse), P(sums), P(dlogits2d), T, V, ld, float(gscale),
-             dt_code(logits2d), stream())
+    _timed("masked_ce_bwd", float(2 * T * V * logits2d.element_size()),
+           lambda: lib.call("db1_masked_ce_bwd", P(logits2d), P(labels), P(mask), P(lse), P(sums), P(dlogits2d), T, V, ld, float(gscale),
+                            dt_code(logits2d), stream()))
 
 
 def relattn_add_head_bias(qkv, u, vb, qu, qv, B, Lq, Lk, H, D):
@@ -329,15 +363,19 @@ def relattn_flash_supported(B, L, H, D, dtype) -> bool:
 def relattn_flash_fwd(qu, qv, qkv5, R, out, lse, B, L, H, D, shift, scale):
     """qkv5: the packed activations viewed [B, L, 3, H, D]; k / v are addressed inside it by stride."""
     k, v = qkv5[:, :, 1], qkv5[:, :, 2]
-    lib.call("db1_relattn_flash_fwd", P(qu), P(qv), P(k), P(v), k.stride(1), k.stride(0), P(R), P(out), P(lse),
-             B, L, H, D, shift, float(scale), stream())
+    vis = L * (L + 1) / 2 if shift >= L else (shift * (shift + 1) / 2 + (L - shift) * shift)   # visible (query, key) pairs
+    _timed("flash_fwd", 3 * 2.0 * B * H * vis * D,   # (q+u).k, (q+v).R, P.v over the visible pairs (SURVEY 8d)
+           lambda: lib.call("db1_relattn_flash_fwd", P(qu), P(qv), P(k), P(v), k.stride(1), k.stride(0), P(R), P(out), P(lse),
+                            B, L, H, D, shift, float(scale), stream()))
 
 
 def relattn_flash_bwd(qu, qv, qkv5, R, out, dout, lse, delta, dqkv5, dT, B, L, H, D, shift, scale):
     k, v = qkv5[:, :, 1], qkv5[:, :, 2]
     dq, dk, dv = dqkv5[:, :, 0], dqkv5[:, :, 1], dqkv5[:, :, 2]
-    lib.call("db1_relattn_flash_bwd", P(qu), P(qv), P(k), P(v), k.stride(1), k.stride(0), P(R), P(out), P(dout), P(lse), P(delta),
-             P(dq), P(dk), P(dv), dq.stride(1), dq.stride(0), P(dT), B, L, H, D, shift, float(scale), stream())
+    vis = L * (L + 1) / 2 if shift >= L else (shift * (shift + 1) / 2 + (L - shift) * shift)
+    _timed("flash_bwd", 6 * 2.0 * B * H * vis * D,   # twice the forward's algorithmic work (bwd_q + bwd_kv; dq_r / dR run as separate kernels)
+           lambda: lib.call("db1_relattn_flash_bwd", P(qu), P(qv), P(k), P(v), k.stride(1), k.stride(0), P(R), P(out), P(dout), P(lse), P(delta),
+                            P(dq), P(dk), P(dv), dq.stride(1), dq.stride(0), P(dT), B, L, H, D, shift, float(scale), stream()))
 
 
 def patch_normalize(pixels, patches, p):
@@ -419,13 +457,15 @@ def groupnorm_gelu_nhwc_bwd(dy, x, gamma, beta, mean, rstd, dx, dgamma_acc, dbet
 
 
 def sumsq_acc(x, acc):
-    lib.call("db1_sumsq_acc", P(x), P(acc), x.numel(), dt_code(x), stream())
+    _timed("sumsq", float(x.numel() * x.element_size()), lambda: lib.call("db1_sumsq_acc", P(x), P(acc), x.numel(), dt_code(x), stream()))
 
 
 def adam_step(p32, g, m, v, p_work, lr, beta1, beta2, eps, wd, adamw, step, gscale=1.0, clip=0.0, norm_sq=None):
-    lib.call("db1_adam_step", P(p32), P(g), P(m), P(v), P(p_work), p32.numel(), float(lr), float(beta1), float(beta2), float(eps),
-             float(wd), int(bool(adamw)), int(step), float(gscale), float(clip), P(norm_sq), dt_code(g),
-             dt_code(p_work) if p_work is not None else 0, stream())
+    # p, m, v read + written (24 B), g read, bf16 working copy written
+    _timed("adam", float(p32.numel() * (24 + g.element_size() + (2 if p_work is not None else 0))),
+           lambda: lib.call("db1_adam_step", P(p32), P(g), P(m), P(v), P(p_work), p32.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                            float(wd), int(bool(adamw)), int(step), float(gscale), float(clip), P(norm_sq), dt_code(g),
+                            dt_code(p_work) if p_work is not None else 0, stream()))
 
 
 def mulaw_discretize(x, ids, is_action, num_bins=1024, mu=100.0, M=256.0):

@@ -517,7 +517,8 @@ def test_out_of_table_ids_and_labels_touch_nothing(ops):
     ops.rl_assemble_fwd(dev(word), dev(post), None, torch.from_numpy(rid).to(DEV), torch.from_numpy(pos).to(DEV), None, o)
     ref = np.where((rid < V)[..., None], word[np.minimum(rid, V - 1)], 0.0) + np.where(((pos >= 0) & (pos < 513))[..., None], post[np.clip(pos, 0, 512)], 0.0)
     close(o, ref, 1e-6, name="rl oob")
-    # masked CE: labels -100 / V are skipped like mask = 0
+    # masked CE: labels -100 / V add no loss and get no gradient; the normaliser stays sum(mask), as in the reference, where
+    # CrossEntropyLoss(reduction="none") returns 0 for an ignored label and the loss is (loss * mask).sum() / mask.sum()
     T, ld = 6, 24
     logits = rng.standard_normal((T, ld)).astype(np.float32)
     lab = np.array([1, -100, V - 1, V, 0, 3], np.int64)
@@ -528,7 +529,7 @@ def test_out_of_table_ids_and_labels_touch_nothing(ops):
     lz = logits[:, :V].astype(np.float64)
     ref_lse = np.log(np.exp(lz - lz.max(1, keepdims=True)).sum(1)) + lz.max(1)
     nll = np.where(good, ref_lse - lz[np.arange(T), np.where(good, lab, 0)], 0.0)
-    assert abs(float(sums[0]) - nll.sum()) < 1e-4 and float(sums[1]) == good.sum()
+    assert abs(float(sums[0]) - nll.sum()) < 1e-4 and float(sums[1]) == T
     dl = torch.empty(T, ld, device=DEV)
     ops.masked_ce_bwd(dev(logits), torch.from_numpy(lab).to(DEV), dev(msk), lse, sums, dl, V)
     assert float(dl[~torch.from_numpy(good).to(DEV)].abs().max()) == 0.0 and float(dl[0].abs().max()) > 0

@@ -1,9 +1,22 @@
-# Round evidence on the GPU box: default bench line, kernel-trace stats, PMC traffic.  Outputs under gpurun_out/evidence/.
+# Round evidence on the GPU box: bench lines for every workload, kernel-trace stats, decode timing, the 2-rank gloo record.
+#   TAG=r02a bash tools/evidence.sh [pmc]        outputs under gpurun_out/evidence_$TAG/ (copy what is to be judged into profiles/)
 R=$GRAFT_REPO_ROOT
-E=$R/gpurun_out/evidence
+TAG=${TAG:-r02}
+E=$R/gpurun_out/evidence_$TAG
 mkdir -p $E
 cd $R
-timeout 900 python bench.py > $E/bench_default.json 2> $E/bench_default.err </dev/null
-bash tools/prof_step.sh; cp gpurun_out/step_stats.csv $E/kernel_stats_short.csv; cp $(ls gpurun_out/prof_step/*kernel_stats.csv | head -1) $E/kernel_stats.csv
-timeout 1500 python tools/pmc_traffic.py $E/traffic > $E/traffic.log 2>&1 </dev/null
-cp $E/traffic/hbm_traffic_pmc.json $E/ 2>/dev/null
+timeout 900 python bench.py > $E/${TAG}_bench_default.json 2> $E/bench_default.err </dev/null
+for w in caption rl mixture; do
+  timeout 600 python bench.py --workload $w --no-cpu-baseline > $E/${TAG}_bench_${w}.json 2> $E/bench_$w.err </dev/null
+done
+timeout 600 python tools/bench_decode.py > $E/${TAG}_decode.txt 2> $E/decode.err </dev/null
+# the multi-rank path on this 1-GPU box: two ranks share the GPU, gloo instead of RCCL (which refuses two ranks on one device)
+DB1_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --batch 16 --steps 3 --warmup 1 > $E/${TAG}_bench_gloo_2ranks_b16.json 2> $E/bench_gloo.err </dev/null
+BENCH_ARGS="--no-cpu-baseline" bash tools/prof_step.sh
+cp gpurun_out/step_stats.csv $E/${TAG}_kernel_stats_short.csv
+cp $(ls gpurun_out/prof_step/*kernel_stats.csv | head -1) $E/${TAG}_bench_b64_kernel_stats.csv
+if [ "$1" = "pmc" ]; then
+  timeout 1500 python tools/pmc_traffic.py $E/traffic > $E/traffic.log 2>&1 </dev/null
+  cp $E/traffic/hbm_traffic_pmc.json $E/${TAG}_hbm_traffic_pmc.json 2>/dev/null
+fi
+tail -c 1500 $E/${TAG}_bench_default.json
