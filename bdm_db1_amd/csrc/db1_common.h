@@ -152,6 +152,50 @@ template <typename T> __device__ __forceinline__ void gelu_both_t(float x, float
     dy = fmaf(x * 0.39894228040143267794f, e, phi);
 }
 
+// ---- dropout (transformer_xl.py:229,262-269,409,545,575): counter-based, no mask tensors.  The keep decision of element e of a tensor is a
+// pure function of (seed, step, site, e): Philox4x32-10 on the counter (e / 8 [64 bit], site, step) under the key (seed), whose 128
+// output bits are eight 16-bit uniforms u; element e keeps its value (scaled by 65536 / (65536 - thr)) iff u[e % 8] >= thr, with
+// thr = round(p * 65536) -- so E[output] = input exactly.  The backward regenerates the same decisions.  site = which tensor of the
+// step (layer * 4 + {0: attention output, 1: feed-forward output}, 0xE0000000: embeddings, 0xE0000001: position table), step = the
+// engine's micro-step counter.  oracle/db1_oracle.py holds the same function in NumPy, which is how parity at p > 0 is checked.
+struct Db1Drop {
+    unsigned thr;   // 0 = dropout off
+    float scale;
+    unsigned k0, k1, site, step;
+};
+static inline Db1Drop db1_drop_make(float p, uint64_t seed, uint32_t site, uint32_t step) {
+    Db1Drop d;
+    long t = p > 0.f ? lrintf(p * 65536.f) : 0;
+    d.thr = (unsigned)(t < 0 ? 0 : (t > 65535 ? 65535 : t));
+    d.scale = 65536.f / (float)(65536 - (long)d.thr);
+    d.k0 = (unsigned)(seed & 0xffffffffu); d.k1 = (unsigned)(seed >> 32); d.site = site; d.step = step;
+    return d;
+}
+__device__ __forceinline__ void db1_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned o[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+// multiplies the V consecutive elements starting at element index e0 (a multiple of V; V = 4 or 8) by their keep-scales
+template <int V>
+__device__ __forceinline__ void db1_drop_apply(const Db1Drop& dr, int64_t e0, float* v) {
+    unsigned o[4];
+    const unsigned long long blk = (unsigned long long)e0 >> 3;
+    db1_philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), dr.site, dr.step, dr.k0, dr.k1, o);
+    const int w0 = V == 8 ? 0 : (int)((e0 >> 2) & 1) * 2;
+#pragma unroll
+    for (int j = 0; j < V; j += 2) {
+        const unsigned w = o[w0 + (j >> 1)];
+        v[j] *= (w & 0xffffu) >= dr.thr ? dr.scale : 0.f;
+        v[j + 1] *= (w >> 16) >= dr.thr ? dr.scale : 0.f;
+    }
+}
+
 // dtype dispatch helpers (host)
 #define DB1_DISPATCH_DT(dt, T, ...)                          \
     do {                                                     \

@@ -12,7 +12,7 @@ template <typename T, typename TP>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ r, float alpha,
                                                      const TP* __restrict__ gamma, const TP* __restrict__ beta,
                                                      T* __restrict__ y, T* s_out, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int64_t rows, int d, float eps) {
+                                                     float* __restrict__ rstd, int64_t rows, int d, float eps, Db1Drop drp) {
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         if (rr) {
             Vec16<T> b;
             b.load(rr + i);
+            if (drp.thr) db1_drop_apply<V>(drp, row * d + i, b.v);   // dropout on the sub-layer output, before the residual sum
 #pragma unroll
             for (int j = 0; j < V; j++) a.v[j] = alpha * a.v[j] + b.v[j];
         } else {
@@ -68,7 +69,7 @@ template <typename T, typename TP>
 __global__ __launch_bounds__(256) void ln_bwd_ds_kernel(const T* __restrict__ dy, const T* __restrict__ s,
                                                         const TP* __restrict__ gamma, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, T* __restrict__ ds,
-                                                        int64_t rows, int d) {
+                                                        int64_t rows, int d, T* __restrict__ dr_out, Db1Drop drp) {
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -102,6 +103,10 @@ __global__ __launch_bounds__(256) void ln_bwd_ds_kernel(const T* __restrict__ dy
             o.v[j] = rs * (g - c1 - xh * c2);
         }
         o.store(dsr + i);
+        if (dr_out) {   // gradient of the dropped sub-layer output: the same keep decisions as the forward
+            if (drp.thr) db1_drop_apply<V>(drp, row * d + i, o.v);
+            o.store(dr_out + row * d + i);
+        }
     }
 }
 
@@ -133,7 +138,7 @@ template <typename T, typename TP, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const T* __restrict__ x, const T* __restrict__ r, float alpha,
                                                          const TP* __restrict__ gamma, const TP* __restrict__ beta,
                                                          T* __restrict__ y, T* s_out, float* __restrict__ mean,
-                                                         float* __restrict__ rstd, int64_t rows, int d, float eps) {
+                                                         float* __restrict__ rstd, int64_t rows, int d, float eps, Db1Drop drp) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const T* __restrict__ x
         for (int k = 0; k < NV; k++) {
             Vec16<T> b;
             b.load(r + row * d + (k * 64 + lane) * V);
+            if (drp.thr) db1_drop_apply<V>(drp, row * d + (k * 64 + lane) * V, b.v);   // dropout on the sub-layer output (:229, :269)
 #pragma unroll
             for (int j = 0; j < V; j++) a[k].v[j] = alpha * a[k].v[j] + b.v[j];
         }
@@ -185,7 +191,8 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const T* __restrict__ x
 template <typename T, typename TP, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ s, const TP* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ ds,
-                                                           float* __restrict__ part, int64_t rows, int d, int rows_per_block) {
+                                                           float* __restrict__ part, int64_t rows, int d, int rows_per_block,
+                                                           T* __restrict__ dr_out, Db1Drop drp) {
     constexpr int V = Vec16<T>::N;
     __shared__ float red[2 * 64 * V * NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -221,6 +228,10 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const T* __restrict__
 #pragma unroll
             for (int j = 0; j < V; j++) o.v[j] = rs * (a[k].v[j] * gam[k][j] - c1 - b[k].v[j] * c2);
             o.store(ds + row * d + (k * 64 + lane) * V);
+            if (dr_out) {   // gradient of the dropped sub-layer output: ds under the forward's keep decisions (regenerated, not stored)
+                if (drp.thr) db1_drop_apply<V>(drp, row * d + (k * 64 + lane) * V, o.v);
+                o.store(dr_out + row * d + (k * 64 + lane) * V);
+            }
         }
     }
     if (!part) return;
@@ -268,7 +279,11 @@ template <typename T> static int ln_reg_nv(int d) {  // NV such that d == 64 * V
 
 extern "C" int db1_layernorm_residual_fwd(const void* x, const void* r, float alpha, const void* gamma, const void* beta,
                                           void* y, void* s_out, float* mean, float* rstd, int64_t rows, int d, float eps,
+                                          float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step,
                                           int dt, int dtParam, void* stream) {
+    if (drop_p < 0.f || drop_p >= 1.f) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm fwd: dropout p=%g", (double)drop_p);
+    if (drop_p > 0.f && !r) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm fwd: dropout applies to the residual input r, which is NULL");
+    const Db1Drop drp = db1_drop_make(drop_p, drop_seed, drop_site, drop_step);
     if (!db1_dt_ok(dt) || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "layernorm fwd: dtype");
     const int V = dt == DB1_F32 ? 4 : 8;
     if (rows <= 0 || d <= 0 || d % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm fwd: d=%d must be a multiple of %d", d, V);
@@ -278,7 +293,7 @@ extern "C" int db1_layernorm_residual_fwd(const void* x, const void* r, float al
     hipStream_t st = (hipStream_t)stream;
     if (dt == DB1_BF16 && ln_reg_nv<bf16_t>(d)) {  // register-resident one-pass kernel
         const int nv = ln_reg_nv<bf16_t>(d);
-#define LN_FWD_REG(TP, NV) ln_fwd_reg_kernel<bf16_t, TP, NV><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)r, alpha, (const TP*)gamma, (const TP*)beta, (bf16_t*)y, (bf16_t*)s_out, mean, rstd, rows, d, eps)
+#define LN_FWD_REG(TP, NV) ln_fwd_reg_kernel<bf16_t, TP, NV><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)r, alpha, (const TP*)gamma, (const TP*)beta, (bf16_t*)y, (bf16_t*)s_out, mean, rstd, rows, d, eps, drp)
 #define LN_FWD_NV(TP) do { if (nv == 1) LN_FWD_REG(TP, 1); else if (nv == 2) LN_FWD_REG(TP, 2); else LN_FWD_REG(TP, 4); } while (0)
         if (dtParam == DB1_BF16) LN_FWD_NV(bf16_t); else LN_FWD_NV(float);
 #undef LN_FWD_NV
@@ -286,7 +301,7 @@ extern "C" int db1_layernorm_residual_fwd(const void* x, const void* r, float al
         DB1_CHECK_LAUNCH("layernorm fwd (registers)");
         return DB1_OK;
     }
-#define LN_FWD(T, TP) ln_fwd_kernel<T, TP><<<grid, 256, 0, st>>>((const T*)x, (const T*)r, alpha, (const TP*)gamma, (const TP*)beta, (T*)y, (T*)s_out, mean, rstd, rows, d, eps)
+#define LN_FWD(T, TP) ln_fwd_kernel<T, TP><<<grid, 256, 0, st>>>((const T*)x, (const T*)r, alpha, (const TP*)gamma, (const TP*)beta, (T*)y, (T*)s_out, mean, rstd, rows, d, eps, drp)
     if (dt == DB1_F32 && dtParam == DB1_F32) LN_FWD(float, float);
     else if (dt == DB1_BF16 && dtParam == DB1_BF16) LN_FWD(bf16_t, bf16_t);
     else if (dt == DB1_BF16 && dtParam == DB1_F32) LN_FWD(bf16_t, float);
@@ -302,8 +317,12 @@ extern "C" int64_t db1_layernorm_residual_bwd_workspace_bytes(int64_t rows, int 
     return ((rows + LN_BWD_RPB - 1) / LN_BWD_RPB) * 2 * (int64_t)d * (int64_t)sizeof(float);
 }
 extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
-                                          void* ds, float* dgamma_acc, float* dbeta_acc, int64_t rows, int d, int dt,
+                                          void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc, int64_t rows, int d,
+                                          float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, int dt,
                                           int dtParam, void* ws_, int64_t ws_bytes, void* stream) {
+    if (drop_p < 0.f || drop_p >= 1.f) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd: dropout p=%g", (double)drop_p);
+    if (dr_out && !db1_aligned16(dr_out)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "layernorm bwd: dr_out alignment");
+    const Db1Drop drp = db1_drop_make(drop_p, drop_seed, drop_site, drop_step);
     if (!db1_dt_ok(dt) || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "layernorm bwd: dtype");
     const int V = dt == DB1_F32 ? 4 : 8;
     if (rows <= 0 || d <= 0 || d % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd: d=%d must be a multiple of %d", d, V);
@@ -318,7 +337,7 @@ extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const v
             DB1_NEED_WS(ws_, ws_bytes, db1_layernorm_residual_bwd_workspace_bytes(rows, d, dt), "layernorm bwd");
             ws = (float*)ws_;
         }
-#define LN_BWD_F(TP, NV) ln_bwd_fused_kernel<bf16_t, TP, NV><<<nblocks, 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)s, (const TP*)gamma, mean, rstd, (bf16_t*)ds, ws, rows, d, rpb)
+#define LN_BWD_F(TP, NV) ln_bwd_fused_kernel<bf16_t, TP, NV><<<nblocks, 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)s, (const TP*)gamma, mean, rstd, (bf16_t*)ds, ws, rows, d, rpb, (bf16_t*)dr_out, drp)
 #define LN_BWD_NV(TP) do { if (nv == 1) LN_BWD_F(TP, 1); else if (nv == 2) LN_BWD_F(TP, 2); else LN_BWD_F(TP, 4); } while (0)
         if (dtParam == DB1_BF16) LN_BWD_NV(bf16_t); else LN_BWD_NV(float);
 #undef LN_BWD_NV
@@ -331,7 +350,7 @@ extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const v
         return DB1_OK;
     }
     dim3 grid((unsigned)((rows + 3) / 4));
-#define LN_BWD(T, TP) ln_bwd_ds_kernel<T, TP><<<grid, 256, 0, st>>>((const T*)dy, (const T*)s, (const TP*)gamma, mean, rstd, (T*)ds, rows, d)
+#define LN_BWD(T, TP) ln_bwd_ds_kernel<T, TP><<<grid, 256, 0, st>>>((const T*)dy, (const T*)s, (const TP*)gamma, mean, rstd, (T*)ds, rows, d, (T*)dr_out, drp)
     if (dt == DB1_F32 && dtParam == DB1_F32) LN_BWD(float, float);
     else if (dt == DB1_BF16 && dtParam == DB1_BF16) LN_BWD(bf16_t, bf16_t);
     else if (dt == DB1_BF16 && dtParam == DB1_F32) LN_BWD(bf16_t, float);
@@ -795,6 +814,31 @@ extern "C" int db1_add2d_colsums(const void* a, int64_t lda, const void* b, int6
     colsum_part_reduce_strided_kernel<<<(cols + 63) / 64, 64 * CSR_WAVES, 0, st>>>(ws, sum_a_acc, nchunks, cols, 2 * cols);
     colsum_part_reduce_strided_kernel<<<(cols + 63) / 64, 64 * CSR_WAVES, 0, st>>>(ws + cols, sum_b_acc, nchunks, cols, 2 * cols);
     DB1_CHECK_LAUNCH("add2d_colsums reduce");
+    return DB1_OK;
+}
+
+// y = dropout(x) (y may alias x): the sites that are not fused into a neighbouring kernel -- the embeddings and the position table
+// (transformer_xl.py:545,575; one pass over B x L x d per step) and the pre-LN residual branches
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, Db1Drop drp) {
+    constexpr int V = Vec16<T>::N;
+    const int64_t nv = n / V;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        Vec16<T> a;
+        a.load(x + i * V);
+        db1_drop_apply<V>(drp, i * V, a.v);
+        a.store(y + i * V);
+    }
+}
+extern "C" int db1_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint32_t site, uint32_t step, int dt, void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "dropout: dtype");
+    const int V = dt == DB1_F32 ? 4 : 8;
+    if (n <= 0 || (n % 8)) DB1_FAIL(DB1_ERR_BAD_SHAPE, "dropout: n=%lld must be a positive multiple of 8 (one Philox block)", (long long)n);
+    if (p < 0.f || p >= 1.f) DB1_FAIL(DB1_ERR_BAD_SHAPE, "dropout: p=%g", (double)p);
+    if (!db1_aligned16(x) || !db1_aligned16(y)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "dropout: alignment");
+    const Db1Drop drp = db1_drop_make(p, seed, site, step);
+    DB1_DISPATCH_DT(dt, T, (dropout_kernel<T><<<grid_for(n / V), 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)y, n, drp)));
+    DB1_CHECK_LAUNCH("dropout");
     return DB1_OK;
 }
 

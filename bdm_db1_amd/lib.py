@@ -19,6 +19,7 @@ ACT_CODES = {"geglu": 0, "gelu": 1, "relu": 2}
 
 _CTYPES = {
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32,
+    "uint64_t": ctypes.c_uint64, "uint32_t": ctypes.c_uint32,
     "void": None,
 }
 

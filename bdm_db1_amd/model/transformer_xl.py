@@ -125,9 +125,16 @@ class TransformerXL(nn.Module):
         self.use_deepnorm = bool(g("use_deepnorm", False))
         self.deepnorm_alpha = (2 * self.n_layer) ** 0.25 if self.use_deepnorm else None
         self.deepnorm_beta = (8 * self.n_layer) ** -0.25 if self.use_deepnorm else None
-        for pname in ("embd_pdrop", "drop", "dropattn"):
-            if float(g(pname, 0.0) or 0.0) != 0.0:
-                raise NotImplementedError(f"{pname} != 0: dropout is not part of the HIP hot path (parity and benchmarks run with p = 0)")
+        # dropout (training mode only): embeddings + position table (embd_pdrop, :409,545,575), attention and feed-forward outputs
+        # (drop, :229,262-269).  Keep decisions are counter-based (Philox on (seed, step, site, element); db1_dropout in the header),
+        # regenerated in the backward: no mask tensors.  The reference's released configuration has dropattn = 0 (config.py:167).
+        self.embd_pdrop = float(g("embd_pdrop", 0.0) or 0.0)
+        self.drop_p = float(g("drop", 0.0) or 0.0)
+        if float(g("dropattn", 0.0) or 0.0) != 0.0:
+            raise NotImplementedError("dropattn != 0: attention-probability dropout is not implemented (the reference trains with dropattn = 0)")
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        self.dropout_seed = ((torch.initial_seed() * 0x9E3779B97F4A7C15) + rank) & 0xFFFFFFFFFFFFFFFF   # every data-parallel rank draws its own masks
+        self._drop_step = 0                # bumped by every training forward: a new mask per micro-step
         self.patch_size = int(g("vision_patch_size", 16))
         self.vision_channels = int(g("vision_num_input_channels", 3))
         self.vision_position_vocab_size = int(g("vision_position_vocab_size", 128))
@@ -272,6 +279,12 @@ class TransformerXL(nn.Module):
         return self.dev
 
     # ------------------------------------------------------------------ helpers
+    SITE_EMBED, SITE_POS = 0xE0000000, 0xE0000001
+
+    def _drop_args(self, p: float, site: int, step: Optional[int]):
+        """(p, seed, site, step) of one dropout site, or ops.NO_DROP outside training / at p = 0"""
+        return (p, self.dropout_seed, site, step) if (step is not None and p > 0.0) else ops.NO_DROP
+
     def _new(self, *shape, dtype=None):
         return torch.empty(*shape, device=self.dev, dtype=self.compute_dtype if dtype is None else dtype)
 
@@ -767,7 +780,7 @@ class TransformerXL(nn.Module):
         return dqkv, dR
 
     # ------------------------------------------------------------------ one decoder layer (post-LN; transformer_xl.py:112-353)
-    def _layer_fwd(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool, dec=None):
+    def _layer_fwd(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool, dec=None, dstep=None):
         d, di, dff = self.d_model, self.d_inner, self.d_ff
         a = 1.0 if self.deepnorm_alpha is None else self.deepnorm_alpha
         p = f"h.{i}."
@@ -803,7 +816,8 @@ class TransformerXL(nn.Module):
         h1 = self._new(T, d)
         m1, r1 = self._new(T, dtype=torch.float32), self._new(T, dtype=torch.float32)
         ops.layernorm_residual_fwd(x, o, a, self.W(p + "dec_attn.layer_norm.weight"), self.W(p + "dec_attn.layer_norm.bias"),
-                                   h1, o if keep else None, m1, r1, self.layer_norm_epsilon)  # s1 overwrites o
+                                   h1, o if keep else None, m1, r1, self.layer_norm_epsilon,
+                                   drop=self._drop_args(self.drop_p, 4 * i, dstep))  # s1 = a x + dropout(o) overwrites o
         z = self._new(T, di)
         ops.gemm(h1, self.W(p + "pos_ff.CoreNet.0.weight").t(), z, bias=self.W(p + "pos_ff.CoreNet.0.bias"))
         act = self._new(T, dff)
@@ -813,14 +827,15 @@ class TransformerXL(nn.Module):
         out = self._new(T, d)
         m2, r2 = self._new(T, dtype=torch.float32), self._new(T, dtype=torch.float32)
         ops.layernorm_residual_fwd(h1, f, a, self.W(p + "pos_ff.layer_norm.weight"), self.W(p + "pos_ff.layer_norm.bias"),
-                                   out, f if keep else None, m2, r2, self.layer_norm_epsilon)
+                                   out, f if keep else None, m2, r2, self.layer_norm_epsilon,
+                                   drop=self._drop_args(self.drop_p, 4 * i + 1, dstep))
         if keep:
             c.x, c.qkv, c.R, c.av, c.s1, c.m1, c.r1 = x, qkv, R, av, o, m1, r1
             c.h1, c.z, c.act, c.s2, c.m2, c.r2 = h1, z, act, f, m2, r2
         return out, c
 
     # ---- pre-LN ordering of the same kernels (config default `--pre-lnorm True`; transformer_xl.py:126-137,231-233,277-282)
-    def _layer_fwd_prelnorm(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool, dec=None):
+    def _layer_fwd_prelnorm(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool, dec=None, dstep=None):
         d, di, dff = self.d_model, self.d_inner, self.d_ff
         p = f"h.{i}."
         c = _Ctx() if keep else None
@@ -845,6 +860,8 @@ class TransformerXL(nn.Module):
             av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c)
         o = self._new(T, d)
         ops.gemm(av.view(T, d), self.W(p + "dec_attn.o_net.weight").t(), o)
+        if dstep is not None and self.drop_p > 0:
+            ops.dropout(o, o, self._drop_args(self.drop_p, 4 * i, dstep))      # :229
         h1 = self._new(T, d)
         ops.add(x, o, h1)                                                      # residual (:233)
         fin = self._new(T, d)
@@ -857,21 +874,27 @@ class TransformerXL(nn.Module):
         ops.ffn_act_fwd(z, act, self.activation_fn)
         out = self._new(T, d)
         ops.gemm(act, self.W(p + "pos_ff.CoreNet.2.weight").t(), out, bias=self.W(p + "pos_ff.CoreNet.2.bias"))
+        if dstep is not None and self.drop_p > 0:
+            ops.dropout(out, out, self._drop_args(self.drop_p, 4 * i + 1, dstep))  # CoreNet's trailing Dropout (:262-269)
         ops.add(out, h1, out)                                                  # residual (:282)
         if keep:
             c.x, c.hin, c.qkv, c.R, c.av, c.m1, c.r1 = x, hin, qkv, R, av, m1, r1
             c.h1, c.fin, c.z, c.act, c.m2, c.r2 = h1, fin, z, act, m2, r2
         return out, c
 
-    def _layer_bwd_prelnorm(self, i, dout, c: _Ctx, R_in, B, L, shift):
+    def _layer_bwd_prelnorm(self, i, dout, c: _Ctx, R_in, B, L, shift, dstep=None):
         d, di, dff = self.d_model, self.d_inner, self.d_ff
         p = f"h.{i}."
         T = B * L
         W, G = self.W, self.G
-        ops.gemm(dout.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=1.0)
-        ops.colsum_acc(dout, G(p + "pos_ff.CoreNet.2.bias"))
+        df = dout
+        if dstep is not None and self.drop_p > 0:                              # gradient through the feed-forward output's dropout
+            df = self._new(T, d)
+            ops.dropout(dout, df, self._drop_args(self.drop_p, 4 * i + 1, dstep))
+        ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=1.0)
+        ops.colsum_acc(df, G(p + "pos_ff.CoreNet.2.bias"))
         dact = self._new(T, dff)
-        ops.gemm(dout, W(p + "pos_ff.CoreNet.2.weight"), dact)
+        ops.gemm(df, W(p + "pos_ff.CoreNet.2.weight"), dact)
         dz = self._new(T, di)
         ops.ffn_act_bwd_bias(c.z, dact, dz, G(p + "pos_ff.CoreNet.0.bias"), self.activation_fn)
         ops.gemm(dz.t(), c.fin, G(p + "pos_ff.CoreNet.0.weight"), beta=1.0)
@@ -881,9 +904,13 @@ class TransformerXL(nn.Module):
         ops.layernorm_residual_bwd(dfin, c.h1, W(p + "pos_ff.layer_norm.weight"), c.m2, c.r2, dh1,
                                    G(p + "pos_ff.layer_norm.weight"), G(p + "pos_ff.layer_norm.bias"))
         ops.add(dh1, dout, dh1)                                                # + the residual branch
-        ops.gemm(dh1.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=1.0)
+        do = dh1
+        if dstep is not None and self.drop_p > 0:                              # gradient through the attention output's dropout
+            do = self._new(T, d)
+            ops.dropout(dh1, do, self._drop_args(self.drop_p, 4 * i, dstep))
+        ops.gemm(do.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=1.0)
         dav = self._new(T, d)
-        ops.gemm(dh1, W(p + "dec_attn.o_net.weight"), dav)
+        ops.gemm(do, W(p + "dec_attn.o_net.weight"), dav)
         dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift)
         ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=1.0)
         ops.gemm(dqkv.t(), c.hin, G(p + "dec_attn.qkv_net.weight"), beta=1.0)
@@ -895,20 +922,24 @@ class TransformerXL(nn.Module):
         ops.add(dx, dh1, dx)
         return dx
 
-    def _layer_bwd(self, i, dout, c: _Ctx, R_in, B, L, shift):
+    def _layer_bwd(self, i, dout, c: _Ctx, R_in, B, L, shift, dstep=None):
         d, di, dff = self.d_model, self.d_inner, self.d_ff
         a = 1.0 if self.deepnorm_alpha is None else self.deepnorm_alpha
         p = f"h.{i}."
         T = B * L
         W, G = self.W, self.G
-        # ---- feed-forward
+        dropping = dstep is not None and self.drop_p > 0
+        # ---- feed-forward.  s2 = a h1 + dropout(f): the residual branch takes ds2 as it is, the feed-forward branch takes it under
+        # the forward's keep decisions (df, written by the same kernel from the same registers)
         ds2 = self._new(T, d)
+        df = self._new(T, d) if dropping else ds2
         ops.layernorm_residual_bwd(dout, c.s2, W(p + "pos_ff.layer_norm.weight"), c.m2, c.r2, ds2,
-                                   G(p + "pos_ff.layer_norm.weight"), G(p + "pos_ff.layer_norm.bias"))
-        ops.gemm(ds2.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=1.0)
-        ops.colsum_acc(ds2, G(p + "pos_ff.CoreNet.2.bias"))
+                                   G(p + "pos_ff.layer_norm.weight"), G(p + "pos_ff.layer_norm.bias"),
+                                   dr_out=df if dropping else None, drop=self._drop_args(self.drop_p, 4 * i + 1, dstep))
+        ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=1.0)
+        ops.colsum_acc(df, G(p + "pos_ff.CoreNet.2.bias"))
         dact = self._new(T, dff)
-        ops.gemm(ds2, W(p + "pos_ff.CoreNet.2.weight"), dact)
+        ops.gemm(df, W(p + "pos_ff.CoreNet.2.weight"), dact)
         dz = self._new(T, di)
         ops.ffn_act_bwd_bias(c.z, dact, dz, G(p + "pos_ff.CoreNet.0.bias"), self.activation_fn)
         ops.gemm(dz.t(), c.h1, G(p + "pos_ff.CoreNet.0.weight"), beta=1.0)
@@ -916,11 +947,13 @@ class TransformerXL(nn.Module):
         dh1 = ds2
         # ---- attention
         ds1 = self._new(T, d)
+        do = self._new(T, d) if dropping else ds1
         ops.layernorm_residual_bwd(dh1, c.s1, W(p + "dec_attn.layer_norm.weight"), c.m1, c.r1, ds1,
-                                   G(p + "dec_attn.layer_norm.weight"), G(p + "dec_attn.layer_norm.bias"))
-        ops.gemm(ds1.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=1.0)
+                                   G(p + "dec_attn.layer_norm.weight"), G(p + "dec_attn.layer_norm.bias"),
+                                   dr_out=do if dropping else None, drop=self._drop_args(self.drop_p, 4 * i, dstep))
+        ops.gemm(do.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=1.0)
         dav = self._new(T, d)
-        ops.gemm(ds1, W(p + "dec_attn.o_net.weight"), dav)
+        ops.gemm(do, W(p + "dec_attn.o_net.weight"), dav)
         dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift)
         ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=1.0)
         ops.gemm(dqkv.t(), c.x, G(p + "dec_attn.qkv_net.weight"), beta=1.0)
@@ -953,6 +986,12 @@ class TransformerXL(nn.Module):
                 labels.append(lab); masks.append(msk)
         h = embs[0] if len(embs) == 1 else torch.cat(embs, dim=0)  # concat on the batch dim (:541-545): data movement only
         B, L, _ = h.shape
+        dstep = None
+        if self.training and mems is None and (self.drop_p > 0 or self.embd_pdrop > 0):
+            self._drop_step += 1
+            dstep = self._drop_step
+            if self.embd_pdrop > 0:
+                ops.dropout(h, h, self._drop_args(self.embd_pdrop, self.SITE_EMBED, dstep))                     # :545
         mlen = mems[0].size(1) if mems is not None else 0
         klen = L + mlen
         shift = self._window(L, mlen)
@@ -965,12 +1004,16 @@ class TransformerXL(nn.Module):
             raise ValueError("attention mask hides nothing (transformer_xl.py:177,205-206)")
         dec = self._decode_begin(mems, B, L, mlen) if (mems is not None and mlen > 0) else None
         R_in = self._sinusoid(klen) if dec is None else None
+        if dstep is not None and self.embd_pdrop > 0:   # the position table goes through the same nn.Dropout (:575); the cached table stays intact
+            R_drop = torch.empty_like(R_in)
+            ops.dropout(R_in, R_drop, self._drop_args(self.embd_pdrop, self.SITE_POS, dstep))
+            R_in = R_drop
         x = h.view(B * L, d)
         hids, lcs = [], []
         for i in range(self.n_layer):
             hids.append(x)
             layer_fwd = self._layer_fwd_prelnorm if self.pre_lnorm else self._layer_fwd
-            x, c = layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep, dec)
+            x, c = layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep, dec, dstep)
             lcs.append(c)
         Wout = self.arena.view(self.arena.work, "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight",
                                full=True).view(self.vocab_pad, d)
@@ -991,7 +1034,7 @@ class TransformerXL(nn.Module):
                 ctx = _Ctx()
                 ctx.ecs, ctx.shapes, ctx.lcs, ctx.R_in, ctx.hfin = ecs, shapes, lcs, R_in, x
                 ctx.logits_pad, ctx.lab, ctx.msk, ctx.lse, ctx.sums = logits_pad, lab, msk, lse, sums
-                ctx.B, ctx.L, ctx.shift = B, L, shift
+                ctx.B, ctx.L, ctx.shift, ctx.dstep = B, L, shift, dstep
                 self._ctx = ctx
         res = (lm_logits, loss)
         if mems is not None:  # _update_mem (:487-504)
@@ -1029,10 +1072,12 @@ class TransformerXL(nn.Module):
         ops.gemm(dlogits, Wout, dh, useful_flops=2.0 * T * V * d)
         del dlogits
         for i in reversed(range(self.n_layer)):
-            dh = (self._layer_bwd_prelnorm if self.pre_lnorm else self._layer_bwd)(i, dh, ctx.lcs[i], ctx.R_in, B, L, ctx.shift)
+            dh = (self._layer_bwd_prelnorm if self.pre_lnorm else self._layer_bwd)(i, dh, ctx.lcs[i], ctx.R_in, B, L, ctx.shift, ctx.dstep)
             ctx.lcs[i] = None
             if layer_done_hook is not None:
                 layer_done_hook(f"h.{i}")
+        if ctx.dstep is not None and self.embd_pdrop > 0:   # gradient through the embedding dropout: the same keep decisions
+            ops.dropout(dh, dh, self._drop_args(self.embd_pdrop, self.SITE_EMBED, ctx.dstep))
         self._embed_bwd(dh.view(B, L, d), ctx.ecs, ctx.shapes)
         if layer_done_hook is not None:
             layer_done_hook("embeddings")

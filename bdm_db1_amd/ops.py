@@ -221,20 +221,30 @@ def relattn_dqr(dT, R, dqv):
            lambda: lib.call("db1_relattn_dqr", P(dT), P(R), R.stride(0), P(dqv), dqv.stride(1), dqv.stride(0), B, L, H, D, ws, wsn, stream()))
 
 
-def layernorm_residual_fwd(x, r, alpha, gamma, beta, y, s_out, mean, rstd, eps):
+NO_DROP = (0.0, 0, 0, 0)   # (p, seed, site, step)
+
+
+def dropout(x, y, drop):
+    """y = dropout(x) with the counter-based keep decisions of ``drop = (p, seed, site, step)`` (y may alias x; also its own backward)"""
+    p, seed, site, step = drop
+    lib.call("db1_dropout", P(x), P(y), x.numel(), float(p), int(seed), int(site), int(step), dt_code(x), stream())
+
+
+def layernorm_residual_fwd(x, r, alpha, gamma, beta, y, s_out, mean, rstd, eps, drop=NO_DROP):
     rows, d = x.numel() // x.shape[-1], x.shape[-1]
     nstreams = 2 + (r is not None) + (s_out is not None)   # x [, r] in; y [, s] out
     _timed("layernorm_fwd", float(rows * d * x.element_size() * nstreams),
            lambda: lib.call("db1_layernorm_residual_fwd", P(x), P(r), float(alpha), P(gamma), P(beta), P(y), P(s_out), P(mean), P(rstd),
-                            rows, d, float(eps), dt_code(x), dt_code(gamma), stream()))
+                            rows, d, float(eps), float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), dt_code(x), dt_code(gamma), stream()))
 
 
-def layernorm_residual_bwd(dy, s, gamma, mean, rstd, ds, dgamma_acc, dbeta_acc):
+def layernorm_residual_bwd(dy, s, gamma, mean, rstd, ds, dgamma_acc, dbeta_acc, dr_out=None, drop=NO_DROP):
+    """``dr_out``: gradient of the (dropped) residual input r = ds under the forward's keep decisions; None when nothing was dropped"""
     rows, d = dy.numel() // dy.shape[-1], dy.shape[-1]
     ws, wsn = _ws("db1_layernorm_residual_bwd_workspace_bytes", (rows, d, dt_code(dy)), dy.device)
-    _timed("layernorm_bwd", float(rows * d * dy.element_size() * 3),   # dy, s in; ds out
-           lambda: lib.call("db1_layernorm_residual_bwd", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dgamma_acc), P(dbeta_acc),
-                            rows, d, dt_code(dy), dt_code(gamma), ws, wsn, stream()))
+    _timed("layernorm_bwd", float(rows * d * dy.element_size() * (3 + (dr_out is not None))),   # dy, s in; ds [, dr] out
+           lambda: lib.call("db1_layernorm_residual_bwd", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dr_out), P(dgamma_acc), P(dbeta_acc),
+                            rows, d, float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), dt_code(dy), dt_code(gamma), ws, wsn, stream()))
 
 
 def ffn_act_fwd(z, out, act: str):

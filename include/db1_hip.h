@@ -114,14 +114,29 @@ int db1_gemm_would_use_fast(int M, int N, int K, int dtA, int dtB, int dtC,
  * s = alpha * x + r ; y = LayerNorm(s) * gamma + beta   (transformer_xl.py:231-238, 288-290;
  * alpha = DeepNorm alpha or 1).  r may be NULL (plain LN, pre-LN models).  s_out (may alias r,
  * may be NULL) receives s for the backward.  mean/rstd: float32 [rows]. */
+/* Dropout (transformer_xl.py:229,262-269: on the attention / feed-forward output before the residual sum) is part of this kernel:
+ * with drop_p > 0, s = alpha * x + dropout(r).  No mask is stored: keep decisions are a counter-based function (Philox4x32-10) of
+ * (drop_seed, drop_step, drop_site, element index) -- see db1_dropout -- and the backward regenerates them. */
 int db1_layernorm_residual_fwd(const void* x, const void* r, float alpha, const void* gamma, const void* beta,
                                void* y, void* s_out, float* mean, float* rstd,
-                               int64_t rows, int d, float eps, int dt, int dtParam, void* stream);
-/* ds = dL/ds (dtype dt); dgamma_acc / dbeta_acc: float32 [d], accumulated. */
+                               int64_t rows, int d, float eps,
+                               float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step,
+                               int dt, int dtParam, void* stream);
+/* ds = dL/ds (dtype dt); dr_out (nullable) = dL/dr = ds under the forward's keep decisions (== ds when drop_p = 0);
+ * dgamma_acc / dbeta_acc: float32 [d], accumulated. */
 int64_t db1_layernorm_residual_bwd_workspace_bytes(int64_t rows, int d, int dt);   /* per-block parameter-gradient partials */
 int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
-                               void* ds, float* dgamma_acc, float* dbeta_acc,
-                               int64_t rows, int d, int dt, int dtParam, void* ws, int64_t ws_bytes, void* stream);
+                               void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc,
+                               int64_t rows, int d,
+                               float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step,
+                               int dt, int dtParam, void* ws, int64_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ dropout
+ * y[e] = x[e] * keep(e) * 65536 / (65536 - thr),  thr = round(p * 65536)   (nn.Dropout, transformer_xl.py:409,545,575; y may alias x).
+ * keep(e) = [ u16(e) >= thr ] where the eight 16-bit uniforms of elements 8b .. 8b+7 are the 128 output bits of Philox4x32-10 on
+ * counter (b lo, b hi, site, step) under key (seed lo, seed hi), low half-word first.  The same call is its own backward
+ * (dx = dropout(dy) with the same seed / site / step).  n: a multiple of 8. */
+int db1_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint32_t site, uint32_t step, int dt, void* stream);
 
 /* ------------------------------------------------------------------ feed-forward activation
  * GEGLU: out[r, j] = z[r, j] * gelu_erf(z[r, n + j]) (activations.py:19-32); GELU/RELU: elementwise. */

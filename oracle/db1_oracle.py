@@ -388,6 +388,50 @@ def vision_embed_bwd(params, dout: Array, cache):
 
 
 # --------------------------------------------------------------------------------------
+# dropout (nn.Dropout, transformer_xl.py:229,262-269,409,545,575) with the counter-based keep decisions of the HIP kernels
+# (bdm_db1_amd/csrc/db1_common.h: Db1Drop / db1_drop_apply).  torch's own RNG stream cannot be reproduced on another device, so
+# parity at p > 0 is defined on the mask function: both sides draw keep(e) from Philox4x32-10 on (e / 8, site, step) keyed by the
+# seed; everything downstream of the mask is then compared as usual.
+# --------------------------------------------------------------------------------------
+SITE_EMBED, SITE_POS = 0xE0000000, 0xE0000001
+
+
+def site_of(layer: int, which: int) -> int:
+    """which: 0 = attention output (:229), 1 = feed-forward output (:269)"""
+    return layer * 4 + which
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32 with 10 rounds (Salmon et al. 2011; the Random123 / cuRAND generator) on uint32 arrays -> four uint32 arrays"""
+    M = np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(x, np.uint64) & M for x in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0) & M, np.uint64(k1) & M
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M, p1 & M, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M, p0 & M
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    return c0, c1, c2, c3
+
+
+def dropout_scale(n: int, p: float, seed: int, site: int, step: int) -> Array:
+    """float64 [n] (n a multiple of 8): 0 where element e is dropped, 65536 / (65536 - thr) where it is kept, thr = round(p * 65536);
+    keep(e) = [u16 >= thr], the eight u16 of elements 8b .. 8b+7 being the output words of philox(b lo, b hi, site, step; seed) split
+    low half first"""
+    assert n % 8 == 0 and 0.0 <= p < 1.0
+    thr = int(min(65535, max(0, np.rint(np.float32(p) * np.float32(65536.0))))) if p > 0 else 0
+    if thr == 0:
+        return np.ones(n)
+    blk = np.arange(n // 8, dtype=np.uint64)
+    o = philox4x32_10(blk & np.uint64(0xFFFFFFFF), blk >> np.uint64(32), np.uint64(site), np.uint64(step), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = np.empty((n // 8, 8), np.uint64)
+    for w in range(4):
+        u[:, 2 * w] = o[w] & np.uint64(0xFFFF)
+        u[:, 2 * w + 1] = o[w] >> np.uint64(16)
+    return np.where(u.reshape(-1) >= thr, 65536.0 / (65536 - thr), 0.0)
+
+
+# --------------------------------------------------------------------------------------
 # scalar tokenizer (src/tokenizer/scalar_tokenizer.py:28-63)
 # --------------------------------------------------------------------------------------
 def mulaw_discretize(x: Array, is_action: bool, num_bins: int = 1024, mu: float = 100.0, M: float = 256.0) -> Array:
@@ -528,6 +572,7 @@ class OracleModel:
         self.p = {k: np.asarray(v, dtype=dtype) for k, v in params.items() if k != "pos_emb.inv_freq"}
         self.inv_freq = np.asarray(params["pos_emb.inv_freq"], np.float32) if "pos_emb.inv_freq" in params \
             else inv_freq_f32(cfg.n_embed)
+        self._dropout = None
 
     # ---- helpers
     def _bias(self, name, i):
@@ -575,6 +620,13 @@ class OracleModel:
                 masks.append(np.asarray(t.loss_mask, dtype=self.dtype))
         return embs, labels, masks, caches
 
+    def _drop(self, x, p, site):
+        """nn.Dropout in training mode with the shared counter-based mask function; returns (dropped x, scale array or None)"""
+        if self._dropout is None or p <= 0:
+            return x, None
+        m = dropout_scale(x.size, p, self._dropout["seed"], site, self._dropout["step"]).reshape(x.shape).astype(self.dtype)
+        return x * m, m
+
     def _layer_fwd(self, i, x, R_in, masked, mlen, mem=None):
         """RelPartialLearnableDecoderLayer.forward (:326-353) -> dec_attn (:112-243) + pos_ff (:276-292)."""
         cfg, P = self.cfg, self.p
@@ -600,6 +652,7 @@ class OracleModel:
         av, ac = relattn_core_fwd(q, k, v, R, u, vb, masked, scale, mlen)
         av2 = av.reshape(B, L, H * D)
         o = av2 @ P[pre + "dec_attn.o_net.weight"].T
+        o, c["drop_o"] = self._drop(o, cfg.drop, site_of(i, 0))                 # :229
         if cfg.pre_lnorm:
             h1 = x + o
         else:
@@ -622,6 +675,7 @@ class OracleModel:
         else:
             raise NotImplementedError(cfg.activation_fn)
         f = act @ P[pre + "pos_ff.CoreNet.2.weight"].T + P[pre + "pos_ff.CoreNet.2.bias"]
+        f, c["drop_f"] = self._drop(f, cfg.drop, site_of(i, 1))                 # CoreNet's trailing nn.Dropout, :262-269
         if cfg.pre_lnorm:
             out = f + h1
         else:
@@ -643,6 +697,8 @@ class OracleModel:
             ds, dg, db = layernorm_bwd(dout, P[pre + "pos_ff.layer_norm.weight"], c["ln2"])
             G(pre + "pos_ff.layer_norm.weight", dg); G(pre + "pos_ff.layer_norm.bias", db)
             df, dh1 = ds, ds * a
+        if c.get("drop_f") is not None:
+            df = df * c["drop_f"]
         W2 = P[pre + "pos_ff.CoreNet.2.weight"]
         G(pre + "pos_ff.CoreNet.2.weight", df.reshape(-1, d).T @ c["act"].reshape(-1, W2.shape[1]))
         G(pre + "pos_ff.CoreNet.2.bias", df.reshape(-1, d).sum(0))
@@ -672,6 +728,8 @@ class OracleModel:
             ds, dg, db = layernorm_bwd(dh1, P[pre + "dec_attn.layer_norm.weight"], c["ln1"])
             G(pre + "dec_attn.layer_norm.weight", dg); G(pre + "dec_attn.layer_norm.bias", db)
             do, dx = ds, ds * a
+        if c.get("drop_o") is not None:
+            do = do * c["drop_o"]
         Wo = P[pre + "dec_attn.o_net.weight"]
         G(pre + "dec_attn.o_net.weight", do.reshape(-1, d).T @ c["av2"].reshape(-1, d))
         dav = (do @ Wo).reshape(B, L, H, D)
@@ -692,11 +750,15 @@ class OracleModel:
 
     # ---- public
     def forward(self, tasks: Sequence[TaskBatch], compute_loss=True, mems: Optional[List[Array]] = None,
-                keep_cache=True):
+                keep_cache=True, dropout: Optional[dict] = None):
+        """``dropout = {"seed": int, "step": int}`` = training mode with cfg.drop / cfg.embd_pdrop under the shared mask function
+        (None = eval mode / p = 0, the reference's behaviour in ``model.eval()``)"""
         cfg, P = self.cfg, self.p
         assert not (compute_loss and mems is not None)
+        self._dropout = dropout
         embs, labels, masks, ecaches = self._embed_tasks(tasks)
         h = np.concatenate(embs, axis=0)
+        h, drop_e = self._drop(h, cfg.embd_pdrop, SITE_EMBED)                    # :545
         B, L, d = h.shape
         mlen = mems[0].shape[1] if mems is not None else 0
         klen = L + mlen
@@ -706,6 +768,7 @@ class OracleModel:
         # distance table: pos_seq = [klen-1..0] clamped (:569-575) re-indexed by distance
         dist = np.minimum(np.arange(klen, dtype=np.float32), np.float32(cfg.n_position))
         R_in = sinusoid_table(dist, self.inv_freq).astype(self.dtype)
+        R_in, _ = self._drop(R_in, cfg.embd_pdrop, SITE_POS)                     # :575 (a constant input: no gradient to carry)
         hids, lcaches = [], []
         for i in range(cfg.n_layer):
             hids.append(h)
@@ -714,7 +777,7 @@ class OracleModel:
         Wout = P["word_embedding.weight"] if cfg.share_input_output_embedding else P["lm_head.weight"]
         logits = h @ Wout.T
         loss = None
-        cache = dict(ecaches=ecaches, lcaches=lcaches, R_in=R_in, hfin=h, embs_shapes=[e.shape for e in embs])
+        cache = dict(ecaches=ecaches, lcaches=lcaches, R_in=R_in, hfin=h, embs_shapes=[e.shape for e in embs], drop_e=drop_e)
         if compute_loss:
             lab = np.concatenate(labels, axis=0).astype(np.int64).reshape(-1)
             msk = np.concatenate(masks, axis=0).reshape(-1)
@@ -749,6 +812,8 @@ class OracleModel:
         dh = (dlg @ P[wname]).reshape(B, L, d)
         for i in reversed(range(cfg.n_layer)):
             dh = self._layer_bwd(i, dh, c["lcaches"][i], c["R_in"], grads)
+        if c.get("drop_e") is not None:
+            dh = dh * c["drop_e"]
         # embeddings
         E = "word_embedding.weight"
         gE = grads.get(E, np.zeros_like(P[E]))

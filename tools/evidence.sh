@@ -11,7 +11,8 @@ for w in caption rl mixture; do
 done
 timeout 600 python tools/bench_decode.py > $E/${TAG}_decode.txt 2> $E/decode.err </dev/null
 # the multi-rank path on this 1-GPU box: two ranks share the GPU, gloo instead of RCCL (which refuses two ranks on one device)
-DB1_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --batch 16 --steps 3 --warmup 1 > $E/${TAG}_bench_gloo_2ranks_b16.json 2> $E/bench_gloo.err </dev/null
+# (gloo prints a connection line on stdout: only the JSON line is kept)
+DB1_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --batch 16 --steps 3 --warmup 1 2> $E/bench_gloo.err </dev/null | grep "^{" > $E/${TAG}_bench_gloo_2ranks_b16.json
 BENCH_ARGS="--no-cpu-baseline" bash tools/prof_step.sh
 cp gpurun_out/step_stats.csv $E/${TAG}_kernel_stats_short.csv
 cp $(ls gpurun_out/prof_step/*kernel_stats.csv | head -1) $E/${TAG}_bench_b64_kernel_stats.csv
