@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DB1_BENCH_BATCH", 64)), help="sequences per GPU per step")
     ap.add_argument("--layers", type=int, default=24, help="debug only: anything but 24 is not the benchmark config")
     ap.add_argument("--workload", default="text", choices=["text", "caption", "rl", "mixture"])
+    ap.add_argument("--dropout", type=float, default=0.1, help="drop = embd_pdrop of the training step (the reference's defaults, src/config.py:123,161: 0.1)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flash", action="store_true")
@@ -156,7 +157,7 @@ def main():
     from types import SimpleNamespace
     if world > 1:
         mpu.initialize_model_parallel()
-    cfg = synth.db1_config("1.3B", n_layer=args.layers)
+    cfg = synth.db1_config("1.3B", n_layer=args.layers, drop=args.dropout, embd_pdrop=args.dropout)
     torch.manual_seed(1234)
     model = TransformerXL(cfg, device=dev)
     model.use_flash = not args.no_flash
@@ -173,7 +174,6 @@ def main():
         batch = [synth.rl_batch(B, L, seed, dev, cfg)]
     else:
         batch = synth.mixture_batch(B, L, seed, dev, cfg)
-    model.eval() if args.workload != "text" else None  # deterministic patch position ids; dropout is 0 either way
     n_patches = 0
     for t in batch:
         if getattr(t, "img_seq", None) is not None:
@@ -217,8 +217,9 @@ def main():
         "metric": "pretrain tokens/sec (whole node) DB1-1.3B seq1024", "value": round(tok_s, 1), "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"DB1-1.3B {args.workload} causal LM pre-training step (fwd+bwd+clip+Adam), seq_len 1024, "
-                               f"{B} sequences/GPU/step, random-init weights", "n_layer": args.layers, "n_embed": 2048, "n_head": 16,
+        "config": {"workload": f"DB1-1.3B {args.workload} causal LM pre-training step (fwd+bwd+clip+Adam, training mode: dropout "
+                               f"{args.dropout:g} on embeddings / attention / feed-forward outputs as the reference's defaults), seq_len 1024, "
+                               f"{B} sequences/GPU/step, random-init weights", "dropout": args.dropout, "n_layer": args.layers, "n_embed": 2048, "n_head": 16,
                    "seq_len": L, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "params": int(sum(int(np.prod(s)) for _, s, _ in model.arena.offsets.values()))},
         "pct_mfma_peak_step": round(100.0 * flops_step_all / (dt / args.steps) / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 2),

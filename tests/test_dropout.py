@@ -1,0 +1,219 @@
+"""Dropout at p > 0 (transformer_xl.py:229,262-269,409,545,575; defaults drop = embd_pdrop = 0.1, config.py:123,161).
+torch's RNG stream cannot be reproduced on another device, so parity is defined on the MASK FUNCTION: the HIP kernels and the oracle
+draw keep(e) from the same counter-based generator (Philox4x32-10 on (element / 8, site, step) keyed by the seed); these tests pin
+  * CPU: the NumPy Philox against the published known-answer vectors, the mask's statistics, and the oracle's analytic gradients
+    under dropout against finite differences (the mask is a constant of the step);
+  * GPU: db1_dropout against the oracle's mask function BIT FOR BIT, the fused LayerNorm forward / backward against the oracle's
+    formulae under the same mask, and the whole model (post-LN and pre-LN, mixed batch) forward + backward + every gradient at
+    p = 0.1 in fp32, then the bf16 path with the stated bf16 tolerance."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+from oracle import db1_oracle as O  # noqa: E402
+from golden_util import CASES, case_cfg, make_batch, make_params  # noqa: E402
+
+torch = pytest.importorskip("torch")
+DEV = "cuda"
+
+
+# ----------------------------------------------------------------------------------------------------------------- CPU
+def test_philox_known_answers_and_mask_statistics():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = O.philox4x32_10(*[np.array([c]) for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+    n = 1 << 20
+    m = O.dropout_scale(n, 0.1, seed=1234, site=O.site_of(3, 1), step=7)
+    thr = 6554  # round(0.1 * 65536)
+    assert set(np.unique(m)) == {0.0, 65536.0 / (65536 - thr)}
+    assert abs((m == 0).mean() - thr / 65536) < 4 * np.sqrt(0.1 * 0.9 / n)            # drop rate
+    assert abs(m.mean() - 1.0) < 4 * np.sqrt(0.1 / 0.9 / n)                            # unbiased: E[mask] = 1
+    # a different step, site or seed gives an independent mask; the same arguments give the same mask
+    assert np.array_equal(m, O.dropout_scale(n, 0.1, 1234, O.site_of(3, 1), 7))
+    for other in (O.dropout_scale(n, 0.1, 1234, O.site_of(3, 1), 8), O.dropout_scale(n, 0.1, 1234, O.site_of(3, 0), 7), O.dropout_scale(n, 0.1, 1235, O.site_of(3, 1), 7)):
+        agree = ((m == 0) == (other == 0)).mean()
+        assert abs(agree - (0.9 * 0.9 + 0.1 * 0.1)) < 5e-3
+    assert np.all(O.dropout_scale(64, 0.0, 1, 2, 3) == 1.0)
+
+
+@pytest.mark.parametrize("pre_lnorm", [False, True])
+def test_oracle_gradients_under_dropout_match_finite_differences(pre_lnorm):
+    cfg = dict(case_cfg("small_window"), n_embed=32, n_head=2, n_position=16, mem_len=16, text_vocab_size=50, num_continuous_bin=8, num_discrete_values=8,
+               drop=0.25, embd_pdrop=0.2, pre_lnorm=pre_lnorm)
+    params = {k: v.astype(np.float64) for k, v in make_params(cfg, 5).items()}
+    rng = np.random.default_rng(3)
+    ids = rng.integers(0, 50, (2, 17))
+    task = O.TaskBatch(kind="nlp", text_seq=ids[:, :-1], label=ids[:, 1:], loss_mask=np.ones((2, 16)))
+    dr = {"seed": 99, "step": 4}
+    model = O.OracleModel(O.OracleConfig(**cfg), params)
+    _, loss, _ = model.forward([task], dropout=dr)
+    _, loss_eval, _ = model.forward([task])
+    assert abs(loss - loss_eval) > 1e-3                        # the masks really bite
+    _, loss, _ = model.forward([task], dropout=dr)
+    grads = model.backward()
+    for name in ("h.0.dec_attn.o_net.weight", "h.1.pos_ff.CoreNet.2.weight", "h.0.pos_ff.CoreNet.2.bias", "word_embedding.weight", "h.1.dec_attn.r_net.weight",
+                 "h.0.dec_attn.qkv_net.weight"):
+        g = grads[name]
+        for _ in range(3):
+            idx = tuple(rng.integers(0, s) for s in g.shape)
+            eps = 1e-5
+            old = model.p[name][idx]
+            model.p[name][idx] = old + eps
+            lp = model.forward([task], dropout=dr)[1]
+            model.p[name][idx] = old - eps
+            lm = model.forward([task], dropout=dr)[1]
+            model.p[name][idx] = old
+            fd = (lp - lm) / (2 * eps)
+            assert abs(fd - g[idx]) < 1e-6 + 1e-4 * abs(fd), (name, idx, fd, g[idx])
+
+
+# ----------------------------------------------------------------------------------------------------------------- GPU
+def _dev(a, dt=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_dropout_kernel_draws_the_oracles_mask_bit_for_bit(dtype):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bdm_db1_amd import ops
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    n = 8 * 50021
+    x = torch.ones(n, device=DEV, dtype=td)
+    for p, seed, site, step in ((0.1, 1234, O.site_of(7, 1), 3), (0.5, (1 << 63) + 12345, O.SITE_EMBED, 4000000000), (0.25, 0, O.SITE_POS, 0)):
+        y = torch.empty_like(x)
+        ops.dropout(x, y, (p, seed, site, step))
+        want = O.dropout_scale(n, p, seed, site, step)
+        got = y.double().cpu().numpy()
+        assert np.array_equal(got == 0, want == 0), (p, seed)
+        scale = want.max()
+        assert abs(got.max() - scale) <= (2e-7 if dtype == "f32" else 4e-3) * scale
+    ops.dropout(x, y, (0.0, 1, 2, 3))
+    assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,d", [("f32", 96), ("bf16", 2048), ("bf16", 512)])
+def test_layernorm_residual_with_fused_dropout(dtype, d):
+    """s = alpha x + dropout(r) in the forward; ds and dr = ds * mask in the backward (register-resident kernels at d = 2048 / 512 bf16)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bdm_db1_amd import ops
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    rng = np.random.default_rng(5)
+    rows, alpha, eps = 37, 1.3, 1e-5
+    rt = lambda a: _dev(a, td).double().cpu().numpy()       # round to the storage dtype
+    x, r, dy = rt(rng.standard_normal((rows, d))), rt(rng.standard_normal((rows, d))), rt(rng.standard_normal((rows, d)))
+    gam, bet = rt(1 + 0.1 * rng.standard_normal(d)), rt(0.1 * rng.standard_normal(d))
+    drop = (0.1, 77, O.site_of(2, 0), 9)
+    mask = O.dropout_scale(rows * d, *drop).reshape(rows, d)
+    y, s = torch.empty(rows, d, device=DEV, dtype=td), torch.empty(rows, d, device=DEV, dtype=td)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    ops.layernorm_residual_fwd(_dev(x, td), _dev(r, td), alpha, _dev(gam, td), _dev(bet, td), y, s, mean, rstd, eps, drop=drop)
+    s_ref = alpha * x + r * mask
+    tol = 1e-5 if dtype == "f32" else 1.2e-2
+    assert np.abs(s.double().cpu().numpy() - s_ref).max() <= tol * np.abs(s_ref).max()
+    sq = s.double().cpu().numpy()                            # the statistics are taken on s as stored
+    mu, var = sq.mean(1, keepdims=True), sq.var(1, keepdims=True)
+    y_ref = (sq - mu) / np.sqrt(var + eps) * gam + bet
+    assert np.abs(y.double().cpu().numpy() - y_ref).max() <= tol * np.abs(y_ref).max()
+    ds, dr = torch.empty(rows, d, device=DEV, dtype=td), torch.empty(rows, d, device=DEV, dtype=td)
+    dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    ops.layernorm_residual_bwd(_dev(dy, td), s, _dev(gam, td), mean, rstd, ds, dg, db, dr_out=dr, drop=drop)
+    xh = (sq - mu) / np.sqrt(var + eps)
+    g = dy * gam
+    ds_ref = (g - g.mean(1, keepdims=True) - xh * (g * xh).mean(1, keepdims=True)) / np.sqrt(var + eps)
+    assert np.abs(ds.double().cpu().numpy() - ds_ref).max() <= tol * np.abs(ds_ref).max()
+    dsq = ds.double().cpu().numpy()
+    assert np.abs(dr.double().cpu().numpy() - dsq * mask).max() <= (1e-6 if dtype == "f32" else 8e-3) * np.abs(dsq).max()
+    assert np.array_equal(dr.double().cpu().numpy() == 0, (mask == 0) | (dsq == 0))
+    assert np.abs(dg.double().cpu().numpy() - (dy * xh).sum(0)).max() <= tol * np.abs((dy * xh).sum(0)).max() + 1e-6
+
+
+def _build(name, over, dtype):
+    from bdm_db1_amd import TransformerXL
+    seed = 100 + list(CASES).index(name)
+    cfg = dict(case_cfg(name), **over)
+    params = make_params(cfg, seed)
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", f"model_{name}.npz")))
+    params["pos_emb.inv_freq"] = gold["inv_freq"] if gold["inv_freq"].size == cfg["n_embed"] // 2 else O.inv_freq_f32(cfg["n_embed"])
+    model = TransformerXL(SimpleNamespace(**cfg), compute_dtype=dtype)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    oracle = O.OracleModel(O.OracleConfig(**cfg), params)
+    return cfg, model, oracle, seed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small_mixed", "small_prelnorm", "small_flags"])
+def test_model_with_dropout_matches_oracle_fp32(name):
+    """training mode at the reference's default p = 0.1 (embeddings, position table, attention and feed-forward outputs): loss, logits
+    and EVERY parameter gradient against the oracle under the same mask function; two consecutive steps use different masks"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_model_gpu import to_inputs, rel_err
+    cfg, model, oracle, seed = _build(name, dict(drop=0.1, embd_pdrop=0.1), torch.float32)
+    tasks = make_batch(name, cfg, seed)
+    model.train()
+    if name == "small_mixed":   # train-mode vision position ids are random picks (vision_embedding.py:150-169): inject the eval rule's ids on both sides
+        for t in tasks:
+            if t["kind"] in ("rl", "ic"):
+                img = t["vision_seq"] if t["kind"] == "rl" else t["img_seq"]
+                h0, w0 = img.shape[-2] // 16, img.shape[-1] // 16
+                n_img = int(np.prod(img.shape[:-3]))
+                r, c = O.vision_position_ids_eval(h0, w0, cfg["vision_position_vocab_size"])
+                t["vision_row_ids"], t["vision_col_ids"] = np.tile(r, (n_img, 1)), np.tile(c, (n_img, 1))
+    losses = []
+    for step in (1, 2):
+        inp = to_inputs(tasks)
+        for t, x in zip(tasks, inp):
+            if "vision_row_ids" in t:
+                x.vision_row_ids, x.vision_col_ids = t["vision_row_ids"], t["vision_col_ids"]
+        logits, loss = model(inp)
+        assert model._drop_step == step
+        ref_logits, ref_loss, _ = oracle.forward([O.TaskBatch(**t) for t in tasks], dropout={"seed": model.dropout_seed, "step": step})
+        assert rel_err(logits, ref_logits) < 1e-4 and abs(float(loss) - ref_loss) < 2e-5 * max(1.0, abs(ref_loss))
+        model.arena.grad.zero_()
+        model.backward()
+        ref_grads = oracle.backward()
+        worst = max((rel_err(model.G(n), g), n) for n, g in ref_grads.items())
+        assert worst[0] < 1e-3, worst
+        losses.append(float(loss))
+    assert abs(losses[0] - losses[1]) > 1e-4
+    model.eval()
+    _, loss_eval = model(to_inputs(tasks))
+    _, ref_eval, _ = oracle.forward([O.TaskBatch(**t) for t in tasks])
+    assert abs(float(loss_eval) - ref_eval) < 2e-5 * max(1.0, abs(ref_eval))   # eval mode: no dropout
+
+
+@pytest.mark.gpu
+def test_model_with_dropout_bf16_close_to_oracle():
+    """bf16 path (register-resident LayerNorm kernels with the fused masks need d in {512, 1024, 2048}: d = 512 here).
+    Stated tolerance: logits 3e-2 of max |logit|, loss 2e-2 abs, gradients 6e-2 of each tensor's max."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_model_gpu import to_inputs, rel_err
+    cfg, model, oracle, seed = _build("small_window", dict(drop=0.1, embd_pdrop=0.1, n_embed=512, n_head=4, n_position=64, mem_len=64), torch.bfloat16)
+    tasks = make_batch("small_window", cfg, seed)
+    model.train()
+    logits, loss = model(to_inputs(tasks))
+    ref_logits, ref_loss, _ = oracle.forward([O.TaskBatch(**t) for t in tasks], dropout={"seed": model.dropout_seed, "step": 1})
+    assert rel_err(logits, ref_logits) < 3e-2 and abs(float(loss) - ref_loss) < 2e-2
+    model.backward()
+    ref_grads = oracle.backward()
+    for n in ("h.0.dec_attn.qkv_net.weight", "h.1.pos_ff.CoreNet.0.weight", "h.0.pos_ff.CoreNet.2.weight", "h.1.dec_attn.o_net.weight", "word_embedding.weight",
+              "h.0.pos_ff.CoreNet.2.bias", "h.1.pos_ff.layer_norm.weight"):
+        assert rel_err(model.G(n), ref_grads[n]) < 6e-2, n
