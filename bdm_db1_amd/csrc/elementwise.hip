@@ -842,6 +842,27 @@ extern "C" int db1_dropout(const void* x, void* y, int64_t n, float p, uint64_t 
     return DB1_OK;
 }
 
+// base[off .. off+len) = 0 for every (off, len) pair of a device table: ONE launch clears the scattered small accumulators of the gradient
+// arena (LayerNorm / bias / u, v / embedding-table gradients) -- the large weight gradients are not cleared at all, their first
+// writer of a step is a GEMM with beta = 0 (bdm_db1_amd/engine.py)
+__global__ __launch_bounds__(256) void zero_segments_kernel(float* __restrict__ base, const int64_t* __restrict__ seg) {
+    const int64_t off = seg[2 * blockIdx.y], len = seg[2 * blockIdx.y + 1];
+    float* p = base + off;
+    if (((off | len) & 3) == 0) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (len >> 2); i += (int64_t)gridDim.x * 256)
+            reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
+    }
+}
+extern "C" int db1_zero_segments(float* base, const int64_t* segments, int n_segments, void* stream) {
+    if (!base || !segments || n_segments <= 0 || n_segments > 65535) DB1_FAIL(DB1_ERR_BAD_SHAPE, "zero_segments: n=%d", n_segments);
+    if (!db1_aligned16(base)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "zero_segments: base alignment");
+    zero_segments_kernel<<<dim3(64, (unsigned)n_segments), 256, 0, (hipStream_t)stream>>>(base, segments);
+    DB1_CHECK_LAUNCH("zero_segments");
+    return DB1_OK;
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) stf(y + i, ldf(x + i));

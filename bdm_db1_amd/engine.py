@@ -97,6 +97,7 @@ class DB1Engine:
         if ga is None:
             ga = max(1, glob // (micro * self.dp_world)) if (micro and glob) else 1
         self._ga = int(ga)
+        model.loss_grad_scale = 1.0 / self._ga
         self.micro_steps = 0
         self.global_steps = 0
         self.beta1, self.beta2 = float(g("adam_beta1", 0.9)), float(g("adam_beta2", 0.999))
@@ -110,11 +111,14 @@ class DB1Engine:
         # DeepSpeed's engine hands back logits the caller may keep; `keep_logits=False` (bench.py, memory-tight training) lets the CE backward
         # overwrite the logits buffer with dlogits in place (4.4 GB at 64 x 1024 tokens)
         model.keep_logits = bool(g("keep_logits", True))
+        # without kept logits the head + loss (+ the head's backward) run as one chunked sweep and `engine(batch)` returns (None, loss)
+        model.fuse_head_loss = not model.keep_logits and bool(g("fuse_head_loss", True))
         ar = model.arena
         if ar.exp_avg is None:
             ar.exp_avg = torch.zeros_like(ar.master)
             ar.exp_avg_sq = torch.zeros_like(ar.master)
         self._norm_sq = torch.zeros(1, device=model.device, dtype=torch.float32)
+        self._acc_segments = model.accumulator_segments()   # the small accumulators of the gradient arena (cleared after every step)
         # gradients cross xGMI in bf16 (the reference's DeepSpeed fp16 engine reduces 2-byte gradients too: 2.42 GB per step,
         # SURVEY 8e); "fp32" keeps the 4-byte arena on the wire (bit-comparable with a single-rank run up to summation order)
         rdt = str(g("grad_reduce_dtype", "bf16")).lower()
@@ -182,7 +186,10 @@ class DB1Engine:
         ops.adam_step(ar.master, grad, ar.exp_avg, ar.exp_avg_sq, None if ar.work is ar.master else ar.work,
                       grp["lr"], self.beta1, self.beta2, self.eps, grp["weight_decay"], self.adamw, self.global_steps,
                       gscale=gscale, clip=self.clip, norm_sq=self._norm_sq if self.clip > 0 else None)
-        ar.grad.zero_()
+        # the weight gradients (99.9 % of the arena) are not cleared: the next backward's GEMMs write them with beta = 0; only the
+        # scattered accumulators (LayerNorm / bias / u, v / embedding-table gradients) are, in one launch
+        ops.zero_segments(ar.grad, self._acc_segments)
+        self.module._grad_fresh = True
         self.module.mark_weights_changed()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step(1)

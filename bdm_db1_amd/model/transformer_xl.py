@@ -148,6 +148,10 @@ class TransformerXL(nn.Module):
         self.compute_dtype = compute_dtype
         self.vocab_pad = _round_up(self.total_vocab_size, 256)  # whole 256x256 GEMM tiles for the tied head
         self.keep_logits = True          # False: the CE backward overwrites the logits buffer (training engines)
+        # training without a logits tensor: head GEMM, masked CE and the head's two gradient GEMMs in ONE sweep over 16 384-row chunks
+        # (db1_lmhead_ce_fwd_bwd) during the forward; forward then returns (None, loss).  Set by the engine when keep_logits is False.
+        self.fuse_head_loss = False
+        self.loss_grad_scale = 1.0       # d(loss * this) is what backward() accumulates: 1 / gradient-accumulation steps (set by the engine)
         self.use_flash = True            # fused attention when the shape is supported
         self.use_flash_bwd = True        # fused backward kernels (False: recompute through the materialised path)
         self.use_headbias_epilogue = True  # q + r_w_bias / q + r_r_bias written by the qkv projection's epilogue (large bf16 batches)
@@ -159,6 +163,9 @@ class TransformerXL(nn.Module):
         self._dec_state = None           # K/V cache of the memory returned by the last forward (see _decode_begin)
         self._dec_R = None               # (version, [R_i = r_net_i(sinusoid(dist)) for dist < mem_len + 64])
         self._ctx: Optional[_Ctx] = None
+        # True: the gradient arena is logically zero -> the weight-gradient GEMMs of the next backward WRITE (beta = 0) instead of
+        # accumulating, so the 4.8 GB of weight gradients are neither cleared after a step nor read back by their first writer
+        self._grad_fresh = True
         self._tables: Dict[Tuple[int, int], torch.Tensor] = {}
 
         # ---- parameters: arena in backward-completion order (last layer first, embeddings last)
@@ -891,13 +898,13 @@ class TransformerXL(nn.Module):
         if dstep is not None and self.drop_p > 0:                              # gradient through the feed-forward output's dropout
             df = self._new(T, d)
             ops.dropout(dout, df, self._drop_args(self.drop_p, 4 * i + 1, dstep))
-        ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=1.0)
+        ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=self._gb)
         ops.colsum_acc(df, G(p + "pos_ff.CoreNet.2.bias"))
         dact = self._new(T, dff)
         ops.gemm(df, W(p + "pos_ff.CoreNet.2.weight"), dact)
         dz = self._new(T, di)
         ops.ffn_act_bwd_bias(c.z, dact, dz, G(p + "pos_ff.CoreNet.0.bias"), self.activation_fn)
-        ops.gemm(dz.t(), c.fin, G(p + "pos_ff.CoreNet.0.weight"), beta=1.0)
+        ops.gemm(dz.t(), c.fin, G(p + "pos_ff.CoreNet.0.weight"), beta=self._gb)
         dfin = self._new(T, d)
         ops.gemm(dz, W(p + "pos_ff.CoreNet.0.weight"), dfin)
         dh1 = self._new(T, d)
@@ -908,12 +915,12 @@ class TransformerXL(nn.Module):
         if dstep is not None and self.drop_p > 0:                              # gradient through the attention output's dropout
             do = self._new(T, d)
             ops.dropout(dh1, do, self._drop_args(self.drop_p, 4 * i, dstep))
-        ops.gemm(do.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=1.0)
+        ops.gemm(do.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=self._gb)
         dav = self._new(T, d)
         ops.gemm(do, W(p + "dec_attn.o_net.weight"), dav)
         dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift)
-        ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=1.0)
-        ops.gemm(dqkv.t(), c.hin, G(p + "dec_attn.qkv_net.weight"), beta=1.0)
+        ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=self._gb)
+        ops.gemm(dqkv.t(), c.hin, G(p + "dec_attn.qkv_net.weight"), beta=self._gb)
         dhin = self._new(T, d)
         ops.gemm(dqkv, W(p + "dec_attn.qkv_net.weight"), dhin)
         dx = self._new(T, d)
@@ -936,13 +943,13 @@ class TransformerXL(nn.Module):
         ops.layernorm_residual_bwd(dout, c.s2, W(p + "pos_ff.layer_norm.weight"), c.m2, c.r2, ds2,
                                    G(p + "pos_ff.layer_norm.weight"), G(p + "pos_ff.layer_norm.bias"),
                                    dr_out=df if dropping else None, drop=self._drop_args(self.drop_p, 4 * i + 1, dstep))
-        ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=1.0)
+        ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=self._gb)
         ops.colsum_acc(df, G(p + "pos_ff.CoreNet.2.bias"))
         dact = self._new(T, dff)
         ops.gemm(df, W(p + "pos_ff.CoreNet.2.weight"), dact)
         dz = self._new(T, di)
         ops.ffn_act_bwd_bias(c.z, dact, dz, G(p + "pos_ff.CoreNet.0.bias"), self.activation_fn)
-        ops.gemm(dz.t(), c.h1, G(p + "pos_ff.CoreNet.0.weight"), beta=1.0)
+        ops.gemm(dz.t(), c.h1, G(p + "pos_ff.CoreNet.0.weight"), beta=self._gb)
         ops.gemm(dz, W(p + "pos_ff.CoreNet.0.weight"), ds2, beta=a)          # dh1 = a*ds2 + dz W1   (in place over ds2)
         dh1 = ds2
         # ---- attention
@@ -951,12 +958,12 @@ class TransformerXL(nn.Module):
         ops.layernorm_residual_bwd(dh1, c.s1, W(p + "dec_attn.layer_norm.weight"), c.m1, c.r1, ds1,
                                    G(p + "dec_attn.layer_norm.weight"), G(p + "dec_attn.layer_norm.bias"),
                                    dr_out=do if dropping else None, drop=self._drop_args(self.drop_p, 4 * i, dstep))
-        ops.gemm(do.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=1.0)
+        ops.gemm(do.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=self._gb)
         dav = self._new(T, d)
         ops.gemm(do, W(p + "dec_attn.o_net.weight"), dav)
         dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift)
-        ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=1.0)
-        ops.gemm(dqkv.t(), c.x, G(p + "dec_attn.qkv_net.weight"), beta=1.0)
+        ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=self._gb)
+        ops.gemm(dqkv.t(), c.x, G(p + "dec_attn.qkv_net.weight"), beta=self._gb)
         ops.gemm(dqkv, W(p + "dec_attn.qkv_net.weight"), ds1, beta=a)        # dx = a*ds1 + dqkv Wqkv (in place over ds1)
         return ds1
 
@@ -1018,24 +1025,38 @@ class TransformerXL(nn.Module):
         Wout = self.arena.view(self.arena.work, "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight",
                                full=True).view(self.vocab_pad, d)
         T = B * L
-        logits_pad = self._new(T, self.vocab_pad)
         V = self.total_vocab_size
-        ops.gemm(x, Wout.t(), logits_pad, useful_flops=2.0 * T * V * d)   # (the padded vocabulary columns are not counted as work)
-        lm_logits = logits_pad.view(B, L, self.vocab_pad)[:, :, :V]
-        loss = None
+        loss, lm_logits = None, None
+        fused = compute_loss and keep and self.fuse_head_loss and not self.keep_logits
         if compute_loss:
             lab = (labels[0] if len(labels) == 1 else torch.cat(labels, dim=0)).reshape(-1).contiguous()
             msk = (masks[0] if len(masks) == 1 else torch.cat(masks, dim=0)).reshape(-1).contiguous()
             lse = self._new(T, dtype=torch.float32)
             sums = torch.zeros(2, device=self.dev, dtype=torch.float32)
-            ops.masked_ce_fwd(logits_pad, lab, msk, lse, sums, V)
+        if fused:
+            # loss, dh and the head's weight gradient in one sweep: the logits only ever exist 16 384 rows at a time (in the workspace)
+            wname = "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight"
+            gW = self.arena.view(self.arena.grad, wname, full=True).view(self.vocab_pad, d)
+            dh = self._new(T, d)
+            ops.lmhead_ce(x, Wout, lab, msk, lse, sums, V, dh=dh, dW_acc=gW, beta_dw=0.0 if self._grad_fresh else 1.0, gscale=self.loss_grad_scale)
             loss = sums[0] / sums[1]
-            if keep:
-                ctx = _Ctx()
-                ctx.ecs, ctx.shapes, ctx.lcs, ctx.R_in, ctx.hfin = ecs, shapes, lcs, R_in, x
-                ctx.logits_pad, ctx.lab, ctx.msk, ctx.lse, ctx.sums = logits_pad, lab, msk, lse, sums
-                ctx.B, ctx.L, ctx.shift, ctx.dstep = B, L, shift, dstep
-                self._ctx = ctx
+            ctx = _Ctx()
+            ctx.ecs, ctx.shapes, ctx.lcs, ctx.R_in, ctx.dh_head = ecs, shapes, lcs, R_in, dh
+            ctx.B, ctx.L, ctx.shift, ctx.dstep, ctx.fused_scale = B, L, shift, dstep, self.loss_grad_scale
+            self._ctx = ctx
+        else:
+            logits_pad = self._new(T, self.vocab_pad)
+            ops.gemm(x, Wout.t(), logits_pad, useful_flops=2.0 * T * V * d)   # (the padded vocabulary columns are not counted as work)
+            lm_logits = logits_pad.view(B, L, self.vocab_pad)[:, :, :V]
+            if compute_loss:
+                ops.masked_ce_fwd(logits_pad, lab, msk, lse, sums, V)
+                loss = sums[0] / sums[1]
+                if keep:
+                    ctx = _Ctx()
+                    ctx.ecs, ctx.shapes, ctx.lcs, ctx.R_in, ctx.hfin = ecs, shapes, lcs, R_in, x
+                    ctx.logits_pad, ctx.lab, ctx.msk, ctx.lse, ctx.sums = logits_pad, lab, msk, lse, sums
+                    ctx.B, ctx.L, ctx.shift, ctx.dstep, ctx.dh_head = B, L, shift, dstep, None
+                    self._ctx = ctx
         res = (lm_logits, loss)
         if mems is not None:  # _update_mem (:487-504)
             end_idx = mlen + max(0, L)
@@ -1059,18 +1080,25 @@ class TransformerXL(nn.Module):
         if ctx is None:
             raise RuntimeError("backward() without a preceding forward(compute_loss=True)")
         self._ctx = None
+        self._gb = 0.0 if self._grad_fresh else 1.0   # beta of the weight-gradient GEMMs: write on a fresh arena, accumulate otherwise
+        self._grad_fresh = False
         d, V = self.d_model, self.total_vocab_size
         B, L = ctx.B, ctx.L
         T = B * L
-        dlogits = self._new(T, self.vocab_pad) if self.keep_logits else ctx.logits_pad
-        ops.masked_ce_bwd(ctx.logits_pad, ctx.lab, ctx.msk, ctx.lse, ctx.sums, dlogits, V, gscale=grad_scale)
-        wname = "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight"
-        Wout = self.arena.view(self.arena.work, wname, full=True).view(self.vocab_pad, d)
-        gW = self.arena.view(self.arena.grad, wname, full=True).view(self.vocab_pad, d)
-        ops.gemm(dlogits.t(), ctx.hfin, gW, beta=1.0, useful_flops=2.0 * T * V * d)
-        dh = self._new(T, d)
-        ops.gemm(dlogits, Wout, dh, useful_flops=2.0 * T * V * d)
-        del dlogits
+        if ctx.dh_head is not None:   # the head's backward already ran inside the forward's sweep (fuse_head_loss)
+            if abs(grad_scale - ctx.fused_scale) > 1e-12 * max(1.0, abs(grad_scale)):
+                raise RuntimeError(f"backward(grad_scale={grad_scale}) after a fused head sweep taken at loss_grad_scale={ctx.fused_scale}")
+            dh = ctx.dh_head
+        else:
+            dlogits = self._new(T, self.vocab_pad) if self.keep_logits else ctx.logits_pad
+            ops.masked_ce_bwd(ctx.logits_pad, ctx.lab, ctx.msk, ctx.lse, ctx.sums, dlogits, V, gscale=grad_scale)
+            wname = "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight"
+            Wout = self.arena.view(self.arena.work, wname, full=True).view(self.vocab_pad, d)
+            gW = self.arena.view(self.arena.grad, wname, full=True).view(self.vocab_pad, d)
+            ops.gemm(dlogits.t(), ctx.hfin, gW, beta=self._gb, useful_flops=2.0 * T * V * d)
+            dh = self._new(T, d)
+            ops.gemm(dlogits, Wout, dh, useful_flops=2.0 * T * V * d)
+            del dlogits
         for i in reversed(range(self.n_layer)):
             dh = (self._layer_bwd_prelnorm if self.pre_lnorm else self._layer_bwd)(i, dh, ctx.lcs[i], ctx.R_in, B, L, ctx.shift, ctx.dstep)
             ctx.lcs[i] = None
@@ -1084,6 +1112,29 @@ class TransformerXL(nn.Module):
 
     def zero_grad(self, set_to_none: bool = False):
         self.arena.grad.zero_()
+        self._grad_fresh = True
+
+    def gemm_first_grads(self) -> List[str]:
+        """parameters whose gradient's FIRST writer in a backward is a GEMM (which can write with beta = 0): the five weight matrices of
+        every decoder layer and the output-embedding matrix (with tied embeddings the token scatter-add comes after the head's GEMM)"""
+        names = [f"h.{i}.{n}" for i in range(self.n_layer) for n in ("pos_ff.CoreNet.2.weight", "pos_ff.CoreNet.0.weight", "dec_attn.o_net.weight",
+                                                                    "dec_attn.r_net.weight", "dec_attn.qkv_net.weight")]
+        return names + ["word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight"]
+
+    def accumulator_segments(self) -> torch.Tensor:
+        """int64 [n, 2] device table of (offset, length) runs of the gradient arena that are NOT covered by ``gemm_first_grads``: what has
+        to be cleared after an optimizer step (db1_zero_segments)"""
+        skip = set(self.gemm_first_grads())
+        runs: List[List[int]] = []
+        for name, (off, shape, alloc) in self.arena.offsets.items():
+            if name in skip:
+                continue
+            n = _round_up(alloc, 8)
+            if runs and runs[-1][0] + runs[-1][1] == off:
+                runs[-1][1] += n
+            else:
+                runs.append([off, n])
+        return torch.tensor(runs, dtype=torch.int64, device=self.dev)
 
     # layer -> contiguous [start, end) element range of the gradient arena (bucket boundaries for data parallelism)
     def grad_buckets(self) -> List[Tuple[str, int, int]]:

@@ -297,6 +297,12 @@ def add2d_colsums(a2d, b2d, y2d, sum_a_acc, sum_b_acc):
                             rows, cols, dt_code(y2d), ws, wsn, stream()))
 
 
+def zero_segments(base, segments):
+    """base[off : off + len] = 0 for every row (off, len) of the int64 device table ``segments`` [n, 2]; one launch"""
+    assert base.dtype == torch.float32 and segments.dtype == torch.int64 and segments.dim() == 2 and segments.shape[1] == 2 and segments.is_contiguous()
+    lib.call("db1_zero_segments", P(base), P(segments), segments.shape[0], stream())
+
+
 def cast(x, y):
     lib.call("db1_cast", P(x), P(y), x.numel(), dt_code(x), dt_code(y), stream())
 
@@ -340,6 +346,26 @@ def masked_ce_bwd(logits2d, labels, mask, lse, sums, dlogits2d, V, gscale=1.0):
     _timed("masked_ce_bwd", float(2 * T * V * logits2d.element_size()),
            lambda: lib.call("db1_masked_ce_bwd", P(logits2d), P(labels), P(mask), P(lse), P(sums), P(dlogits2d), T, V, ld, float(gscale),
                             dt_code(logits2d), stream()))
+
+
+def lmhead_ce(h2d, W, labels, mask, lse, sums, V, dh=None, dW_acc=None, beta_dw=1.0, gscale=1.0, chunk_rows=0):
+    """tied head + masked CE without the logits tensor (db1_lmhead_ce_fwd / _fwd_bwd): ``dh`` and ``dW_acc`` given -> the training sweep"""
+    T, d = h2d.shape
+    rows = W.shape[0]
+    assert h2d.is_contiguous() and W.is_contiguous() and W.shape[1] == d and h2d.dtype == W.dtype and rows >= V
+    train = dh is not None
+    assert (dW_acc is not None) == train and (not train or (dh.is_contiguous() and dW_acc.dtype == torch.float32 and dW_acc.shape == (rows, d)))
+    ws, wsn = _ws("db1_lmhead_ce_workspace_bytes", (T, rows, d, int(chunk_rows), dt_code(h2d), int(train)), h2d.device)
+    flops = 2.0 * T * V * d * (3 if train else 1)
+
+    def run():
+        if train:
+            lib.call("db1_lmhead_ce_fwd_bwd", P(h2d), P(W), P(labels), P(mask), P(lse), P(sums), P(dh), P(dW_acc), float(beta_dw), float(gscale),
+                     T, V, rows, d, int(chunk_rows), dt_code(h2d), ws, wsn, stream())
+        else:
+            lib.call("db1_lmhead_ce_fwd", P(h2d), P(W), P(labels), P(mask), P(lse), P(sums), T, V, rows, d, int(chunk_rows), dt_code(h2d), ws, wsn, stream())
+
+    _timed("lmhead_ce", flops, run)   # (GEMM-dominated: reported as its own MFMA-bound family by bench.py)
 
 
 def relattn_add_head_bias(qkv, u, vb, qu, qv, B, Lq, Lk, H, D):

@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flash", action="store_true")
+    ap.add_argument("--materialise-logits", action="store_true", help="A/B: head GEMM + CE on a full (tokens x vocabulary) logits buffer instead of the chunked sweep")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -161,7 +162,7 @@ def main():
     torch.manual_seed(1234)
     model = TransformerXL(cfg, device=dev)
     model.use_flash = not args.no_flash
-    eargs = SimpleNamespace(lr=1e-4, weight_decay=0.01, clip_grad=1.0, optimizer="adam", keep_logits=False)
+    eargs = SimpleNamespace(lr=1e-4, weight_decay=0.01, clip_grad=1.0, optimizer="adam", keep_logits=False, fuse_head_loss=not args.materialise_logits)
     engine, _, _, _ = initialize(eargs, model, mpu=mpu if world > 1 else None)
     engine.train()
     B, L = args.batch, cfg.n_position
@@ -252,7 +253,7 @@ def main():
         for fam, (fms, work, n) in sorted(summ.items()):
             if fam == "gemm" or fms <= 0:
                 continue
-            mfma = fam.startswith("flash")
+            mfma = fam.startswith("flash") or fam == "lmhead_ce"
             rate = work / (fms * 1e-3) / (1e12 if mfma else 1e9)
             peak = MFMA_BF16_PEAK_TFLOPS if mfma else HBM_PEAK_GBPS
             ks[fam] = {"bound": "mfma" if mfma else "hbm", "achieved": round(rate, 1), "unit": "TFLOP/s" if mfma else "GB/s",

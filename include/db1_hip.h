@@ -161,6 +161,9 @@ int db1_add2d_colsums(const void* a, int64_t lda, const void* b, int64_t ldb, vo
 /* y[r, c] = a[r, c] + b[r, c] with row strides (a may have a different dtype; y may alias b) */
 int db1_add2d(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows, int cols,
               int dtA, int dt, void* stream);
+/* base[segments[2i] .. + segments[2i+1]) = 0 for i < n_segments (offsets / lengths in elements, a device table of int64 pairs): one
+ * launch clears the scattered small float32 accumulators of the gradient arena after an optimizer step. */
+int db1_zero_segments(float* base, const int64_t* segments, int n_segments, void* stream);
 /* y[i] = (dtOut) x[i] */
 int db1_cast(const void* x, void* y, int64_t n, int dtIn, int dtOut, void* stream);
 
@@ -192,6 +195,21 @@ int db1_masked_ce_fwd(const void* logits, const int64_t* labels, const float* ma
                       int64_t T, int V, int64_t ld, int dt, void* ws, int64_t ws_bytes, void* stream);
 int db1_masked_ce_bwd(const void* logits, const int64_t* labels, const float* mask, const float* lse, const float* sums,
                       void* dlogits, int64_t T, int V, int64_t ld, float gscale, int dt, void* stream);
+
+/* ------------------------------------------------------------------ tied LM head + masked cross-entropy, chunked over the token rows
+ * (transformer_xl.py:593-613).  The (T x vocabulary) logits tensor is never materialised: chunk_rows rows of logits at a time
+ * live in the workspace (chunk_rows <= 0: 16 384).  h [T, d], W [n_w_rows, d] (rows >= V are zero padding, n_w_rows a multiple of
+ * 256 keeps the tile GEMMs on their fast path), both of dtype dt.  Same loss / lse / gradient arithmetic as db1_gemm_* +
+ * db1_masked_ce_* on a materialised tensor (the reductions inside a chunk and across chunks run in a fixed order).
+ *   _fwd     : lse [T]; sums[0] += sum(mask * nll), sums[1] += sum(mask)                     (evaluation, logits-free forward)
+ *   _fwd_bwd : additionally dh [T, d] (dtype dt) and dW_acc [n_w_rows, d] float32 = beta_dw * dW_acc + dW, both for
+ *              loss * gscale -- one sweep, no recomputation: the normaliser sum(mask) is known before the first chunk. */
+int64_t db1_lmhead_ce_workspace_bytes(int64_t T, int n_w_rows, int d, int chunk_rows, int dt, int train);
+int db1_lmhead_ce_fwd(const void* h, const void* W, const int64_t* labels, const float* mask, float* lse, float* sums,
+                      int64_t T, int V, int n_w_rows, int d, int chunk_rows, int dt, void* ws, int64_t ws_bytes, void* stream);
+int db1_lmhead_ce_fwd_bwd(const void* h, const void* W, const int64_t* labels, const float* mask, float* lse, float* sums,
+                          void* dh, float* dW_acc, float beta_dw, float gscale,
+                          int64_t T, int V, int n_w_rows, int d, int chunk_rows, int dt, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ relative-position attention for inference with memory
  * (evaluate_rl.py:157-266; transformer_xl.py:124-133,160-225).  q = 1..64 new queries per sequence against klen = mlen + q cached

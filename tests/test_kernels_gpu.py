@@ -648,6 +648,51 @@ def test_adam_matches_torch_golden(ops):
             close(V_[:257], gold[f"{mode}/v{i + 1}"], 3e-6, name=f"{mode} v{i + 1}")
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_lmhead_ce_chunked_sweep(ops, dtype):
+    """db1_lmhead_ce_fwd / _fwd_bwd (tied head + masked CE without the logits tensor; transformer_xl.py:593-613) against the closed form
+    in float64: ragged last chunk (300 rows in chunks of 128), padded vocabulary rows, masked rows, beta on the weight gradient"""
+    rng = np.random.default_rng(31)
+    T, V, rows, d, chunk = 300, 1000, 1024, 64, 128
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    rt = lambda a: dev(a, td).double().cpu().numpy()
+    h, W = rt(rng.standard_normal((T, d))), np.zeros((rows, d))
+    W[:V] = rt(0.2 * rng.standard_normal((V, d)))
+    lab = rng.integers(0, V, T)
+    msk = (rng.random(T) > 0.3).astype(np.float32)
+    logits = h @ W[:V].T
+    mx = logits.max(1, keepdims=True)
+    lse_ref = mx[:, 0] + np.log(np.exp(logits - mx).sum(1))
+    nll = lse_ref - logits[np.arange(T), lab]
+    gscale = 0.5
+    dlog = (np.exp(logits - lse_ref[:, None]) - np.eye(V)[lab]) * (msk / msk.sum() * gscale)[:, None]
+    dh_ref, dW_ref = dlog @ W[:V], dlog.T @ h
+    tol = 2e-5 if dtype == "f32" else 2e-2
+    hd, Wd, labd, mskd = dev(h, td), dev(W, td), torch.from_numpy(lab).to(DEV), dev(msk)
+    # loss only
+    lse, sums = torch.zeros(T, device=DEV), torch.tensor([1.0, 2.0], device=DEV)
+    ops.lmhead_ce(hd, Wd, labd, mskd, lse, sums, V, chunk_rows=chunk)
+    assert abs(float(sums[0]) - 1.0 - (nll * msk).sum()) < tol * (nll * msk).sum() and abs(float(sums[1]) - 2.0 - msk.sum()) < 1e-4
+    close(lse, lse_ref, 1e-5 if dtype == "f32" else 5e-3, name="lse")
+    # training sweep, accumulating onto an existing weight gradient
+    lse2, sums2 = torch.zeros(T, device=DEV), torch.zeros(2, device=DEV)
+    dh = torch.empty(T, d, device=DEV, dtype=td)
+    prev = rng.standard_normal((rows, d))
+    dW = dev(prev)
+    ops.lmhead_ce(hd, Wd, labd, mskd, lse2, sums2, V, dh=dh, dW_acc=dW, beta_dw=1.0, gscale=gscale, chunk_rows=chunk)
+    assert abs(float(sums2[0] / sums2[1]) - (nll * msk).sum() / msk.sum()) < tol * 10
+    close(dh, dh_ref, tol, name="dh")
+    got = dW.double().cpu().numpy() - prev
+    assert np.abs(got[:V] - dW_ref).max() <= tol * np.abs(dW_ref).max() + 1e-6 and np.abs(got[V:]).max() <= 1e-6
+    dW0 = dev(prev)
+    ops.lmhead_ce(hd, Wd, labd, mskd, lse2, torch.zeros(2, device=DEV), V, dh=dh, dW_acc=dW0, beta_dw=0.0, gscale=gscale, chunk_rows=chunk)
+    assert np.abs(dW0.double().cpu().numpy()[:V] - dW_ref).max() <= tol * np.abs(dW_ref).max() + 1e-6   # beta = 0: the old content is gone
+    # one chunk (default size) gives the same numbers as three
+    dW1, dh1 = torch.zeros(rows, d, device=DEV), torch.empty(T, d, device=DEV, dtype=td)
+    ops.lmhead_ce(hd, Wd, labd, mskd, lse2, torch.zeros(2, device=DEV), V, dh=dh1, dW_acc=dW1, beta_dw=0.0, gscale=gscale)
+    close(dh1, dh.double().cpu().numpy(), 1e-6 if dtype == "f32" else 1e-2, name="dh chunking")
+
+
 # ------------------------------------------------------------------------------- tokenizer (bit-exact)
 def test_mulaw_discretize_bit_exact(ops):
     gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "scalar_tokenizer.npz")))

@@ -146,7 +146,22 @@ def test_engine_three_adam_steps_match_oracle(adamw):
     sd = model.state_dict()
     worst = max(rel_err(sd[k], oracle.p[k]) for k in oracle.p)
     assert worst < 2e-4, worst
-    assert float(model.arena.grad.abs().max()) == 0.0  # zeroed after the step
+    # after the step: the scattered accumulators are cleared (one launch over a segment table); the weight gradients are NOT -- the next
+    # backward's GEMMs write them with beta = 0 (which the three matching steps above depend on)
+    assert model._grad_fresh
+    big = set(model.gemm_first_grads())
+    for n in model.arena.offsets:
+        if n not in big:
+            assert float(model.G(n).abs().max()) == 0.0, n
+    assert float(model.G("h.0.dec_attn.qkv_net.weight").abs().max()) > 0.0
+    # a second backward without a step in between accumulates (gradient accumulation): twice the single gradient
+    model.zero_grad()
+    model(to_inputs(tasks))[1]
+    model.backward()
+    g1 = model.G("h.1.pos_ff.CoreNet.0.weight").clone()
+    model(to_inputs(tasks))
+    model.backward()
+    assert rel_err(model.G("h.1.pos_ff.CoreNet.0.weight"), 2 * g1.double().cpu().numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("name", list(MEM_CASES))
@@ -218,6 +233,35 @@ def test_mask_edge_cases_follow_the_reference():
         x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=torch.zeros(2, 1, dtype=torch.long, device=DEV), text_len=None)
         logits, _, mems = model([x], compute_loss=False, mems=model.init_mem(2))
     assert tuple(logits.shape) == (2, 1, model.total_vocab_size)
+
+
+def test_fused_head_loss_engine_matches_materialised_logits():
+    """keep_logits=False: head GEMM + masked CE + the head's backward run as one chunked sweep inside the forward (db1_lmhead_ce_fwd_bwd)
+    and engine(batch) returns (None, loss).  Two Adam steps, with gradient accumulation over two micro-steps, must give the losses and
+    parameters of the engine that materialises the logits (same kernels underneath: fp32 agreement to round-off)"""
+    from bdm_db1_amd import initialize
+    name = "small_window"
+    res = {}
+    for fused in (False, True):
+        cfg, params, gold, model, oracle, seed = build(name)
+        args = SimpleNamespace(lr=2e-3, weight_decay=0.01, clip_grad=1.0, optimizer="adamw", keep_logits=not fused, gradient_accumulation_steps=2)
+        engine, _, _, _ = initialize(args, model)
+        assert model.fuse_head_loss == fused
+        tasks = make_batch(name, cfg, seed)
+        engine.train()
+        losses = []
+        for micro in range(4):
+            logits, loss = engine(to_inputs(tasks))
+            assert (logits is None) == fused
+            engine.backward(loss)
+            engine.step()
+            losses.append(float(loss))
+        assert engine.global_steps == 2
+        res[fused] = (losses, {k: v.detach().double().cpu().numpy() for k, v in model.state_dict().items()})
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) < 1e-5 * max(1.0, abs(b))
+    for k, v in res[False][1].items():
+        assert rel_err(res[True][1][k], v) < 2e-5, k
 
 
 def test_state_dict_names_match_reference():
