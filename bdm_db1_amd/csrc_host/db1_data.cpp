@@ -89,7 +89,7 @@ extern "C" int db1_idx_open(const char* prefix, db1_idx** out) {
     h->docs = (int64_t)docs;
     const size_t need = header + (size_t)len * 4 + (size_t)len * 8 + (size_t)docs * 8;
     if (h->idx.bytes < need) return bad("truncated index");
-    h->sizes = (const int32_t*)(p + header);
+    h->sizes = (const int32_t*)(p + header);   // NOTE: only 2-byte aligned (34-byte header): never dereferenced as typed pointers, see the memcpy reads below
     h->pointers = (const int64_t*)(p + header + (size_t)len * 4);   // (the reference reads these unaligned arrays the same way)
     h->doc_idx = (const int64_t*)(p + header + (size_t)len * 12);
     *out = h;
@@ -105,9 +105,9 @@ extern "C" int64_t db1_idx_len(const db1_idx* h) { return h->len; }
 extern "C" int64_t db1_idx_doc_count(const db1_idx* h) { return h->docs; }
 extern "C" int db1_idx_dtype_code(const db1_idx* h) { return h->dtype_code; }
 extern "C" int db1_idx_elem_size(const db1_idx* h) { return h->elem; }
-extern "C" const int32_t* db1_idx_sizes(const db1_idx* h) { return h->sizes; }
-extern "C" const int64_t* db1_idx_pointers(const db1_idx* h) { return h->pointers; }
-extern "C" const int64_t* db1_idx_doc_idx(const db1_idx* h) { return h->doc_idx; }
+extern "C" const void* db1_idx_sizes(const db1_idx* h) { return h->sizes; }
+extern "C" const void* db1_idx_pointers(const db1_idx* h) { return h->pointers; }
+extern "C" const void* db1_idx_doc_idx(const db1_idx* h) { return h->doc_idx; }
 
 extern "C" int db1_idx_get(const db1_idx* h, int64_t idx, int64_t offset, int64_t length, const void** data, int64_t* n_elems) {
     if (!h || !data || !n_elems) return fail(-2, "idx_get: null argument");

@@ -23,9 +23,12 @@ int64_t db1_idx_len(const db1_idx* h);                         /* number of item
 int64_t db1_idx_doc_count(const db1_idx* h);
 int db1_idx_dtype_code(const db1_idx* h);
 int db1_idx_elem_size(const db1_idx* h);                       /* bytes per element */
-const int32_t* db1_idx_sizes(const db1_idx* h);                /* views into the mapping, valid until close */
-const int64_t* db1_idx_pointers(const db1_idx* h);
-const int64_t* db1_idx_doc_idx(const db1_idx* h);
+/* Views into the mapping, valid until close: int32 sizes[len], int64 pointers[len], int64 doc_idx[doc_count].  The format puts them
+ * behind a 34-byte header, so they are only 2-BYTE ALIGNED: read them with memcpy (C) / numpy.frombuffer (Python), never through a
+ * typed pointer (found by the UBSan run of tests/csrc/data_sanitize_main.c; the library's own reads are memcpy-based). */
+const void* db1_idx_sizes(const db1_idx* h);
+const void* db1_idx_pointers(const db1_idx* h);
+const void* db1_idx_doc_idx(const db1_idx* h);
 /* MMapIndexedDataset.get(idx, offset, length) (indexed_dataset.py:522-536): pointer to `*n_elems` elements of item idx starting
  * at element `offset`; length < 0 = to the end of the item.  Zero-copy (points into the mapping). */
 int db1_idx_get(const db1_idx* h, int64_t idx, int64_t offset, int64_t length, const void** data, int64_t* n_elems);

@@ -112,3 +112,29 @@ def test_index_builders_against_compiled_reference_helpers(D):
         D.build_blending_indices(a, b, w, nd, size)
         ref.build_blending_indices(c, e, w, nd, size, False)
         assert np.array_equal(a, c) and np.array_equal(b, e)
+
+
+def test_c_abi_under_address_and_undefined_behaviour_sanitizers(tmp_path, gold):
+    """the data library's C ABI compiled with -fsanitize=address,undefined and driven from C over the reference-written
+    store, including every error path and a truncated index: any out-of-bounds access of the mapping aborts the driver"""
+    import shutil
+    import subprocess
+    src = os.path.join(ROOT, "bdm_db1_amd", "csrc_host", "db1_data.cpp")
+    drv = os.path.join(ROOT, "tests", "csrc", "data_sanitize_main.c")
+    exe = str(tmp_path / "data_sanitize")
+    obj = str(tmp_path / "main.o")
+    flags = ["-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer"]
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror"] + flags + ["-c", drv, "-o", obj], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run(["g++", "-std=c++17", "-Wall"] + flags + [src, obj, "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0 and "asan" in r.stderr.lower():
+        pytest.skip("libasan is not installed on this box")
+    assert r.returncode == 0, r.stderr[-3000:]
+    prefix = os.path.join(G, "data_fixture")
+    trunc = str(tmp_path / "trunc")
+    blob = open(prefix + ".idx", "rb").read()
+    open(trunc + ".idx", "wb").write(blob[:len(blob) - 9])
+    shutil.copy(prefix + ".bin", trunc + ".bin")
+    r = subprocess.run([exe, prefix, trunc], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert r.stdout.startswith("ok items=%d tokens=%d " % (len(gold["store_sizes"]), int(gold["store_sizes"].sum()))), r.stdout
