@@ -27,9 +27,6 @@ struct DqrArgs {
     const bf16_t* dT; const bf16_t* Rt; bf16_t* out;
     int B, L, H, wph;              // wph = workgroups per head
     int64_t o_rs, o_bs;            // row / batch strides of out (elements); head h at + h * 128
-    // fused mode (dqk != nullptr): out = dq_r + dqk (out may alias dqk: same strides), and the column sums of dqk and of dq_r over this
-    // workgroup's rows go to part[0][j][h*128 + c] / part[1][j][h*128 + c] (j = workgroup of the head, added in order by a reduce kernel)
-    const bf16_t* dqk; float* part;
 };
 
 __device__ __forceinline__ int dqr_swz(int row) { return ((((row & 7) ^ ((row & 8) >> 1))) << 1) | ((row >> 3) & 1); }  // natural-order row fragments
@@ -82,13 +79,7 @@ __global__ __launch_bounds__(512, 1) void relattn_dqr_kernel(DqrArgs p) {
         dqr_glds(src + (int64_t)4 * L + schunk1, dst + 1024);
     };
     Cur cs, cc;                      // staging cursor (DQR_STAGES - 1 tiles ahead), compute cursor
-    if (j >= n_items) {              // (more workgroups than items: never at the model's sizes) -- its partial rows must still be defined
-        if (p.part && tid < 128) {
-            p.part[(int64_t)j * p.H * 128 + h * 128 + tid] = 0.f;
-            p.part[((int64_t)p.wph + j) * p.H * 128 + h * 128 + tid] = 0.f;
-        }
-        return;
-    }
+    if (j >= n_items) return;
     item_of(j, cs);
     cc = cs;
     int issued = 0;
@@ -99,14 +90,6 @@ __global__ __launch_bounds__(512, 1) void relattn_dqr_kernel(DqrArgs p) {
     dqr_f32x4 acc[4];
 #pragma unroll
     for (int rt = 0; rt < 4; rt++) acc[rt] = (dqr_f32x4){0.f, 0.f, 0.f, 0.f};
-    uint2 qk[4];                     // fused mode: this lane's dq_k values of the current item, requested when the item starts
-    float sum_k[4] = {0.f, 0.f, 0.f, 0.f}, sum_r[4] = {0.f, 0.f, 0.f, 0.f};   // column sums over this lane's rows (all items)
-    auto fetch_qk = [&](const Cur& c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int rt = 0; rt < 4; rt++)
-            qk[rt] = *reinterpret_cast<const uint2*>(p.dqk + (int64_t)c.b * p.o_bs + (int64_t)(c.i0 + 16 * rt + a) * p.o_rs + h * 128 + 16 * wave + 4 * g);
-    };
-    if (p.dqk) fetch_qk(cc);
     int st = 0;  // stage of the compute cursor's tile
     for (; cc.t < n_items;) {
         // the tile of the compute cursor must have landed: all but the (issued - 1) pieces pairs issued after it
@@ -129,42 +112,18 @@ __global__ __launch_bounds__(512, 1) void relattn_dqr_kernel(DqrArgs p) {
             case 0: DQR_TILE(0) break; case 1: DQR_TILE(1) break; case 2: DQR_TILE(2) break; case 3: DQR_TILE(3) break;
             case 4: DQR_TILE(4) break; case 5: DQR_TILE(5) break; case 6: DQR_TILE(6) break; default: DQR_TILE(7) break;
         }
-        const bool item_done = cc.kt == cc.nk - 1;
-        if (item_done) {             // out[b][i0 + 16 rt + a][h][16 wave + 4 g .. +3]
+        if (cc.kt == cc.nk - 1) {    // item done: out[b][i0 + 16 rt + a][h][16 wave + 4 g .. +3]
 #pragma unroll
             for (int rt = 0; rt < 4; rt++) {
-                float v[4] = {acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]};
-                if (p.dqk) {         // dq = dq_k + dq_r (one rounding), du += colsum(dq_k), dv_bias += colsum(dq_r)
-                    const float k0 = __uint_as_float(qk[rt].x << 16), k1 = __uint_as_float(qk[rt].x & 0xffff0000u);
-                    const float k2 = __uint_as_float(qk[rt].y << 16), k3 = __uint_as_float(qk[rt].y & 0xffff0000u);
-                    sum_k[0] += k0; sum_k[1] += k1; sum_k[2] += k2; sum_k[3] += k3;
-                    sum_r[0] += v[0]; sum_r[1] += v[1]; sum_r[2] += v[2]; sum_r[3] += v[3];
-                    v[0] += k0; v[1] += k1; v[2] += k2; v[3] += k3;
-                }
                 uint2 o;
-                o.x = f2bf_pk(v[0], v[1]);
-                o.y = f2bf_pk(v[2], v[3]);
+                o.x = f2bf_pk(acc[rt][0], acc[rt][1]);
+                o.y = f2bf_pk(acc[rt][2], acc[rt][3]);
                 *reinterpret_cast<uint2*>(p.out + (int64_t)cc.b * p.o_bs + (int64_t)(cc.i0 + 16 * rt + a) * p.o_rs + h * 128 + 16 * wave + 4 * g) = o;
                 acc[rt] = (dqr_f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
         advance(cc);
-        if (item_done && p.dqk && cc.t < n_items) fetch_qk(cc);   // the next item's dq_k: in flight while its tiles are multiplied
         st = (st + 1) % DQR_STAGES;
-    }
-    if (p.part) {   // this workgroup's column sums: over the 16 row lanes (fixed butterfly order), then one row of the partial table per sum
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { sum_k[c] += __shfl_xor(sum_k[c], o, 64); sum_r[c] += __shfl_xor(sum_r[c], o, 64); }
-        }
-        if (a == 0) {
-            const int64_t HD = (int64_t)p.H * 128, col = (int64_t)h * 128 + 16 * wave + 4 * g;
-            float* pk = p.part + (int64_t)j * HD + col;
-            float* pr = p.part + ((int64_t)p.wph + j) * HD + col;
-#pragma unroll
-            for (int c = 0; c < 4; c++) { pk[c] = sum_k[c]; pr[c] = sum_r[c]; }
-        }
     }
 }
 
@@ -182,38 +141,12 @@ extern "C" int db1_relattn_dqr_supported(int B, int L, int H, int D, int dt) {
     return (dt == DB1_BF16 && D == 128 && B > 0 && H > 0 && H <= 256 && L >= 128 && (L % 128) == 0 && L <= DQR_MAX_L) ? 1 : 0;
 }
 
-static inline int dqr_wph(int H) { return 256 / H > 0 ? 256 / H : 1; }
-static inline int64_t dqr_rt_bytes(int L, int H) { return (((int64_t)H * 128 * L * (int64_t)sizeof(bf16_t)) + 255) & ~(int64_t)255; }
-// R^T, and (fused entry point) the per-workgroup column-sum partials [2][wph][H * 128]
-extern "C" int64_t db1_relattn_dqr_workspace_bytes(int L, int H) { return dqr_rt_bytes(L, H) + 2 * (int64_t)dqr_wph(H) * H * 128 * (int64_t)sizeof(float); }
+extern "C" int64_t db1_relattn_dqr_workspace_bytes(int L, int H) { return (int64_t)H * 128 * L * (int64_t)sizeof(bf16_t); }  // R^T
 
 /* dq_r[b, i, h, :] = sum_dist dT[h, b, i, dist] * R[dist, h, :]; dT [H, B, L, L] bf16 (zero for dist > i), R [L, H, 128] with row stride r_rs,
  * out [B, L, H, 128] with row / batch strides (elements) */
-__global__ __launch_bounds__(64 * 4) void dqr_part_reduce_kernel(const float* __restrict__ part, float* acc, int n, int cols) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float t = 0.f;
-    for (int j = 0; j < n; j++) t += part[(int64_t)j * cols + c];   // workgroup order: deterministic
-    acc[c] += t;
-}
-
-static int dqr_run(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride, const void* dqk,
-                   float* du_acc, float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream);
-
 extern "C" int db1_relattn_dqr(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride,
                                int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream) {
-    return dqr_run(dT, R, r_row_stride, out, out_row_stride, out_batch_stride, nullptr, nullptr, nullptr, B, L, H, D, ws, ws_bytes, stream);
-}
-/* the same stream, finishing the query gradient in its epilogue: dq[b,i,h,:] = dq_k[b,i,h,:] + dq_r (in place over dq_k, one rounding),
- * du_acc[h*128 + c] += sum_{b,i} dq_k, dv_acc[h*128 + c] += sum_{b,i} dq_r (float32; per-workgroup partials added in a fixed order) */
-extern "C" int db1_relattn_dqr_fused(const void* dT, const void* R, int64_t r_row_stride, void* dq, int64_t dq_row_stride, int64_t dq_batch_stride,
-                                     float* du_acc, float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream) {
-    if (!du_acc || !dv_acc) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_dqr_fused: null accumulator");
-    return dqr_run(dT, R, r_row_stride, dq, dq_row_stride, dq_batch_stride, dq, du_acc, dv_acc, B, L, H, D, ws, ws_bytes, stream);
-}
-
-static int dqr_run(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride, const void* dqk,
-                   float* du_acc, float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream) {
     if (!db1_relattn_dqr_supported(B, L, H, D, DB1_BF16)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_dqr: needs bf16, d_head = 128, L %% 128 == 0, L <= 1024 (got L=%d D=%d)", L, D);
     if (!dT || !R || !out) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_dqr: null buffer");
     if (!db1_aligned16(dT) || !db1_aligned16(out) || (out_row_stride % 4) || (out_batch_stride % 4)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_dqr: alignment");
@@ -224,19 +157,11 @@ static int dqr_run(const void* dT, const void* R, int64_t r_row_stride, void* ou
     DB1_CHECK_LAUNCH("relattn_dqr transpose");
     DqrArgs a;
     a.dT = (const bf16_t*)dT; a.Rt = Rt; a.out = (bf16_t*)out; a.B = B; a.L = L; a.H = H;
-    a.wph = dqr_wph(H);
+    a.wph = 256 / H > 0 ? 256 / H : 1;
     a.o_rs = out_row_stride; a.o_bs = out_batch_stride;
-    a.dqk = (const bf16_t*)dqk;
-    a.part = dqk ? (float*)((char*)ws + dqr_rt_bytes(L, H)) : nullptr;
     static Db1PerDeviceOnce attr_once;
     attr_once.run([] { hipFuncSetAttribute((const void*)relattn_dqr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQR_STAGES * DQR_TILE_BYTES); });
     relattn_dqr_kernel<<<dim3((unsigned)(H * a.wph)), 512, DQR_STAGES * DQR_TILE_BYTES, st>>>(a);
     DB1_CHECK_LAUNCH("relattn_dqr");
-    if (dqk) {
-        const int cols = H * 128;
-        dqr_part_reduce_kernel<<<(cols + 255) / 256, 256, 0, st>>>(a.part, du_acc, a.wph, cols);
-        dqr_part_reduce_kernel<<<(cols + 255) / 256, 256, 0, st>>>(a.part + (int64_t)a.wph * cols, dv_acc, a.wph, cols);
-        DB1_CHECK_LAUNCH("relattn_dqr reduce");
-    }
     return DB1_OK;
 }
