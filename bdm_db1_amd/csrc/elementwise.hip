@@ -909,25 +909,9 @@ extern "C" int db1_embed_gather_fwd(const void* table, const int64_t* ids, void*
     return DB1_OK;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void scatter_add_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids, float* dtable,
-                                                          int64_t n_tokens, int d, int64_t ld, int64_t n_rows) {
-    int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= n_tokens) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t id = ids[t];
-    if (id < 0 || id >= n_rows) return;
-    for (int i = lane; i < d; i += 64) atomicAdd(dtable + id * d + i, ldf(dout + t * ld + i));
-}
-extern "C" int db1_embed_scatter_add_bwd(const void* dout, const int64_t* ids, float* dtable_acc, int64_t n_tokens, int d,
-                                         int64_t ld_dout, int64_t n_table_rows, int dt, void* stream) {
-    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "embed_scatter: dtype");
-    if (n_tokens <= 0 || d <= 0 || ld_dout < d || n_table_rows <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "embed_scatter: shape");
-    dim3 g((unsigned)((n_tokens + 3) / 4));
-    DB1_DISPATCH_DT(dt, T, (scatter_add_kernel<T><<<g, 256, 0, (hipStream_t)stream>>>((const T*)dout, ids, dtable_acc, n_tokens, d, ld_dout, n_table_rows)));
-    DB1_CHECK_LAUNCH("embed_scatter");
-    return DB1_OK;
-}
+// (the embedding-table gradient, db1_embed_scatter_add_bwd, lives in scatter.hip: sorted runs instead of float atomics)
+int db1_scatter_add_impl(const void* dout, const int64_t* ids, float* dtable_acc, int64_t n_tokens, int d, int64_t ld_dout, int64_t n_table_rows, int dt,
+                         void* ws, int64_t ws_bytes, hipStream_t st, const char* who);
 
 // RL assembly: grid (L / 32 token chunks, B).  The rank of a -1 placeholder inside its row = placeholders before the chunk (counted
 // by the whole block) + ballot / popcount prefix inside the chunk.  (One block per ROW left 240 of 256 CUs idle: 3.6 ms per call
@@ -977,9 +961,8 @@ __global__ __launch_bounds__(256) void rl_assemble_kernel(const TT* __restrict__
                 stf(out + o + i, v);
             } else {
                 const float g = ldf(out + o + i);  // 'out' carries dout in the backward
-                if (id_ok) atomicAdd(dword + id * d + i, g);
-                else if (rk >= 0 && rk < nvis && dvis) stf(dvis + ((int64_t)b * nvis + rk) * d + i, g);
-                if (pid_ok) atomicAdd(dpos + pid * d + i, g);
+                // (the word / position table gradients are two deterministic sorted-run scatters issued by the host function)
+                if (!id_ok && rk >= 0 && rk < nvis && dvis) stf(dvis + ((int64_t)b * nvis + rk) * d + i, g);
             }
         }
     }
@@ -1002,9 +985,11 @@ extern "C" int db1_rl_assemble_fwd(const void* word_table, const void* pos_table
     return DB1_OK;
 }
 
+extern "C" int64_t db1_embed_scatter_add_workspace_bytes(int64_t n_tokens);
+extern "C" int64_t db1_rl_assemble_bwd_workspace_bytes(int B, int L) { return db1_embed_scatter_add_workspace_bytes((int64_t)B * L); }
 extern "C" int db1_rl_assemble_bwd(const void* dout, const int64_t* ids, const int64_t* position_id, float* dword_acc,
                                    float* dpos_acc, void* dvis, int B, int L, int d, int n_vis_per_row, int64_t n_word_rows, int64_t n_pos_rows,
-                                   int dt, void* stream) {
+                                   int dt, void* ws, int64_t ws_bytes, void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "rl_assemble_bwd: dtype");
     if (B <= 0 || L <= 0 || d <= 0 || L > 12288) DB1_FAIL(DB1_ERR_BAD_SHAPE, "rl_assemble_bwd: shape");
     hipStream_t st = (hipStream_t)stream;
@@ -1013,7 +998,9 @@ extern "C" int db1_rl_assemble_bwd(const void* dout, const int64_t* ids, const i
     DB1_DISPATCH_DT(dt, T, (rl_assemble_kernel<float, T, true><<<g, 256, 0, st>>>(nullptr, nullptr, nullptr, ids, position_id, nullptr,
                                                                                   (T*)const_cast<void*>(dout), dword_acc, dpos_acc, (T*)dvis, L, d, n_vis_per_row, n_word_rows, n_pos_rows)));
     DB1_CHECK_LAUNCH("rl_assemble_bwd");
-    return DB1_OK;
+    int rc = db1_scatter_add_impl(dout, ids, dword_acc, (int64_t)B * L, d, d, n_word_rows, dt, ws, ws_bytes, st, "rl_assemble_bwd (word table)");
+    if (rc) return rc;
+    return db1_scatter_add_impl(dout, position_id, dpos_acc, (int64_t)B * L, d, d, n_pos_rows, dt, ws, ws_bytes, st, "rl_assemble_bwd (position table)");
 }
 
 // =====================================================================================

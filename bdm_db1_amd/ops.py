@@ -316,7 +316,8 @@ def embed_gather(table, ids, out2d):
 def embed_scatter_add(dout2d, ids, dtable_acc):
     n, d = dout2d.shape
     assert ids.dtype == torch.int64 and dtable_acc.dtype == torch.float32 and dout2d.stride(1) == 1
-    lib.call("db1_embed_scatter_add_bwd", P(dout2d), P(ids), P(dtable_acc), n, d, dout2d.stride(0), dtable_acc.shape[0], dt_code(dout2d), stream())
+    ws, wsn = _ws("db1_embed_scatter_add_workspace_bytes", (n,), dout2d.device)
+    lib.call("db1_embed_scatter_add_bwd", P(dout2d), P(ids), P(dtable_acc), n, d, dout2d.stride(0), dtable_acc.shape[0], dt_code(dout2d), ws, wsn, stream())
 
 
 def rl_assemble_fwd(word_table, pos_table, vis, ids, position_id, labels, out):
@@ -329,8 +330,9 @@ def rl_assemble_fwd(word_table, pos_table, vis, ids, position_id, labels, out):
 def rl_assemble_bwd(dout, ids, position_id, dword_acc, dpos_acc, dvis):
     B, L, d = dout.shape
     nvis = 0 if dvis is None else dvis.shape[1]
+    ws, wsn = _ws("db1_rl_assemble_bwd_workspace_bytes", (B, L), dout.device)
     lib.call("db1_rl_assemble_bwd", P(dout), P(ids), P(position_id), P(dword_acc), P(dpos_acc), P(dvis), B, L, d, nvis,
-             dword_acc.shape[0], dpos_acc.shape[0], dt_code(dout), stream())
+             dword_acc.shape[0], dpos_acc.shape[0], dt_code(dout), ws, wsn, stream())
 
 
 def masked_ce_fwd(logits2d, labels, mask, lse, sums, V):

@@ -171,9 +171,12 @@ int db1_cast(const void* x, void* y, int64_t n, int dtIn, int dtOut, void* strea
  * out[t, :] = table[ids[t], :] (zeros where ids[t] < 0)   (transformer_xl.py:627-629, 665, 677, 686) */
 int db1_embed_gather_fwd(const void* table, const int64_t* ids, void* out, int64_t n_tokens, int d,
                          int64_t ld_out, int64_t n_table_rows, int dtTable, int dtOut, void* stream);
-/* dtable_acc[ids[t], :] += dout[t, :] (float32 atomics; ids outside [0, n_table_rows) are skipped, as they read zeros in the forward) */
+/* dtable_acc[ids[t], :] += dout[t, :]; ids outside [0, n_table_rows) are skipped, as they read zeros in the forward.  Deterministic: no
+ * float atomics -- the tokens are ordered by table row with a stable device radix sort and every table row is written by the one wave
+ * that adds its tokens in token order.  d and ld_dout: multiples of 16 bytes. */
+int64_t db1_embed_scatter_add_workspace_bytes(int64_t n_tokens);   /* sort keys / values + the sort's own scratch */
 int db1_embed_scatter_add_bwd(const void* dout, const int64_t* ids, float* dtable_acc, int64_t n_tokens, int d,
-                              int64_t ld_dout, int64_t n_table_rows, int dt, void* stream);
+                              int64_t ld_dout, int64_t n_table_rows, int dt, void* ws, int64_t ws_bytes, void* stream);
 /* RL sequence assembly (transformer_xl.py:621-660): rows with ids >= 0 take word_table[ids];
  * the k-th "-1" placeholder of row b takes vis[b, k, :]; then + pos_table[position_id].
  * labels (may be NULL): label == -1 -> 0 in place (:644-645).  Token ids >= n_word_rows / position ids outside [0, n_pos_rows)
@@ -181,9 +184,11 @@ int db1_embed_scatter_add_bwd(const void* dout, const int64_t* ids, float* dtabl
 int db1_rl_assemble_fwd(const void* word_table, const void* pos_table, const void* vis, const int64_t* ids,
                         const int64_t* position_id, int64_t* labels, void* out,
                         int B, int L, int d, int n_vis_per_row, int64_t n_word_rows, int64_t n_pos_rows, int dtTable, int dt, void* stream);
+int64_t db1_rl_assemble_bwd_workspace_bytes(int B, int L);   /* the two table gradients are sorted-run scatters (db1_embed_scatter_add_bwd) */
 int db1_rl_assemble_bwd(const void* dout, const int64_t* ids, const int64_t* position_id,
                         float* dword_acc, float* dpos_acc, void* dvis,
-                        int B, int L, int d, int n_vis_per_row, int64_t n_word_rows, int64_t n_pos_rows, int dt, void* stream);
+                        int B, int L, int d, int n_vis_per_row, int64_t n_word_rows, int64_t n_pos_rows, int dt,
+                        void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ masked cross-entropy on materialised logits
  * (transformer_xl.py:602-609). logits [T, ld] (columns >= V are padding); a label outside [0, V) adds no loss and gets no gradient

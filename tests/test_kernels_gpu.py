@@ -492,6 +492,18 @@ def test_embedding_gather_scatter(ops, dtype):
     g = np.zeros((V, d))
     np.add.at(g, ids[ids >= 0], dout[ids >= 0])
     close(acc, g, 1e-6, name="scatter")
+    # deterministic (sorted runs, no float atomics): many tokens per row, two runs, same bits; accumulates onto what is there
+    n2 = 20000
+    ids2 = torch.from_numpy(rng.integers(-1, 7, n2)).to(DEV)              # ~2 500 tokens per table row
+    dout2 = dev(rng.standard_normal((n2, d)), td)
+    acc_a, acc_b = torch.full((V, d), 0.5, device=DEV), torch.full((V, d), 0.5, device=DEV)
+    ops.embed_scatter_add(dout2, ids2, acc_a)
+    ops.embed_scatter_add(dout2, ids2, acc_b)
+    assert torch.equal(acc_a, acc_b)
+    ref2 = np.full((V, d), 0.5)
+    idn = ids2.cpu().numpy()
+    np.add.at(ref2, idn[idn >= 0], dout2.double().cpu().numpy()[idn >= 0])
+    close(acc_a, ref2, 2e-5, name="scatter long runs")
 
 
 def test_out_of_table_ids_and_labels_touch_nothing(ops):

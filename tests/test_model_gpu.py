@@ -264,6 +264,26 @@ def test_fused_head_loss_engine_matches_materialised_logits():
         assert rel_err(res[True][1][k], v) < 1e-4, k
 
 
+def test_bf16_text_step_is_bit_reproducible():
+    """every reduction on the bf16 text path is order-fixed (split-K partials, the register-resident LayerNorm's parameter sums, bias
+    column sums, the CE loss, and -- since round 2 -- the embedding-table gradient, which used float atomics): two runs of forward +
+    backward on the same inputs give the same bits.  (d = 512: the generic LayerNorm kernels of the fp32 parity path still use atomics.)"""
+    from bdm_db1_amd import TransformerXL
+    cfg = dict(case_cfg("small_window"), n_embed=512, n_head=4, n_position=64, mem_len=64)
+    params = make_params(cfg, 5)
+    tasks = make_batch("small_window", cfg, 5)
+    runs = []
+    for _ in range(2):
+        model = TransformerXL(SimpleNamespace(**cfg), compute_dtype=torch.bfloat16)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+        logits, loss = model(to_inputs(tasks))
+        model.backward()
+        runs.append((float(loss), logits.clone(), model.arena.grad.clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    bad = [n for n in model.arena.offsets if not torch.equal(model.arena.view(runs[0][2], n), model.arena.view(runs[1][2], n))]
+    assert not bad, bad
+
+
 def test_state_dict_names_match_reference():
     cfg, params, gold, model, oracle, seed = build("small_mixed")
     names = set(model.state_dict().keys())
