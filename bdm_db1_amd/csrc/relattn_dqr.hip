@@ -27,6 +27,12 @@ struct DqrArgs {
     const bf16_t* dT; const bf16_t* Rt; bf16_t* out;
     int B, L, H, wph;              // wph = workgroups per head
     int64_t o_rs, o_bs;            // row / batch strides of out (elements); head h at + h * 128
+    // fused mode (part != nullptr): out holds dq_k = the (q+u).k branch on entry and dq = dq_k + dq_r on exit; the column sums of dq_k
+    // and of dq_r over this workgroup's rows go to part[0][j][h*128 + c] / part[1][j][h*128 + c] (j = workgroup of the head; a reduce
+    // kernel adds the rows of that table in order).  The 64 x 128 dq_k tile of an item travels through the SAME LDS-DMA stream as the
+    // dT tiles -- one more tile per item -- so the counted vmcnt waits of the stream stay valid (plain global loads in the epilogue sit in
+    // the same queue and broke them: measured and reverted before this version).
+    float* part;
 };
 
 __device__ __forceinline__ int dqr_swz(int row) { return ((((row & 7) ^ ((row & 8) >> 1))) << 1) | ((row >> 3) & 1); }  // natural-order row fragments
@@ -65,21 +71,34 @@ __global__ __launch_bounds__(512, 1) void relattn_dqr_kernel(DqrArgs p) {
     // the stream of tiles: items t = j, j + wph, ... (t -> batch b = t / NT, row tile (t + b) % NT: every workgroup sees every row tile
     // equally often), and inside an item the k-tiles 0 .. (i0 + 63) / 128
     const int n_items = p.B * NT;
-    struct Cur { int t, kt, nk, b, i0; };
+    const int fused = p.part != nullptr ? 1 : 0;
+    struct Cur { int t, kt, nk, b, i0; };   // nk = tiles of the item in the stream: its dT k-tiles (+ the dq_k tile in fused mode, last)
     auto item_of = [&](int t, Cur& c) __attribute__((always_inline)) {
-        c.t = t; c.kt = 0; c.b = t / NT; c.i0 = ((t + c.b) % NT) * DQR_ROWS; c.nk = (c.i0 + DQR_ROWS - 1) / DQR_KT + 1;
+        c.t = t; c.kt = 0; c.b = t / NT; c.i0 = ((t + c.b) % NT) * DQR_ROWS; c.nk = (c.i0 + DQR_ROWS - 1) / DQR_KT + 1 + fused;
     };
     auto advance = [&](Cur& c) __attribute__((always_inline)) {  // next tile of the stream (c.t >= n_items: past the end)
         if (++c.kt >= c.nk) { const int t = c.t + p.wph; if (t < n_items) item_of(t, c); else { c.t = t; c.kt = 0; c.nk = 1; } }
     };
     auto stage = [&](const Cur& c, int st) __attribute__((always_inline)) {
-        const bf16_t* src = p.dT + (((int64_t)h * p.B + c.b) * L + c.i0 + srow) * L + c.kt * DQR_KT;
         const unsigned dst = lds0 + st * DQR_TILE_BYTES + wave * 2048;
-        dqr_glds(src + schunk0, dst);
-        dqr_glds(src + (int64_t)4 * L + schunk1, dst + 1024);
+        if (fused && c.kt == c.nk - 1) {   // the item's dq_k rows (128 columns of head h), same 64 x 256-byte image as a dT tile
+            const bf16_t* src = p.out + (int64_t)c.b * p.o_bs + (int64_t)(c.i0 + srow) * p.o_rs + h * 128;
+            dqr_glds(src + schunk0, dst);
+            dqr_glds(src + (int64_t)4 * p.o_rs + schunk1, dst + 1024);
+        } else {
+            const bf16_t* src = p.dT + (((int64_t)h * p.B + c.b) * L + c.i0 + srow) * L + c.kt * DQR_KT;
+            dqr_glds(src + schunk0, dst);
+            dqr_glds(src + (int64_t)4 * L + schunk1, dst + 1024);
+        }
     };
     Cur cs, cc;                      // staging cursor (DQR_STAGES - 1 tiles ahead), compute cursor
-    if (j >= n_items) return;
+    if (j >= n_items) {              // (more workgroups than items: never at the model's sizes) -- its partial rows must still be defined
+        if (p.part && tid < 128) {
+            p.part[(int64_t)j * p.H * 128 + h * 128 + tid] = 0.f;
+            p.part[((int64_t)p.wph + j) * p.H * 128 + h * 128 + tid] = 0.f;
+        }
+        return;
+    }
     item_of(j, cs);
     cc = cs;
     int issued = 0;
@@ -90,6 +109,10 @@ __global__ __launch_bounds__(512, 1) void relattn_dqr_kernel(DqrArgs p) {
     dqr_f32x4 acc[4];
 #pragma unroll
     for (int rt = 0; rt < 4; rt++) acc[rt] = (dqr_f32x4){0.f, 0.f, 0.f, 0.f};
+    float sum_k[4] = {0.f, 0.f, 0.f, 0.f}, sum_r[4] = {0.f, 0.f, 0.f, 0.f};   // fused mode: column sums over this lane's rows (all items)
+    // fused mode: this lane's 4 dq_k values of row 16 rt + a inside a staged dq_k tile: columns 16 wave + 4 g .. +3 = chunk 2 wave + (g >> 1)
+    unsigned qaddr = lds0 + a * 256 + (((2 * wave + (g >> 1)) ^ dqr_swz(a)) << 4) + (g & 1) * 8;
+    asm volatile("" : "+v"(qaddr));
     int st = 0;  // stage of the compute cursor's tile
     for (; cc.t < n_items;) {
         // the tile of the compute cursor must have landed: all but the (issued - 1) pieces pairs issued after it
@@ -108,22 +131,49 @@ __global__ __launch_bounds__(512, 1) void relattn_dqr_kernel(DqrArgs p) {
                 acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rfr[(KT) * 4 + ks], bf, acc[rt], 0, 0, 0);             \
             }                                                                                                            \
         }
-        switch (cc.kt) {
-            case 0: DQR_TILE(0) break; case 1: DQR_TILE(1) break; case 2: DQR_TILE(2) break; case 3: DQR_TILE(3) break;
-            case 4: DQR_TILE(4) break; case 5: DQR_TILE(5) break; case 6: DQR_TILE(6) break; default: DQR_TILE(7) break;
+        const bool dq_tile = fused && cc.kt == cc.nk - 1;
+        if (!dq_tile) {
+            switch (cc.kt) {
+                case 0: DQR_TILE(0) break; case 1: DQR_TILE(1) break; case 2: DQR_TILE(2) break; case 3: DQR_TILE(3) break;
+                case 4: DQR_TILE(4) break; case 5: DQR_TILE(5) break; case 6: DQR_TILE(6) break; default: DQR_TILE(7) break;
+            }
         }
         if (cc.kt == cc.nk - 1) {    // item done: out[b][i0 + 16 rt + a][h][16 wave + 4 g .. +3]
 #pragma unroll
             for (int rt = 0; rt < 4; rt++) {
+                float v[4] = {acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]};
+                if (fused) {         // dq = dq_k + dq_r (one rounding), du += colsum(dq_k), dv_bias += colsum(dq_r)
+                    typedef __attribute__((ext_vector_type(2))) unsigned dqr_u32x2;
+                    const dqr_u32x2 qk = *(__attribute__((address_space(3))) const dqr_u32x2*)(size_t)(qaddr + sb + rt * 4096);
+                    const float k0 = __uint_as_float(qk[0] << 16), k1 = __uint_as_float(qk[0] & 0xffff0000u);
+                    const float k2 = __uint_as_float(qk[1] << 16), k3 = __uint_as_float(qk[1] & 0xffff0000u);
+                    sum_k[0] += k0; sum_k[1] += k1; sum_k[2] += k2; sum_k[3] += k3;
+                    sum_r[0] += v[0]; sum_r[1] += v[1]; sum_r[2] += v[2]; sum_r[3] += v[3];
+                    v[0] += k0; v[1] += k1; v[2] += k2; v[3] += k3;
+                }
                 uint2 o;
-                o.x = f2bf_pk(acc[rt][0], acc[rt][1]);
-                o.y = f2bf_pk(acc[rt][2], acc[rt][3]);
+                o.x = f2bf_pk(v[0], v[1]);
+                o.y = f2bf_pk(v[2], v[3]);
                 *reinterpret_cast<uint2*>(p.out + (int64_t)cc.b * p.o_bs + (int64_t)(cc.i0 + 16 * rt + a) * p.o_rs + h * 128 + 16 * wave + 4 * g) = o;
                 acc[rt] = (dqr_f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
         advance(cc);
         st = (st + 1) % DQR_STAGES;
+    }
+    if (fused) {   // this workgroup's column sums: over the 16 row lanes (fixed butterfly order), then one row of the partial table per sum
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { sum_k[c] += __shfl_xor(sum_k[c], o, 64); sum_r[c] += __shfl_xor(sum_r[c], o, 64); }
+        }
+        if (a == 0) {
+            const int64_t HD = (int64_t)p.H * 128, col = (int64_t)h * 128 + 16 * wave + 4 * g;
+            float* pk = p.part + (int64_t)j * HD + col;
+            float* pr = p.part + ((int64_t)p.wph + j) * HD + col;
+#pragma unroll
+            for (int c = 0; c < 4; c++) { pk[c] = sum_k[c]; pr[c] = sum_r[c]; }
+        }
     }
 }
 
@@ -141,12 +191,39 @@ extern "C" int db1_relattn_dqr_supported(int B, int L, int H, int D, int dt) {
     return (dt == DB1_BF16 && D == 128 && B > 0 && H > 0 && H <= 256 && L >= 128 && (L % 128) == 0 && L <= DQR_MAX_L) ? 1 : 0;
 }
 
-extern "C" int64_t db1_relattn_dqr_workspace_bytes(int L, int H) { return (int64_t)H * 128 * L * (int64_t)sizeof(bf16_t); }  // R^T
+static inline int dqr_wph(int H) { return 256 / H > 0 ? 256 / H : 1; }
+static inline int64_t dqr_rt_bytes(int L, int H) { return (((int64_t)H * 128 * L * (int64_t)sizeof(bf16_t)) + 255) & ~(int64_t)255; }
+// R^T, and (fused entry point) the per-workgroup column-sum partials [2][wph][H * 128]
+extern "C" int64_t db1_relattn_dqr_workspace_bytes(int L, int H) { return dqr_rt_bytes(L, H) + 2 * (int64_t)dqr_wph(H) * H * 128 * (int64_t)sizeof(float); }
 
 /* dq_r[b, i, h, :] = sum_dist dT[h, b, i, dist] * R[dist, h, :]; dT [H, B, L, L] bf16 (zero for dist > i), R [L, H, 128] with row stride r_rs,
  * out [B, L, H, 128] with row / batch strides (elements) */
+__global__ __launch_bounds__(256) void dqr_part_reduce_kernel(const float* __restrict__ part, float* acc, int n, int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float t = 0.f;
+    for (int j = 0; j < n; j++) t += part[(int64_t)j * cols + c];   // workgroup order: deterministic
+    acc[c] += t;
+}
+
+static int dqr_run(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride, float* du_acc,
+                   float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream);
+
 extern "C" int db1_relattn_dqr(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride,
                                int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream) {
+    return dqr_run(dT, R, r_row_stride, out, out_row_stride, out_batch_stride, nullptr, nullptr, B, L, H, D, ws, ws_bytes, stream);
+}
+/* the same stream, finishing the query gradient: dq[b,i,h,:] = dq_k + dq_r in place over dq_k (one rounding), du_acc[h*128 + c] += sum_{b,i}
+ * dq_k, dv_acc[h*128 + c] += sum_{b,i} dq_r (float32; per-workgroup partials added in a fixed order) */
+extern "C" int db1_relattn_dqr_fused(const void* dT, const void* R, int64_t r_row_stride, void* dq, int64_t dq_row_stride, int64_t dq_batch_stride,
+                                     float* du_acc, float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream) {
+    if (!du_acc || !dv_acc) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_dqr_fused: null accumulator");
+    if ((dq_row_stride % 8) || (dq_batch_stride % 8)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_dqr_fused: dq strides must be multiples of 8 elements (16-byte LDS-DMA pieces)");
+    return dqr_run(dT, R, r_row_stride, dq, dq_row_stride, dq_batch_stride, du_acc, dv_acc, B, L, H, D, ws, ws_bytes, stream);
+}
+
+static int dqr_run(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride, float* du_acc,
+                   float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream) {
     if (!db1_relattn_dqr_supported(B, L, H, D, DB1_BF16)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_dqr: needs bf16, d_head = 128, L %% 128 == 0, L <= 1024 (got L=%d D=%d)", L, D);
     if (!dT || !R || !out) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_dqr: null buffer");
     if (!db1_aligned16(dT) || !db1_aligned16(out) || (out_row_stride % 4) || (out_batch_stride % 4)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_dqr: alignment");
@@ -157,11 +234,18 @@ extern "C" int db1_relattn_dqr(const void* dT, const void* R, int64_t r_row_stri
     DB1_CHECK_LAUNCH("relattn_dqr transpose");
     DqrArgs a;
     a.dT = (const bf16_t*)dT; a.Rt = Rt; a.out = (bf16_t*)out; a.B = B; a.L = L; a.H = H;
-    a.wph = 256 / H > 0 ? 256 / H : 1;
+    a.wph = dqr_wph(H);
     a.o_rs = out_row_stride; a.o_bs = out_batch_stride;
+    a.part = du_acc ? (float*)((char*)ws + dqr_rt_bytes(L, H)) : nullptr;
     static Db1PerDeviceOnce attr_once;
     attr_once.run([] { hipFuncSetAttribute((const void*)relattn_dqr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQR_STAGES * DQR_TILE_BYTES); });
     relattn_dqr_kernel<<<dim3((unsigned)(H * a.wph)), 512, DQR_STAGES * DQR_TILE_BYTES, st>>>(a);
     DB1_CHECK_LAUNCH("relattn_dqr");
+    if (du_acc) {
+        const int cols = H * 128;
+        dqr_part_reduce_kernel<<<(cols + 255) / 256, 256, 0, st>>>(a.part, du_acc, a.wph, cols);
+        dqr_part_reduce_kernel<<<(cols + 255) / 256, 256, 0, st>>>(a.part + (int64_t)a.wph * cols, dv_acc, a.wph, cols);
+        DB1_CHECK_LAUNCH("relattn_dqr reduce");
+    }
     return DB1_OK;
 }

@@ -772,18 +772,21 @@ class TransformerXL(nn.Module):
             ops.gemm_batched(dS, qkv5[:, :, 1].permute(2, 0, 1, 3), dqkv5[:, :, 0].permute(2, 0, 1, 3))                  # dq_k
             ops.gemm_batched(dS.transpose(2, 3), qu.permute(2, 0, 1, 3), dqkv5[:, :, 1].permute(2, 0, 1, 3))             # dK
         dq2d = dqkv.view(B * L, 3 * d)[:, :d]
-        dqv = self._new(B, L, H, D)
         tri = c.flash and self.use_flash_bwd  # the fused backward's dT is zero above the causal diagonal (dist > i): skip those k-tiles
-        if tri and nd == L and ops.relattn_dqr_supported(B, L, H, D, self.compute_dtype):
-            ops.relattn_dqr(dT, R, dqv)                                                                                   # dq_r, dT streamed once
+        fused_dq = tri and nd == L and ops.relattn_dqr_supported(B, L, H, D, self.compute_dtype)
+        if fused_dq:
+            # dq_r streamed out of dT once, added onto dq_k in the same kernel's epilogue together with the u / v gradients' column sums
+            ops.relattn_dqr_fused(dT, R, dqkv5[:, :, 0], self._bias_grad("r_w_bias", i).view(-1), self._bias_grad("r_r_bias", i).view(-1))
         else:
+            dqv = self._new(B, L, H, D)
             ops.gemm_batched(dT, R.view(nd, H, D).permute(1, 0, 2).unsqueeze(1).expand(H, B, nd, D), dqv.permute(2, 0, 1, 3),
                              tri=(1, 0) if tri else (0, 0))                                                               # dq_r
         dR = self._new(nd, d)
         ops.gemm_batched(dT.view(H, B * L, nd).transpose(1, 2).unsqueeze(1), qv.view(B * L, H, D).permute(1, 0, 2).unsqueeze(1),
                          dR.view(nd, H, D).permute(1, 0, 2).unsqueeze(1), tri=(2, L) if tri else (0, 0))
-        # dq = dq_k + dq_r, du = colsum(dq_k), dv_bias = colsum(dq_r): one pass over the two matrices
-        ops.add2d_colsums(dqv.view(B * L, d), dq2d, dq2d, self._bias_grad("r_r_bias", i).view(-1), self._bias_grad("r_w_bias", i).view(-1))
+        if not fused_dq:
+            # dq = dq_k + dq_r, du = colsum(dq_k), dv_bias = colsum(dq_r): one pass over the two matrices
+            ops.add2d_colsums(dqv.view(B * L, d), dq2d, dq2d, self._bias_grad("r_r_bias", i).view(-1), self._bias_grad("r_w_bias", i).view(-1))
         return dqkv, dR
 
     # ------------------------------------------------------------------ one decoder layer (post-LN; transformer_xl.py:112-353)

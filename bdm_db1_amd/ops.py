@@ -230,6 +230,20 @@ def dropout(x, y, drop):
     lib.call("db1_dropout", P(x), P(y), x.numel(), float(p), int(seed), int(site), int(step), dt_code(x), stream())
 
 
+def relattn_dqr_fused(dT, R, dq, du_acc, dv_acc):
+    """dq[b,i,h,:] += sum_dist dT[h,b,i,dist] R[dist,h,:] (dq: a [B,L,H,D] view, e.g. the q slot of dqkv), du_acc += colsum of the incoming dq
+    (the (q+u).k branch), dv_acc += colsum of the added term"""
+    H, B, L, _ = dT.shape
+    D = dq.shape[-1]
+    assert dT.is_contiguous() and R.stride(1) == 1 and dq.stride(3) == 1 and dq.stride(2) == D and dq.shape == (B, L, H, D)
+    assert du_acc.dtype == torch.float32 and dv_acc.dtype == torch.float32 and du_acc.numel() == H * D == dv_acc.numel()
+    ws, wsn = _ws("db1_relattn_dqr_workspace_bytes", (L, H), dT.device)
+    # algorithmic bytes: the causal half of dT read once, dq read and written
+    _timed("relattn_dqr", 2.0 * (H * B * L * (L + 1) / 2 + 2 * dq.numel()),
+           lambda: lib.call("db1_relattn_dqr_fused", P(dT), P(R), R.stride(0), P(dq), dq.stride(1), dq.stride(0), P(du_acc), P(dv_acc),
+                            B, L, H, D, ws, wsn, stream()))
+
+
 def layernorm_residual_fwd(x, r, alpha, gamma, beta, y, s_out, mean, rstd, eps, drop=NO_DROP):
     rows, d = x.numel() // x.shape[-1], x.shape[-1]
     nstreams = 2 + (r is not None) + (s_out is not None)   # x [, r] in; y [, s] out

@@ -264,9 +264,16 @@ int db1_relattn_flash_bwd(const void* qu, const void* qv, const void* k, const v
  * stream over dT with R stationary in registers: dT [H,B,L,L] bf16 (zero for dist > i), R [L, H*128] bf16 with row stride r_row_stride,
  * out [B,L,H,128] bf16 with row / batch strides in elements.  Same result as db1_gemm_strided_tri on the same operands. */
 int db1_relattn_dqr_supported(int B, int L, int H, int D, int dt);
-int64_t db1_relattn_dqr_workspace_bytes(int L, int H);   /* the transposed copy of R the stream kernel keeps in registers */
+int64_t db1_relattn_dqr_workspace_bytes(int L, int H);   /* the transposed copy of R the stream kernel keeps in registers (+ the fused entry point's column-sum partials) */
 int db1_relattn_dqr(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride,
                     int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream);
+
+/* The same stream with the rest of the query gradient in its epilogue (one pass less over two [B, L, H, 128] tensors):
+ *   dq[b,i,h,:] = dq[b,i,h,:] + dq_r          (dq holds the (q+u).k branch from db1_relattn_flash_bwd on entry; one rounding)
+ *   du_acc[h*128 + c] += sum_{b,i} dq_k[b,i,h,c]   (r_w_bias gradient),   dv_acc[h*128 + c] += sum_{b,i} dq_r[b,i,h,c]   (r_r_bias gradient)
+ * float32 accumulators; the per-workgroup partial sums are added in a fixed order (deterministic). */
+int db1_relattn_dqr_fused(const void* dT, const void* R, int64_t r_row_stride, void* dq, int64_t dq_row_stride, int64_t dq_batch_stride,
+                          float* du_acc, float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ image-patch embedder pieces
  * (src/tokenizer/vision_embedding.py:65-86).  pixels [N_img, C, Himg, Wimg] -> normalised patches

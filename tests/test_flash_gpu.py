@@ -204,3 +204,20 @@ def test_dq_r_stream_kernel_matches_the_batched_gemm(B, L, H):
     ref = torch.einsum("hbik,khd->bihd", dT.float(), R.view(L, H, D).float())
     err = float((out.float() - ref).abs().max() / ref.abs().max())
     assert err < 6e-3, err
+    # fused epilogue: dq = dq_k + dq_r in place over the q slot of a packed [B, L, 3, H, D] gradient (row stride 3 H D, like the model's
+    # dqkv), with the column sums of both terms accumulated onto existing float32 accumulators (the u / v bias gradients)
+    dqkv = (torch.randn(B, L, 3, H, D, generator=g) * 0.3).to(torch.bfloat16).to(DEV)
+    dq_k = dqkv[:, :, 0].float().clone()
+    others = dqkv[:, :, 1:].clone()
+    du, dv = torch.full((H * D,), 0.25, device=DEV), torch.full((H * D,), -0.5, device=DEV)
+    ops.relattn_dqr_fused(dT, R, dqkv[:, :, 0], du, dv)
+    want = dq_k + ref
+    assert float((dqkv[:, :, 0].float() - want).abs().max() / want.abs().max()) < 6e-3
+    assert torch.equal(dqkv[:, :, 1:], others)                       # the k / v slots are untouched
+    su, sv = dq_k.sum((0, 1)).reshape(-1) + 0.25, ref.sum((0, 1)).reshape(-1) - 0.5
+    assert float((du - su).abs().max() / su.abs().max()) < 1e-4 and float((dv - sv).abs().max() / sv.abs().max()) < 2e-3
+    # deterministic: a second run on the same inputs gives the same bits
+    dqkv2 = torch.cat([dq_k.to(torch.bfloat16).unsqueeze(2), others], dim=2).contiguous()
+    du2, dv2 = torch.full((H * D,), 0.25, device=DEV), torch.full((H * D,), -0.5, device=DEV)
+    ops.relattn_dqr_fused(dT, R, dqkv2[:, :, 0], du2, dv2)
+    assert torch.equal(dqkv2[:, :, 0], dqkv[:, :, 0]) and torch.equal(du2, du) and torch.equal(dv2, dv)
