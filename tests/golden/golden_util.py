@@ -254,3 +254,27 @@ def caption_samples(seed: int = 41, eos: int = 0):
                         img=torch.from_numpy(rng.standard_normal((3, 32, 32)).astype(np.float32)), ques_id=7000 + k, img_id=200 + k,
                         prompt=np.array([9, 10, 11], np.int32), ques_len=ql))
     return ic, vqa
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# action decoding (get_action.npz): the call sequences both sides replay
+# ---------------------------------------------------------------------------------------------------------------------
+GET_ACTION_CASES = {
+    # name: (use memory, discrete action, obs_length, action_length, steps, prompt strategy, use_prompt, fixed prompt length)
+    "mem_continuous": (True, False, 4, 2, 3, "moving_prompt", False, 0),
+    "mem_discrete_masked": (True, True, 3, 1, 3, "moving_prompt", False, 0),
+    "window_continuous": (False, False, 4, 2, 4, "moving_prompt", False, 0),
+    "window_fixed_prompt": (False, False, 4, 2, 4, "fixed_prompt", True, 7),
+}
+
+
+def get_action_inputs(name: str, cfg: dict, seed: int = 61):
+    """per environment step: the new observation tokens (continuous-bin ids) the episode loop would append, + the separator"""
+    mem, disc, ol, al, steps, strat, use_prompt, lfp = GET_ACTION_CASES[name]
+    rng = np.random.default_rng(seed + len(name))
+    tv, nb = cfg["text_vocab_size"], cfg["num_continuous_bin"]
+    sep = tv + nb + (0 if cfg["overlap_with_text"] else cfg["num_discrete_values"])
+    obs = [np.concatenate([tv + rng.integers(0, nb, ol), [sep]]).astype(np.int64) for _ in range(steps)]
+    prompt = np.concatenate([tv + rng.integers(0, nb, ol), [sep], tv + rng.integers(0, nb, al)]).astype(np.int64) if lfp else None
+    masks = [None, np.array([1, 0, 1, 0, 0, 1], np.float64), None] if name == "mem_discrete_masked" else [None] * steps
+    return obs, prompt, masks

@@ -333,6 +333,52 @@ def gen_caption_vqa():
     return out
 
 
+def gen_get_action():
+    """get_action (src/evaluation/evaluate_rl.py:157-266) of the reference, on the reference model, replaying an episode's call pattern:
+    with Transformer-XL memory (observation tokens, then one token per call, then the memorising call) and without (sliding window,
+    fixed prompt).  deepspeed / gym / d4rl / tree are import-time dependencies of that module only: stubbed."""
+    import importlib.machinery
+    from golden_util import GET_ACTION_CASES, get_action_inputs
+    gym = types.ModuleType("gym")
+    gym.Wrapper, gym.Env = object, object
+    spaces = types.ModuleType("gym.spaces")
+    spaces.Discrete = type("Discrete", (), {"__init__": lambda self, n: setattr(self, "n", n)})
+    spaces.Box = type("Box", (), {})
+    gym.spaces = spaces
+    sys.modules["gym"], sys.modules["gym.spaces"] = gym, spaces
+    for n in ("d4rl", "deepspeed"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["tree"] = _tree_stub()
+    sys.modules["deepspeed"].DeepSpeedEngine = object
+    for n in ("d4rl", "deepspeed", "tree", "gym"):
+        sys.modules[n].__spec__ = importlib.machinery.ModuleSpec(n, None)
+    from src.evaluation import evaluate_rl as E
+    from src.tokenizer.scalar_tokenizer import ContinuousScalarTokenizer
+    name = "small_mems"
+    cfg = case_cfg(name)
+    params = make_params(cfg, 100 + list(CASES).index(name))
+    m = build_ref_model(cfg, params)
+    m.device = torch.device("cpu")
+    tok = ContinuousScalarTokenizer(cfg["num_continuous_bin"])
+    out = {}
+    for case, (mem, disc, ol, al, steps, strat, use_prompt, lfp) in GET_ACTION_CASES.items():
+        args = SimpleNamespace(overlap_with_text=cfg["overlap_with_text"], text_vocab_size=cfg["text_vocab_size"], num_discrete_values=cfg["num_discrete_values"],
+                               n_position=cfg["n_position"], use_prompt=use_prompt)
+        obs, prompt, masks = get_action_inputs(case, cfg)
+        space = spaces.Discrete(6) if disc else None
+        memory = m.init_mem(1) if mem else None
+        seq = torch.from_numpy(prompt) if prompt is not None else torch.zeros(0, dtype=torch.long)
+        with torch.no_grad():
+            for st in range(steps):
+                seq = torch.from_numpy(obs[st]) if mem else torch.cat([seq, torch.from_numpy(obs[st])])
+                act, (seq, _), memory = E.get_action(args, m, seq, None, tok, lfp, 0, ol, al, disc, space, memory, prompt_strategy=strat, action_mask=masks[st])
+                out[f"{case}/{st}/act"] = np.asarray(act, dtype=np.float64)
+                out[f"{case}/{st}/seq"] = seq.numpy().copy()
+                if mem:
+                    out[f"{case}/{st}/mem_last"] = memory[-1].numpy().copy()
+    return out
+
+
 SAMPLER_CASES = [  # (total, consumed, micro_batch, rank, world)
     (100, 0, 4, 0, 2), (100, 0, 4, 1, 2), (64, 16, 2, 3, 4), (37, 0, 5, 0, 1), (1000, 256, 8, 5, 8), (96, 192, 4, 1, 2),
 ]
@@ -425,6 +471,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "data":
         np.savez_compressed(os.path.join(HERE, "data_ingest.npz"), **gen_data_ingest())
         print("wrote data_ingest + data_fixture.idx/.bin")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "get_action":
+        np.savez_compressed(os.path.join(HERE, "get_action.npz"), **gen_get_action())
+        print("wrote get_action")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "packers":
         np.savez_compressed(os.path.join(HERE, "rl_dataset.npz"), **gen_rl_dataset())

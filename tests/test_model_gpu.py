@@ -284,6 +284,73 @@ def test_bf16_text_step_is_bit_reproducible():
     assert not bad, bad
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_get_action_replays_the_references_episode_calls(dtype):
+    """bdm_db1_amd.evaluation.get_action (evaluate_rl.py:157-266) on the HIP model against the REFERENCE's get_action on the reference
+    model (tests/golden/get_action.npz): memory mode (observation tokens, one token per call, the memorising call; also a discrete
+    action space with an environment action mask) and window mode (sliding window, fixed prompt).  fp32: actions, token windows and
+    the last layer's memory must match; bf16 (d_head 32: the materialised path): the same actions and windows."""
+    from golden_util import GET_ACTION_CASES, get_action_inputs
+    from bdm_db1_amd.evaluation import get_action
+    from bdm_db1_amd.tokenizer import ContinuousScalarTokenizer
+    gold = dict(np.load(os.path.join(G, "get_action.npz")))
+    cfg, params, _, model, oracle, seed = build("small_mems", compute_dtype=dtype)
+    tok = ContinuousScalarTokenizer(cfg["num_continuous_bin"])
+    for case, (mem, disc, ol, al, steps, strat, use_prompt, lfp) in GET_ACTION_CASES.items():
+        args = SimpleNamespace(overlap_with_text=cfg["overlap_with_text"], text_vocab_size=cfg["text_vocab_size"], num_discrete_values=cfg["num_discrete_values"],
+                               n_position=cfg["n_position"], use_prompt=use_prompt)
+        obs, prompt, masks = get_action_inputs(case, cfg)
+        space = SimpleNamespace(n=6) if disc else None
+        memory = model.init_mem(1) if mem else None
+        seq = torch.from_numpy(prompt) if prompt is not None else torch.zeros(0, dtype=torch.long)
+        with torch.no_grad():
+            for st in range(steps):
+                seq = torch.from_numpy(obs[st]) if mem else torch.cat([seq, torch.from_numpy(obs[st])])
+                act, (seq, vis), memory = get_action(args, model, seq, None, tok, lfp, 0, ol, al, disc, space, memory, prompt_strategy=strat, action_mask=masks[st])
+                assert np.array_equal(np.asarray(act, np.float64), gold[f"{case}/{st}/act"]), (case, st, act)
+                assert seq.device.type == "cpu" and np.array_equal(seq.numpy(), gold[f"{case}/{st}/seq"]), (case, st)
+                if mem:
+                    assert rel_err(memory[-1], gold[f"{case}/{st}/mem_last"]) < (1e-4 if dtype == torch.float32 else 3e-2), (case, st)
+
+
+def test_training_procedure_with_the_references_surface(tmp_path):
+    """bdm_db1_amd.train_utils.train (the reference's train / train_step / forward_and_backward_step, src/train_utils/train.py:32-243):
+    4 optimizer steps of 2 micro-steps each from an iterator of batches, losses returned per micro-step, TensorBoard-style writer calls,
+    validation loss without gradient side effects, a checkpoint at the save interval that a fresh engine resumes from"""
+    from bdm_db1_amd import initialize
+    from bdm_db1_amd.train_utils import train, evaluate_loss
+    name = "small_window"
+    cfg, params, gold, model, oracle, seed = build(name)
+    args = SimpleNamespace(lr=2e-3, weight_decay=0.01, clip_grad=1.0, optimizer="adamw", keep_logits=False, gradient_accumulation_steps=2,
+                           iteration=0, train_iters=4, eval_interval=2, eval_iters=1, save_dir=str(tmp_path), save_interval=2)
+    engine, _, _, _ = initialize(args, model)
+    tasks = make_batch(name, cfg, seed)
+    calls = {"train": 0, "valid": 0}
+
+    def batches(kind):
+        while True:
+            calls[kind] += 1
+            yield to_inputs(tasks)
+
+    get_batch = lambda a, it: next(it)
+    log = []
+    writer = SimpleNamespace(add_scalar=lambda tag, v, it: log.append((tag, float(v), it)))
+    first = evaluate_loss(args, engine, batches("valid"), get_batch)
+    assert abs(first - float(gold["loss"])) < 1e-4 and engine.global_steps == 0 and float(model.arena.grad.abs().max()) == 0.0
+    done = train(args, engine, batches("train"), batches("valid"), get_batch, sm_writer=writer)
+    assert done == 4 and args.iteration == 3 and engine.global_steps == 4 and calls["train"] == 8
+    tr = [v for tag, v, it in log if tag == "Train loss"]
+    assert len(tr) == 4 and tr[-1] < tr[0] - 0.05                      # the same batch four times: the loss goes down
+    assert [it for tag, v, it in log if tag == "Valid loss"] == [0, 2, 3]
+    assert (tmp_path / "latest").read_text().strip() == "latest_model"
+    cfg2, _, _, model2, _, _ = build(name)
+    engine2, _, _, _ = initialize(args, model2)
+    path, client = engine2.load_checkpoint(str(tmp_path), None)
+    assert client["iteration"] == 4 and engine2.global_steps == 4
+    for k, v in model.state_dict().items():
+        assert torch.equal(model2.state_dict()[k], v), k
+
+
 def test_state_dict_names_match_reference():
     cfg, params, gold, model, oracle, seed = build("small_mixed")
     names = set(model.state_dict().keys())
