@@ -8,6 +8,12 @@ def __getattr__(name):  # the token store / index builders / sample builders nee
     if name in ("RLFullDataset", "RLDataset"):
         import importlib
         return getattr(importlib.import_module(".rl_dataset", __name__), name)
+    if name in ("GPTDataset",):
+        import importlib
+        return getattr(importlib.import_module(".gpt_dataset", __name__), name)
+    if name in ("BlendableDataset",):
+        import importlib
+        return getattr(importlib.import_module(".blendable_dataset", __name__), name)
     if name in ("ICDataset", "VQADataset", "get_ltor_masks_and_position_ids", "get_loss_mask_vqa", "fit_caption_length"):
         import importlib
         return getattr(importlib.import_module(".coco_token_dataset", __name__), name)

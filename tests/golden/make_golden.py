@@ -333,6 +333,59 @@ def gen_caption_vqa():
     return out
 
 
+def gen_gpt_dataset():
+    """GPTDataset (src/data/gpt_dataset.py:86-180) on the fixture store written by the reference's builder, its index arrays from the
+    reference's own _build_doc_idx / _build_shuffle_idx / _num_epochs and compiled helpers.build_sample_idx (the wrapper
+    _build_index_mappings needs a CUDA tensor and an initialised process group for its barrier: its body is replayed here), and
+    BlendableDataset (blendable_dataset.py:30-72)."""
+    if not hasattr(np, "float"):
+        np.float = np.float64
+    from src.data import indexed_dataset as ref_idx
+    from src.data import gpt_dataset as G
+    from src.data.blendable_dataset import BlendableDataset
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref"))
+    import helpers as ref_helpers
+    ds = ref_idx.MMapIndexedDataset(os.path.join(HERE, "data_fixture"), skip_warmup=True)
+    out = {}
+    for k, (docs, seq, seed, eod_mask) in enumerate([(np.arange(11), 16, 1234, False), (np.array([0, 2, 3, 5, 6, 8, 9]), 7, 7, True),
+                                                     (np.arange(3, 11), 50, 99, False)]):
+        sizes = ds.sizes
+        num_samples = np.sum(sizes[docs]) // seq
+        tpe = G._num_tokens(docs, sizes)
+        ne = G._num_epochs(tpe, seq, num_samples)
+        rng = np.random.RandomState(seed=seed)
+        if ne == 1:
+            sep = False
+        else:
+            before = ((ne - 1) * tpe - 1) // seq
+            sep = (num_samples - before) < int(0.80 * ((tpe - 1) // seq))
+        doc_idx = G._build_doc_idx(docs, ne, rng, sep)
+        sample_idx = np.array(ref_helpers.build_sample_idx(sizes, doc_idx, seq, ne, tpe))
+        shuffle_idx = G._build_shuffle_idx(before if sep else sample_idx.shape[0] - 1, sample_idx.shape[0] - 1, rng)
+        g = G.GPTDataset.__new__(G.GPTDataset)
+        g.name, g.indexed_dataset, g.seq_length, g.eos_token_id = "t", ds, seq, 3
+        g.reset_position_ids = g.reset_attention_mask = False
+        g.eod_mask_loss = eod_mask
+        g.doc_idx, g.sample_idx, g.shuffle_idx = doc_idx, sample_idx, shuffle_idx
+        out[f"case{k}/args"] = np.array([seq, seed, int(eod_mask), ne, int(sep)])
+        out[f"case{k}/docs"], out[f"case{k}/doc_idx"], out[f"case{k}/sample_idx"], out[f"case{k}/shuffle_idx"] = docs, doc_idx, sample_idx, shuffle_idx
+        items = [g[i] for i in range(len(g))]
+        out[f"case{k}/text_seq"] = np.concatenate([x.text_seq.numpy() for x in items])
+        out[f"case{k}/label"] = np.concatenate([x.label.numpy() for x in items])
+        out[f"case{k}/loss_mask"] = np.concatenate([x.loss_mask.numpy() for x in items])
+        out[f"case{k}/position_id"] = items[0].position_id.numpy()
+    # BlendableDataset: three list-backed datasets, global batch 8, weights 0.5 / 0.3 / 0.2
+    dsets = [list(range(100, 110)), list(range(200, 205)), list(range(300, 303))]
+    b = BlendableDataset(dsets, [0.5, 0.3, 0.2], global_batch_size=8)
+    np.random.seed(5)
+    out["blend/offsets"], out["blend/len"] = b.offset_in_batch, np.int64(len(b))
+    out["blend/items"] = np.array([b[i] for i in range(40)])
+    b2 = BlendableDataset(dsets, [1.0, 1.0, 2.0])
+    np.random.seed(6)
+    out["blend2/offsets"], out["blend2/items"] = b2.offset_in_batch, np.array([b2[i] for i in range(12)])
+    return out
+
+
 def gen_get_action():
     """get_action (src/evaluation/evaluate_rl.py:157-266) of the reference, on the reference model, replaying an episode's call pattern:
     with Transformer-XL memory (observation tokens, then one token per call, then the memorising call) and without (sliding window,
@@ -471,6 +524,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "data":
         np.savez_compressed(os.path.join(HERE, "data_ingest.npz"), **gen_data_ingest())
         print("wrote data_ingest + data_fixture.idx/.bin")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "gpt":
+        np.savez_compressed(os.path.join(HERE, "gpt_dataset.npz"), **gen_gpt_dataset())
+        print("wrote gpt_dataset")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "get_action":
         np.savez_compressed(os.path.join(HERE, "get_action.npz"), **gen_get_action())
