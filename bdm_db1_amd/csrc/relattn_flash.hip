@@ -53,6 +53,7 @@ struct FlashArgs {
     const bf16_t* out; const bf16_t* dout; const float* lse; float* delta;
     bf16_t* o; float* lse_out;
     bf16_t* dq; bf16_t* dk; bf16_t* dv; bf16_t* dT;
+    bf16_t* pbuf; bf16_t* dsbuf;  // P and dS as fragment images [B*H][L/32 key blocks][L/16 query tiles][64 lanes][8] bf16 (stored-probabilities backward), or null
     int64_t kv_rs, kv_bs;     // row / batch strides (elements) of k and v (they live inside the packed qkv activations)
     int64_t dq_rs, dq_bs;     // same for dq / dk / dv
     int B, L, H, shift;
@@ -247,6 +248,17 @@ __device__ __forceinline__ void w16_stage_kv(W16Stage& s, int stage, int wave) {
     w16_stage_v(s, stage, wave);
 }
 template <int N> __device__ __forceinline__ void w16_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most n vector-memory operations are outstanding, n wave-uniform at run time (the instruction takes an immediate)
+__device__ __forceinline__ void w16_vmcnt_dyn(int n) {
+    switch (n) {
+#define W16_VMC(k) case k: w16_vmcnt<k>(); break;
+        W16_VMC(0) W16_VMC(1) W16_VMC(2) W16_VMC(3) W16_VMC(4) W16_VMC(5) W16_VMC(6) W16_VMC(7) W16_VMC(8) W16_VMC(9) W16_VMC(10)
+        W16_VMC(11) W16_VMC(12) W16_VMC(13) W16_VMC(14) W16_VMC(15) W16_VMC(16) W16_VMC(17) W16_VMC(18) W16_VMC(19) W16_VMC(20)
+        W16_VMC(21) W16_VMC(22) W16_VMC(23)
+#undef W16_VMC
+        default: w16_vmcnt<24>(); break;
+    }
+}
 __device__ __forceinline__ void w16_stage_ring(const W16Stage& s, int dist0, int wave) {  // distances dist0 .. dist0+31 (dist0 a multiple of 16)
     const int slot0 = (dist0 + wave * 4) & (FA_RING - 1);
     const int dist = dist0 + s.srow;
@@ -410,7 +422,12 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
 // per wave-block (16 queries x 32 keys): S^T = K.Qu^T, dP^T = V.dO^T, the relative-term band (incremental), dS^T -> dq^T += K^T.dS^T, and
 // dT[i][i - j] = dS[i][j]: in row i the 32 keys of a block are 32 CONSECUTIVE distances in reverse key order, so the lane's packed
 // bf16 pairs go to a small [16 q][32] scratch (two ds_write_b64) and leave as 64 contiguous bytes per row.
+// SAVE: the block's P and dS (bf16, masked entries zero) also leave for relattn_flash_bwd_kv2_kernel, as FRAGMENT IMAGES: the wave's
+// 16 x 32 tile is the 1 KiB [lane][8] the lanes hold anyway (lane (a, g): query a, keys kk(0, g) + 0..3, kk(1, g) + 0..3), stored with
+// one global_store_dwordx4 per lane = eight full 128-byte lines per wave and matrix.  (Plain [query][key] rows cost 64-byte partial
+// lines and an LDS round trip: +470 us per layer at B = 64 against +180 us for this form.)
 typedef unsigned __attribute__((aligned(2))) u32_a2_t;
+template <bool SAVE>
 __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q_kernel(FlashArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -433,6 +450,9 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
     for (int t = 0; t < 2; t++) { dsw[t] = dw0 + a * W16_DP + (14 - kk16(t, g) / 2) * 4; W16_OPAQUE(dsw[t]); }
     dsr = dw0 + (lane >> 4) * W16_DP + (lane & 15) * 4;  // + it * 4 rows
     W16_OPAQUE(dsr);
+    // fragment image of tile (key block jb, query tile iw / 16): + jb * (L / 16) * 512 elements
+    const int64_t sv_tile = (((int64_t)b * p.H + h) * (p.L / FA_BK) * (p.L / 16) + (iw / 16)) * 512 + lane * 8;
+    const int64_t sv_step = (int64_t)(p.L / 16) * 512;
 
     bf16x8_t fqu[4], fqv[4], fdo[4];
 #pragma unroll
@@ -478,6 +498,8 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
     __syncthreads();
 
     bool have_prev = false;
+    int prev_sure = 0;   // lower bound of the stores the previous block issued behind its prefetch pieces
+    constexpr int sure_tiles = SAVE ? 2 : 0;
     auto block = [&](auto STG, auto PARC, int jb) __attribute__((always_inline)) {
         constexpr int stg = decltype(STG)::value, par = decltype(PARC)::value;
         const int j0 = jb * FA_BK;
@@ -486,6 +508,7 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
             w16_stage_kv(sg, (stg + 2) % W16_STAGES, wave);
             w16_stage_ring(sg, i0 - j0 - 96, wave);
         }
+        int cur_sure = 0;
         if (j0 > iw + 15 || j0 + 31 <= iw - p.shift) have_prev = false;
         else {
             const int dist_lo = iw - j0 - 32;
@@ -523,11 +546,13 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
                         ds[t * 4 + r] = ((j <= i) && (j > i - p.shift)) ? ds[t * 4 + r] : 0.f;
                     }
             }
+            if (SAVE) *reinterpret_cast<bf16x8_t*>(p.pbuf + sv_tile + jb * sv_step) = pack8(ds);
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) ds[t * 4 + r] = ds[t * 4 + r] * (acc_dp[t][r] - delta_a) * p.scale;
             const bf16x8_t db8 = pack8(ds);
+            if (SAVE) *reinterpret_cast<bf16x8_t*>(p.dsbuf + sv_tile + jb * sv_step) = db8;
 #pragma unroll
             for (int db = 0; db < 8; db++) acc_dq[db] = MFMA16(kt[db], db8, acc_dq[db]);  // dq^T[d][query] += K^T . dS^T
             // dT: element 31 - key of row a; the pairs are (key+1, key) in memory order
@@ -550,8 +575,16 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
                     else if (d == -1) dst[1] = (bf16_t)(v >> 16);
                 }
             }
+            cur_sure = edge ? sure_tiles : 4 + sure_tiles;
         }
-        if (pf) w16_vmcnt<3>(); else w16_vmcnt<0>();
+        // Block jb+1 must have landed; its pieces were issued at the top of block jb-1.  vmcnt counts loads and stores alike and
+        // retires them in issue order, so everything issued after those pieces may stay outstanding: the stores of block jb-1, the
+        // three pieces of this block and this block's stores (a plain vmcnt(3) would wait for the acknowledgement of stores issued
+        // a few cycles ago, and for a write to reach the L2 takes longer than a block under load).  The counts are LOWER bounds of
+        // what was issued: an interior block stores its four dT dwords (+ the two saved images) unconditionally, an edge block's dT
+        // stores are predicated and are not counted, a skipped block stores nothing.
+        w16_vmcnt_dyn(prev_sure + (pf ? 3 : 0) + cur_sure);
+        prev_sure = cur_sure;
         __syncthreads();
     };
     W16_BLOCK_LOOP(block)
@@ -749,6 +782,123 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv_kernel(FlashArgs 
     store_acc_t16(acc_dv, 1.f, Ow, p.dv + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
 }
 
+
+// ======================================================================================= backward w.r.t. keys / values from stored P / dS
+// The key side without recomputation: relattn_flash_bwd_q_kernel<true> leaves P and dS as fragment images (bf16, masked entries zero,
+// tiles without a visible pair untouched) and this kernel is the pair of causal contractions dV^T += dO^T.P, dK^T += Qu^T.dS over them:
+// 16 MFMAs per (32 queries x 16 keys) wave-block instead of 48, no relative term, no ring, no softmax.  One workgroup = 128 keys of one
+// (batch, head), wave = 16 keys x all 128 d.  Per 32-query block the 2 x 4 (query tile, key block) images of P and of dS (1 KiB each,
+// copied verbatim by one LDS-DMA per wave) and the [32][128 d] tiles of Qu and dO come through four LDS stages, requested three
+// blocks ahead.  It is a stream over HBM: 2 x L x L x 2 B per (batch, head) over the causal half for 4 L^2 d FLOPs.  Every operand
+// fragment is a ds_read_b64_tr_b16 pair: A = dO^T / Qu^T (d on the lane axis, as in the other kernels), B = the wave's 16 keys on the
+// lane axis, k-slots = queries kk(t, g) + r for both.  In an image the 8-byte unit (query q, keys 4 n .. 4 n + 3) of a key block sits
+// in chunk 16 g_f + (q & 15), half t_f, with kk(t_f, g_f) = 4 n; the copy permutes the 16-byte chunks (c -> c ^ 4 (bit 5 of c) ^
+// 8 (query tile & 1)) so that the 32 lanes of a tr read hit 32 distinct bank pairs.
+// Measured at B = 64 (8192 workgroups): 770 us = 2.8 TB/s of images; staging alone out of a hot L2 takes 240 us, the arithmetic
+// 230 us on top of it, the HBM misses the rest, and they add: a seven-stage image ring with per-wave request roles (96 KiB in flight
+// per CU), register staging through global_load_dwordx4 + ds_write_b128, and a rotated visiting order all measured 770-820 us.
+#define KV2_STAGES 4
+#define KV2_OFF_P 0
+#define KV2_OFF_DS (KV2_STAGES * 8192)
+#define KV2_OFF_QU (2 * KV2_STAGES * 8192)
+#define KV2_OFF_DO (3 * KV2_STAGES * 8192)
+#define KV2_LDS (4 * KV2_STAGES * 8192)        // the output staging of the epilogue reuses the stages
+
+__device__ __forceinline__ int kv2_chunk_pos(int c, int qtl) { return c ^ (((c >> 5) & 1) << 2) ^ (qtl << 3); }
+
+__global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int kt, h, b;
+    if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, kt, h, b)) return;
+    const int H = p.H, L = p.L, HD = H * FA_D;
+    const int j0 = kt * FA_BQ, kw = j0 + 16 * wave;
+    const int a = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+    W16Lane ln;
+    w16_lane_init(ln, lds0, lds0, lane);   // the tr addresses of a [32][128] tile at LDS offset 0 (scratch addresses unused)
+    unsigned btr[2];   // B fragments out of the images of key block (wave >> 1): k-slot group t <-> queries kk(t, g) + (a >> 2), keys 16 (wave & 1) + 4 (a & 3) ..
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int q = kk16(t, g) + (a >> 2), qtl = q >> 4, qa = q & 15;
+        const int tf = a & 1, gh = (a >> 1) & 1, gl = (wave & 1) ^ tf;
+        const int c = (2 * gh + gl) * 16 + qa;
+        btr[t] = lds0 + ((wave >> 1) * 2 + qtl) * 1024 + kv2_chunk_pos(c, qtl) * 16 + tf * 8;
+        W16_OPAQUE(btr[t]);
+    }
+    const int ib_lo = j0 / FA_BK;
+    int ihi = j0 + FA_BQ - 1 + p.shift - 1;
+    if (ihi > L - 1) ihi = L - 1;
+    const int ib_hi = ihi / FA_BK;
+    const int srow = wave * 4 + (lane >> 4);
+    const int schunk = ((lane & 15) ^ swz_kv(srow)) << 3;
+    const bf16_t* quptr = p.qu + ((int64_t)b * L + ib_lo * FA_BK + srow) * HD + h * FA_D + schunk;
+    const bf16_t* doptr = p.dout + ((int64_t)b * L + ib_lo * FA_BK + srow) * HD + h * FA_D + schunk;
+    // this wave copies image (key block j0 / 32 + (wave >> 1), query tile 2 ib + (wave & 1)); LDS chunk `lane` takes source chunk pos^-1 = pos
+    const int64_t img = ((((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + (wave >> 1)) * (L / 16) + 2 * ib_lo + (wave & 1)) * 512 +
+                        kv2_chunk_pos(lane, wave & 1) * 8;
+    const bf16_t* pptr = p.pbuf + img;
+    const bf16_t* sptr = p.dsbuf + img;
+    const int64_t q_step = (int64_t)FA_BK * HD;
+    auto stage = [&](int stg) __attribute__((always_inline)) {
+        glds16(pptr, lds0 + KV2_OFF_P + stg * 8192 + wave * 1024);
+        glds16(sptr, lds0 + KV2_OFF_DS + stg * 8192 + wave * 1024);
+        glds16(quptr, lds0 + KV2_OFF_QU + stg * 8192 + wave * 1024);
+        glds16(doptr, lds0 + KV2_OFF_DO + stg * 8192 + wave * 1024);
+        pptr += 1024; sptr += 1024; quptr += q_step; doptr += q_step;   // the next 32 queries: two images further
+    };
+    stage(0);
+    if (ib_lo + 1 <= ib_hi) stage(1);
+    if (ib_lo + 2 <= ib_hi) stage(2);
+    f32x4 acc_dk[8], acc_dv[8];
+#pragma unroll
+    for (int db = 0; db < 8; db++) { zero4(acc_dk[db]); zero4(acc_dv[db]); }
+    if (ib_lo + 2 <= ib_hi) w16_vmcnt<8>(); else if (ib_lo + 1 <= ib_hi) w16_vmcnt<4>(); else w16_vmcnt<0>();   // block ib_lo has landed
+    __syncthreads();
+
+    auto block = [&](auto STG, int ib) __attribute__((always_inline)) {
+        constexpr int stg = decltype(STG)::value;
+        const int i0q = ib * FA_BK;
+        if (ib + 3 <= ib_hi) stage((stg + 3) % KV2_STAGES);
+        if (!(i0q + 31 < kw || i0q >= kw + 15 + p.shift)) {  // some (i, j) of this block pair is visible
+            bf16x8_t pb = lds_tr_pair(btr[0] + KV2_OFF_P + stg * 8192, btr[1] + KV2_OFF_P + stg * 8192);
+            bf16x8_t sb = lds_tr_pair(btr[0] + KV2_OFF_DS + stg * 8192, btr[1] + KV2_OFF_DS + stg * 8192);
+            if (i0q < kw + 15 || i0q + 31 >= kw + p.shift) {
+                // diagonal / window-edge pairs: masked entries of a written tile are zero already, but a 16 x 32 tile without any
+                // visible pair was never written by bwd_q -- select, do not multiply (the bytes there are arbitrary)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = i0q + kk16(t, g) + r, j = kw + a;
+                        const bool keep = (j <= i) && (j > i - p.shift);
+                        pb[t * 4 + r] = keep ? pb[t * 4 + r] : (short)0;
+                        sb[t * 4 + r] = keep ? sb[t * 4 + r] : (short)0;
+                    }
+            }
+#pragma unroll
+            for (int db = 0; db < 8; db++) {
+                const bf16x8_t dot = lds_tr_pair(ln.tr[0][db] + KV2_OFF_DO + stg * 8192, ln.tr[1][db] + KV2_OFF_DO + stg * 8192);
+                const bf16x8_t qut = lds_tr_pair(ln.tr[0][db] + KV2_OFF_QU + stg * 8192, ln.tr[1][db] + KV2_OFF_QU + stg * 8192);
+                acc_dv[db] = MFMA16(dot, pb, acc_dv[db]);   // dV^T[d][key] += dO^T . P
+                acc_dk[db] = MFMA16(qut, sb, acc_dk[db]);   // dK^T[d][key] += Qu^T . dS
+            }
+        }
+        // block ib+1 must have landed: everything but the pieces of the (up to two) later blocks already requested
+        if (ib + 3 <= ib_hi) w16_vmcnt<8>(); else if (ib + 2 <= ib_hi) w16_vmcnt<4>(); else w16_vmcnt<0>();
+        __syncthreads();
+    };
+    for (int ib = ib_lo; ib <= ib_hi; ib += 4) {
+        block(std::integral_constant<int, 0>{}, ib);
+        if (ib + 1 <= ib_hi) block(std::integral_constant<int, 1>{}, ib + 1);
+        if (ib + 2 <= ib_hi) block(std::integral_constant<int, 2>{}, ib + 2);
+        if (ib + 3 <= ib_hi) block(std::integral_constant<int, 3>{}, ib + 3);
+    }
+    bf16_t* Ow = reinterpret_cast<bf16_t*>(smem + wave * W16_TW_BYTES);   // (every wave is past the final barrier: the stages are free)
+    store_acc_t16(acc_dk, 1.f, Ow, p.dk + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
+    store_acc_t16(acc_dv, 1.f, Ow, p.dv + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
+}
+
 // ======================================================================================= host side
 extern "C" int db1_relattn_flash_supported(int B, int L, int H, int D, int dt) {
     return (dt == DB1_BF16 && D == FA_D && B > 0 && H > 0 && L >= FA_BQ && (L % FA_BQ) == 0 && B <= 65535 && H <= 65535) ? 1 : 0;
@@ -780,10 +930,14 @@ extern "C" int db1_relattn_flash_fwd(const void* qu, const void* qv, const void*
     return DB1_OK;
 }
 
+extern "C" int64_t db1_relattn_flash_bwd_workspace_bytes(int B, int L, int H) {
+    return 2 * (int64_t)B * H * L * L * (int64_t)sizeof(bf16_t);   // P and dS, [B*H][L][L] bf16 each
+}
+
 extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
                                      int64_t kv_batch_stride, const void* R, const void* out, const void* dout, const float* lse,
                                      float* delta, void* dq, void* dk, void* dv, int64_t dqkv_row_stride, int64_t dqkv_batch_stride,
-                                     void* dT, int B, int L, int H, int D, int shift, float scale, void* stream) {
+                                     void* dT, int B, int L, int H, int D, int shift, float scale, void* ws, int64_t ws_bytes, void* stream) {
     FlashArgs a = {};
     a.qu = (const bf16_t*)qu; a.qv = (const bf16_t*)qv; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.R = (const bf16_t*)R;
     a.out = (const bf16_t*)out; a.dout = (const bf16_t*)dout; a.lse = lse; a.delta = delta;
@@ -798,11 +952,24 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
     hipStream_t s = (hipStream_t)stream;
     static Db1PerDeviceOnce attr_once;
     attr_once.run([] {
-        hipFuncSetAttribute((const void*)relattn_flash_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W16_BQ_LDS);
+        hipFuncSetAttribute((const void*)relattn_flash_bwd_q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_BQ_LDS);
+        hipFuncSetAttribute((const void*)relattn_flash_bwd_q_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_BQ_LDS);
         hipFuncSetAttribute((const void*)relattn_flash_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV16_LDS);
+        hipFuncSetAttribute((const void*)relattn_flash_bwd_kv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV2_LDS);
     });
     const dim3 grid(flash_grid(L / FA_BQ, H, B));
-    relattn_flash_bwd_q_kernel<<<grid, 512, W16_BQ_LDS, s>>>(a);
+    const int64_t need = db1_relattn_flash_bwd_workspace_bytes(B, L, H);
+    if (ws && ws_bytes >= need && db1_aligned16(ws)) {
+        // stored-probabilities backward: the query side leaves P and dS in the workspace, the key side is two contractions over them
+        a.pbuf = (bf16_t*)ws;
+        a.dsbuf = a.pbuf + (int64_t)B * H * L * L;
+        relattn_flash_bwd_q_kernel<true><<<grid, 512, W16_BQ_LDS, s>>>(a);
+        DB1_CHECK_LAUNCH("relattn_flash_bwd_q");
+        relattn_flash_bwd_kv2_kernel<<<grid, 512, KV2_LDS, s>>>(a);
+        DB1_CHECK_LAUNCH("relattn_flash_bwd_kv2");
+        return DB1_OK;
+    }
+    relattn_flash_bwd_q_kernel<false><<<grid, 512, W16_BQ_LDS, s>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_bwd_q");
     relattn_flash_bwd_kv_kernel<<<grid, 512, KV16_LDS, s>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_bwd_kv");

@@ -154,6 +154,7 @@ class TransformerXL(nn.Module):
         self.loss_grad_scale = 1.0       # d(loss * this) is what backward() accumulates: 1 / gradient-accumulation steps (set by the engine)
         self.use_flash = True            # fused attention when the shape is supported
         self.use_flash_bwd = True        # fused backward kernels (False: recompute through the materialised path)
+        self.flash_store_probs = True    # key-side flash backward over the P / dS the query side leaves in scratch (2 x B*H*L*L bf16) instead of recomputing
         self.use_headbias_epilogue = True  # q + r_w_bias / q + r_r_bias written by the qkv projection's epilogue (large bf16 batches)
         self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
@@ -760,7 +761,7 @@ class TransformerXL(nn.Module):
             else:
                 dT = torch.zeros(H, B, L, L, device=self.dev, dtype=self.compute_dtype)
             delta = self._new(B, H, L, dtype=torch.float32)
-            ops.relattn_flash_bwd(qu, qv, qkv5, R, c.av, dav4, c.lse, delta, dqkv5, dT, B, L, H, D, shift, scale)
+            ops.relattn_flash_bwd(qu, qv, qkv5, R, c.av, dav4, c.lse, delta, dqkv5, dT, B, L, H, D, shift, scale, store_probs=self.flash_store_probs)
         else:
             Pm, T, qu, qv = self._attn_probs(qkv, R, u, vb, B, L, L, 0, shift)
             dP = self._new(H, B, L, L, dtype=torch.float32)

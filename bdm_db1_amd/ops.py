@@ -421,13 +421,16 @@ def relattn_flash_fwd(qu, qv, qkv5, R, out, lse, B, L, H, D, shift, scale):
                             B, L, H, D, shift, float(scale), stream()))
 
 
-def relattn_flash_bwd(qu, qv, qkv5, R, out, dout, lse, delta, dqkv5, dT, B, L, H, D, shift, scale):
+def relattn_flash_bwd(qu, qv, qkv5, R, out, dout, lse, delta, dqkv5, dT, B, L, H, D, shift, scale, store_probs=True):
+    """store_probs: give the library the scratch for P and dS as plain matrices (the key side then runs without recomputation);
+    False = the recomputing key-side kernel (no scratch)."""
     k, v = qkv5[:, :, 1], qkv5[:, :, 2]
+    ws, wsn = _ws("db1_relattn_flash_bwd_workspace_bytes", (B, L, H), out.device) if store_probs else (_vp(0), 0)
     dq, dk, dv = dqkv5[:, :, 0], dqkv5[:, :, 1], dqkv5[:, :, 2]
     vis = L * (L + 1) / 2 if shift >= L else (shift * (shift + 1) / 2 + (L - shift) * shift)
     _timed("flash_bwd", 6 * 2.0 * B * H * vis * D,   # twice the forward's algorithmic work (bwd_q + bwd_kv; dq_r / dR run as separate kernels)
            lambda: lib.call("db1_relattn_flash_bwd", P(qu), P(qv), P(k), P(v), k.stride(1), k.stride(0), P(R), P(out), P(dout), P(lse), P(delta),
-                            P(dq), P(dk), P(dv), dq.stride(1), dq.stride(0), P(dT), B, L, H, D, shift, float(scale), stream()))
+                            P(dq), P(dk), P(dv), dq.stride(1), dq.stride(0), P(dT), B, L, H, D, shift, float(scale), ws, wsn, stream()))
 
 
 def patch_normalize(pixels, patches, p):

@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flash", action="store_true")
+    ap.add_argument("--flash-recompute", action="store_true", help="A/B: the key-side flash backward recomputes scores / softmax instead of reading the P / dS scratch")
     ap.add_argument("--materialise-logits", action="store_true", help="A/B: head GEMM + CE on a full (tokens x vocabulary) logits buffer instead of the chunked sweep")
     args = ap.parse_args()
 
@@ -162,6 +163,7 @@ def main():
     torch.manual_seed(1234)
     model = TransformerXL(cfg, device=dev)
     model.use_flash = not args.no_flash
+    model.flash_store_probs = not args.flash_recompute
     eargs = SimpleNamespace(lr=1e-4, weight_decay=0.01, clip_grad=1.0, optimizer="adam", keep_logits=False, fuse_head_loss=not args.materialise_logits)
     engine, _, _, _ = initialize(eargs, model, mpu=mpu if world > 1 else None)
     engine.train()
@@ -211,6 +213,7 @@ def main():
     dt = float(tmax.item())
     loss_v = float(loss)
 
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 2**30
     tokens = world * B * L * args.steps
     tok_s = tokens / dt
     flops_step_all = world * (B * L * FLOP_PER_TOKEN + n_patches * FLOP_PER_PATCH)
@@ -225,6 +228,7 @@ def main():
                    "params": int(sum(int(np.prod(s)) for _, s, _ in model.arena.offsets.values()))},
         "pct_mfma_peak_step": round(100.0 * flops_step_all / (dt / args.steps) / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 2),
         "final_loss": round(loss_v, 4),
+        "peak_hbm_gib": round(peak_gb, 1),
     }
     summ = timer.summary() if timer is not None else {}
     if "gemm" in summ:

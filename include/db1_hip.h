@@ -254,11 +254,16 @@ int db1_relattn_flash_fwd(const void* qu, const void* qv, const void* k, const v
                           int B, int L, int H, int D, int shift, float scale, void* stream);
 /* dq (the (q+u).k branch only), dk, dv are written with their own row / batch strides (they live inside dqkv);
  * dT [H,B,L,L] bf16 = dS re-indexed by distance (input of the dq_r / dR GEMMs, zero where nothing is visible);
- * delta [B,H,L] f32 scratch (rowsum(dout * out): written by the query-side kernel, read by the key-side kernel). */
+ * delta [B,H,L] f32 scratch (rowsum(dout * out): written by the query-side kernel, read by the key-side kernel).
+ * Workspace (optional): with db1_relattn_flash_bwd_workspace_bytes(B, L, H) bytes of scratch (2 x B*H*L*L bf16) the query-side kernel
+ * also leaves P and dS (as MFMA fragment images) and the key side runs as two causal contractions over them instead of recomputing scores,
+ * relative term and softmax per key tile (memory for time: 2 x 2 GiB at B = 64, L = 1024, H = 16).  Without it (ws NULL / smaller) the
+ * recomputing key-side kernel runs; both are valid backward passes (P enters dV as bf16 either way). */
+int64_t db1_relattn_flash_bwd_workspace_bytes(int B, int L, int H);
 int db1_relattn_flash_bwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
                           int64_t kv_batch_stride, const void* R, const void* out, const void* dout, const float* lse,
                           float* delta, void* dq, void* dk, void* dv, int64_t dqkv_row_stride, int64_t dqkv_batch_stride,
-                          void* dT, int B, int L, int H, int D, int shift, float scale, void* stream);
+                          void* dT, int B, int L, int H, int D, int shift, float scale, void* ws, int64_t ws_bytes, void* stream);
 
 /* dq_r[b, i, h, :] = sum_{dist} dT[h, b, i, dist] * R[dist, h, :] (the (q+v).R branch of the query gradient, transformer_xl.py:160-209) as a
  * stream over dT with R stationary in registers: dT [H,B,L,L] bf16 (zero for dist > i), R [L, H*128] bf16 with row stride r_row_stride,

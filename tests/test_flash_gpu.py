@@ -113,8 +113,11 @@ def test_flash_forward_matches_materialised_path_full_size():
 
 @pytest.mark.parametrize("B,L,H,shift", [(2, 256, 2, 256), (1, 512, 2, 130), (1, 384, 1, 384), (1, 128, 1, 128), (3, 256, 3, 70),
                                          (1, 1024, 1, 1024), (1, 640, 1, 40)])
-def test_flash_backward_matches_oracle(B, L, H, shift):
-    from bdm_db1_amd import ops
+@pytest.mark.parametrize("store_probs", [True, False], ids=["stored_p_ds", "recompute"])
+def test_flash_backward_matches_oracle(B, L, H, shift, store_probs):
+    """both key-side kernels: the one that recomputes scores / relative term / softmax per key tile and the one that contracts over the
+    P and dS the query-side kernel left in the workspace (pre-filled with NaN patterns here: tiles bwd_q never writes must not leak)"""
+    from bdm_db1_amd import lib, ops
     D = 128
     qkv, R, u, vb = make_inputs(B, L, H, D, seed=11 + L + shift, scale_q=0.8)
     rng = np.random.default_rng(99)
@@ -132,7 +135,11 @@ def test_flash_backward_matches_oracle(B, L, H, shift):
     dqkv = torch.full((B, L, 3, H, D), 3.0, device=DEV, dtype=torch.bfloat16)
     dT = torch.zeros(H, B, L, L, device=DEV, dtype=torch.bfloat16)
     delta = torch.empty(B, H, L, device=DEV, dtype=torch.float32)
-    ops.relattn_flash_bwd(qu, qv, QKV, Rd, out, dev16(dout), lse, delta, dqkv, dT, B, L, H, D, shift, scale)
+    if store_probs:
+        ops.reserve_workspace(int(lib.load().db1_relattn_flash_bwd_workspace_bytes(B, L, H)))
+        for buf in ops._workspace.bufs.values():
+            buf.fill_(0xFF)
+    ops.relattn_flash_bwd(qu, qv, QKV, Rd, out, dev16(dout), lse, delta, dqkv, dT, B, L, H, D, shift, scale, store_probs=store_probs)
     torch.cuda.synchronize()
     g = dqkv.to(torch.float64).cpu().numpy()
     dTn = dT.to(torch.float64).cpu().numpy()

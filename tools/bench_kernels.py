@@ -46,8 +46,9 @@ def flash(B=16, L=1024, H=16, D=128):
     unit = 2.0 * B * H * (L * (L + 1) / 2) * D  # one causal-counted L x L x D contraction
     t = timeit(lambda: ops.relattn_flash_fwd(qu, qv, qkv, R, out, lse, B, L, H, D, L, scale))
     print(f"flash fwd  B={B}: {t * 1e3:8.1f} us   {3 * unit / t / 1e9:7.1f} TFLOP/s algorithmic (3 contractions)")
-    t = timeit(lambda: ops.relattn_flash_bwd(qu, qv, qkv, R, out, dout, lse, delta, dqkv, dT, B, L, H, D, L, scale))
-    print(f"flash bwd  B={B}: {t * 1e3:8.1f} us   {6 * unit / t / 1e9:7.1f} TFLOP/s algorithmic (6 contractions, excl. dq_r/dR GEMMs)")
+    for sp in (True, False):
+        t = timeit(lambda: ops.relattn_flash_bwd(qu, qv, qkv, R, out, dout, lse, delta, dqkv, dT, B, L, H, D, L, scale, store_probs=sp))
+        print(f"flash bwd  B={B} ({'stored P/dS' if sp else 'recompute  '}): {t * 1e3:8.1f} us   {6 * unit / t / 1e9:7.1f} TFLOP/s algorithmic (6 contractions, excl. dq_r/dR GEMMs)")
 
 
 def gemm(B=16, L=1024):
