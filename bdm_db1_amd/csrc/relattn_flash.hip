@@ -53,6 +53,8 @@ struct FlashArgs {
     const bf16_t* out; const bf16_t* dout; const float* lse; float* delta;
     bf16_t* o; float* lse_out;
     bf16_t* dq; bf16_t* dk; bf16_t* dv; bf16_t* dT;
+    bf16_t* pt; float* mblk;       // forward-stored p~ = exp2(s - m_blk) images (same layout as pbuf) and the running maxima they refer to, [B*H][L/32][L] (x scale*log2 e), or null
+    float* fblk;                   // exp2(m_blk c2 - lse log2 e) per (key block, query): written by bwd_q2, read by kv2<true>; same shape as mblk (+ 64 floats)
     bf16_t* pbuf; bf16_t* dsbuf;  // P and dS as fragment images [B*H][L/32 key blocks][L/16 query tiles][64 lanes][8] bf16 (stored-probabilities backward), or null
     int64_t kv_rs, kv_bs;     // row / batch strides (elements) of k and v (they live inside the packed qkv activations)
     int64_t dq_rs, dq_bs;     // same for dq / dk / dv
@@ -303,6 +305,10 @@ __device__ __forceinline__ void store_acc_t16(const f32x4* acc, float mul, bf16_
     }
 
 // ======================================================================================= forward
+// SAVE: every processed (16 queries x 32 keys) wave-block also leaves its UNNORMALISED probabilities p~ = exp2((s - m) c2) as a fragment
+// image (the bf16x8 the lane feeds to the P.V MFMA: one global_store_dwordx4 per lane, 1 KiB contiguous per wave) and the running
+// maximum m c2 they were computed against; P = p~ exp2(m c2 - lse log2 e) is what the stored-probabilities backward rebuilds.
+template <bool SAVE>
 __global__ __launch_bounds__(512, 1) void relattn_flash_fwd_kernel(FlashArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -343,6 +349,9 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    const int64_t sv_tile = (((int64_t)b * H + h) * (L / FA_BK) * (L / 16) + (iw / 16)) * 512 + lane * 8;   // + jb * (L / 16) * 512
+    const int64_t sv_step = (int64_t)(L / 16) * 512;
+    float* mrow = SAVE ? p.mblk + ((int64_t)b * H + h) * (L / FA_BK) * L + iw + a : nullptr;                   // + jb * L
     bool have_prev = false;  // did this wave process the previous key block?  (wave-uniform)
     auto block = [&](auto STG, auto PARC, int jb) __attribute__((always_inline)) {
         constexpr int stg = decltype(STG)::value, par = decltype(PARC)::value;
@@ -404,11 +413,16 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
 #pragma unroll
             for (int r = 0; r < 8; r++) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, mc)); l_i += s[r]; }
             const bf16x8_t pb = pack8(s);
+            if (SAVE) {
+                *reinterpret_cast<bf16x8_t*>(p.pt + sv_tile + jb * sv_step) = pb;
+                if (g == 0) mrow[(int64_t)jb * L] = -mc;
+            }
 #pragma unroll
             for (int db = 0; db < 8; db++) acc_o[db] = MFMA16(vt[db], pb, acc_o[db]);  // O^T[d][query] += V^T . P^T
+            if (SAVE) { if (pf) w16_vmcnt<3 + 2>(); else w16_vmcnt<2>(); }   // (the two stores sit behind this block's prefetch pieces)
         }
         // block jb+1 must have landed: all but the three pieces issued at the top of this block
-        if (pf) w16_vmcnt<3>(); else w16_vmcnt<0>();
+        if (!SAVE || !have_prev) { if (pf) w16_vmcnt<3>(); else w16_vmcnt<0>(); }
         __syncthreads();  // every wave is done reading stage stg (refilled by the next block's prefetch)
     };
     W16_BLOCK_LOOP(block)
@@ -589,6 +603,149 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
     };
     W16_BLOCK_LOOP(block)
     bf16_t* Ow = reinterpret_cast<bf16_t*>(smem + W16_OFF_T + wave * W16_TW_BYTES);
+    store_acc_t16(acc_dq, 1.f, Ow, p.dq + (int64_t)b * p.dq_bs + (int64_t)iw * p.dq_rs + h * FA_D, p.dq_rs, lane);
+}
+
+// ======================================================================================= backward w.r.t. queries from forward-stored p~
+// relattn_flash_fwd_kernel<true> left p~ = exp2((s - m_blk) c2) per (16 queries x 32 keys) wave-block in exactly the lane layout this
+// kernel computes in, and m_blk c2 per (key block, query).  So nothing is recomputed: P = p~ f with f = exp2(m_blk c2 - lse log2 e)
+// (one exp2 per query and block instead of 32 + the two score contractions + the relative-term band and its skew), dP^T = V.dO^T,
+// dS = P (dP - delta) scale, dq^T += K^T.dS^T, dT as in relattn_flash_bwd_q_kernel; dS leaves as a fragment image and f as a float per
+// (key block, query) for relattn_flash_bwd_kv2_kernel<true>.  No ring, no relative-term scratch: 57 KiB of LDS.  p~ and m come through
+// plain global loads two blocks ahead (16 B + 4 B per lane); they and the stores share vmcnt with the LDS-DMA pieces, see the wait.
+// dT leaves through a per-wave ring [16 queries][64 distances] indexed by the ABSOLUTE distance (column = d & 63): the skew is taken by
+// the 2-byte LDS writes, and after block jb the aligned window [iw - j0 - 16, iw - j0 + 16) is complete in every row, so it goes out
+// as 16 rows x 64 B = one ds_read_b128 + one 16-byte-aligned global_store_dwordx4 per lane.  (The direct form -- 4-byte stores at
+// 2-byte-aligned addresses, four per lane and block -- cost 330 us of this kernel's 1330 at B = 64.)  Distances above the diagonal
+// (d < 0) are not stored; entries of the window nobody wrote are the ring's initial zeros, which is what dT holds there anyway.
+#define DTR_PITCH 144                          // bytes per ring row: 64 bf16 + 16
+#define Q2_OFF_D (2 * W16_STAGES * 8192)
+#define Q2_LDS (Q2_OFF_D + W16_WAVES * 16 * DTR_PITCH)
+typedef __attribute__((address_space(3))) unsigned short* lds_u16_ptr;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((address_space(3))) const u32x4_t* lds_u128_ptr;
+__global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q2_kernel(FlashArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rank, h, b;
+    if (!flash_wg_coords(p.L / FA_BQ, p.H, p.B, rank, h, b)) return;
+    const int qt = p.L / FA_BQ - 1 - rank;
+    const int H = p.H, L = p.L, HD = H * FA_D;
+    const int i0 = qt * FA_BQ, iw = i0 + 16 * wave;
+    const int a = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+    const bf16_t* dog = p.dout + ((int64_t)b * L) * HD + h * FA_D;
+    W16Lane ln;
+    w16_lane_init(ln, lds0, lds0, lane);
+    const unsigned dw0 = lds0 + Q2_OFF_D + wave * 16 * DTR_PITCH;
+    const unsigned dwrow = dw0 + a * DTR_PITCH;            // ring row of this lane's query
+    const unsigned drrow = dw0 + (lane >> 2) * DTR_PITCH;  // flush: row lane >> 2, 16-byte piece lane & 3
+    for (int o = lane * 4; o < 16 * DTR_PITCH; o += 256) *(lds_u32_ptr)(size_t)(dw0 + o) = 0u;
+    const int64_t sv_tile = (((int64_t)b * H + h) * (L / FA_BK) * (L / 16) + (iw / 16)) * 512 + lane * 8;   // + jb * (L / 16) * 512
+    const int64_t sv_step = (int64_t)(L / 16) * 512;
+    const int64_t mrow = ((int64_t)b * H + h) * (L / FA_BK) * L + iw + a;                                     // + jb * L
+
+    bf16x8_t fdo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) fdo[ks] = *reinterpret_cast<const bf16x8_t*>(dog + (int64_t)(iw + a) * HD + ks * 32 + g * 8);
+    const float lse2 = p.lse[((int64_t)b * H + h) * L + iw + a] * LOG2E;
+    float delta_a = 0.f;
+    {
+        const bf16_t* og = p.out + ((int64_t)b * L + iw + a) * HD + h * FA_D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const bf16x8_t fo = *reinterpret_cast<const bf16x8_t*>(og + ks * 32);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                delta_a += __uint_as_float((unsigned)(unsigned short)fo[e] << 16) * __uint_as_float((unsigned)(unsigned short)fdo[ks][e] << 16);
+        }
+        delta_a = sum_x32(sum_x16(delta_a));
+        if (g == 0) p.delta[((int64_t)b * H + h) * L + iw + a] = delta_a;
+    }
+    bf16_t* dtp = p.dT + (((int64_t)h * p.B + b) * L + iw + (lane >> 2)) * L + 8 * (lane & 3);   // + window start
+    int jlo = i0 - p.shift + 1;
+    if (jlo < 0) jlo = 0;
+    const int jb_lo = jlo / FA_BK, jb_hi = (i0 + FA_BQ - 1) / FA_BK;
+    W16Stage sg;
+    w16_stage_init(sg, p.k + (int64_t)b * p.kv_bs + h * FA_D, p.v + (int64_t)b * p.kv_bs + h * FA_D, p.R + h * FA_D, p.kv_rs, HD, jb_lo * FA_BK, L,
+                   lds0, wave, lane);
+    w16_stage_kv(sg, 0, wave);
+    if (jb_lo + 1 <= jb_hi) w16_stage_kv(sg, 1, wave);
+    bf16x8_t ptq[2];   // p~ of the current / next block (slot = position in the loop & 1), m likewise
+    float mq[2];
+    ptq[0] = *reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + jb_lo * sv_step);
+    mq[0] = p.mblk[mrow + (int64_t)jb_lo * L];
+    if (jb_lo + 1 <= jb_hi) {
+        ptq[1] = *reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + (jb_lo + 1) * sv_step);
+        mq[1] = p.mblk[mrow + (int64_t)(jb_lo + 1) * L];
+    }
+    f32x4 acc_dq[8];
+#pragma unroll
+    for (int db = 0; db < 8; db++) zero4(acc_dq[db]);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int prev_sure = 0;
+    auto block = [&](auto STG, auto PARC, int jb) __attribute__((always_inline)) {
+        constexpr int stg = decltype(STG)::value, par = decltype(PARC)::value;
+        const int j0 = jb * FA_BK;
+        const bool pf = jb + 2 <= jb_hi;
+        const bf16x8_t pt = ptq[par];
+        const float m2 = mq[par];
+        if (pf) {   // block jb+2: K / V tiles (two LDS-DMA pieces), then its p~ image and maxima into the slot just read
+            w16_stage_kv(sg, (stg + 2) % W16_STAGES, wave);
+            ptq[par] = *reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + (jb + 2) * sv_step);
+            mq[par] = p.mblk[mrow + (int64_t)(jb + 2) * L];
+        }
+        int cur_sure = 0;
+        if (!(j0 > iw + 15 || j0 + 31 <= iw - p.shift)) {
+            f32x4 acc_dp[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                zero4(acc_dp[t]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) acc_dp[t] = MFMA16(lds_ld128(ln.rowf[t][ks] + W16_OFF_V + stg * 8192), fdo[ks], acc_dp[t]);  // dP^T[key][query]
+            }
+            bf16x8_t kt[8];
+#pragma unroll
+            for (int db = 0; db < 8; db++) kt[db] = lds_tr_pair(ln.tr[0][db] + W16_OFF_K + stg * 8192, ln.tr[1][db] + W16_OFF_K + stg * 8192);
+            const float f = __builtin_amdgcn_exp2f(m2 - lse2);
+            if (g == 0) p.fblk[mrow + (int64_t)jb * L] = f;
+            const float fs = f * p.scale;
+            float ds[8];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)   // masked pairs: the forward stored p~ = 0 there
+                    ds[t * 4 + r] = __uint_as_float((unsigned)(unsigned short)pt[t * 4 + r] << 16) * fs * (acc_dp[t][r] - delta_a);
+            const bf16x8_t db8 = pack8(ds);
+            *reinterpret_cast<bf16x8_t*>(p.dsbuf + sv_tile + jb * sv_step) = db8;
+#pragma unroll
+            for (int db = 0; db < 8; db++) acc_dq[db] = MFMA16(kt[db], db8, acc_dq[db]);  // dq^T[d][query] += K^T . dS^T
+            {   // ring column of key kk(t, g) + r of this lane's query: (iw + a - j0 - kk - r) & 63
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const unsigned col = (unsigned)(iw + a - j0 - kk16(t, g) - r) & 63u;
+                        *(lds_u16_ptr)(size_t)(dwrow + col * 2) = (unsigned short)db8[t * 4 + r];
+                    }
+                const int w0 = iw - j0 - 16;   // window start (a multiple of 16)
+                const u32x4_t win = *(lds_u128_ptr)(size_t)(drrow + (((unsigned)(w0 + 8 * (lane & 3)) & 63u) * 2));
+                if (w0 + 8 * (lane & 3) >= 0) *reinterpret_cast<u32x4_t*>(dtp + w0) = win;
+            }
+            cur_sure = 3;   // f, the dS image, the dT window
+        }
+        // The K / V pieces of block jb+1 were issued at the top of block jb-1; vmcnt retires in issue order, so what may stay outstanding
+        // is everything issued after them: the two loads that followed them, the stores of block jb-1, this block's four requests and
+        // its stores (all counted as lower bounds).  The last block drains: the epilogue reuses the stages.
+        if (jb + 1 <= jb_hi) w16_vmcnt_dyn(2 + prev_sure + (pf ? 4 : 0) + cur_sure); else w16_vmcnt<0>();
+        prev_sure = cur_sure;
+        __syncthreads();
+    };
+    W16_BLOCK_LOOP(block)
+    bf16_t* Ow = reinterpret_cast<bf16_t*>(smem + wave * W16_TW_BYTES);
     store_acc_t16(acc_dq, 1.f, Ow, p.dq + (int64_t)b * p.dq_bs + (int64_t)iw * p.dq_rs + h * FA_D, p.dq_rs, lane);
 }
 
@@ -806,6 +963,11 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv_kernel(FlashArgs 
 
 __device__ __forceinline__ int kv2_chunk_pos(int c, int qtl) { return c ^ (((c >> 5) & 1) << 2) ^ (qtl << 3); }
 
+// FACT: the P images are the forward's p~ and P = p~ f with f [key block][query] from relattn_flash_bwd_q2_kernel: 64 floats per wave and
+// block (the block's 32 queries + the next 32, one 4-byte LDS-DMA per lane) into a per-wave slot of the stage, two 16-byte reads per lane.
+#define KV2_OFF_F (4 * KV2_STAGES * 8192)       // [stage][wave][64] floats
+#define KV2_LDS_F (KV2_OFF_F + KV2_STAGES * W16_WAVES * 256)
+template <bool FACT>
 __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -837,10 +999,22 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs
     // this wave copies image (key block j0 / 32 + (wave >> 1), query tile 2 ib + (wave & 1)); LDS chunk `lane` takes source chunk pos^-1 = pos
     const int64_t img = ((((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + (wave >> 1)) * (L / 16) + 2 * ib_lo + (wave & 1)) * 512 +
                         kv2_chunk_pos(lane, wave & 1) * 8;
-    const bf16_t* pptr = p.pbuf + img;
+    const bf16_t* pptr = (FACT ? p.pt : p.pbuf) + img;
     const bf16_t* sptr = p.dsbuf + img;
     const int64_t q_step = (int64_t)FA_BK * HD;
+    const float* fptr = FACT ? p.fblk + (((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + (wave >> 1)) * L + ib_lo * FA_BK + lane : nullptr;
+    unsigned fld[2];   // f of queries kk(t, g) .. + 3
+#pragma unroll
+    for (int t = 0; t < 2; t++) { fld[t] = lds0 + KV2_OFF_F + wave * 256 + kk16(t, g) * 4; W16_OPAQUE(fld[t]); }
+    constexpr int NP = FACT ? 5 : 4;   // requests per wave and block
     auto stage = [&](int stg) __attribute__((always_inline)) {
+        if (FACT) {
+            const unsigned dstf = __builtin_amdgcn_readfirstlane(lds0 + KV2_OFF_F + stg * (W16_WAVES * 256) + wave * 256);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(fptr), "s"(dstf) : "memory");
+            fptr += FA_BK;
+        }
         glds16(pptr, lds0 + KV2_OFF_P + stg * 8192 + wave * 1024);
         glds16(sptr, lds0 + KV2_OFF_DS + stg * 8192 + wave * 1024);
         glds16(quptr, lds0 + KV2_OFF_QU + stg * 8192 + wave * 1024);
@@ -853,7 +1027,7 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs
     f32x4 acc_dk[8], acc_dv[8];
 #pragma unroll
     for (int db = 0; db < 8; db++) { zero4(acc_dk[db]); zero4(acc_dv[db]); }
-    if (ib_lo + 2 <= ib_hi) w16_vmcnt<8>(); else if (ib_lo + 1 <= ib_hi) w16_vmcnt<4>(); else w16_vmcnt<0>();   // block ib_lo has landed
+    if (ib_lo + 2 <= ib_hi) w16_vmcnt<2 * NP>(); else if (ib_lo + 1 <= ib_hi) w16_vmcnt<NP>(); else w16_vmcnt<0>();   // block ib_lo has landed
     __syncthreads();
 
     auto block = [&](auto STG, int ib) __attribute__((always_inline)) {
@@ -863,6 +1037,16 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs
         if (!(i0q + 31 < kw || i0q >= kw + 15 + p.shift)) {  // some (i, j) of this block pair is visible
             bf16x8_t pb = lds_tr_pair(btr[0] + KV2_OFF_P + stg * 8192, btr[1] + KV2_OFF_P + stg * 8192);
             bf16x8_t sb = lds_tr_pair(btr[0] + KV2_OFF_DS + stg * 8192, btr[1] + KV2_OFF_DS + stg * 8192);
+            if (FACT) {
+                float pf32[8];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const f32x4 f4 = *(lds_f32x4_ptr)(size_t)(fld[t] + stg * (W16_WAVES * 256));
+#pragma unroll
+                    for (int r = 0; r < 4; r++) pf32[t * 4 + r] = __uint_as_float((unsigned)(unsigned short)pb[t * 4 + r] << 16) * f4[r];
+                }
+                pb = pack8(pf32);
+            }
             if (i0q < kw + 15 || i0q + 31 >= kw + p.shift) {
                 // diagonal / window-edge pairs: masked entries of a written tile are zero already, but a 16 x 32 tile without any
                 // visible pair was never written by bwd_q -- select, do not multiply (the bytes there are arbitrary)
@@ -885,7 +1069,7 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs
             }
         }
         // block ib+1 must have landed: everything but the pieces of the (up to two) later blocks already requested
-        if (ib + 3 <= ib_hi) w16_vmcnt<8>(); else if (ib + 2 <= ib_hi) w16_vmcnt<4>(); else w16_vmcnt<0>();
+        if (ib + 3 <= ib_hi) w16_vmcnt<2 * NP>(); else if (ib + 2 <= ib_hi) w16_vmcnt<NP>(); else w16_vmcnt<0>();
         __syncthreads();
     };
     for (int ib = ib_lo; ib <= ib_hi; ib += 4) {
@@ -915,7 +1099,7 @@ static int flash_check(const FlashArgs& a, int D, const char* what) {
 
 extern "C" int db1_relattn_flash_fwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
                                      int64_t kv_batch_stride, const void* R, void* out, float* lse, int B, int L, int H, int D,
-                                     int shift, float scale, void* stream) {
+                                     int shift, float scale, void* probs, float* mblk, void* stream) {
     FlashArgs a = {};
     a.qu = (const bf16_t*)qu; a.qv = (const bf16_t*)qv; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.R = (const bf16_t*)R;
     a.o = (bf16_t*)out; a.lse_out = lse; a.kv_rs = kv_row_stride; a.kv_bs = kv_batch_stride;
@@ -923,21 +1107,30 @@ extern "C" int db1_relattn_flash_fwd(const void* qu, const void* qv, const void*
     int st = flash_check(a, D, "relattn_flash_fwd");
     if (st) return st;
     if (!db1_aligned16(out)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_flash_fwd: out alignment");
+    if ((probs == nullptr) != (mblk == nullptr) || !db1_aligned16(probs)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_flash_fwd: probs and mblk go together, probs 16-byte aligned");
+    a.pt = (bf16_t*)probs; a.mblk = mblk;
     static Db1PerDeviceOnce attr_once;
-    attr_once.run([] { hipFuncSetAttribute((const void*)relattn_flash_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W16_FWD_LDS); });
-    relattn_flash_fwd_kernel<<<dim3(flash_grid(L / FA_BQ, H, B)), 512, W16_FWD_LDS, (hipStream_t)stream>>>(a);
+    attr_once.run([] {
+        hipFuncSetAttribute((const void*)relattn_flash_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_FWD_LDS);
+        hipFuncSetAttribute((const void*)relattn_flash_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_FWD_LDS);
+    });
+    if (probs) relattn_flash_fwd_kernel<true><<<dim3(flash_grid(L / FA_BQ, H, B)), 512, W16_FWD_LDS, (hipStream_t)stream>>>(a);
+    else relattn_flash_fwd_kernel<false><<<dim3(flash_grid(L / FA_BQ, H, B)), 512, W16_FWD_LDS, (hipStream_t)stream>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_fwd");
     return DB1_OK;
 }
 
-extern "C" int64_t db1_relattn_flash_bwd_workspace_bytes(int B, int L, int H) {
-    return 2 * (int64_t)B * H * L * L * (int64_t)sizeof(bf16_t);   // P and dS, [B*H][L][L] bf16 each
+extern "C" int64_t db1_relattn_flash_bwd_workspace_bytes(int B, int L, int H, int have_probs) {
+    const int64_t img = (int64_t)B * H * L * L * (int64_t)sizeof(bf16_t);   // one set of fragment images, [B*H][L/32][L/16][64][8] bf16
+    if (have_probs) return img + ((int64_t)B * H * (L / FA_BK) * L + 64) * (int64_t)sizeof(float);   // dS + the factors f (+ the over-read of the last row)
+    return 2 * img;                                                                                  // P and dS
 }
 
 extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
                                      int64_t kv_batch_stride, const void* R, const void* out, const void* dout, const float* lse,
                                      float* delta, void* dq, void* dk, void* dv, int64_t dqkv_row_stride, int64_t dqkv_batch_stride,
-                                     void* dT, int B, int L, int H, int D, int shift, float scale, void* ws, int64_t ws_bytes, void* stream) {
+                                     void* dT, int B, int L, int H, int D, int shift, float scale, const void* probs, const float* mblk,
+                                     void* ws, int64_t ws_bytes, void* stream) {
     FlashArgs a = {};
     a.qu = (const bf16_t*)qu; a.qv = (const bf16_t*)qv; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.R = (const bf16_t*)R;
     a.out = (const bf16_t*)out; a.dout = (const bf16_t*)dout; a.lse = lse; a.delta = delta;
@@ -955,17 +1148,32 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
         hipFuncSetAttribute((const void*)relattn_flash_bwd_q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_BQ_LDS);
         hipFuncSetAttribute((const void*)relattn_flash_bwd_q_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_BQ_LDS);
         hipFuncSetAttribute((const void*)relattn_flash_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV16_LDS);
-        hipFuncSetAttribute((const void*)relattn_flash_bwd_kv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV2_LDS);
+        hipFuncSetAttribute((const void*)relattn_flash_bwd_kv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KV2_LDS);
+        hipFuncSetAttribute((const void*)relattn_flash_bwd_kv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KV2_LDS_F);
+        hipFuncSetAttribute((const void*)relattn_flash_bwd_q2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q2_LDS);
     });
     const dim3 grid(flash_grid(L / FA_BQ, H, B));
-    const int64_t need = db1_relattn_flash_bwd_workspace_bytes(B, L, H);
+    if ((probs == nullptr) != (mblk == nullptr) || !db1_aligned16(probs)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_flash_bwd: probs and mblk go together, probs 16-byte aligned");
+    if (probs) {
+        // the forward kept p~ and its maxima: nothing is recomputed on either side
+        DB1_NEED_WS(ws, ws_bytes, db1_relattn_flash_bwd_workspace_bytes(B, L, H, 1), "relattn_flash_bwd (forward-stored probabilities)");
+        a.pt = (bf16_t*)probs; a.mblk = const_cast<float*>(mblk);
+        a.dsbuf = (bf16_t*)ws;
+        a.fblk = reinterpret_cast<float*>(a.dsbuf + (int64_t)B * H * L * L);
+        relattn_flash_bwd_q2_kernel<<<grid, 512, Q2_LDS, s>>>(a);
+        DB1_CHECK_LAUNCH("relattn_flash_bwd_q2");
+        relattn_flash_bwd_kv2_kernel<true><<<grid, 512, KV2_LDS_F, s>>>(a);
+        DB1_CHECK_LAUNCH("relattn_flash_bwd_kv2");
+        return DB1_OK;
+    }
+    const int64_t need = db1_relattn_flash_bwd_workspace_bytes(B, L, H, 0);
     if (ws && ws_bytes >= need && db1_aligned16(ws)) {
         // stored-probabilities backward: the query side leaves P and dS in the workspace, the key side is two contractions over them
         a.pbuf = (bf16_t*)ws;
         a.dsbuf = a.pbuf + (int64_t)B * H * L * L;
         relattn_flash_bwd_q_kernel<true><<<grid, 512, W16_BQ_LDS, s>>>(a);
         DB1_CHECK_LAUNCH("relattn_flash_bwd_q");
-        relattn_flash_bwd_kv2_kernel<<<grid, 512, KV2_LDS, s>>>(a);
+        relattn_flash_bwd_kv2_kernel<false><<<grid, 512, KV2_LDS, s>>>(a);
         DB1_CHECK_LAUNCH("relattn_flash_bwd_kv2");
         return DB1_OK;
     }

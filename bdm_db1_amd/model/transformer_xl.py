@@ -154,7 +154,10 @@ class TransformerXL(nn.Module):
         self.loss_grad_scale = 1.0       # d(loss * this) is what backward() accumulates: 1 / gradient-accumulation steps (set by the engine)
         self.use_flash = True            # fused attention when the shape is supported
         self.use_flash_bwd = True        # fused backward kernels (False: recompute through the materialised path)
-        self.flash_store_probs = True    # key-side flash backward over the P / dS the query side leaves in scratch (2 x B*H*L*L bf16) instead of recomputing
+        # what the flash backward recomputes (include/db1_hip.h, db1_relattn_flash_bwd): "forward" = nothing, the forward keeps its
+        # unnormalised probabilities per layer (B*H*L*L bf16 + B*H*L*L/32 floats each: 2.2 GiB per layer at 64 x 1024 tokens);
+        # "scratch" = the query side recomputes and leaves P / dS in one scratch buffer for the key side; "recompute" = both sides
+        self.flash_probs_mode = "forward"
         self.use_headbias_epilogue = True  # q + r_w_bias / q + r_r_bias written by the qkv projection's epilogue (large bf16 batches)
         self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
@@ -662,9 +665,13 @@ class TransformerXL(nn.Module):
                 qu, qv = self._new(B, Lq, H, D), self._new(B, Lq, H, D)
                 ops.relattn_add_head_bias(qkv, u, vb, qu, qv, B, Lq, Lk, H, D)
             lse = self._new(B, H, Lq, dtype=torch.float32)
-            ops.relattn_flash_fwd(qu, qv, qkv.view(B, Lk, 3, H, D), R, av, lse, B, Lq, H, D, shift, 1.0 / math.sqrt(D))
+            probs = mblk = None
+            if c is not None and self.use_flash_bwd and self.flash_probs_mode == "forward":
+                probs = self._new(B * H, Lq // 32, Lq // 16, 512)
+                mblk = self._new(B * H, Lq // 32, Lq, dtype=torch.float32)
+            ops.relattn_flash_fwd(qu, qv, qkv.view(B, Lk, 3, H, D), R, av, lse, B, Lq, H, D, shift, 1.0 / math.sqrt(D), probs=probs, mblk=mblk)
             if c is not None:
-                c.lse, c.qu, c.qv = lse, qu, qv
+                c.lse, c.qu, c.qv, c.probs, c.mblk = lse, qu, qv, probs, mblk
         else:
             Pm, _, _, _ = self._attn_probs(qkv, R, u, vb, B, Lq, Lk, mlen, shift)
             qkv5 = qkv.view(B, Lk, 3, H, D)
@@ -761,7 +768,9 @@ class TransformerXL(nn.Module):
             else:
                 dT = torch.zeros(H, B, L, L, device=self.dev, dtype=self.compute_dtype)
             delta = self._new(B, H, L, dtype=torch.float32)
-            ops.relattn_flash_bwd(qu, qv, qkv5, R, c.av, dav4, c.lse, delta, dqkv5, dT, B, L, H, D, shift, scale, store_probs=self.flash_store_probs)
+            ops.relattn_flash_bwd(qu, qv, qkv5, R, c.av, dav4, c.lse, delta, dqkv5, dT, B, L, H, D, shift, scale,
+                                  store_probs=self.flash_probs_mode != "recompute", probs=c.probs, mblk=c.mblk)
+            c.probs = c.mblk = None
         else:
             Pm, T, qu, qv = self._attn_probs(qkv, R, u, vb, B, L, L, 0, shift)
             dP = self._new(H, B, L, L, dtype=torch.float32)

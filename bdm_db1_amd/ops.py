@@ -412,25 +412,31 @@ def relattn_flash_supported(B, L, H, D, dtype) -> bool:
     return bool(lib.load().db1_relattn_flash_supported(B, L, H, D, dt_code(dtype)))
 
 
-def relattn_flash_fwd(qu, qv, qkv5, R, out, lse, B, L, H, D, shift, scale):
-    """qkv5: the packed activations viewed [B, L, 3, H, D]; k / v are addressed inside it by stride."""
+def relattn_flash_fwd(qu, qv, qkv5, R, out, lse, B, L, H, D, shift, scale, probs=None, mblk=None):
+    """qkv5: the packed activations viewed [B, L, 3, H, D]; k / v are addressed inside it by stride.
+    probs [B*H, L/32, L/16, 512] bf16 + mblk [B*H, L/32, L] f32 (optional): the unnormalised probabilities and their reference maxima,
+    kept for the stored-probabilities backward."""
     k, v = qkv5[:, :, 1], qkv5[:, :, 2]
     vis = L * (L + 1) / 2 if shift >= L else (shift * (shift + 1) / 2 + (L - shift) * shift)   # visible (query, key) pairs
     _timed("flash_fwd", 3 * 2.0 * B * H * vis * D,   # (q+u).k, (q+v).R, P.v over the visible pairs (SURVEY 8d)
            lambda: lib.call("db1_relattn_flash_fwd", P(qu), P(qv), P(k), P(v), k.stride(1), k.stride(0), P(R), P(out), P(lse),
-                            B, L, H, D, shift, float(scale), stream()))
+                            B, L, H, D, shift, float(scale), P(probs) if probs is not None else _vp(0), P(mblk) if mblk is not None else _vp(0), stream()))
 
 
-def relattn_flash_bwd(qu, qv, qkv5, R, out, dout, lse, delta, dqkv5, dT, B, L, H, D, shift, scale, store_probs=True):
-    """store_probs: give the library the scratch for P and dS as plain matrices (the key side then runs without recomputation);
-    False = the recomputing key-side kernel (no scratch)."""
+def relattn_flash_bwd(qu, qv, qkv5, R, out, dout, lse, delta, dqkv5, dT, B, L, H, D, shift, scale, store_probs=True, probs=None, mblk=None):
+    """probs + mblk (from relattn_flash_fwd): nothing is recomputed.  Otherwise store_probs: give the library the scratch for P and dS
+    (the key side then runs without recomputation); False = both sides recompute (no scratch)."""
     k, v = qkv5[:, :, 1], qkv5[:, :, 2]
-    ws, wsn = _ws("db1_relattn_flash_bwd_workspace_bytes", (B, L, H), out.device) if store_probs else (_vp(0), 0)
+    if probs is not None:
+        ws, wsn = _ws("db1_relattn_flash_bwd_workspace_bytes", (B, L, H, 1), out.device)
+    else:
+        ws, wsn = _ws("db1_relattn_flash_bwd_workspace_bytes", (B, L, H, 0), out.device) if store_probs else (_vp(0), 0)
     dq, dk, dv = dqkv5[:, :, 0], dqkv5[:, :, 1], dqkv5[:, :, 2]
     vis = L * (L + 1) / 2 if shift >= L else (shift * (shift + 1) / 2 + (L - shift) * shift)
     _timed("flash_bwd", 6 * 2.0 * B * H * vis * D,   # twice the forward's algorithmic work (bwd_q + bwd_kv; dq_r / dR run as separate kernels)
            lambda: lib.call("db1_relattn_flash_bwd", P(qu), P(qv), P(k), P(v), k.stride(1), k.stride(0), P(R), P(out), P(dout), P(lse), P(delta),
-                            P(dq), P(dk), P(dv), dq.stride(1), dq.stride(0), P(dT), B, L, H, D, shift, float(scale), ws, wsn, stream()))
+                            P(dq), P(dk), P(dv), dq.stride(1), dq.stride(0), P(dT), B, L, H, D, shift, float(scale),
+                            P(probs) if probs is not None else _vp(0), P(mblk) if mblk is not None else _vp(0), ws, wsn, stream()))
 
 
 def patch_normalize(pixels, patches, p):

@@ -134,7 +134,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flash", action="store_true")
-    ap.add_argument("--flash-recompute", action="store_true", help="A/B: the key-side flash backward recomputes scores / softmax instead of reading the P / dS scratch")
+    ap.add_argument("--flash-probs", choices=["forward", "scratch", "recompute"], default="forward",
+                    help="A/B: what the flash backward recomputes (nothing: the forward keeps p~ per layer / the query side only / both sides)")
     ap.add_argument("--materialise-logits", action="store_true", help="A/B: head GEMM + CE on a full (tokens x vocabulary) logits buffer instead of the chunked sweep")
     args = ap.parse_args()
 
@@ -163,7 +164,7 @@ def main():
     torch.manual_seed(1234)
     model = TransformerXL(cfg, device=dev)
     model.use_flash = not args.no_flash
-    model.flash_store_probs = not args.flash_recompute
+    model.flash_probs_mode = args.flash_probs
     eargs = SimpleNamespace(lr=1e-4, weight_decay=0.01, clip_grad=1.0, optimizer="adam", keep_logits=False, fuse_head_loss=not args.materialise_logits)
     engine, _, _, _ = initialize(eargs, model, mpu=mpu if world > 1 else None)
     engine.train()

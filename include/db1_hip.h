@@ -248,22 +248,30 @@ int db1_relattn_softmax_bwd(const float* P, float* dP, float* dT, int H, int B, 
  * Training shape only: Lq == Lk, causal window i - shift < j <= i (shift >= L means plain causal). */
 int db1_relattn_flash_supported(int B, int L, int H, int D, int dt);
 /* qu = q + u, qv = q + v_bias: [B,L,H,D] contiguous (db1_relattn_add_head_bias); k, v: pointers INTO the packed
- * qkv activations with their row / batch strides in elements. */
+ * qkv activations with their row / batch strides in elements.
+ * probs / mblk (optional, both or neither): keep the unnormalised probabilities p~ = exp2((s - m_blk) c2), c2 = scale log2 e, as bf16 MFMA
+ * fragment images [B*H][L/32 key blocks][L/16 query tiles][64 lanes][8] and the running maxima m_blk c2 they refer to [B*H][L/32][L] f32,
+ * for db1_relattn_flash_bwd (entries of blocks outside the window are not written). */
 int db1_relattn_flash_fwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
                           int64_t kv_batch_stride, const void* R, void* out, float* lse,
-                          int B, int L, int H, int D, int shift, float scale, void* stream);
+                          int B, int L, int H, int D, int shift, float scale, void* probs, float* mblk, void* stream);
 /* dq (the (q+u).k branch only), dk, dv are written with their own row / batch strides (they live inside dqkv);
  * dT [H,B,L,L] bf16 = dS re-indexed by distance (input of the dq_r / dR GEMMs, zero where nothing is visible);
  * delta [B,H,L] f32 scratch (rowsum(dout * out): written by the query-side kernel, read by the key-side kernel).
- * Workspace (optional): with db1_relattn_flash_bwd_workspace_bytes(B, L, H) bytes of scratch (2 x B*H*L*L bf16) the query-side kernel
- * also leaves P and dS (as MFMA fragment images) and the key side runs as two causal contractions over them instead of recomputing scores,
- * relative term and softmax per key tile (memory for time: 2 x 2 GiB at B = 64, L = 1024, H = 16).  Without it (ws NULL / smaller) the
- * recomputing key-side kernel runs; both are valid backward passes (P enters dV as bf16 either way). */
-int64_t db1_relattn_flash_bwd_workspace_bytes(int B, int L, int H);
+ * Three ways to run it, by what the caller provides (all valid backward passes; P enters dV as bf16 in each):
+ *   probs + mblk (what db1_relattn_flash_fwd stored) and db1_relattn_flash_bwd_workspace_bytes(B, L, H, 1) bytes of scratch:
+ *       nothing is recomputed -- P = p~ exp2(m_blk c2 - lse log2 e) on the query side, dS and the factors go through the scratch to
+ *       the key side, which is two causal contractions over the images (memory for time: B*H*L*L bf16 + B*H*L*L/32 floats per LAYER
+ *       kept from the forward, the same again once as scratch);
+ *   no probs, db1_relattn_flash_bwd_workspace_bytes(B, L, H, 0) bytes of scratch (2 x B*H*L*L bf16): the query side recomputes scores,
+ *       relative term and softmax and leaves P and dS in the scratch for the key side;
+ *   neither (ws NULL / smaller): both sides recompute. */
+int64_t db1_relattn_flash_bwd_workspace_bytes(int B, int L, int H, int have_probs);
 int db1_relattn_flash_bwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
                           int64_t kv_batch_stride, const void* R, const void* out, const void* dout, const float* lse,
                           float* delta, void* dq, void* dk, void* dv, int64_t dqkv_row_stride, int64_t dqkv_batch_stride,
-                          void* dT, int B, int L, int H, int D, int shift, float scale, void* ws, int64_t ws_bytes, void* stream);
+                          void* dT, int B, int L, int H, int D, int shift, float scale, const void* probs, const float* mblk,
+                          void* ws, int64_t ws_bytes, void* stream);
 
 /* dq_r[b, i, h, :] = sum_{dist} dT[h, b, i, dist] * R[dist, h, :] (the (q+v).R branch of the query gradient, transformer_xl.py:160-209) as a
  * stream over dT with R stationary in registers: dT [H,B,L,L] bf16 (zero for dist > i), R [L, H*128] bf16 with row stride r_row_stride,

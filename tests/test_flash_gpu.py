@@ -113,10 +113,11 @@ def test_flash_forward_matches_materialised_path_full_size():
 
 @pytest.mark.parametrize("B,L,H,shift", [(2, 256, 2, 256), (1, 512, 2, 130), (1, 384, 1, 384), (1, 128, 1, 128), (3, 256, 3, 70),
                                          (1, 1024, 1, 1024), (1, 640, 1, 40)])
-@pytest.mark.parametrize("store_probs", [True, False], ids=["stored_p_ds", "recompute"])
-def test_flash_backward_matches_oracle(B, L, H, shift, store_probs):
-    """both key-side kernels: the one that recomputes scores / relative term / softmax per key tile and the one that contracts over the
-    P and dS the query-side kernel left in the workspace (pre-filled with NaN patterns here: tiles bwd_q never writes must not leak)"""
+@pytest.mark.parametrize("mode", ["fwd_probs", "scratch_p_ds", "recompute"])
+def test_flash_backward_matches_oracle(B, L, H, shift, mode):
+    """the three backward passes: nothing recomputed (the forward kept p~ and its block maxima), the key side over the P and dS the
+    recomputing query-side kernel left in the workspace, and both sides recomputing.  Saved tensors and workspace are pre-filled with
+    NaN patterns: tiles that are never written (blocks outside the window) must not leak."""
     from bdm_db1_amd import lib, ops
     D = 128
     qkv, R, u, vb = make_inputs(B, L, H, D, seed=11 + L + shift, scale_q=0.8)
@@ -131,15 +132,20 @@ def test_flash_backward_matches_oracle(B, L, H, shift, store_probs):
     ops.relattn_add_head_bias(QKV, U, VB, qu, qv, B, L, L, H, D)
     out = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
     lse = torch.empty(B, H, L, device=DEV, dtype=torch.float32)
-    ops.relattn_flash_fwd(qu, qv, QKV, Rd, out, lse, B, L, H, D, shift, scale)
+    probs = mblk = None
+    if mode == "fwd_probs":
+        probs = torch.full((B * H, L // 32, L // 16, 512), float("nan"), device=DEV, dtype=torch.bfloat16)
+        mblk = torch.full((B * H, L // 32, L), float("nan"), device=DEV, dtype=torch.float32)
+    ops.relattn_flash_fwd(qu, qv, QKV, Rd, out, lse, B, L, H, D, shift, scale, probs=probs, mblk=mblk)
     dqkv = torch.full((B, L, 3, H, D), 3.0, device=DEV, dtype=torch.bfloat16)
     dT = torch.zeros(H, B, L, L, device=DEV, dtype=torch.bfloat16)
     delta = torch.empty(B, H, L, device=DEV, dtype=torch.float32)
-    if store_probs:
-        ops.reserve_workspace(int(lib.load().db1_relattn_flash_bwd_workspace_bytes(B, L, H)))
+    if mode != "recompute":
+        ops.reserve_workspace(int(lib.load().db1_relattn_flash_bwd_workspace_bytes(B, L, H, int(mode == "fwd_probs"))))
         for buf in ops._workspace.bufs.values():
             buf.fill_(0xFF)
-    ops.relattn_flash_bwd(qu, qv, QKV, Rd, out, dev16(dout), lse, delta, dqkv, dT, B, L, H, D, shift, scale, store_probs=store_probs)
+    ops.relattn_flash_bwd(qu, qv, QKV, Rd, out, dev16(dout), lse, delta, dqkv, dT, B, L, H, D, shift, scale, store_probs=mode != "recompute",
+                          probs=probs, mblk=mblk)
     torch.cuda.synchronize()
     g = dqkv.to(torch.float64).cpu().numpy()
     dTn = dT.to(torch.float64).cpu().numpy()
@@ -182,8 +188,9 @@ def test_model_bf16_flash_vs_oracle_and_vs_materialised():
     ref_logits, ref_loss, _ = oracle.forward([O.TaskBatch(kind="nlp", text_seq=ids[:, :-1], label=ids[:, 1:], loss_mask=mask)])
     ref_grads = oracle.backward()
     results = {}
-    for flash in (True, False):
-        model.use_flash = flash
+    for flash in ("forward", "scratch", "recompute", False):   # the three flash backward passes, then the materialised path
+        model.use_flash = bool(flash)
+        model.flash_probs_mode = flash or "forward"
         model.zero_grad()
         logits, loss = model([mk()])
         model.backward()
@@ -192,7 +199,7 @@ def test_model_bf16_flash_vs_oracle_and_vs_materialised():
         assert abs(results[flash][1] - ref_loss) < 2e-2, flash
         for n in ("h.0.dec_attn.qkv_net.weight", "h.1.dec_attn.o_net.weight", "r_w_bias", "r_r_bias", "h.0.dec_attn.r_net.weight", "word_embedding.weight"):
             assert rel_err(results[flash][2][n], ref_grads[n]) < 6e-2, (flash, n)
-    assert np.abs(results[True][0] - results[False][0]).max() / np.abs(ref_logits).max() < 2e-2
+    assert np.abs(results["forward"][0] - results[False][0]).max() / np.abs(ref_logits).max() < 2e-2
 
 
 @pytest.mark.parametrize("B,L,H", [(2, 256, 2), (3, 1024, 3), (1, 640, 1), (20, 128, 16)])

@@ -46,6 +46,18 @@ def flash(B=16, L=1024, H=16, D=128):
     unit = 2.0 * B * H * (L * (L + 1) / 2) * D  # one causal-counted L x L x D contraction
     t = timeit(lambda: ops.relattn_flash_fwd(qu, qv, qkv, R, out, lse, B, L, H, D, L, scale))
     print(f"flash fwd  B={B}: {t * 1e3:8.1f} us   {3 * unit / t / 1e9:7.1f} TFLOP/s algorithmic (3 contractions)")
+    probs = torch.empty(B * H, L // 32, L // 16, 512, device=DEV, dtype=torch.bfloat16)
+    mblk = torch.empty(B * H, L // 32, L, device=DEV, dtype=torch.float32)
+    t = timeit(lambda: ops.relattn_flash_fwd(qu, qv, qkv, R, out, lse, B, L, H, D, L, scale, probs=probs, mblk=mblk))
+    print(f"flash fwd  B={B} (+ stored p~): {t * 1e3:8.1f} us")
+    t = timeit(lambda: ops.relattn_flash_bwd(qu, qv, qkv, R, out, dout, lse, delta, dqkv, dT, B, L, H, D, L, scale, probs=probs, mblk=mblk))
+    print(f"flash bwd  B={B} (forward-stored p~): {t * 1e3:8.1f} us   {6 * unit / t / 1e9:7.1f} TFLOP/s algorithmic")
+    for e in os.environ.get("FLASH_EXPS", "").split(","):
+        if e:
+            os.environ["DB1_FLASH_EXP"] = e
+            t = timeit(lambda: ops.relattn_flash_bwd(qu, qv, qkv, R, out, dout, lse, delta, dqkv, dT, B, L, H, D, L, scale, probs=probs, mblk=mblk))
+            print(f"flash bwd (fwd-stored) exp={e}: {t * 1e3:8.1f} us")
+    os.environ.pop("DB1_FLASH_EXP", None)
     for sp in (True, False):
         t = timeit(lambda: ops.relattn_flash_bwd(qu, qv, qkv, R, out, dout, lse, delta, dqkv, dT, B, L, H, D, L, scale, store_probs=sp))
         print(f"flash bwd  B={B} ({'stored P/dS' if sp else 'recompute  '}): {t * 1e3:8.1f} us   {6 * unit / t / 1e9:7.1f} TFLOP/s algorithmic (6 contractions, excl. dq_r/dR GEMMs)")
