@@ -720,7 +720,6 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q2_kernel(FlashArgs 
                 for (int r = 0; r < 4; r++)   // masked pairs: the forward stored p~ = 0 there
                     ds[t * 4 + r] = __uint_as_float((unsigned)(unsigned short)pt[t * 4 + r] << 16) * fs * (acc_dp[t][r] - delta_a);
             const bf16x8_t db8 = pack8(ds);
-            *reinterpret_cast<bf16x8_t*>(p.dsbuf + sv_tile + jb * sv_step) = db8;
 #pragma unroll
             for (int db = 0; db < 8; db++) acc_dq[db] = MFMA16(kt[db], db8, acc_dq[db]);  // dq^T[d][query] += K^T . dS^T
             {   // ring column of key kk(t, g) + r of this lane's query: (iw + a - j0 - kk - r) & 63
@@ -735,7 +734,7 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q2_kernel(FlashArgs 
                 const u32x4_t win = *(lds_u128_ptr)(size_t)(drrow + (((unsigned)(w0 + 8 * (lane & 3)) & 63u) * 2));
                 if (w0 + 8 * (lane & 3) >= 0) *reinterpret_cast<u32x4_t*>(dtp + w0) = win;
             }
-            cur_sure = 3;   // f, the dS image, the dT window
+            cur_sure = 2;   // f, the dT window
         }
         // The K / V pieces of block jb+1 were issued at the top of block jb-1; vmcnt retires in issue order, so what may stay outstanding
         // is everything issued after them: the two loads that followed them, the stores of block jb-1, this block's four requests and
@@ -1002,11 +1001,20 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs
     const bf16_t* pptr = (FACT ? p.pt : p.pbuf) + img;
     const bf16_t* sptr = p.dsbuf + img;
     const int64_t q_step = (int64_t)FA_BK * HD;
-    const float* fptr = FACT ? p.fblk + (((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + (wave >> 1)) * L + ib_lo * FA_BK + lane : nullptr;
-    unsigned fld[2];   // f of queries kk(t, g) .. + 3
+    // FACT: lanes 0-31 fetch f [key block][query], lanes 32-63 delta [query] of the block's 32 queries (one 4-byte LDS-DMA per lane)
+    const float* fptr = !FACT ? nullptr
+                        : (lane < 32 ? p.fblk + (((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + (wave >> 1)) * L + ib_lo * FA_BK + lane
+                                     : p.delta + ((int64_t)b * H + h) * L + ib_lo * FA_BK + lane - 32);
+    unsigned fld[2];   // f of queries kk(t, g) .. + 3 (delta: + 128 bytes)
 #pragma unroll
     for (int t = 0; t < 2; t++) { fld[t] = lds0 + KV2_OFF_F + wave * 256 + kk16(t, g) * 4; W16_OPAQUE(fld[t]); }
-    constexpr int NP = FACT ? 5 : 4;   // requests per wave and block
+    bf16x8_t fv[4];    // FACT: V of this lane's key (B operand of dP = dO.V^T)
+    if (FACT) {
+        const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * FA_D;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) fv[ks] = *reinterpret_cast<const bf16x8_t*>(vg + (int64_t)(kw + a) * p.kv_rs + ks * 32 + g * 8);
+    }
+    constexpr int NP = 4;   // requests per wave and block
     auto stage = [&](int stg) __attribute__((always_inline)) {
         if (FACT) {
             const unsigned dstf = __builtin_amdgcn_readfirstlane(lds0 + KV2_OFF_F + stg * (W16_WAVES * 256) + wave * 256);
@@ -1016,7 +1024,7 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs
             fptr += FA_BK;
         }
         glds16(pptr, lds0 + KV2_OFF_P + stg * 8192 + wave * 1024);
-        glds16(sptr, lds0 + KV2_OFF_DS + stg * 8192 + wave * 1024);
+        if (!FACT) glds16(sptr, lds0 + KV2_OFF_DS + stg * 8192 + wave * 1024);
         glds16(quptr, lds0 + KV2_OFF_QU + stg * 8192 + wave * 1024);
         glds16(doptr, lds0 + KV2_OFF_DO + stg * 8192 + wave * 1024);
         pptr += 1024; sptr += 1024; quptr += q_step; doptr += q_step;   // the next 32 queries: two images further
@@ -1027,7 +1035,8 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs
     f32x4 acc_dk[8], acc_dv[8];
 #pragma unroll
     for (int db = 0; db < 8; db++) { zero4(acc_dk[db]); zero4(acc_dv[db]); }
-    if (ib_lo + 2 <= ib_hi) w16_vmcnt<2 * NP>(); else if (ib_lo + 1 <= ib_hi) w16_vmcnt<NP>(); else w16_vmcnt<0>();   // block ib_lo has landed
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // (the V fragments; as a builtin so that hipcc's own bookkeeping sees them retired)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     auto block = [&](auto STG, int ib) __attribute__((always_inline)) {
@@ -1036,16 +1045,27 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs
         if (ib + 3 <= ib_hi) stage((stg + 3) % KV2_STAGES);
         if (!(i0q + 31 < kw || i0q >= kw + 15 + p.shift)) {  // some (i, j) of this block pair is visible
             bf16x8_t pb = lds_tr_pair(btr[0] + KV2_OFF_P + stg * 8192, btr[1] + KV2_OFF_P + stg * 8192);
-            bf16x8_t sb = lds_tr_pair(btr[0] + KV2_OFF_DS + stg * 8192, btr[1] + KV2_OFF_DS + stg * 8192);
-            if (FACT) {
-                float pf32[8];
+            bf16x8_t sb;
+            if (!FACT) sb = lds_tr_pair(btr[0] + KV2_OFF_DS + stg * 8192, btr[1] + KV2_OFF_DS + stg * 8192);
+            else {
+                // P = p~ f;  dP[query][key] = dO.V^T (MFMA row 4g + r of tile t is query kk(t, g) + r, like the k-slots);  dS = P (dP - delta) scale
+                float pf32[8], ds32[8];
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
-                    const f32x4 f4 = *(lds_f32x4_ptr)(size_t)(fld[t] + stg * (W16_WAVES * 256));
+                    f32x4 acc_dp;
+                    zero4(acc_dp);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) pf32[t * 4 + r] = __uint_as_float((unsigned)(unsigned short)pb[t * 4 + r] << 16) * f4[r];
+                    for (int ks = 0; ks < 4; ks++) acc_dp = MFMA16(lds_ld128(ln.rowf[t][ks] + KV2_OFF_DO + stg * 8192), fv[ks], acc_dp);
+                    const f32x4 f4 = *(lds_f32x4_ptr)(size_t)(fld[t] + stg * (W16_WAVES * 256));
+                    const f32x4 d4 = *(lds_f32x4_ptr)(size_t)(fld[t] + stg * (W16_WAVES * 256) + 128);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        pf32[t * 4 + r] = __uint_as_float((unsigned)(unsigned short)pb[t * 4 + r] << 16) * f4[r];
+                        ds32[t * 4 + r] = pf32[t * 4 + r] * (acc_dp[r] - d4[r]) * p.scale;
+                    }
                 }
                 pb = pack8(pf32);
+                sb = pack8(ds32);
             }
             if (i0q < kw + 15 || i0q + 31 >= kw + p.shift) {
                 // diagonal / window-edge pairs: masked entries of a written tile are zero already, but a 16 x 32 tile without any
@@ -1122,7 +1142,7 @@ extern "C" int db1_relattn_flash_fwd(const void* qu, const void* qv, const void*
 
 extern "C" int64_t db1_relattn_flash_bwd_workspace_bytes(int B, int L, int H, int have_probs) {
     const int64_t img = (int64_t)B * H * L * L * (int64_t)sizeof(bf16_t);   // one set of fragment images, [B*H][L/32][L/16][64][8] bf16
-    if (have_probs) return img + ((int64_t)B * H * (L / FA_BK) * L + 64) * (int64_t)sizeof(float);   // dS + the factors f (+ the over-read of the last row)
+    if (have_probs) return ((int64_t)B * H * (L / FA_BK) * L + 64) * (int64_t)sizeof(float);   // the factors f, [B*H][L/32][L] floats (+ the over-read of the last row)
     return 2 * img;                                                                                  // P and dS
 }
 
@@ -1158,8 +1178,7 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
         // the forward kept p~ and its maxima: nothing is recomputed on either side
         DB1_NEED_WS(ws, ws_bytes, db1_relattn_flash_bwd_workspace_bytes(B, L, H, 1), "relattn_flash_bwd (forward-stored probabilities)");
         a.pt = (bf16_t*)probs; a.mblk = const_cast<float*>(mblk);
-        a.dsbuf = (bf16_t*)ws;
-        a.fblk = reinterpret_cast<float*>(a.dsbuf + (int64_t)B * H * L * L);
+        a.fblk = reinterpret_cast<float*>(ws);
         relattn_flash_bwd_q2_kernel<<<grid, 512, Q2_LDS, s>>>(a);
         DB1_CHECK_LAUNCH("relattn_flash_bwd_q2");
         relattn_flash_bwd_kv2_kernel<true><<<grid, 512, KV2_LDS_F, s>>>(a);

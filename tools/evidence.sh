@@ -9,6 +9,11 @@ timeout 900 python bench.py > $E/${TAG}_bench_default.json 2> $E/bench_default.e
 for w in caption rl mixture; do
   timeout 600 python bench.py --workload $w --no-cpu-baseline > $E/${TAG}_bench_${w}.json 2> $E/bench_$w.err </dev/null
 done
+# what the flash backward recomputes: same box, same commit
+for m in scratch recompute; do
+  timeout 600 python bench.py --flash-probs $m --no-cpu-baseline --steps 6 --warmup 2 > $E/${TAG}_bench_flash_${m}.json 2> $E/bench_flash_$m.err </dev/null
+done
+timeout 600 python tools/bench_kernels.py flash 64 > $E/${TAG}_flash_kernels.txt 2> $E/flash_kernels.err </dev/null
 timeout 600 python tools/bench_decode.py > $E/${TAG}_decode.txt 2> $E/decode.err </dev/null
 # the multi-rank path on this 1-GPU box: two ranks share the GPU, gloo instead of RCCL (which refuses two ranks on one device)
 # (gloo prints a connection line on stdout: only the JSON line is kept)
