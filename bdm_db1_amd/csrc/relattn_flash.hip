@@ -950,9 +950,9 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv_kernel(FlashArgs 
 // lane axis, k-slots = queries kk(t, g) + r for both.  In an image the 8-byte unit (query q, keys 4 n .. 4 n + 3) of a key block sits
 // in chunk 16 g_f + (q & 15), half t_f, with kk(t_f, g_f) = 4 n; the copy permutes the 16-byte chunks (c -> c ^ 4 (bit 5 of c) ^
 // 8 (query tile & 1)) so that the 32 lanes of a tr read hit 32 distinct bank pairs.
-// Measured at B = 64 (8192 workgroups): 770 us = 2.8 TB/s of images; staging alone out of a hot L2 takes 240 us, the arithmetic
-// 230 us on top of it, the HBM misses the rest, and they add: a seven-stage image ring with per-wave request roles (96 KiB in flight
-// per CU), register staging through global_load_dwordx4 + ds_write_b128, and a rotated visiting order all measured 770-820 us.
+// Measured at B = 64 (8192 workgroups): 770 us for 3.7 GB on the HBM side (PMC): 4.8 TB/s, bandwidth-bound.  A seven-stage image ring
+// with per-wave request roles (96 KiB in flight per CU), register staging through global_load_dwordx4 + ds_write_b128, and a rotated
+// visiting order all measured 770-820 us.
 #define KV2_STAGES 4
 #define KV2_OFF_P 0
 #define KV2_OFF_DS (KV2_STAGES * 8192)
@@ -962,8 +962,9 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv_kernel(FlashArgs 
 
 __device__ __forceinline__ int kv2_chunk_pos(int c, int qtl) { return c ^ (((c >> 5) & 1) << 2) ^ (qtl << 3); }
 
-// FACT: the P images are the forward's p~ and P = p~ f with f [key block][query] from relattn_flash_bwd_q2_kernel: 64 floats per wave and
-// block (the block's 32 queries + the next 32, one 4-byte LDS-DMA per lane) into a per-wave slot of the stage, two 16-byte reads per lane.
+// FACT: the P images are the forward's p~; P = p~ f with f [key block][query] from relattn_flash_bwd_q2_kernel, and dS is formed HERE as
+// P (dP - delta) scale from dP = dO.V^T (8 more MFMAs; V of the lane's key stationary in registers) instead of being read: 64 floats per
+// wave and block -- f and delta of the block's 32 queries, one 4-byte LDS-DMA per lane -- into a per-wave slot of the stage.
 #define KV2_OFF_F (4 * KV2_STAGES * 8192)       // [stage][wave][64] floats
 #define KV2_LDS_F (KV2_OFF_F + KV2_STAGES * W16_WAVES * 256)
 template <bool FACT>

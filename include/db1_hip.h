@@ -260,9 +260,9 @@ int db1_relattn_flash_fwd(const void* qu, const void* qv, const void* k, const v
  * delta [B,H,L] f32 scratch (rowsum(dout * out): written by the query-side kernel, read by the key-side kernel).
  * Three ways to run it, by what the caller provides (all valid backward passes; P enters dV as bf16 in each):
  *   probs + mblk (what db1_relattn_flash_fwd stored) and db1_relattn_flash_bwd_workspace_bytes(B, L, H, 1) bytes of scratch:
- *       nothing is recomputed -- P = p~ exp2(m_blk c2 - lse log2 e) on the query side, dS and the factors go through the scratch to
- *       the key side, which is two causal contractions over the images (memory for time: B*H*L*L bf16 + B*H*L*L/32 floats per LAYER
- *       kept from the forward, the same again once as scratch);
+ *       no score is recomputed -- P = p~ exp2(m_blk c2 - lse log2 e) on both sides, the factors go from the query side to the key side
+ *       through the scratch (B*H*L*L/32 floats), and each side forms its own dS = P (dP - delta) scale from its own dP = dO.V^T
+ *       (memory for time: B*H*L*L bf16 + B*H*L*L/32 floats per LAYER kept from the forward);
  *   no probs, db1_relattn_flash_bwd_workspace_bytes(B, L, H, 0) bytes of scratch (2 x B*H*L*L bf16): the query side recomputes scores,
  *       relative term and softmax and leaves P and dS in the scratch for the key side;
  *   neither (ws NULL / smaller): both sides recompute. */
