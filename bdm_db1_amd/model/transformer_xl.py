@@ -158,6 +158,8 @@ class TransformerXL(nn.Module):
         # unnormalised probabilities per layer (B*H*L*L bf16 + B*H*L*L/32 floats each: 2.2 GiB per layer at 64 x 1024 tokens);
         # "scratch" = the query side recomputes and leaves P / dS in one scratch buffer for the key side; "recompute" = both sides
         self.flash_probs_mode = "forward"
+        self.flash_probs_budget = 0.25   # "forward" only while the kept probabilities of all layers fit in this fraction of the device memory, else "scratch"
+        self._probs_mode_cache = {}
         self.use_headbias_epilogue = True  # q + r_w_bias / q + r_r_bias written by the qkv projection's epilogue (large bf16 batches)
         self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
@@ -298,6 +300,20 @@ class TransformerXL(nn.Module):
 
     def _new(self, *shape, dtype=None):
         return torch.empty(*shape, device=self.dev, dtype=self.compute_dtype if dtype is None else dtype)
+
+    def _probs_mode(self, B: int, L: int) -> str:
+        """flash_probs_mode, demoted from "forward" to "scratch" when keeping B*H*L*L bf16 (+ L/32 floats per row) for every layer would
+        take more than flash_probs_budget of the device memory (decided once per shape)"""
+        if self.flash_probs_mode != "forward":
+            return self.flash_probs_mode
+        key = (B, L, self.flash_probs_budget)
+        mode = self._probs_mode_cache.get(key)
+        if mode is None:
+            need = self.n_layer * B * self.n_head * L * (L * 2 + (L // 32) * 4)
+            total = torch.cuda.get_device_properties(self.dev).total_memory
+            mode = "forward" if need <= self.flash_probs_budget * total else "scratch"
+            self._probs_mode_cache[key] = mode
+        return mode
 
     def _window(self, qlen: int, mlen: int) -> int:
         """shift of the visibility predicate i - shift < j <= i + mlen (transformer_xl.py:551-567)."""
@@ -666,7 +682,7 @@ class TransformerXL(nn.Module):
                 ops.relattn_add_head_bias(qkv, u, vb, qu, qv, B, Lq, Lk, H, D)
             lse = self._new(B, H, Lq, dtype=torch.float32)
             probs = mblk = None
-            if c is not None and self.use_flash_bwd and self.flash_probs_mode == "forward":
+            if c is not None and self.use_flash_bwd and self._probs_mode(B, Lq) == "forward":
                 probs = self._new(B * H, Lq // 32, Lq // 16, 512)
                 mblk = self._new(B * H, Lq // 32, Lq, dtype=torch.float32)
             ops.relattn_flash_fwd(qu, qv, qkv.view(B, Lk, 3, H, D), R, av, lse, B, Lq, H, D, shift, 1.0 / math.sqrt(D), probs=probs, mblk=mblk)
@@ -769,7 +785,7 @@ class TransformerXL(nn.Module):
                 dT = torch.zeros(H, B, L, L, device=self.dev, dtype=self.compute_dtype)
             delta = self._new(B, H, L, dtype=torch.float32)
             ops.relattn_flash_bwd(qu, qv, qkv5, R, c.av, dav4, c.lse, delta, dqkv5, dT, B, L, H, D, shift, scale,
-                                  store_probs=self.flash_probs_mode != "recompute", probs=c.probs, mblk=c.mblk)
+                                  store_probs=self._probs_mode(B, L) != "recompute", probs=c.probs, mblk=c.mblk)
             c.probs = c.mblk = None
         else:
             Pm, T, qu, qv = self._attn_probs(qkv, R, u, vb, B, L, L, 0, shift)

@@ -226,6 +226,8 @@ def main():
                                f"{args.dropout:g} on embeddings / attention / feed-forward outputs as the reference's defaults), seq_len 1024, "
                                f"{B} sequences/GPU/step, random-init weights", "dropout": args.dropout, "n_layer": args.layers, "n_embed": 2048, "n_head": 16,
                    "seq_len": L, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "attention_backward": {"forward": "nothing recomputed (the forward keeps its probabilities)", "scratch": "query side recomputes, P / dS through scratch",
+                                          "recompute": "both sides recompute"}[model._probs_mode(B, L)],
                    "params": int(sum(int(np.prod(s)) for _, s, _ in model.arena.offsets.values()))},
         "pct_mfma_peak_step": round(100.0 * flops_step_all / (dt / args.steps) / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 2),
         "final_loss": round(loss_v, 4),
