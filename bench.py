@@ -266,6 +266,28 @@ def main():
             ks[fam] = {"bound": "mfma" if mfma else "hbm", "achieved": round(rate, 1), "unit": "TFLOP/s" if mfma else "GB/s",
                        "frac": round(rate / peak, 4), "avg_us": round(fms * 1e3 / n, 1), "launches": n,
                        "share_of_step": round(fms / (dt * 1e3), 4)}
+        # the attention kernels are streams since DESIGN 4a: beside the MFMA fraction of their algorithmic FLOPs, the HBM-side bytes per launch of
+        # the committed PMC passes (same workload, an earlier run) over the live HIP-event time
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")))
+            rec = json.load(open(cands[-1])) if cands and args.workload == "text" else None
+            if rec and rec.get("batch_per_gpu", 16) == B:
+                pk = rec["kernels"]
+                groups = {"flash_fwd": ["relattn_flash_fwd_kernel"], "flash_bwd": ["relattn_flash_bwd_q", "relattn_flash_bwd_kv"]}
+                mode_tag = {"forward": ("<true>", "q2_kernel", "kv2_kernel<true>"), "scratch": ("<false>", "q_kernel<true>", "kv2_kernel<false>"),
+                            "recompute": ("<false>", "q_kernel<false>", "kv_kernel")}[model._probs_mode(B, L)]
+                for fam, names in groups.items():
+                    if fam not in ks:
+                        continue
+                    want = [mode_tag[0]] if fam == "flash_fwd" else list(mode_tag[1:])
+                    tot = sum(v["hbm_side_bytes_per_launch"] for k, v in pk.items() if any(k.startswith(nm) for nm in names) and any(w in k for w in want))
+                    if tot > 0:
+                        gbs = tot / (ks[fam]["avg_us"] * 1e-6) / 1e9
+                        ks[fam].update({"hbm_side_bytes_per_launch": int(tot), "hbm_gbps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBPS, 4),
+                                        "hbm_source": os.path.relpath(cands[-1], ROOT)})
+        except Exception:
+            pass
         out["kernels"] = ks
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
