@@ -200,6 +200,12 @@ def test_model_bf16_flash_vs_oracle_and_vs_materialised():
         for n in ("h.0.dec_attn.qkv_net.weight", "h.1.dec_attn.o_net.weight", "r_w_bias", "r_r_bias", "h.0.dec_attn.r_net.weight", "word_embedding.weight"):
             assert rel_err(results[flash][2][n], ref_grads[n]) < 6e-2, (flash, n)
     assert np.abs(results["forward"][0] - results[False][0]).max() / np.abs(ref_logits).max() < 2e-2
+    # the memory guard: "forward" is demoted to "scratch" when the kept probabilities would exceed the budget fraction of the device memory
+    model.flash_probs_mode = "forward"
+    assert model._probs_mode(B, L) == "forward"
+    model.flash_probs_budget = 0.0
+    assert model._probs_mode(B, L) == "scratch"
+    model.flash_probs_budget = 0.25
 
 
 @pytest.mark.parametrize("B,L,H", [(2, 256, 2), (3, 1024, 3), (1, 640, 1), (20, 128, 16)])
