@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DB1_BENCH_BATCH", 64)), help="sequences per GPU per step")
+    ap.add_argument("--ga", type=int, default=1, help="gradient-accumulation micro-steps per optimizer step (the reference trains micro-batch 4 x GA 16, "
+                                                      "scripts/evaluate/evaluate_rl_1.2B.sh:28-42): one timed step = GA x (fwd + bwd) + clip + Adam")
     ap.add_argument("--layers", type=int, default=24, help="debug only: anything but 24 is not the benchmark config")
     ap.add_argument("--workload", default="text", choices=["text", "caption", "rl", "mixture"])
     ap.add_argument("--dropout", type=float, default=0.1, help="drop = embd_pdrop of the training step (the reference's defaults, src/config.py:123,161: 0.1)")
@@ -165,7 +167,8 @@ def main():
     model = TransformerXL(cfg, device=dev)
     model.use_flash = not args.no_flash
     model.flash_probs_mode = args.flash_probs
-    eargs = SimpleNamespace(lr=1e-4, weight_decay=0.01, clip_grad=1.0, optimizer="adam", keep_logits=False, fuse_head_loss=not args.materialise_logits)
+    eargs = SimpleNamespace(lr=1e-4, weight_decay=0.01, clip_grad=1.0, optimizer="adam", keep_logits=False, fuse_head_loss=not args.materialise_logits,
+                            gradient_accumulation_steps=args.ga)
     engine, _, _, _ = initialize(eargs, model, mpu=mpu if world > 1 else None)
     engine.train()
     B, L = args.batch, cfg.n_position
@@ -187,9 +190,10 @@ def main():
             n_patches += v.shape[0] * v.shape[1] * (v.shape[3] // 16) * (v.shape[4] // 16)
 
     def step():
-        logits, loss = engine(batch)
-        engine.backward(loss)
-        engine.step()
+        for _ in range(args.ga):   # train.py:216-232: GA micro-steps of engine(x) -> backward -> step; the optimizer runs on the boundary
+            logits, loss = engine(batch)
+            engine.backward(loss)
+            engine.step()
         return loss
 
     def fence():
@@ -215,17 +219,17 @@ def main():
     loss_v = float(loss)
 
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2**30
-    tokens = world * B * L * args.steps
+    tokens = world * B * L * args.steps * args.ga
     tok_s = tokens / dt
-    flops_step_all = world * (B * L * FLOP_PER_TOKEN + n_patches * FLOP_PER_PATCH)
+    flops_step_all = world * args.ga * (B * L * FLOP_PER_TOKEN + n_patches * FLOP_PER_PATCH)
     out = {
         "metric": "pretrain tokens/sec (whole node) DB1-1.3B seq1024", "value": round(tok_s, 1), "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"DB1-1.3B {args.workload} causal LM pre-training step (fwd+bwd+clip+Adam, training mode: dropout "
                                f"{args.dropout:g} on embeddings / attention / feed-forward outputs as the reference's defaults), seq_len 1024, "
-                               f"{B} sequences/GPU/step, random-init weights", "dropout": args.dropout, "n_layer": args.layers, "n_embed": 2048, "n_head": 16,
-                   "seq_len": L, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                               f"{B} sequences/GPU/micro-step x {args.ga} micro-step(s) per optimizer step, random-init weights", "dropout": args.dropout, "n_layer": args.layers, "n_embed": 2048, "n_head": 16,
+                   "seq_len": L, "batch_per_gpu": B, "grad_accumulation": args.ga, "global_batch": B * world * args.ga, "parallelism": f"dp{world}",
                    "attention_backward": {"forward": "nothing recomputed (the forward keeps its probabilities)", "scratch": "query side recomputes, P / dS through scratch",
                                           "recompute": "both sides recompute"}[model._probs_mode(B, L)],
                    "params": int(sum(int(np.prod(s)) for _, s, _ in model.arena.offsets.values()))},
