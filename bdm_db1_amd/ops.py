@@ -561,3 +561,8 @@ def gemm_force_generic(on: bool):
 def gemm_tile_override(tile: int):
     """test / tuning hook (include/db1_hip_test.h), thread-local: 0 = measured heuristics; 128 / 256 / 512 / 1024 pin one bf16 tile kernel"""
     lib.load().db1_test_gemm_tile_override(int(tile))
+
+
+def flash_fwd2(on: bool):
+    """test hook (include/db1_hip_test.h), thread-local: False = the compiled key-block loop instead of the hand-scheduled forward"""
+    lib.load().db1_test_flash_fwd2(1 if on else 0)
