@@ -16,6 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdb1_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+FLAGS += os.environ.get("DB1_EXTRA_HIPCC_FLAGS", "").split()   # experiments only (tools/exp): e.g. -DFW2_STOP=2; part of the build digest
 
 
 def _hipcc() -> str:

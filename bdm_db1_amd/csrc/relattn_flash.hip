@@ -836,8 +836,9 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs
 }
 
 // ======================================================================================= host side
-extern "C" int db1_relattn_flash_fwd2_launch(const FlashArgs* a, void* stream);   // relattn_flash_fwd2.hip
-static thread_local int g_fwd2_on = 1;   // test hook (include/db1_hip_test.h)
+extern "C" int db1_relattn_flash_fwd2_launch(const FlashArgs* a, void* stream);   // relattn_flash_fwd2.hip (8 waves x 16 rows)
+extern "C" int db1_relattn_flash_fwd3_launch(const FlashArgs* a, void* stream);   // relattn_flash_fwd3.hip (4 waves x 32 rows: the default)
+static thread_local int g_fwd2_on = 1;   // test hook (include/db1_hip_test.h): 0 compiled loop, 1 default (fwd3), 2 fwd2
 extern "C" void db1_test_flash_fwd2(int on) { g_fwd2_on = on; }
 extern "C" int db1_relattn_flash_supported(int B, int L, int H, int D, int dt) {
     return (dt == DB1_BF16 && D == FA_D && B > 0 && H > 0 && L >= FA_BQ && (L % FA_BQ) == 0 && B <= 65535 && H <= 65535) ? 1 : 0;
@@ -871,7 +872,7 @@ extern "C" int db1_relattn_flash_fwd(const void* qu, const void* qv, const void*
     });
     // plain causal window + kept probabilities (the training configuration): the hand-scheduled loop of relattn_flash_fwd2.hip
     static const bool fwd2_off = getenv("DB1_FLASH_FWD2") && atoi(getenv("DB1_FLASH_FWD2")) == 0;   // A/B switch, read once
-    if (probs && shift >= L && !fwd2_off && g_fwd2_on) return db1_relattn_flash_fwd2_launch(&a, stream);
+    if (probs && shift >= L && !fwd2_off && g_fwd2_on) return g_fwd2_on == 2 ? db1_relattn_flash_fwd2_launch(&a, stream) : db1_relattn_flash_fwd3_launch(&a, stream);
     if (probs) relattn_flash_fwd_kernel<true><<<dim3(flash_grid(L / FA_BQ, H, B)), 512, W16_FWD_LDS, (hipStream_t)stream>>>(a);
     else relattn_flash_fwd_kernel<false><<<dim3(flash_grid(L / FA_BQ, H, B)), 512, W16_FWD_LDS, (hipStream_t)stream>>>(a);
     DB1_CHECK_LAUNCH("relattn_flash_fwd");

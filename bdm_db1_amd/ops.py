@@ -563,6 +563,7 @@ def gemm_tile_override(tile: int):
     lib.load().db1_test_gemm_tile_override(int(tile))
 
 
-def flash_fwd2(on: bool):
-    """test hook (include/db1_hip_test.h), thread-local: False = the compiled key-block loop instead of the hand-scheduled forward"""
-    lib.load().db1_test_flash_fwd2(1 if on else 0)
+def flash_fwd2(mode):
+    """test hook (include/db1_hip_test.h), thread-local: 0 / False = the compiled key-block loop, 1 / True = the default (hand-scheduled
+    4-wave forward), 2 = the hand-scheduled 8-wave forward"""
+    lib.load().db1_test_flash_fwd2(int(mode))

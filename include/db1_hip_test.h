@@ -17,8 +17,9 @@ void db1_test_gemm_force_generic(int on);
  * (2 stages of k64), 1024 = the same with a 4-stage ring of k32; 0 = the measured heuristics (the default) */
 void db1_test_gemm_tile_override(int tile);
 
-/* the flash-attention forward that keeps its probabilities: 0 = the compiled key-block loop (relattn_flash.hip) instead of the
- * hand-scheduled one (relattn_flash_fwd2.hip), 1 = the default dispatch; lets the parity tests compare the two on the same inputs */
+/* the flash-attention forward that keeps its probabilities: 0 = the compiled key-block loop (relattn_flash.hip), 1 = the default
+ * dispatch (the hand-scheduled 4-wave loop, relattn_flash_fwd3.hip), 2 = the hand-scheduled 8-wave loop (relattn_flash_fwd2.hip);
+ * lets the parity tests compare them on the same inputs */
 void db1_test_flash_fwd2(int on);
 
 #ifdef __cplusplus

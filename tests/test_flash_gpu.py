@@ -241,3 +241,45 @@ def test_dq_r_stream_kernel_matches_the_batched_gemm(B, L, H):
     du2, dv2 = torch.full((H * D,), 0.25, device=DEV), torch.full((H * D,), -0.5, device=DEV)
     ops.relattn_dqr_fused(dT, R, dqkv2[:, :, 0], du2, dv2)
     assert torch.equal(dqkv2[:, :, 0], dqkv[:, :, 0]) and torch.equal(du2, du) and torch.equal(dv2, dv)
+
+
+@pytest.mark.parametrize("B,L,H", [(1, 128, 1), (2, 256, 2), (1, 384, 1), (1, 1024, 2)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_hand_scheduled_forward_matches_compiled_loop(B, L, H, mode):
+    """the forward that keeps its probabilities, plain causal window: the hand-scheduled key-block loops (1: four waves x 32 rows,
+    relattn_flash_fwd3.hip, the default; 2: eight waves x 16 rows, relattn_flash_fwd2.hip) against the compiled loop on the same inputs.
+    Their block maxima are DEFERRED (the maximum a block was exponentiated against), so what is compared is what the backward rebuilds
+    from the images: P = p~ exp2(m_blk c2 - lse log2 e); plus out, lse and the pattern of never-written (NaN pre-filled) tiles."""
+    from bdm_db1_amd import ops
+    D = 128
+    qkv, R, u, vb = make_inputs(B, L, H, D, seed=3 + L, scale_q=0.8)
+    scale = 1.0 / math.sqrt(D)
+    QKV, Rd, U, VB = dev16(qkv), dev16(R), dev16(u), dev16(vb)
+    qu, qv = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16), torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
+    ops.relattn_add_head_bias(QKV, U, VB, qu, qv, B, L, L, H, D)
+    res = []
+    try:
+        for m in (0, mode):
+            ops.flash_fwd2(m)
+            out = torch.full((B, L, H, D), 7.0, device=DEV, dtype=torch.bfloat16)
+            lse = torch.full((B, H, L), 3.0, device=DEV, dtype=torch.float32)
+            probs = torch.full((B * H, L // 32, L // 16, 512), float("nan"), device=DEV, dtype=torch.bfloat16)
+            mblk = torch.full((B * H, L // 32, L), float("nan"), device=DEV, dtype=torch.float32)
+            ops.relattn_flash_fwd(qu, qv, QKV, Rd, out, lse, B, L, H, D, L, scale, probs=probs, mblk=mblk)
+            torch.cuda.synchronize()
+            res.append((out.float().cpu(), lse.cpu(), probs.float().cpu(), mblk.cpu()))
+    finally:
+        ops.flash_fwd2(1)
+
+    def rebuilt(p, m, l):   # image [bh][jb][qt][lane][8], lane & 15 = query inside its 16-row tile
+        BH, NJ, NQ = p.shape[0], p.shape[1], p.shape[2]
+        f = torch.exp2(m.view(BH, NJ, NQ, 1, 16) - l.reshape(BH, 1, NQ, 1, 16) * 1.4426950408889634).expand(BH, NJ, NQ, 4, 16).reshape(BH, NJ, NQ, 64, 1)
+        return p.view(BH, NJ, NQ, 64, 8) * f
+    (o0, l0, p0, m0), (o1, l1, p1, m1) = res
+    assert bool((torch.isnan(p0) == torch.isnan(p1)).all()) and bool((torch.isnan(m0) == torch.isnan(m1)).all())
+    assert bool(torch.isfinite(o1).all()) and bool(torch.isfinite(l1).all())
+    P0, P1 = torch.nan_to_num(rebuilt(p0, m0, l0)), torch.nan_to_num(rebuilt(p1, m1, l1))
+    assert float((P0 - P1).abs().max()) < 6e-3                    # probabilities (<= 1): bf16 rounding of p~ at two different scales
+    assert float((l0 - l1).abs().max()) < 8e-3                    # row sums over the bf16 p~ (matrix pipe) vs over the fp32 values
+    assert float((o0 - o1).abs().max()) < 1.5e-2 * float(o0.abs().max())
+    assert float(torch.nan_to_num(p1).abs().max()) <= 256.0       # deferred maximum: p~ is bounded by 2^8

@@ -91,10 +91,10 @@ TP = 68
 
 
 class I:
-    __slots__ = ("text", "kind", "rd", "wr", "rare")
+    __slots__ = ("text", "kind", "rd", "wr", "rare", "srcc")
 
-    def __init__(self, text, kind, rd=(), wr=(), rare=False):
-        self.text, self.kind, self.rd, self.wr, self.rare = text, kind, frozenset(rd), frozenset(wr), rare
+    def __init__(self, text, kind, rd=(), wr=(), rare=False, srcc=()):
+        self.text, self.kind, self.rd, self.wr, self.rare, self.srcc = text, kind, frozenset(rd), frozenset(wr), rare, frozenset(srcc)
 
 
 def rng(b, n):
@@ -113,7 +113,7 @@ def sr(b, n=1):
 def mfma(dst, a, b, c=None):
     cs = "0" if c is None else vr(c, 4)
     rd = set(rng(a, 4)) | set(rng(b, 4)) | (set(rng(c, 4)) if c is not None else set())
-    return I(f"v_mfma_f32_16x16x32_bf16 {vr(dst, 4)}, {vr(a, 4)}, {vr(b, 4)}, {cs}", "mfma", rd, rng(dst, 4))
+    return I(f"v_mfma_f32_16x16x32_bf16 {vr(dst, 4)}, {vr(a, 4)}, {vr(b, 4)}, {cs}", "mfma", rd, rng(dst, 4), srcc=(rng(c, 4) if c is not None else ()))
 
 
 def valu(op, dst, *src, kind="valu", extra_rd=()):
@@ -185,7 +185,8 @@ def finalize(seq, name):
         return sum(states(x) for x in out[idx_writer + 1:] if not x.rare)
 
     last_writer = {}    # vgpr -> index in out
-    for ins in seq:
+    look = int(os.environ.get("FW_WAIT_LOOKAHEAD", 8))
+    for idx, ins in enumerate(seq):
         touched = ins.rd | ins.wr
         # LDS results
         need = None
@@ -193,6 +194,15 @@ def finalize(seq, name):
             if dst & touched:
                 need = pos
         if need is not None:
+            # one wait for a run of consumers: also cover what the next few instructions need, as long as no LDS / memory operation or
+            # branch comes first (every s_waitcnt is an issue slot of an issue-bound wave)
+            for nx in seq[idx + 1: idx + 1 + look]:
+                if nx.kind in ("dsr", "dsw", "vmem", "branch", "label", "barrier", "wait"):
+                    break
+                t2 = nx.rd | nx.wr
+                for pos, dst in enumerate(queue):
+                    if dst & t2 and pos > need:
+                        need = pos
             after = min(len(queue) - 1 - need, 15)    # (a smaller count only waits longer: the queue retires in order)
             out.append(I(f"s_waitcnt lgkmcnt({after})", "wait"))
             queue = queue[len(queue) - after:] if after else []
@@ -201,11 +211,7 @@ def finalize(seq, name):
         for r in touched:
             if r in last_writer:
                 w = out[last_writer[r]]
-                srcc = False
-                if ins.kind == "mfma" and w.kind == "mfma":
-                    # SrcC is the last operand; a chain reads its own destination there
-                    srcc = (r in ins.wr) and ins.text.rstrip().endswith(vr(min(ins.wr), 4))
-                req = need_states(w, ins, srcc)
+                req = need_states(w, ins, ins.kind == "mfma" and w.kind == "mfma" and r in ins.srcc and r in ins.wr)   # (an accumulate chain reads its own destination as SrcC)
                 if req:
                     have = dist_back(last_writer[r])
                     worst = max(worst, req - have)
@@ -273,11 +279,18 @@ def ring_addr(tt, ks, dst):
 
 def softmax_top(cur):
     """running maximum update + (rare) rescale of O and l, then mc = -m c2"""
-    o = [valu("v_max_f32", T0, MI, MBLK),
-         I(f"v_cmp_eq_f32 vcc, {vr(T0)}, {vr(MI)}", "valu", {T0, MI}, ()),
-         salu("s_cmp_eq_u64 vcc, exec"),
+    # deferred maximum: the running maximum only moves when a block exceeds it by more than 2^THR (in exp2 units); p~ = exp2((s - m) c2)
+    # is then bounded by 2^THR instead of 1, which fp32 sums and bf16 p~ (a relative format) do not mind, and the stored block maximum is
+    # the one that was USED.  With the exact rule the O-wide rescale ran in most iterations (some row of 16 finds a new maximum).
+    thr = float(os.environ.get("FW2_THR", 8.0))
+    import struct
+    thr_hex = "0x%08x" % struct.unpack("<I", struct.pack("<f", thr))[0]
+    o = [valu("v_sub_f32", T0, MBLK, MI),
+         valu("v_mul_f32", T0, sr(S_C2), T0),
+         I(f"v_cmp_lt_f32 vcc, {thr_hex}, {vr(T0)}", "valu", {T0}, ()),
+         salu("s_cmp_eq_u64 vcc, 0"),
          I("s_cbranch_scc1 L_nr_@", "branch")]
-    rare = [valu("v_sub_f32", T0 + 1, MI, T0), valu("v_mul_f32", T0 + 1, sr(S_C2), T0 + 1), valu("v_exp_f32", T0 + 1, T0 + 1, kind="trans"),
+    rare = [valu("v_max_f32", T0, MI, MBLK), valu("v_sub_f32", T0 + 1, MI, T0), valu("v_mul_f32", T0 + 1, sr(S_C2), T0 + 1), valu("v_exp_f32", T0 + 1, T0 + 1, kind="trans"),
             valu("v_mov_b32", MI, T0), nop(1), valu("v_mul_f32", LI, LI, T0 + 1)]
     rare += [valu("v_mul_f32", O + i, O + i, T0 + 1) for i in range(32)]
     for x in rare:
@@ -376,8 +389,10 @@ def interleave(slots, fillers, per=None):
     return out
 
 
-def tail(nstores, r6):
-    return [I(f"s_waitcnt vmcnt({3 + nstores})", "wait"), I("s_barrier", "barrier"),
+def tail(nstores, r6, prev_stores=0):
+    # everything but this iteration's requests / stores (and the previous iteration's stores, which are younger than ITS requests) has to
+    # have landed: the queue retires in order, so the stores get one more iteration for their acknowledgements
+    return [I(f"s_waitcnt vmcnt({3 + nstores + prev_stores})", "wait"), I("s_barrier", "barrier"),
             salu(f"s_add_u32 {sr(S_R)}, {sr(S_R)}, 1"),
             salu(f"s_cmp_gt_u32 {sr(S_R)}, {sr(S_END)}"),
             I("s_cbranch_scc1 L_done_%=", "branch"),
@@ -449,7 +464,7 @@ def path_steady(r6):
     bm = block_max(nxt)
     fill = [next_scores(nxt), mask_block(nxt), bm[0:4], bm[4:7], bm[7:10]]     # (the mask block is skipped by a branch: it stays in one piece)
     seq += interleave(pv, fill, [3, 4, 5, 6, 7])
-    seq += tail(2, r6)
+    seq += tail(2, r6, int(os.environ.get('FW2_PREVST', 2)) if r6 != 1 else 0)
     return seq
 
 
