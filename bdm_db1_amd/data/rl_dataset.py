@@ -68,6 +68,8 @@ class RLFullDataset(torch.utils.data.Dataset):
         self.prompt_prob, self.prompt_at_final_transition_prob = prompt_prob, prompt_at_final_transition_prob
         self.prompt_ratio, self.mask_prompt_action_loss = prompt_ratio, mask_prompt_action_loss
         self.text_tokenizer, self.discretizer = tokenizers
+        # DataLoader workers of this dataset need their own HIP runtime when the discretizer is the device tokenizer (samplers.py)
+        self.uses_device_tokenizer = type(self.discretizer).__module__.startswith("bdm_db1_amd.")
         self.num_discrete_values, self.overlap_with_text = int(num_discrete_values), bool(overlap_with_text)
         self.observations = [t[0] for t in trajectories]
         self.actions = [np.asarray(t[1]) for t in trajectories]
@@ -274,6 +276,7 @@ class RLDataset(torch.utils.data.Dataset):
     def __init__(self, unused_name, unused_data_prefix, documents: np.ndarray, underlying_dataset, *unused):
         assert documents.ndim == 1 and documents.min() >= 0 and documents.max() < len(underlying_dataset)
         self.dataset, self.indices = underlying_dataset, documents
+        self.uses_device_tokenizer = getattr(underlying_dataset, "uses_device_tokenizer", False)
 
     def __len__(self):
         return len(self.indices)

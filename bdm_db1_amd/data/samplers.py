@@ -147,5 +147,13 @@ def build_pretraining_data_loader(args, dataset, consumed_samples, total_samples
             sampler = RandomPretrainingSampler(dataset, total_samples, consumed_samples, args.micro_batch_size, rank, world, True)
     else:
         raise Exception("{} dataloader type is not supported.".format(args.dataloader_type))
-    return torch.utils.data.DataLoader(dataset, batch_sampler=sampler, num_workers=args.num_workers, pin_memory=True,
-                                       collate_fn=my_collate_fn)
+    # Worker processes: datasets that tokenize on the device (RLFullDataset -> ContinuousScalarTokenizer.discretize, the HIP mu-law kernel)
+    # cannot run in FORKED workers (HIP does not survive a fork: "Cannot re-initialize CUDA in forked subprocess"), so workers are started
+    # with the spawn context -- each initialises its own HIP runtime; num_workers = 0 (the reference's default, src/config.py) stays in-process.
+    nw = int(getattr(args, "num_workers", 0) or 0)
+    ctx = None
+    if nw > 0 and (getattr(dataset, "uses_device_tokenizer", False) or any(getattr(d, "uses_device_tokenizer", False) for d in getattr(dataset, "datasets", []))):
+        import multiprocessing
+        ctx = multiprocessing.get_context("spawn")
+    return torch.utils.data.DataLoader(dataset, batch_sampler=sampler, num_workers=nw, pin_memory=True, collate_fn=my_collate_fn,
+                                       multiprocessing_context=ctx)

@@ -209,7 +209,10 @@ class DB1Engine:
             state = {"module": {k: v.detach().cpu() for k, v in self.module.state_dict().items()},
                      "optimizer": {"exp_avg": ar.exp_avg.cpu(), "exp_avg_sq": ar.exp_avg_sq.cpu(), "step": self.global_steps},
                      "lr_scheduler": self.lr_scheduler.state_dict() if self.lr_scheduler is not None else None,
-                     "global_steps": self.global_steps, "micro_steps": self.micro_steps}
+                     "global_steps": self.global_steps, "micro_steps": self.micro_steps,
+                     # the dropout stream (counter-based Philox on (seed, site, step)): a resumed run continues it instead of replaying the
+                     # masks of the first iterations
+                     "dropout": {"seed": int(self.module.dropout_seed), "step": int(self.module._drop_step)}}
             state.update(client_state or {})
             torch.save(state, os.path.join(path, "mp_rank_00_model_states.pt"))
             with open(os.path.join(save_dir, "latest"), "w") as f:
@@ -232,9 +235,19 @@ class DB1Engine:
             self.global_steps = int(state["optimizer"].get("step", 0))
         if self.lr_scheduler is not None and state.get("lr_scheduler"):
             self.lr_scheduler.load_state_dict(state["lr_scheduler"])
-        # partially accumulated gradients are not part of a checkpoint: resume at the last accumulation boundary
+        # partially accumulated gradients are not part of a checkpoint: resume at the last accumulation boundary, on clean accumulators
         self.micro_steps = int(state.get("micro_steps", 0)) // self._ga * self._ga
-        client = {k: v for k, v in state.items() if k not in ("module", "optimizer", "lr_scheduler")}
+        with torch.cuda.device(self.module.device):
+            ops.zero_segments(self.module.arena.grad, self._acc_segments)
+        self.module._grad_fresh = True
+        self.module._ctx = None
+        self.sync.handles, self.sync.launched = [], set()
+        if state.get("dropout"):
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+            if rank == 0:   # (the other ranks keep their own seed: seed + rank at construction; the step counter is common)
+                self.module.dropout_seed = int(state["dropout"]["seed"])
+            self.module._drop_step = int(state["dropout"]["step"])
+        client = {k: v for k, v in state.items() if k not in ("module", "optimizer", "lr_scheduler", "dropout")}
         return path, client
 
 

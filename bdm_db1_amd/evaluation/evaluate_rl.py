@@ -97,7 +97,9 @@ def get_action(args, model, current_seq, vision_seq, cont_tokenizer, len_fixed_p
                     current_seq[len_fixed_prompt:] = torch.roll(current_seq[len_fixed_prompt:], -trans).clone()
                     current_seq = current_seq[:-trans]
                     if vision_seq is not None:
-                        vision_seq[len_fixed_prompt_img:] = torch.roll(vision_seq[len_fixed_prompt_img:], -1, dims=0).clone()
+                        # the reference rolls WITHOUT dims (evaluate_rl.py:217-219): the image window is flattened and moved by ONE ELEMENT,
+                        # not by one image; reproduced as is (results identical to the reference's on the same inputs)
+                        vision_seq[len_fixed_prompt_img:] = torch.roll(vision_seq[len_fixed_prompt_img:], -1).clone()
                         vision_seq = vision_seq[:-1]
                 else:
                     current_seq, vision_seq = truncate_sequence_by_stepsize(current_seq, vision_seq, obs_length, action_length, None)

@@ -243,7 +243,7 @@ class TransformerXL(nn.Module):
             for name in self.arena.offsets:
                 p = self.arena.view(self.arena.master, name)
                 leaf = name.split(".")[-1]
-                if "layer_norm" in name or ("residual_path" in name and p.dim() == 1):
+                if "layer_norm" in name or ".residual_path.0." in name or ".residual_path.3." in name:   # LayerNorm / GroupNorm: (1, 0)
                     p.fill_(1.0 if leaf == "weight" else 0.0)
                 elif "patch_embeddings" in name:  # nn.Conv2d default init (kaiming_uniform, a = sqrt(5))
                     wname = name.rsplit(".", 1)[0] + ".weight"
@@ -1056,7 +1056,12 @@ class TransformerXL(nn.Module):
         T = B * L
         V = self.total_vocab_size
         loss, lm_logits = None, None
-        fused = compute_loss and keep and self.fuse_head_loss and not self.keep_logits
+        # the fused sweep writes the head's weight gradient during the FORWARD: only forwards that are trained on take it (training mode,
+        # gradients enabled); a validation pass in eval() mode goes through the logits and leaves the accumulators alone
+        fused = compute_loss and keep and self.fuse_head_loss and not self.keep_logits and self.training
+        if fused and self._ctx is not None and getattr(self._ctx, "dh_head", None) is not None:
+            raise RuntimeError("the previous training forward (fused head + loss) was not followed by backward(): its head gradient is already in "
+                               "the accumulators.  Call backward(), or zero_grad(), or run forwards that are not trained on under eval() / torch.no_grad().")
         if compute_loss:
             lab = (labels[0] if len(labels) == 1 else torch.cat(labels, dim=0)).reshape(-1).contiguous()
             msk = (masks[0] if len(masks) == 1 else torch.cat(masks, dim=0)).reshape(-1).contiguous()
@@ -1142,6 +1147,7 @@ class TransformerXL(nn.Module):
     def zero_grad(self, set_to_none: bool = False):
         self.arena.grad.zero_()
         self._grad_fresh = True
+        self._ctx = None
 
     def gemm_first_grads(self) -> List[str]:
         """parameters whose gradient's FIRST writer in a backward is a GEMM (which can write with beta = 0): the five weight matrices of

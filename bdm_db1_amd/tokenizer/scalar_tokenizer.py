@@ -6,7 +6,8 @@ evaluation wrapper (evaluation/rl/wrapper.py:140) and the action read-out (evalu
 Token ids are bit-identical to the reference's torch-CPU result (float32 op order, correctly rounded log); decoded values are
 within 1 ulp.  Inputs may be NumPy arrays, CPU tensors (the reference's case: the result comes back on the CPU) or device tensors
 (the result stays on the device: nothing synchronises).  There is no CPU implementation here: without libdb1_hip.so and an
-MI355X this raises."""
+MI355X this raises.  In DataLoader workers the HIP runtime has to be initialised by the worker itself: forked workers raise with
+that explanation, ``build_pretraining_data_loader`` starts workers with the spawn context for datasets that use this tokenizer."""
 from __future__ import annotations
 
 import numpy as np
@@ -23,6 +24,11 @@ class ContinuousScalarTokenizer:
 
     @staticmethod
     def _device():
+        import os
+        if getattr(torch.cuda, "_is_in_bad_fork", lambda: False)():
+            raise lib.Db1Error("ContinuousScalarTokenizer was called in a FORKED DataLoader worker (pid %d): the HIP runtime does not survive a fork.  "
+                               "Use bdm_db1_amd.data.build_pretraining_data_loader (it starts workers with the spawn context for datasets that "
+                               "tokenize on the device), pass multiprocessing_context='spawn', or num_workers=0." % os.getpid())
         if not torch.cuda.is_available():
             raise lib.Db1Error("ContinuousScalarTokenizer runs on the MI355X kernels (libdb1_hip.so); there is no CPU path")
         return torch.device("cuda", torch.cuda.current_device())

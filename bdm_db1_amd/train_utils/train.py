@@ -41,7 +41,11 @@ def train_step(args, model, data_iterator, get_batch_fn: Callable) -> List[torch
 
 
 def evaluate_loss(args, model, data_iterator, get_batch_fn: Callable) -> float:
-    """mean validation loss over ``args.eval_iters`` optimizer-step-sized groups of batches, no gradients (train.py:97-120)"""
+    """mean validation loss over ``args.eval_iters`` optimizer-step-sized groups of batches, no gradients (train.py:97-120: the sum over
+    iterations of np.mean(loss_list), divided by eval_iters).  ``data_iterator`` may be the reference's (iterator, dict) pair.  The RL / IC /
+    VQA roll-outs that evaluate_and_print_results also starts (simulators, COCO evaluators) are out of scope."""
+    if isinstance(data_iterator, tuple):   # the reference hands (iterator, {name: iterator}) to evaluate_and_print_results (train.py:95): take the iterator
+        data_iterator = data_iterator[0]
     model.eval()
     total, n = 0.0, 0
     with torch.no_grad():

@@ -520,7 +520,36 @@ def gen_data_ingest():
     return out
 
 
+def gen_init_stats():
+    """a14: moments of the reference's own initialisation (transformer_xl.py:444-468 + the nn.Conv2d / nn.GroupNorm defaults it leaves
+    in the patch embedder), plain and DeepNorm: per parameter (mean, std, min, max, numel).  Pins the DISTRIBUTION (the values depend on
+    torch's RNG stream)."""
+    from src.model import TransformerXL
+    out = {}
+    for tag, extra in (("plain", {}), ("deepnorm", {"use_deepnorm": True})):
+        cfg = case_cfg("small_mixed")
+        cfg.update(dict(n_embed=256, n_head=4, n_layer=3, text_vocab_size=4000), **extra)
+        torch.manual_seed(1234)
+        m = TransformerXL(SimpleNamespace(**cfg))
+        names = []
+        for k, v in m.state_dict().items():
+            if k.startswith("ic_encoder.") or k == "pos_emb.inv_freq" or (".dec_attn.r_" in k and not cfg["untie_r"]):
+                continue
+            v = v.double()
+            names.append(k)
+            out[f"{tag}/{k}"] = np.array([float(v.mean()), float(v.std(unbiased=False)), float(v.min()), float(v.max()), v.numel()], np.float64)
+        out[f"{tag}/names"] = np.array(names)
+        if extra:
+            out[f"{tag}/alpha_beta"] = np.array([m.deepnorm_alpha, m.deepnorm_beta], np.float64)
+    out["cfg_n_embed"], out["cfg_n_head"], out["cfg_n_layer"], out["cfg_text_vocab_size"] = np.int64(256), np.int64(4), np.int64(3), np.int64(4000)
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "init":
+        np.savez_compressed(os.path.join(HERE, "init_stats.npz"), **gen_init_stats())
+        print("wrote init_stats")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "data":
         np.savez_compressed(os.path.join(HERE, "data_ingest.npz"), **gen_data_ingest())
         print("wrote data_ingest + data_fixture.idx/.bin")

@@ -2,6 +2,7 @@
 vectors captured from the reference: logits, loss, every parameter gradient, parameters after Adam steps,
 and inference with Transformer-XL memory.  fp32 gate: 1e-3 relative on logits (north_star), in practice ~1e-5;
 bf16 runs are compared with a stated looser tolerance."""
+import math
 import os
 import sys
 from types import SimpleNamespace
@@ -477,3 +478,40 @@ def test_bench_line_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+
+
+@pytest.mark.parametrize("tag", ["plain", "deepnorm"])
+def test_init_matches_reference_distribution(tag):
+    """a14 (transformer_xl.py:444-468): the build's own initialisation against the moments of the REFERENCE's initialisation of the same
+    configuration (tests/golden/init_stats.npz, written by make_golden.py init): constants exactly (LayerNorm / GroupNorm (1, 0), Linear
+    biases 0), random tensors by mean / std / range within sampling error -- N(0, 0.02) for Linear / Embedding / u, v, the nn.Conv2d
+    default U(+-1/sqrt(fan_in)) for the patch embedder's convolutions AND their biases, xavier-uniform with the DeepNorm gains
+    (qkv: gain 1, its value third and o_net / FF: beta = (8 N)^-1/4)."""
+    from bdm_db1_amd import TransformerXL
+    from golden_util import case_cfg
+    ref = np.load(os.path.join(G, "init_stats.npz"))
+    cfg = case_cfg("small_mixed")
+    cfg.update(dict(n_embed=int(ref["cfg_n_embed"]), n_head=int(ref["cfg_n_head"]), n_layer=int(ref["cfg_n_layer"]), text_vocab_size=int(ref["cfg_text_vocab_size"]),
+                    use_deepnorm=(tag == "deepnorm")))
+    torch.manual_seed(4321)
+    model = TransformerXL(SimpleNamespace(**cfg), compute_dtype=torch.float32)
+    sd = model.state_dict()
+    if tag == "deepnorm":
+        assert abs(model.deepnorm_alpha - ref["deepnorm/alpha_beta"][0]) < 1e-6 and abs(model.deepnorm_beta - ref["deepnorm/alpha_beta"][1]) < 1e-6
+    names = [str(n) for n in ref[f"{tag}/names"]]
+    assert len(names) > 40
+    for n in names:
+        rmean, rstd, rmin, rmax, numel = ref[f"{tag}/{n}"]
+        v = sd[n].double().cpu()
+        assert v.numel() == int(numel), n
+        mean, std, mn, mx = float(v.mean()), float(v.std(unbiased=False)), float(v.min()), float(v.max())
+        if rstd == 0.0:
+            assert (mean, mn, mx) == (rmean, rmin, rmax), (n, mean, mn, mx)
+            continue
+        se = 1.0 / math.sqrt(numel)
+        assert abs(mean - rmean) < 6.0 * rstd * se + 1e-9, (n, mean, rmean)
+        assert abs(std / rstd - 1.0) < max(5.0 * se, 0.01) + (0.12 if numel < 200 else 0.0), (n, std, rstd)
+        if numel >= 1000:   # the shape of the distribution: range / std is 2 sqrt(3) for a uniform law, ~8-10 for a normal sample of this size
+            assert abs((mx - mn) / std - (rmax - rmin) / rstd) < 0.18 * (rmax - rmin) / rstd, (n, (mx - mn) / std, (rmax - rmin) / rstd)
+        else:               # small uniform tensors (convolution biases): inside the reference's bound
+            assert mx <= rmax * 1.15 + 1e-6 and mn >= rmin * 1.15 - 1e-6, (n, mn, mx, rmin, rmax)
