@@ -311,7 +311,13 @@ class TransformerXL(nn.Module):
         if mode is None:
             need = self.n_layer * B * self.n_head * L * (L * 2 + (L // 32) * 4)
             total = torch.cuda.get_device_properties(self.dev).total_memory
-            mode = "forward" if need <= self.flash_probs_budget * total else "scratch"
+            # ... and only if it FITS beside what this process (weights, optimizer state, the data-parallel staging arena) and any other
+            # process on the device already hold, plus the activations this shape keeps (~64 KB per token and layer) and the
+            # head's logits chunk: the fallback is the scratch mode, not an out-of-memory error in the middle of the first step
+            free, _ = torch.cuda.mem_get_info(self.dev)
+            free += torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev)
+            acts = int(1.15 * self.n_layer * B * L * 32 * self.d_model) + (6 << 30)
+            mode = "forward" if (need <= self.flash_probs_budget * total and need + acts <= free) else "scratch"
             self._probs_mode_cache[key] = mode
         return mode
 

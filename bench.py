@@ -91,34 +91,70 @@ def cpu_baseline(repeats: int = 3):
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` with no launcher around it: start N copies of this script, one rank per GPU, with the
     rendezvous environment torch.distributed.run would have set (127.0.0.1, a free port).  Rank 0's stdout is ours, so
-    its ONE JSON line is the output.  If any rank fails, the others are stopped (by PID) and its exit code is returned."""
+    its ONE JSON line is the output.  Every rank's stderr goes to a temporary file; when a rank fails (or the job exceeds
+    DB1_LAUNCH_TIMEOUT_S, default 1800 s) the others are stopped by PID and the tail of each failing rank's stderr is shown."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    tmo = float(os.environ.get("DB1_LAUNCH_TIMEOUT_S", 1800))
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL's intra-node transport needs on this driver
+        # dmabuf IPC: this image's host driver supports no other kind, and without the variable RCCL's intra-node transport (and any
+        # sharing of device tensors across processes) fails with `hipIpcGetMemHandle: invalid argument` (the environment notes of this
+        # build; already exported on the GPU boxes -- kept so that a caller's cleaned environment cannot lose it)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+        log = tempfile.NamedTemporaryFile(mode="w+", prefix=f"db1_bench_rank{r}_", suffix=".err", delete=False)
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=log))
+    rc, failed = 0, []
     alive = list(procs)
+    t0 = time.time()
     while alive:
         for p in list(alive):
             code = p.poll()
             if code is None:
                 continue
             alive.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                for q in alive:       # a dead rank leaves the others waiting in a collective forever
-                    q.terminate()
+            if code != 0:
+                failed.append(procs.index(p))
+                if rc == 0:
+                    rc = code
+                    for q in alive:       # a dead rank leaves the others waiting in a collective forever
+                        q.terminate()
+        if alive and time.time() - t0 > tmo:
+            rc = rc or 124
+            failed += [procs.index(q) for q in alive]
+            print(f"bench.py: {len(alive)} rank(s) still running after {tmo:.0f} s (DB1_LAUNCH_TIMEOUT_S): stopping them", file=sys.stderr)
+            for q in alive:
+                q.terminate()
+            for q in alive:
+                try:
+                    q.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    q.kill()
+            alive = []
         time.sleep(0.2)
+    for r, log in enumerate(logs):
+        log.flush()
+        log.seek(0)
+        txt = log.read()
+        log.close()
+        if r in failed and txt.strip():
+            print(f"---- rank {r} stderr (tail) ----\n{txt[-3000:]}", file=sys.stderr)
+        elif r == 0 and txt.strip() and rc == 0 and os.environ.get("DB1_LAUNCH_VERBOSE"):
+            print(txt[-2000:], file=sys.stderr)
+        try:
+            os.unlink(log.name)
+        except OSError:
+            pass
     return rc
 
 
@@ -144,6 +180,8 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if "WORLD_SIZE" in os.environ and os.environ.get("DB1_BENCH_FAIL_RANK") == str(rank):   # test hook: tests/test_dp_gpu.py (failure reporting of self_launch)
+        raise SystemExit(f"DB1_BENCH_FAIL_RANK={rank}: this rank was asked to fail")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
@@ -164,6 +202,8 @@ def main():
         mpu.initialize_model_parallel()
     cfg = synth.db1_config("1.3B", n_layer=args.layers, drop=args.dropout, embd_pdrop=args.dropout)
     torch.manual_seed(1234)
+    if world > 1:   # the ranks build their 22 GB of parameters / optimizer state one after the other (host-side allocation and first-touch
+        time.sleep(float(os.environ.get("DB1_LAUNCH_STAGGER_S", 0.5)) * rank)   # work of eight processes at once helps nobody)
     model = TransformerXL(cfg, device=dev)
     model.use_flash = not args.no_flash
     model.flash_probs_mode = args.flash_probs

@@ -158,3 +158,46 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0 and "cpu_baseline" not in out
+
+
+def test_bench_eight_ranks_on_this_box():
+    """the command the driver's 8-GPU scaling run issues, `python bench.py --gpus 8`, exercised end to end wherever this test runs:
+    eight GPUs -> RCCL, fewer -> DB1_DIST_BACKEND=gloo with the eight ranks sharing the device(s) (2 sequences per rank, the full
+    24-layer model in every rank: 8 x 22 GB of parameters / optimizer state + 8 x 2.4 GB staging on one 288 GB device).  Checks: one
+    JSON line from rank 0, whole-job tokens, dp8, every rank alive to the end, and that the attention backward chose a mode that fits
+    the memory the eight ranks leave (no out-of-memory fallback needed by the caller)."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 8:
+        env["DB1_DIST_BACKEND"] = "gloo"
+    env["DB1_LAUNCH_TIMEOUT_S"] = "1200"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--batch", "2", "--no-cpu-baseline",
+                        "--no-kernel-timing"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8" and out["config"]["global_batch"] == 16
+    assert out["scaling"] == "weak" and out["value"] > 0 and abs(out["value"] - 8 * 2 * 1024 / (out["ms_per_step"] * 1e-3)) < 1e-2 * out["value"]
+    assert "INVALID" not in out and np.isfinite(out["final_loss"]) and 5.0 < out["final_loss"] < 12.0
+    assert "forward" in out["config"]["attention_backward"] or "scratch" in out["config"]["attention_backward"] or "recompute" in out["config"]["attention_backward"]
+
+
+def test_self_launch_reports_a_failing_rank(tmp_path):
+    """a rank that dies must stop the others and surface ITS stderr (not a silent hang): bench.py with an impossible argument for rank 1"""
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, DB1_DIST_BACKEND="gloo", DB1_BENCH_FAIL_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--layers", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "rank 1 stderr" in r.stderr and "DB1_BENCH_FAIL_RANK" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -280,3 +280,94 @@ def test_generated_gemm_loops_are_in_sync_with_their_generator(tmp_path):
         # the LDS-DMA requests: 2 prologue k-tiles + 2 loop bodies, 16 each; none in the two peeled k-tiles
         assert committed.count("global_load_lds_dwordx4") == 64
         assert committed.count("s_barrier") == 1 + 2 * 3 + 1
+
+
+def _dp8_worker(rank, world, port, q):
+    """eight ranks, the engine's use of GradSync over three optimizer steps with gradient accumulation 3: buckets in backward-completion
+    order (decoder layers last-to-first, then the ragged `embeddings` tail bucket), hooks only on the boundary micro-step (earlier
+    micro-steps accumulate locally and must not communicate), the layer hooks fired in backward order with `embeddings` left to
+    finish(), bf16 staging, the data-parallel mean folded into the update"""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bdm_db1_amd import mpu
+    from bdm_db1_amd.engine import GradSync
+    mpu.initialize_model_parallel()
+    nl, per, tail = 5, 96, 37                       # five "layers" of 96 gradients + a ragged 37-element embedding bucket
+    n = nl * per + tail
+    buckets = [(f"h.{i}", (nl - 1 - i) * per, (nl - i) * per) for i in reversed(range(nl))] + [("embeddings", nl * per, n)]   # arena order = completion order
+    assert [b[0] for b in buckets][0] == f"h.{nl - 1}" and buckets[-1] == ("embeddings", nl * per, n)
+    g = torch.zeros(n)
+    stage = torch.zeros(n, dtype=torch.bfloat16)
+    calls = []
+
+    def cast(src, dst):
+        calls.append((src.data_ptr() - g.data_ptr()) // 4)
+        dst.copy_(src)
+    sync = GradSync(g, buckets, mpu.get_data_parallel_group(), stage=stage, cast=cast)
+    ga, ok = 3, True
+    p = torch.ones(n)
+    for step in range(3):
+        g.zero_()
+        for micro in range(ga):
+            torch.manual_seed(1000 * step + 10 * micro + rank)
+            g += torch.randn(n)                                   # this micro-step's local gradients, accumulated in the arena
+            boundary = micro == ga - 1
+            before = len(calls)
+            if boundary:                                          # engine.backward: the hook is sync.launch on the boundary micro-step only
+                for i in reversed(range(nl)):
+                    sync.launch(f"h.{i}")
+            else:
+                ok = ok and len(sync.handles) == 0 and len(calls) == before   # nothing is cast or sent before the boundary
+        local = g.clone()
+        ok = ok and len(sync.handles) == nl                       # five collectives in flight, the tail bucket not yet
+        sync.finish()                                             # engine.step: the tail bucket, then wait for all
+        ok = ok and calls[-(nl + 1):] == [s for _, s, _ in buckets]                  # cast (= launch) order is the arena order
+        gathered = [torch.zeros(n) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        expect = sum(x.to(torch.bfloat16).float() for x in gathered)
+        ok = ok and torch.equal(g, local)                         # the fp32 arena stays this rank's own sum
+        ok = ok and torch.allclose(sync.reduced.float(), expect, atol=6e-2, rtol=2e-2)   # eight bf16 terms, bf16 partial sums on the wire
+        allst = [torch.zeros(n, dtype=torch.bfloat16) for _ in range(world)]
+        dist.all_gather(allst, stage)
+        ok = ok and all(torch.equal(allst[0], x) for x in allst)  # every rank reads the same reduced gradients ...
+        p = p - 0.1 * sync.reduced.float() * (1.0 / (world * ga))
+        allp = [torch.zeros(n) for _ in range(world)]
+        dist.all_gather(allp, p)
+        ok = ok and all(torch.equal(allp[0], x) for x in allp)    # ... so the replicas stay bit-identical over the steps
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    mpu.destroy_model_parallel()
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_eight_ranks_gloo_with_accumulation():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(8)]
+
+
+def test_generated_flash_loops_are_in_sync_with_their_generators(tmp_path):
+    """relattn_flash_fwd{2,3}_loop.inc are generated (tools/gen_flash_fwd.py, tools/gen_flash_fwd3.py): the committed files must be what
+    the generators emit with their defaults; every iteration path ends in exactly one barrier, and a steady iteration holds the MFMAs of
+    one score phase + one P.V phase"""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("FW2_", "FW3_", "FW_"))}
+    for gen, inc, n_mfma_steady in (("gen_flash_fwd.py", "relattn_flash_fwd2_loop.inc", 24), ("gen_flash_fwd3.py", "relattn_flash_fwd3_loop.inc", 50)):
+        subprocess.run([sys.executable, os.path.join(root, "tools", gen), str(tmp_path)], check=True, env=env, capture_output=True)
+        fresh = open(os.path.join(tmp_path, inc)).read()
+        committed = open(os.path.join(root, "bdm_db1_amd", "csrc", inc)).read()
+        assert fresh == committed, f"{inc} is stale: run python tools/{gen}"
+        assert committed.count("s_barrier") == 6 * 3 + 1          # steady / last / idle of the six unrolled instances + the first iteration
+        body = committed.split("L_ns1_%=:")[0].split("L_inst1_%=:")[-1]  # instance 1: from its label to the end of its steady path
+        assert body.count("v_mfma_f32_16x16x32_bf16") == n_mfma_steady
