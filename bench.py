@@ -88,6 +88,56 @@ def cpu_baseline(repeats: int = 3):
                                             "container (SURVEY.md section 6); context only, not re-timed on this box"}}
 
 
+def decode_leg(model, dev, calls: int = 30):
+    """SURVEY 8f-1 (evaluate_rl.py:157-266): inference with a full Transformer-XL memory, batch 1, ONE new token per call -- the loop the
+    released evaluation runs -- on the model the training steps just used: ms per call as one hipGraph replay and eager, and the call
+    against its roofline: it has to stream every bf16 decoder / head weight and the cached K / V of the memory once (algorithmic bytes)
+    at the HBM rate."""
+    from bdm_db1_amd import GraphedMemoryStep
+    from bdm_db1_amd.data import NLPTaskInput
+    was_training = model.training
+    model.eval()
+    d, H, V, nl, mem = model.d_model, model.n_head, model.total_vocab_size, model.n_layer, int(model.mem_len)
+    di = model.d_inner if hasattr(model, "d_inner") else 4 * d
+    w_layer = (3 * d * d + d * d + di * d + d * (di // 2 if str(getattr(model, "activation_fn", "geglu")) == "geglu" else di)) * 2
+    bytes_call = nl * (w_layer + 2 * mem * d * 2) + V * d * 2        # weights + K / V of the memory per layer + the tied head
+    try:
+        step = GraphedMemoryStep(model, batch_size=1, n_new=1)
+        ids = torch.randint(0, 32000, (1, 1), device=dev)
+        for _ in range(5):
+            step(ids)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(calls):
+            step(ids)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_graph = e0.elapsed_time(e1) / calls
+        del step
+        mems = model.init_mem(1)
+        x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
+        with torch.no_grad():
+            for _ in range(3):
+                _, _, mems = model([x], compute_loss=False, mems=mems)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                _, _, mems = model([x], compute_loss=False, mems=mems)
+            torch.cuda.synchronize()
+        ms_eager = (time.perf_counter() - t0) / calls * 1e3
+        gbps = bytes_call / (ms_graph * 1e-3) / 1e9
+        out = {"workload": f"inference with Transformer-XL memory, batch 1, mem_len {mem}, 1 new token per call (evaluate_rl.py:157-266), bf16, K / V of the memory cached",
+               "ms_per_call": round(ms_graph, 4), "ms_per_call_eager": round(ms_eager, 4), "calls": calls, "tokens_per_s": round(1e3 / ms_graph, 1),
+               "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                            "algorithmic_bytes_per_call": int(bytes_call),
+                            "kernel": "the whole call as one hipGraph replay (skinny GEMMs over the bf16 weights + relattn_decode over the cached K / V)"}}
+    except Exception as e:   # the decode leg must never take the bench line down
+        out = {"ms_per_call": None, "error": repr(e)}
+    model.train(was_training)
+    return out
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` with no launcher around it: start N copies of this script, one rank per GPU, with the
     rendezvous environment torch.distributed.run would have set (127.0.0.1, a free port).  Rank 0's stdout is ours, so
@@ -171,6 +221,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1, help="drop = embd_pdrop of the training step (the reference's defaults, src/config.py:123,161: 0.1)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the inference-with-memory leg after the timed steps")
     ap.add_argument("--no-flash", action="store_true")
     ap.add_argument("--flash-probs", choices=["forward", "scratch", "recompute"], default="forward",
                     help="A/B: what the flash backward recomputes (nothing: the forward keeps p~ per layer / the query side only / both sides)")
@@ -333,6 +384,8 @@ def main():
         except Exception:
             pass
         out["kernels"] = ks
+    if rank == 0 and world == 1 and not args.no_decode and args.layers == 24:
+        out["decode"] = decode_leg(model, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline()

@@ -351,6 +351,43 @@ int db1_mulaw_discretize(const float* x, int32_t* ids, int64_t n, int is_action,
 int db1_mulaw_decode(const void* ids, float* out, int64_t n, int ids_are_int64, int is_action, int num_bins, float mu, float M,
                      int* oob_flag, void* stream);
 
+/* ------------------------------------------------------------------ composite entry points: one call per block of the
+ * reference's forward / backward, sequencing the launches above (csrc/composite.hip), so that a host in any language drives the hot
+ * path without re-implementing the Python orchestration.  bf16 activations; same conventions (caller-owned device pointers, (ws, ws_bytes)
+ * scratch with a size query, asynchronous on `stream`, int status). */
+/* acc[0] = sum(g^2) over a flat gradient segment: the global-norm clip's reduction (train_config.py:211-215) */
+int db1_grad_norm_sq(const void* g, float* acc, int64_t n, int dt, void* stream);
+/* backward of the tied head + masked CE (transformer_xl.py:593-613) from the (lse, sums) a previous db1_lmhead_ce_fwd left: the logits are
+ * recomputed 16 384 rows at a time; dh [T, d] = d(loss * gscale) / dh, dW_acc [n_w_rows, d] (float32) = beta_dw * dW_acc + d(loss * gscale) / dW */
+int64_t db1_lmhead_ce_bwd_workspace_bytes(int64_t T, int n_w_rows, int d, int chunk_rows, int dt);
+int db1_lmhead_ce_bwd(const void* h, const void* W, const int64_t* labels, const float* mask, const float* lse, const float* sums, void* dh,
+                      float* dW_acc, float beta_dw, float gscale, int64_t T, int V, int n_w_rows, int d, int chunk_rows, int dt, void* ws,
+                      int64_t ws_bytes, void* stream);
+/* RelPartialLearnableMultiHeadAttn score / softmax / P.V (transformer_xl.py:160-225, _rel_shift :98-110, mask :551-567) on the packed
+ * projections qkv [B, L, 3, H, D] (bf16, D = 128, L % 128 == 0), u / vb [H, D], R [L, H, D] = r_net(position table):
+ *   fwd: qu = q + u, qv = q + vb (outputs, [B, L, H, D], kept by the caller for the backward), out [B, L, H, D], lse [B, H, L];
+ *        probs [B*H, L/32, L/16, 512] bf16 + mblk [B*H, L/32, L] float32 (both or neither): the forward keeps its probabilities;
+ *   bwd: dqkv [B, L, 3, H, D] and dR [L, H, D] written, du_acc / dvb_acc [H, D] float32 += ; dT [H, B, L, L] bf16 is caller scratch that must
+ *        be ZERO above the causal diagonal on entry (every other entry is rewritten: one zero-initialised buffer serves all calls);
+ *        plain causal window only (shift >= L). */
+int db1_relattn_fwd(const void* qkv, const void* u, const void* vb, const void* R, void* qu, void* qv, void* out, float* lse, void* probs,
+                    float* mblk, int B, int L, int H, int D, int shift, float scale, void* stream);
+int64_t db1_relattn_bwd_workspace_bytes(int B, int L, int H, int D, int have_probs);
+int db1_relattn_bwd(const void* qkv, const void* qu, const void* qv, const void* R, const void* out, const void* dout, const float* lse,
+                    const void* probs, const float* mblk, void* dqkv, void* dR, float* du_acc, float* dvb_acc, void* dT, int B, int L, int H,
+                    int D, int shift, float scale, void* ws, int64_t ws_bytes, void* stream);
+/* PatchEmbeddings.forward / its backward (vision_embedding.py:65-86) on 16 x 16 patches: pixels [n_img, C, Himg, Wimg] float32 ->
+ * emb [N, d] bf16, N = n_img * (Himg / 16) * (Wimg / 16) (position embeddings are the caller's gather).  weights[12] (bf16, the reference's
+ * layouts) / grads[12] (float32 accumulators, +=) in state-dict order: conv1.{weight,bias}, residual_path.0.{weight,bias},
+ * residual_path.2.{weight,bias}, residual_path.3.{weight,bias}, residual_path.5.{weight,bias}, projection.{weight,bias}.
+ * `save` (db1_patch_embed_save_bytes) carries the forward's activations to the backward. */
+int64_t db1_patch_embed_save_bytes(int n_img, int C, int Himg, int Wimg, int p);
+int64_t db1_patch_embed_workspace_bytes(int n_img, int C, int Himg, int Wimg, int p, int d, int backward);
+int db1_patch_embed_fwd(const float* pixels, const void* const* weights, void* emb, void* save, int n_img, int C, int Himg, int Wimg, int p,
+                        int d, void* ws, int64_t ws_bytes, void* stream);
+int db1_patch_embed_bwd(const void* demb, const void* const* weights, const void* save, float* const* grads, int n_img, int C, int Himg,
+                        int Wimg, int p, int d, void* ws, int64_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

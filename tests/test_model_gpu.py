@@ -458,12 +458,14 @@ def test_bf16_channels_last_vision_path_matches_nchw_path_and_oracle():
         assert rel_err(res[True][1][n], res["explicit-columns"][1][n]) < 3e-2, n
 
 
-def test_bench_line_contract():
-    """bench.py prints ONE JSON line with the driver's keys, the roofline and (here skipped) cpu_baseline objects; tiny debug geometry"""
+@pytest.mark.parametrize("workload", ["text", "mixture"])
+def test_bench_line_contract(workload):
+    """bench.py prints ONE JSON line with the driver's keys, the roofline and (here skipped) cpu_baseline objects; tiny debug geometry.
+    `mixture` = RL + text + caption rows through the patch embedder"""
     import json
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--layers", "2", "--batch", "4",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--no-cpu-baseline", "--workload", workload], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -478,6 +480,7 @@ def test_bench_line_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert workload in d["config"]["workload"] and np.isfinite(d["final_loss"])
 
 
 @pytest.mark.parametrize("tag", ["plain", "deepnorm"])
