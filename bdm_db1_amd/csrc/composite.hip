@@ -14,11 +14,14 @@ static inline int64_t al256(int64_t x) { return (x + 255) & ~(int64_t)255; }
     } while (0)
 
 // ======================================================================================================= gradient norm
-/* acc[0] = sum(g^2) over a flat gradient segment (bf16 or fp32): the global-norm clip's reduction (train_config.py:211-215), one call per arena */
-extern "C" int db1_grad_norm_sq(const void* g, float* acc, int64_t n, int dt, void* stream) {
-    if (!g || !acc || n < 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "grad_norm_sq: null buffer");
-    if (hipMemsetAsync(acc, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "grad_norm_sq: memset");
-    return n ? db1_sumsq_acc(g, acc, n, dt, stream) : DB1_OK;
+/* acc[0] = sum(g^2) over a flat gradient segment (bf16 or fp32): the global-norm clip's reduction (train_config.py:211-215), one call per
+ * arena.  Deterministic: per-workgroup partial sums through the workspace, added in a fixed order (no atomics). */
+extern "C" int db1_sumsq_det(const void* x, float* acc, int64_t n, int dt, int overwrite, void* ws, int64_t ws_bytes, void* stream);
+extern "C" int64_t db1_sumsq_det_workspace_bytes(int64_t n);
+extern "C" int64_t db1_grad_norm_sq_workspace_bytes(int64_t n) { return db1_sumsq_det_workspace_bytes(n); }
+extern "C" int db1_grad_norm_sq(const void* g, float* acc, int64_t n, int dt, void* ws, int64_t ws_bytes, void* stream) {
+    if (!g || !acc || n <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "grad_norm_sq: null buffer / empty segment");
+    return db1_sumsq_det(g, acc, n, dt, 1, ws, ws_bytes, stream);
 }
 
 // ======================================================================================================= head backward
@@ -166,6 +169,10 @@ extern "C" int64_t db1_patch_embed_workspace_bytes(int n_img, int C, int Himg, i
         g = g > g2 ? g : g2;
         g2 = db1_colsum_acc_workspace_bytes(s.N, d);
         g = g > g2 ? g : g2;
+        g2 = db1_conv3x3_implicit_wgrad_workspace_bytes(s.N);
+        g = g > g2 ? g : g2;
+        g2 = db1_groupnorm_gelu_nhwc_bwd_workspace_bytes(s.N);
+        g = g > g2 ? g : g2;
         fixed += s.y + 3 * al256(s.rows * 64 * 2) + al256(64 * 576 * 4) + al256(64 * s.kp1 * 4) + al256(64 * 576 * 2);   // dy (NCHW), three gradient tiles, permuted weight gradients, W^T operand
     }
     return fixed + al256(g) + 256;
@@ -236,20 +243,20 @@ extern "C" int db1_patch_embed_bwd(const void* demb, const void* const* weights,
     CK(db1_nchw_to_nhwc(dyn, t1, s.N, 64, hw, bf, stream));                                // t1 = dy (channels-last): gradient of the residual sum
     // conv3 (residual_path.5): weight / bias gradients, data gradient
     if (hipMemsetAsync(gp, 0, 64 * 576 * 4, st) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "patch_embed_bwd: memset");
-    CK(db1_conv3x3_implicit_wgrad(t1, a1, gp, s.N, stream));
+    CK(db1_conv3x3_implicit_wgrad(t1, a1, gp, s.N, gws, gws_b, stream));
     CK(db1_conv_wgrad_unpermute(gp, grads[8], 64, 64, 576, stream));
     CK(db1_colsum_acc(t1, grads[9], s.rows, 64, 64, bf, gws, gws_b, stream));
     CK(db1_conv_weight_permute_t(weights[8], wt, 64, 64, bf, bf, stream));
     CK(db1_conv3x3_implicit_fwd(t1, wt, nullptr, t2, s.N, -1, 0, stream));                  // t2 = da1
-    CK(db1_groupnorm_gelu_nhwc_bwd(t2, c2, weights[6], weights[7], m1, r1, t3, grads[6], grads[7], s.N, 64, hw, 32, bf, bf, stream));   // t3 = dc2
+    CK(db1_groupnorm_gelu_nhwc_bwd(t2, c2, weights[6], weights[7], m1, r1, t3, grads[6], grads[7], s.N, 64, hw, 32, bf, bf, gws, gws_b, stream));   // t3 = dc2
     // conv2 (residual_path.2)
     if (hipMemsetAsync(gp, 0, 64 * 576 * 4, st) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "patch_embed_bwd: memset");
-    CK(db1_conv3x3_implicit_wgrad(t3, a0, gp, s.N, stream));
+    CK(db1_conv3x3_implicit_wgrad(t3, a0, gp, s.N, gws, gws_b, stream));
     CK(db1_conv_wgrad_unpermute(gp, grads[4], 64, 64, 576, stream));
     CK(db1_colsum_acc(t3, grads[5], s.rows, 64, 64, bf, gws, gws_b, stream));
     CK(db1_conv_weight_permute_t(weights[4], wt, 64, 64, bf, bf, stream));
     CK(db1_conv3x3_implicit_fwd(t3, wt, nullptr, t2, s.N, -1, 0, stream));                  // t2 = da0
-    CK(db1_groupnorm_gelu_nhwc_bwd(t2, c1, weights[2], weights[3], m0, r0, t3, grads[2], grads[3], s.N, 64, hw, 32, bf, bf, stream));   // t3 = dc1 (GroupNorm branch)
+    CK(db1_groupnorm_gelu_nhwc_bwd(t2, c1, weights[2], weights[3], m0, r0, t3, grads[2], grads[3], s.N, 64, hw, 32, bf, bf, gws, gws_b, stream));   // t3 = dc1 (GroupNorm branch)
     CK(db1_add(t3, t1, t3, s.rows * 64, bf, stream));                                       // + the residual branch
     // conv1: weight / bias gradients only (the pixels need none)
     if (hipMemsetAsync(gp1, 0, 64 * s.kp1 * 4, st) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "patch_embed_bwd: memset");

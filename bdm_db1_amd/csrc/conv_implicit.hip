@@ -8,7 +8,8 @@
 //       one workgroup = one patch (256 pixels) x 64 outputs, 4 waves x (64 pixels x 64 outputs), 9 k-steps = the 9 taps.
 //   conv_wgrad_implicit_kernel:  gp[o, tap*64 + c] += sum_pix dY[pix, o] * X[pix + s(tap), c]
 //       a TN product with M = 64, N = 576, K = all pixels; the B operand tile (64 pixels x 128 columns = 2 taps) is gathered;
-//       the pixel range is split over blockIdx.z and the partial sums are added with fp32 atomics (as the explicit path did).
+//       the pixel range is split over blockIdx.z; the partial sums go through the caller's workspace and are added in a fixed order
+//       (without a workspace: fp32 atomics, as the explicit path did).
 #include "gemm_tile.h"
 
 #define CI_C 64
@@ -25,6 +26,7 @@ struct ConvArgs {
     const void* bias;
     int64_t n_patches;
     int sign, ksplit;
+    float* part;          // wgrad: per-pixel-range partial sums [ksplit][64][576] (deterministic mode), or null (fp32 atomics onto y)
 };
 
 // source of the 16-byte chunk `c` (8 channels) of pixel `pix` shifted by tap `tap`, or the zero page
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_implicit_kernel(ConvArgs p)
         __syncthreads();
         cur ^= 1;
     }
-    float* G = (float*)p.y;
+    float* G = p.part ? p.part + (int64_t)blockIdx.z * (CI_C * 9 * CI_C) : (float*)p.y;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -175,9 +177,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_implicit_kernel(ConvArgs p)
             const int m = wm * 32 + i * 16 + (lane & 15);
             const int n = tn * 128 + wn * 64 + j * 16 + (lane >> 4) * 4;
             if (n >= 9 * CI_C) continue;
+            if (p.part) *reinterpret_cast<float4*>(G + (int64_t)m * (9 * CI_C) + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; r++) atomicAdd(G + (int64_t)m * (9 * CI_C) + n + r, acc[i][j][r]);
+                for (int r = 0; r < 4; r++) atomicAdd(G + (int64_t)m * (9 * CI_C) + n + r, acc[i][j][r]);
+            }
         }
+}
+// gp[i] += sum over the pixel ranges of part[z][i], z in increasing order (deterministic)
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gp, int nz) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= CI_C * 9 * CI_C) return;
+    float s = 0.f;
+    for (int z = 0; z < nz; z++) s += part[(int64_t)z * (CI_C * 9 * CI_C) + i];
+    gp[i] += s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------- host side
@@ -187,7 +200,7 @@ extern "C" int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const v
     if (!x || !w_op || !y || !db1_aligned16(x) || !db1_aligned16(w_op) || !db1_aligned16(y)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "conv3x3_implicit_fwd: operands must be 16-byte aligned");
     if (n_patches > 8000000) DB1_FAIL(DB1_ERR_BAD_SHAPE, "conv3x3_implicit_fwd: too many patches");
     ConvArgs a;
-    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w_op; a.y = y; a.bias = bias; a.n_patches = n_patches; a.sign = sign; a.ksplit = 1;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w_op; a.y = y; a.bias = bias; a.n_patches = n_patches; a.sign = sign; a.ksplit = 1; a.part = nullptr;
     static Db1PerDeviceOnce attr_once;
     attr_once.run([] {
         hipFuncSetAttribute((const void*)conv_implicit_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CI_STAGE_BYTES);
@@ -200,18 +213,31 @@ extern "C" int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const v
     return DB1_OK;
 }
 
-extern "C" int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, int64_t n_patches, void* stream) {
+static int ci_wgrad_ksplit(int64_t n_patches) {
+    const int64_t nk = n_patches * (CI_HW / TBK);
+    int ks = 128;                                        // 5 column tiles x 128 pixel ranges = 640 workgroups
+    while (ks > 1 && nk / ks < 8) ks >>= 1;
+    return ks;
+}
+extern "C" int64_t db1_conv3x3_implicit_wgrad_workspace_bytes(int64_t n_patches) {
+    return n_patches > 0 ? (int64_t)ci_wgrad_ksplit(n_patches) * CI_C * 9 * CI_C * (int64_t)sizeof(float) : 0;
+}
+extern "C" int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, int64_t n_patches, void* ws, int64_t ws_bytes, void* stream) {
     if (n_patches <= 0 || n_patches > 8000000) DB1_FAIL(DB1_ERR_BAD_SHAPE, "conv3x3_implicit_wgrad: n_patches=%lld", (long long)n_patches);
     if (!dy || !x || !gp_acc || !db1_aligned16(dy) || !db1_aligned16(x)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "conv3x3_implicit_wgrad: operands must be 16-byte aligned");
     ConvArgs a;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)dy; a.y = gp_acc; a.bias = nullptr; a.n_patches = n_patches; a.sign = 1;
-    const int64_t nk = n_patches * (CI_HW / TBK);
-    int ks = 128;                                        // 5 column tiles x 128 pixel ranges = 640 workgroups
-    while (ks > 1 && nk / ks < 8) ks >>= 1;
+    const int ks = ci_wgrad_ksplit(n_patches);
     a.ksplit = ks;
+    // with the workspace: per-range partial sums + a fixed-order reduce (bit-reproducible); without: fp32 atomics onto gp_acc
+    a.part = (ws && ws_bytes >= db1_conv3x3_implicit_wgrad_workspace_bytes(n_patches) && db1_aligned16(ws)) ? (float*)ws : nullptr;
     static Db1PerDeviceOnce attr_once;
     attr_once.run([] { hipFuncSetAttribute((const void*)conv_wgrad_implicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); });
     conv_wgrad_implicit_kernel<<<dim3(5, 1, (unsigned)ks), 256, 4 * TILE_BYTES, (hipStream_t)stream>>>(a);
     DB1_CHECK_LAUNCH("conv3x3_implicit_wgrad");
+    if (a.part) {
+        conv_wgrad_reduce_kernel<<<(CI_C * 9 * CI_C + 255) / 256, 256, 0, (hipStream_t)stream>>>(a.part, gp_acc, ks);
+        DB1_CHECK_LAUNCH("conv3x3_implicit_wgrad reduce");
+    }
     return DB1_OK;
 }

@@ -162,13 +162,15 @@ struct Db1Drop {
     unsigned thr;   // 0 = dropout off
     float scale;
     unsigned k0, k1, site, step;
+    const unsigned* step_dev;   // nullable: the step used is step + *step_dev (a device counter: the value a captured hipGraph reads at REPLAY time)
 };
-static inline Db1Drop db1_drop_make(float p, uint64_t seed, uint32_t site, uint32_t step) {
+static inline Db1Drop db1_drop_make(float p, uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev = nullptr) {
     Db1Drop d;
     long t = p > 0.f ? lrintf(p * 65536.f) : 0;
     d.thr = (unsigned)(t < 0 ? 0 : (t > 65535 ? 65535 : t));
     d.scale = 65536.f / (float)(65536 - (long)d.thr);
     d.k0 = (unsigned)(seed & 0xffffffffu); d.k1 = (unsigned)(seed >> 32); d.site = site; d.step = step;
+    d.step_dev = step_dev;
     return d;
 }
 __device__ __forceinline__ void db1_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned o[4]) {
@@ -186,7 +188,8 @@ template <int V>
 __device__ __forceinline__ void db1_drop_apply(const Db1Drop& dr, int64_t e0, float* v) {
     unsigned o[4];
     const unsigned long long blk = (unsigned long long)e0 >> 3;
-    db1_philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), dr.site, dr.step, dr.k0, dr.k1, o);
+    const unsigned step = dr.step_dev ? dr.step + *dr.step_dev : dr.step;   // (uniform address: a scalar load)
+    db1_philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), dr.site, step, dr.k0, dr.k1, o);
     const int w0 = V == 8 ? 0 : (int)((e0 >> 2) & 1) * 2;
 #pragma unroll
     for (int j = 0; j < V; j += 2) {

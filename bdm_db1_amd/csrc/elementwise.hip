@@ -279,11 +279,11 @@ template <typename T> static int ln_reg_nv(int d) {  // NV such that d == 64 * V
 
 extern "C" int db1_layernorm_residual_fwd(const void* x, const void* r, float alpha, const void* gamma, const void* beta,
                                           void* y, void* s_out, float* mean, float* rstd, int64_t rows, int d, float eps,
-                                          float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step,
+                                          float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
                                           int dt, int dtParam, void* stream) {
     if (drop_p < 0.f || drop_p >= 1.f) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm fwd: dropout p=%g", (double)drop_p);
     if (drop_p > 0.f && !r) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm fwd: dropout applies to the residual input r, which is NULL");
-    const Db1Drop drp = db1_drop_make(drop_p, drop_seed, drop_site, drop_step);
+    const Db1Drop drp = db1_drop_make(drop_p, drop_seed, drop_site, drop_step, drop_step_dev);
     if (!db1_dt_ok(dt) || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "layernorm fwd: dtype");
     const int V = dt == DB1_F32 ? 4 : 8;
     if (rows <= 0 || d <= 0 || d % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm fwd: d=%d must be a multiple of %d", d, V);
@@ -318,11 +318,11 @@ extern "C" int64_t db1_layernorm_residual_bwd_workspace_bytes(int64_t rows, int 
 }
 extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                                           void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc, int64_t rows, int d,
-                                          float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, int dt,
+                                          float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev, int dt,
                                           int dtParam, void* ws_, int64_t ws_bytes, void* stream) {
     if (drop_p < 0.f || drop_p >= 1.f) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd: dropout p=%g", (double)drop_p);
     if (dr_out && !db1_aligned16(dr_out)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "layernorm bwd: dr_out alignment");
-    const Db1Drop drp = db1_drop_make(drop_p, drop_seed, drop_site, drop_step);
+    const Db1Drop drp = db1_drop_make(drop_p, drop_seed, drop_site, drop_step, drop_step_dev);
     if (!db1_dt_ok(dt) || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "layernorm bwd: dtype");
     const int V = dt == DB1_F32 ? 4 : 8;
     if (rows <= 0 || d <= 0 || d % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd: d=%d must be a multiple of %d", d, V);
@@ -681,8 +681,8 @@ extern "C" int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int c
             DB1_CHECK_LAUNCH("colsum reduce");
             return DB1_OK;
         }
-        const int rpbv = 256;
-        dim3 gv((unsigned)((cols / V + 63) / 64), (unsigned)((rows + rpbv - 1) / rpbv));
+        const int rpbv = (int)rows;   // short inputs (< 1024 rows): ONE workgroup per 64 column vectors walks all rows, so every accumulator has a single
+        dim3 gv((unsigned)((cols / V + 63) / 64), 1u);   // contributor and the result does not depend on arrival order (it used to be 4 row blocks + atomics)
         DB1_DISPATCH_DT(dt, T, (colsum_vec_kernel<T><<<gv, 256, 0, (hipStream_t)stream>>>((const T*)x, out_acc, rows, cols, ldx, rpbv)));
         DB1_CHECK_LAUNCH("colsum_vec");
         return DB1_OK;
@@ -830,13 +830,14 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
         a.store(y + i * V);
     }
 }
-extern "C" int db1_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint32_t site, uint32_t step, int dt, void* stream) {
+extern "C" int db1_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev, int dt,
+                           void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "dropout: dtype");
     const int V = dt == DB1_F32 ? 4 : 8;
     if (n <= 0 || (n % 8)) DB1_FAIL(DB1_ERR_BAD_SHAPE, "dropout: n=%lld must be a positive multiple of 8 (one Philox block)", (long long)n);
     if (p < 0.f || p >= 1.f) DB1_FAIL(DB1_ERR_BAD_SHAPE, "dropout: p=%g", (double)p);
     if (!db1_aligned16(x) || !db1_aligned16(y)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "dropout: alignment");
-    const Db1Drop drp = db1_drop_make(p, seed, site, step);
+    const Db1Drop drp = db1_drop_make(p, seed, site, step, step_dev);
     DB1_DISPATCH_DT(dt, T, (dropout_kernel<T><<<grid_for(n / V), 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)y, n, drp)));
     DB1_CHECK_LAUNCH("dropout");
     return DB1_OK;
@@ -1137,6 +1138,46 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ x, flo
     a = block_sum256(a, sm);
     if (threadIdx.x == 0) atomicAdd(acc, a);
 }
+// deterministic variant: per-workgroup partial sums into the caller's workspace, then ONE workgroup adds them in a fixed order (the
+// atomicAdd of sumsq_kernel makes the global norm -- and through the clip coefficient every parameter -- depend on arrival order)
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_part_kernel(const T* __restrict__ x, float* __restrict__ part, int64_t n) {
+    __shared__ float sm[4];
+    float a = 0.f;
+    constexpr int V = Vec16<T>::N;
+    const int64_t nv = n / V;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        Vec16<T> v;
+        v.load(x + i * V);
+#pragma unroll
+        for (int j = 0; j < V; j++) a += v.v[j] * v.v[j];
+    }
+    if (blockIdx.x == 0) for (int64_t i = nv * V + threadIdx.x; i < n; i += 256) { float f = ldf(x + i); a += f * f; }
+    a = block_sum256(a, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int nparts, float* acc, int overwrite) {
+    __shared__ float sm[4];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];      // thread t: parts t, t + 256, ... in order
+    a = block_sum256(a, sm);
+    if (threadIdx.x == 0) acc[0] = overwrite ? a : acc[0] + a;
+}
+extern "C" int64_t db1_sumsq_det_workspace_bytes(int64_t n) { return n > 0 ? (int64_t)(256 * 16) * (int64_t)sizeof(float) : 0; }
+extern "C" int db1_sumsq_det(const void* x, float* acc, int64_t n, int dt, int overwrite, void* ws, int64_t ws_bytes, void* stream) {
+    if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "sumsq_det: dtype");
+    if (n <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "sumsq_det: n");
+    if (!db1_aligned16(x)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "sumsq_det: alignment");
+    DB1_NEED_WS(ws, ws_bytes, db1_sumsq_det_workspace_bytes(n), "sumsq_det");
+    const int V = dt == DB1_F32 ? 4 : 8;
+    const unsigned g = grid_for(n / V + 1);
+    DB1_DISPATCH_DT(dt, T, (sumsq_part_kernel<T><<<g, 256, 0, (hipStream_t)stream>>>((const T*)x, (float*)ws, n)));
+    DB1_CHECK_LAUNCH("sumsq_part");
+    sumsq_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>((const float*)ws, (int)g, acc, overwrite);
+    DB1_CHECK_LAUNCH("sumsq_final");
+    return DB1_OK;
+}
+
 extern "C" int db1_sumsq_acc(const void* x, float* acc, int64_t n, int dt, void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "sumsq: dtype");
     if (n <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "sumsq: n");

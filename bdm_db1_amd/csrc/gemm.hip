@@ -95,12 +95,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tile_kernel(GemmTileArgs p) 
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = p.alpha * acc[i][j][r];
-            if (p.bias && blockIdx.z == 0) {
+            if (p.bias && blockIdx.z == 0 && p.c_zs == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] += ldf((const TBIAS*)p.bias + n + r);
             }
             TC* c = C + (int64_t)m * p.ldc + n;
-            if (sizeof(TC) == 4 && p.ksplit > 1) {  // split-K: C already holds beta*C (beta == 1); partial sums are added atomically
+            if (sizeof(TC) == 4 && p.ksplit > 1 && p.c_zs != 0) {  // split-K through the workspace: this slice's partial sum, plain store
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(c) + (int64_t)blockIdx.z * p.c_zs) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (sizeof(TC) == 4 && p.ksplit > 1) {  // split-K: C already holds beta*C (beta == 1); partial sums are added atomically
 #pragma unroll
                 for (int r = 0; r < 4; r++) atomicAdd(reinterpret_cast<float*>(c) + r, v[r]);
             } else if (sizeof(TC) == 4) {
@@ -345,8 +347,9 @@ static GemmShape gemm_shape(int M, int N, int K, int dtA, int dtB, int dtC, int6
 extern "C" int64_t db1_gemm_workspace_bytes(int M, int N, int K, int dtA, int dtB, int dtC, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs,
                                             int64_t c_rs, int64_t c_cs, int batch0, int batch1) {
     if (M <= 0 || N <= 0 || K <= 0 || batch0 <= 0 || batch1 <= 0) return 0;
-    // (batch strides only enter through their alignment, which the model's operands satisfy; beta does not change a split-K decision)
-    GemmShape g = gemm_shape(M, N, K, dtA, dtB, dtC, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, batch0, batch1, 0, 0, 0, 0, 0, 0, 0.f);
+    // (batch strides only enter through their alignment, which the model's operands satisfy; beta only matters for the 128-tile split of
+    // small fp32 accumulators, which exists for beta = 1: asked for here, so that an accumulating call finds its partial-sum space)
+    GemmShape g = gemm_shape(M, N, K, dtA, dtB, dtC, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, batch0, batch1, 0, 0, 0, 0, 0, 0, 1.f);
     const GemmPlan pl = gemm_plan(g, true, -1);
     if (pl.kind & GK_TAIL) {
         GemmShape tail = g;
@@ -354,6 +357,7 @@ extern "C" int64_t db1_gemm_workspace_bytes(int M, int N, int K, int dtA, int dt
         const GemmPlan tp = gemm_plan(tail, true, -1);
         return (tp.kind & GK_SPLITK) ? splitk_bytes(tail, tp.S, tail.M) : 0;
     }
+    if (pl.ksplit > 1) return (int64_t)pl.ksplit * M * N * (int64_t)sizeof(float);   // 128-tile split-K: partial sums instead of atomics
     return (pl.kind & GK_SPLITK) ? splitk_bytes(g, pl.S, M) : 0;
 }
 
@@ -428,6 +432,12 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
     if (base == GK_TILE256) return db1_gemm_tile256_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
     t.ksplit = pl.ksplit;
     dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch, (unsigned)t.ksplit);
+    // long-contraction split of a small fp32 output (weight gradients of the patch convolutions): with a workspace the slices' partial
+    // sums are stored and added in a fixed order (bit-reproducible); without one they are added onto C with fp32 atomics
+    const bool ws_split = pl.ksplit > 1 && batch == 1 && ws && db1_aligned16(ws) && ws_bytes >= (int64_t)pl.ksplit * M * N * (int64_t)sizeof(float) &&
+                          (N % 4) == 0 && g.c_cs == 1;
+    void* C_final = C;
+    if (ws_split) { t.C = ws; t.ldc = N; t.c_zs = (int64_t)M * N; t.bias = nullptr; t.beta = 0.f; }
     static Db1PerDeviceOnce attr_once;   // 64 KiB of dynamic LDS needs the opt-in attribute: once per device, every instantiation
     attr_once.run([] {
 #define SET_ATTR(AK, BK_, TC, TB) hipFuncSetAttribute((const void*)gemm_bf16_tile_kernel<AK, BK_, TC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES)
@@ -440,6 +450,12 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
     else if (fa == 0 && fb == 1) launch_tile<true, false>(t, dtC, dtBias, grid, st);
     else launch_tile<false, false>(t, dtC, dtBias, grid, st);
     DB1_CHECK_LAUNCH("gemm_bf16_tile");
+    if (ws_split) {
+        dim3 rg((unsigned)(((int64_t)M * (N / 4) + 255) / 256), 1u);
+        if (dtBias == DB1_BF16) splitk_reduce_kernel<float, bf16_t><<<rg, 256, 0, st>>>((const float*)ws, (float*)C_final, (const bf16_t*)bias, M, N, pl.ksplit, c_rs, 0, beta);
+        else splitk_reduce_kernel<float, float><<<rg, 256, 0, st>>>((const float*)ws, (float*)C_final, (const float*)bias, M, N, pl.ksplit, c_rs, 0, beta);
+        DB1_CHECK_LAUNCH("splitk_reduce (128-tile)");
+    }
     return DB1_OK;
 }
 

@@ -21,7 +21,8 @@ struct GemmTileArgs {
     int64_t a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
     float alpha, beta;
     int tiles_m, tiles_n;
-    int ksplit;  // > 1: blockIdx.z owns K / ksplit of the contraction and accumulates into fp32 C with atomics (beta must be 1)
+    int ksplit;  // > 1: blockIdx.z owns K / ksplit of the contraction and accumulates into fp32 C with atomics (beta must be 1) ...
+    int64_t c_zs = 0;   // ... or, when != 0, STORES its partial sum at C + blockIdx.z * c_zs (a workspace; splitk_reduce_kernel adds the slices in order)
     // structural-zero hint for A (256x128 kernel only; elsewhere ignored, the zeros are simply multiplied):
     //   1: A[m, k] == 0 for k > m                      -> k-tiles beyond the tile's last row are skipped (dq_r = dT . R)
     //   2: A[m, k] == 0 for (k mod tri_period) < m     -> per period only the k-tiles from the tile's first row on (dR = dT^T . qv)

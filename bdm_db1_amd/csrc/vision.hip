@@ -457,7 +457,8 @@ extern "C" int db1_conv_wgrad_unpermute(const float* gp, float* g_acc, int Cout,
 template <typename T, typename TP, bool BWD>
 __global__ __launch_bounds__(256) void gn_gelu_nhwc_kernel(const T* __restrict__ x, const T* __restrict__ dy, const TP* __restrict__ gamma,
                                                            const TP* __restrict__ beta, T* __restrict__ out, float* __restrict__ mean,
-                                                           float* __restrict__ rstd, float* dgamma, float* dbeta, int cpg, float eps) {
+                                                           float* __restrict__ rstd, float* dgamma, float* dbeta, int cpg, float eps,
+                                                           float* __restrict__ pgrad) {   // bwd: per-sample (dgamma | dbeta) rows [N][128], or null (atomics)
     __shared__ float part[256][8];
     __shared__ float stat[2][GNV_C];   // per channel: (mean, rstd) fwd / (c1, c2) bwd, replicated over the channels of a group
     const int t = threadIdx.x, chunk = t & 7, prow = t >> 3;
@@ -547,12 +548,12 @@ __global__ __launch_bounds__(256) void gn_gelu_nhwc_kernel(const T* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; j++) part[t][j] = sg[j];
         __syncthreads();
-        if (t < GNV_C) { float s = 0.f; for (int r = 0; r < 32; r++) s += part[r * 8 + (t >> 3)][t & 7]; atomicAdd(dgamma + t, s); stat[1][t] = s * ldf(gamma + t); }
+        if (t < GNV_C) { float s = 0.f; for (int r = 0; r < 32; r++) s += part[r * 8 + (t >> 3)][t & 7]; if (pgrad) pgrad[n * (2 * GNV_C) + t] = s; else atomicAdd(dgamma + t, s); stat[1][t] = s * ldf(gamma + t); }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; j++) part[t][j] = sb[j];
         __syncthreads();
-        if (t < GNV_C) { float s = 0.f; for (int r = 0; r < 32; r++) s += part[r * 8 + (t >> 3)][t & 7]; atomicAdd(dbeta + t, s); stat[0][t] = s * ldf(gamma + t); }
+        if (t < GNV_C) { float s = 0.f; for (int r = 0; r < 32; r++) s += part[r * 8 + (t >> 3)][t & 7]; if (pgrad) pgrad[n * (2 * GNV_C) + GNV_C + t] = s; else atomicAdd(dbeta + t, s); stat[0][t] = s * ldf(gamma + t); }
         __syncthreads();
         // group sums c1 = sum(dh * gamma), c2 = sum(dh * gamma * xhat) over the cpg channels of the group
         __shared__ float cg[2][GNV_C];
@@ -579,19 +580,33 @@ extern "C" int db1_groupnorm_gelu_nhwc_fwd(const void* x, const void* gamma, con
     if (dt != DB1_BF16 || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "groupnorm_gelu_nhwc_fwd: bf16 activations only");
     if (N <= 0 || C != GNV_C || hw != GNV_HW || groups <= 0 || C % groups) DB1_FAIL(DB1_ERR_UNSUPPORTED, "groupnorm_gelu_nhwc_fwd: needs C=64, hw=256 (got %d, %d)", C, hw);
     hipStream_t st = (hipStream_t)stream;
-    if (dtParam == DB1_BF16) gn_gelu_nhwc_kernel<bf16_t, bf16_t, false><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, nullptr, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, mean, rstd, nullptr, nullptr, C / groups, eps);
-    else gn_gelu_nhwc_kernel<bf16_t, float, false><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, nullptr, (const float*)gamma, (const float*)beta, (bf16_t*)y, mean, rstd, nullptr, nullptr, C / groups, eps);
+    if (dtParam == DB1_BF16) gn_gelu_nhwc_kernel<bf16_t, bf16_t, false><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, nullptr, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, mean, rstd, nullptr, nullptr, C / groups, eps, nullptr);
+    else gn_gelu_nhwc_kernel<bf16_t, float, false><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, nullptr, (const float*)gamma, (const float*)beta, (bf16_t*)y, mean, rstd, nullptr, nullptr, C / groups, eps, nullptr);
     DB1_CHECK_LAUNCH("groupnorm_gelu_nhwc_fwd");
     return DB1_OK;
 }
+extern "C" int64_t db1_groupnorm_gelu_nhwc_bwd_workspace_bytes(int64_t N) {   // per-sample parameter-gradient rows + the ordered column sum's partials
+    return N > 0 ? ((N * 2 * GNV_C * (int64_t)sizeof(float) + 255) & ~(int64_t)255) + db1_colsum_acc_workspace_bytes(N, 2 * GNV_C) : 0;
+}
 extern "C" int db1_groupnorm_gelu_nhwc_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean, const float* rstd,
                                            void* dx, float* dgamma_acc, float* dbeta_acc, int64_t N, int C, int hw, int groups, int dt,
-                                           int dtParam, void* stream) {
+                                           int dtParam, void* ws, int64_t ws_bytes, void* stream) {
     if (dt != DB1_BF16 || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "groupnorm_gelu_nhwc_bwd: bf16 activations only");
     if (N <= 0 || C != GNV_C || hw != GNV_HW || groups <= 0 || C % groups) DB1_FAIL(DB1_ERR_UNSUPPORTED, "groupnorm_gelu_nhwc_bwd: needs C=64, hw=256 (got %d, %d)", C, hw);
     hipStream_t st = (hipStream_t)stream;
-    if (dtParam == DB1_BF16) gn_gelu_nhwc_kernel<bf16_t, bf16_t, true><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)dx, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma_acc, dbeta_acc, C / groups, 0.f);
-    else gn_gelu_nhwc_kernel<bf16_t, float, true><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, (const float*)gamma, (const float*)beta, (bf16_t*)dx, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma_acc, dbeta_acc, C / groups, 0.f);
+    // with the workspace: every sample leaves its (dgamma | dbeta) row and the rows are summed in a fixed order; without: fp32 atomics.
+    // (dgamma_acc and dbeta_acc must then be the two halves of ONE [128] accumulator, or are summed by two strided column sums below.)
+    const int64_t rows_b = (N * 2 * GNV_C * (int64_t)sizeof(float) + 255) & ~(int64_t)255;
+    float* pgrad = (ws && ws_bytes >= db1_groupnorm_gelu_nhwc_bwd_workspace_bytes(N) && db1_aligned16(ws)) ? (float*)ws : nullptr;
+    if (dtParam == DB1_BF16) gn_gelu_nhwc_kernel<bf16_t, bf16_t, true><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)dx, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma_acc, dbeta_acc, C / groups, 0.f, pgrad);
+    else gn_gelu_nhwc_kernel<bf16_t, float, true><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, (const float*)gamma, (const float*)beta, (bf16_t*)dx, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma_acc, dbeta_acc, C / groups, 0.f, pgrad);
+    if (pgrad) {
+        DB1_CHECK_LAUNCH("groupnorm_gelu_nhwc_bwd");
+        void* cws = (char*)ws + rows_b;
+        int rc = db1_colsum_acc(pgrad, dgamma_acc, N, GNV_C, 2 * GNV_C, DB1_F32, cws, ws_bytes - rows_b, stream);
+        if (rc) return rc;
+        return db1_colsum_acc(pgrad + GNV_C, dbeta_acc, N, GNV_C, 2 * GNV_C, DB1_F32, cws, ws_bytes - rows_b, stream);
+    }
     DB1_CHECK_LAUNCH("groupnorm_gelu_nhwc_bwd");
     return DB1_OK;
 }

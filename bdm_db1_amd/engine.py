@@ -178,9 +178,10 @@ class DB1Engine:
         ar = self.module.arena
         grad = self.sync.reduced      # the fp32 arena, or the all-reduced bf16 staging copy
         gscale = 1.0 / self.dp_world  # it holds the SUM over ranks
-        self._norm_sq.zero_()
         if self.clip > 0:
-            ops.sumsq_acc(grad, self._norm_sq)
+            ops.grad_norm_sq(grad, self._norm_sq)   # overwrites; fixed-order partial sums: the clip coefficient is reproducible run to run
+        else:
+            self._norm_sq.zero_()
         self.global_steps += 1
         grp = self.optimizer.param_groups[0]
         ops.adam_step(ar.master, grad, ar.exp_avg, ar.exp_avg_sq, None if ar.work is ar.master else ar.work,

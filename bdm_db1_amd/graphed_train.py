@@ -1,0 +1,110 @@
+"""Forward + backward of ONE training micro-step as a hipGraph replay.
+
+At the reference's own batch geometry -- micro-batch 4, gradient accumulation 16 (scripts/evaluate/evaluate_rl_1.2B.sh:28-42,
+src/train_utils/train.py:216-232) -- a micro-step is ~1040 short launches for ~28 ms of GPU work, and issuing them from Python / ctypes takes
+~44 ms: the step is host-bound (profiles/r03a_bench_b4.json: 92.9 k tokens/s against 149.1 k with 64 sequences per micro-step).  The library is
+capture-legal by construction (no allocation / synchronisation behind any entry point, scratch from the caller), so the micro-step's
+forward + backward is captured once per (batch shape, first / accumulating) and replayed: same kernels, same results, one launch.
+
+What makes it legal to replay:
+  * inputs live in static tensors (the batch of every call is copied into them);
+  * dropout: the keep decisions are a counter-based function of (seed, site, STEP); the step is read from a device counter the graph
+    itself bumps (``drop_step_dev`` of include/db1_hip.h), so every replay draws new masks -- the same stream of masks as the eager engine
+    (step 1, 2, 3, ...);
+  * gradient accumulation: the first micro-step after an optimizer step WRITES the weight gradients (beta = 0), later ones accumulate:
+    two graphs;
+  * per-weight-version caches (permuted convolution weights) are rebuilt inside the graph, into static buffers;
+  * the optimizer step, the data-parallel all-reduce and its hooks stay outside: with more than one rank the boundary micro-step (the one
+    that launches the bucket all-reduces from inside the backward) runs eagerly.
+"""
+from __future__ import annotations
+
+import copy
+import dataclasses
+from typing import List, Sequence
+
+import torch
+
+
+def _tensor_fields(task):
+    if dataclasses.is_dataclass(task):
+        names = [f.name for f in dataclasses.fields(task)]
+    else:
+        names = [k for k in vars(task)]
+    return [n for n in names if torch.is_tensor(getattr(task, n, None))]
+
+
+class GraphedTrainStep:
+    def __init__(self, engine, example_batch: Sequence):
+        """``engine``: bdm_db1_amd.engine.DB1Engine in train() mode with keep_logits=False (the fused head + loss sweep);
+        ``example_batch``: a list of task inputs with the shapes / dtypes every later batch will have"""
+        model = engine.module
+        if not model.training or model.keep_logits or not model.fuse_head_loss:
+            raise ValueError("GraphedTrainStep captures the training micro-step with the fused head + loss (engine.train(), keep_logits=False)")
+        self.engine, self.model = engine, model
+        dev = model.dev
+        self.static: List = []
+        for t in example_batch:
+            st = copy.copy(t)
+            for n in _tensor_fields(t):
+                setattr(st, n, getattr(t, n).to(dev).clone())
+            self.static.append(st)
+        self._fields = [_tensor_fields(t) for t in self.static]
+        # the dropout step counter moves to the device; it continues the eager engine's count
+        self.step_dev = torch.full((1,), int(model._drop_step), dtype=torch.int32, device=dev)
+        model._drop_step_dev = self.step_dev
+        model._graph_static = True
+        self.graphs = {}
+        self.loss = {}
+        # eager warm-up on the static inputs (allocates every workspace / cached table, decides the attention-backward mode), then the
+        # accumulators it touched are cleared again
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.step_dev.add_(1)
+                _, loss = model(self.static)
+                model.backward(grad_scale=model.loss_grad_scale, layer_done_hook=None)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        model.zero_grad()
+        self.step_dev.fill_(int(model._drop_step))
+        for fresh in (True, False):
+            model._grad_fresh = fresh
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step_dev.add_(1)
+                _, loss = model(self.static)
+                model.backward(grad_scale=model.loss_grad_scale, layer_done_hook=None)
+            self.graphs[fresh], self.loss[fresh] = g, loss
+        model._grad_fresh = True
+        model._ctx = None
+
+    def __call__(self, batch: Sequence):
+        """one micro-step: returns the loss (a static device scalar, overwritten by the next call); follow it with ``engine.step()``"""
+        eng, model = self.engine, self.model
+        assert len(batch) == len(self.static)
+        for st, t, names in zip(self.static, batch, self._fields):
+            for n in names:
+                src = getattr(t, n)
+                dst = getattr(st, n)
+                if src.data_ptr() != dst.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+        boundary = eng.is_gradient_accumulation_boundary()
+        if eng.dp_world > 1 and boundary:
+            # the bucket all-reduces are launched from inside this backward: eager, on the same device counter
+            self.step_dev.add_(1)
+            _, loss = model(self.static)
+            eng.backward(loss)
+            return loss
+        fresh = bool(model._grad_fresh)
+        self.graphs[fresh].replay()
+        model._grad_fresh = False
+        model._drop_step += 1          # (host mirror of the device counter: checkpoints / a later switch back to eager steps)
+        return self.loss[fresh]
+
+    def close(self):
+        """back to eager steps: the dropout counter returns to the host"""
+        self.model._drop_step = int(self.step_dev.item())
+        self.model._drop_step_dev = None
+        self.model._graph_static = False

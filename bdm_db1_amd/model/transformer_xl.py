@@ -135,6 +135,8 @@ class TransformerXL(nn.Module):
         rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
         self.dropout_seed = ((torch.initial_seed() * 0x9E3779B97F4A7C15) + rank) & 0xFFFFFFFFFFFFFFFF   # every data-parallel rank draws its own masks
         self._drop_step = 0                # bumped by every training forward: a new mask per micro-step
+        self._drop_step_dev = None         # hipGraph-captured training steps (graphed_train.py): the counter lives on the device instead
+        self._graph_static = False         # ... and per-weight-version caches are rebuilt inside every forward (static buffers)
         self.patch_size = int(g("vision_patch_size", 16))
         self.vision_channels = int(g("vision_num_input_channels", 3))
         self.vision_position_vocab_size = int(g("vision_position_vocab_size", 128))
@@ -295,8 +297,10 @@ class TransformerXL(nn.Module):
     SITE_EMBED, SITE_POS = 0xE0000000, 0xE0000001
 
     def _drop_args(self, p: float, site: int, step: Optional[int]):
-        """(p, seed, site, step) of one dropout site, or ops.NO_DROP outside training / at p = 0"""
-        return (p, self.dropout_seed, site, step) if (step is not None and p > 0.0) else ops.NO_DROP
+        """(p, seed, site, step[, device step counter]) of one dropout site, or ops.NO_DROP outside training / at p = 0"""
+        if step is None or p <= 0.0:
+            return ops.NO_DROP
+        return (p, self.dropout_seed, site, step, self._drop_step_dev) if self._drop_step_dev is not None else (p, self.dropout_seed, site, step)
 
     def _new(self, *shape, dtype=None):
         return torch.empty(*shape, device=self.dev, dtype=self.compute_dtype if dtype is None else dtype)
@@ -391,9 +395,15 @@ class TransformerXL(nn.Module):
     # between the convolutions (vision.hip).  The fp32 parity path below keeps the reference's NCHW order end to end.
     def _conv_operand_cl(self, wname, Cin):
         """GEMM operand [64, kpad] (tap-major columns, zero padded to a multiple of 8) of a 3x3 conv weight, per weight version"""
+        if self._graph_static:   # captured training step: the permuted copy is rebuilt by every replay, always into the same buffer
+            key = (wname, "static")
+            if key not in self._conv_ops:
+                self._conv_ops[key] = torch.empty(64, _round_up(9 * Cin, 8), device=self.dev, dtype=self.compute_dtype)
+            ops.conv_weight_permute(self.W(wname), self._conv_ops[key], 64, Cin)
+            return self._conv_ops[key]
         key = (wname, self._wversion)
         if key not in self._conv_ops:
-            self._conv_ops = {k: v for k, v in self._conv_ops.items() if k[1] == self._wversion}
+            self._conv_ops = {k: v for k, v in self._conv_ops.items() if k[1] in (self._wversion, "static")}
             wp = torch.empty(64, _round_up(9 * Cin, 8), device=self.dev, dtype=self.compute_dtype)
             ops.conv_weight_permute(self.W(wname), wp, 64, Cin)
             self._conv_ops[key] = wp
@@ -401,6 +411,12 @@ class TransformerXL(nn.Module):
 
     def _conv_operand_t_cl(self, wname):
         """data-gradient operand [c_in, tap*64 + c_out] of a 64 -> 64 conv weight, per weight version"""
+        if self._graph_static:
+            key = (wname + "^T", "static")
+            if key not in self._conv_ops:
+                self._conv_ops[key] = torch.empty(64, 576, device=self.dev, dtype=self.compute_dtype)
+            ops.conv_weight_permute_t(self.W(wname), self._conv_ops[key], 64, 64)
+            return self._conv_ops[key]
         key = (wname + "^T", self._wversion)
         if key not in self._conv_ops:
             wt = torch.empty(64, 576, device=self.dev, dtype=self.compute_dtype)
@@ -1030,8 +1046,11 @@ class TransformerXL(nn.Module):
         B, L, _ = h.shape
         dstep = None
         if self.training and mems is None and (self.drop_p > 0 or self.embd_pdrop > 0):
-            self._drop_step += 1
-            dstep = self._drop_step
+            if self._drop_step_dev is not None:      # graph mode: step = 0 + the device counter (bumped by the captured graph itself)
+                dstep = 0
+            else:
+                self._drop_step += 1
+                dstep = self._drop_step
             if self.embd_pdrop > 0:
                 ops.dropout(h, h, self._drop_args(self.embd_pdrop, self.SITE_EMBED, dstep))                     # :545
         mlen = mems[0].size(1) if mems is not None else 0

@@ -221,13 +221,17 @@ def relattn_dqr(dT, R, dqv):
            lambda: lib.call("db1_relattn_dqr", P(dT), P(R), R.stride(0), P(dqv), dqv.stride(1), dqv.stride(0), B, L, H, D, ws, wsn, stream()))
 
 
-NO_DROP = (0.0, 0, 0, 0)   # (p, seed, site, step)
+NO_DROP = (0.0, 0, 0, 0)   # (p, seed, site, step[, device step counter: the step used is step + *counter, read when the kernel runs])
+
+
+def _drop_dev(drop):
+    return P(drop[4]) if len(drop) > 4 and drop[4] is not None else _vp(0)
 
 
 def dropout(x, y, drop):
     """y = dropout(x) with the counter-based keep decisions of ``drop = (p, seed, site, step)`` (y may alias x; also its own backward)"""
-    p, seed, site, step = drop
-    lib.call("db1_dropout", P(x), P(y), x.numel(), float(p), int(seed), int(site), int(step), dt_code(x), stream())
+    p, seed, site, step = drop[:4]
+    lib.call("db1_dropout", P(x), P(y), x.numel(), float(p), int(seed), int(site), int(step), _drop_dev(drop), dt_code(x), stream())
 
 
 def relattn_dqr_fused(dT, R, dq, du_acc, dv_acc):
@@ -249,7 +253,7 @@ def layernorm_residual_fwd(x, r, alpha, gamma, beta, y, s_out, mean, rstd, eps, 
     nstreams = 2 + (r is not None) + (s_out is not None)   # x [, r] in; y [, s] out
     _timed("layernorm_fwd", float(rows * d * x.element_size() * nstreams),
            lambda: lib.call("db1_layernorm_residual_fwd", P(x), P(r), float(alpha), P(gamma), P(beta), P(y), P(s_out), P(mean), P(rstd),
-                            rows, d, float(eps), float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), dt_code(x), dt_code(gamma), stream()))
+                            rows, d, float(eps), float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), _drop_dev(drop), dt_code(x), dt_code(gamma), stream()))
 
 
 def layernorm_residual_bwd(dy, s, gamma, mean, rstd, ds, dgamma_acc, dbeta_acc, dr_out=None, drop=NO_DROP):
@@ -258,7 +262,7 @@ def layernorm_residual_bwd(dy, s, gamma, mean, rstd, ds, dgamma_acc, dbeta_acc, 
     ws, wsn = _ws("db1_layernorm_residual_bwd_workspace_bytes", (rows, d, dt_code(dy)), dy.device)
     _timed("layernorm_bwd", float(rows * d * dy.element_size() * (3 + (dr_out is not None))),   # dy, s in; ds [, dr] out
            lambda: lib.call("db1_layernorm_residual_bwd", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dr_out), P(dgamma_acc), P(dbeta_acc),
-                            rows, d, float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), dt_code(dy), dt_code(gamma), ws, wsn, stream()))
+                            rows, d, float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), _drop_dev(drop), dt_code(dy), dt_code(gamma), ws, wsn, stream()))
 
 
 def ffn_act_fwd(z, out, act: str):
@@ -504,7 +508,8 @@ def conv3x3_implicit_fwd(x, w_op, bias, y, n_patches, sign=1):
 
 def conv3x3_implicit_wgrad(dy, x, gp_acc, n_patches):
     assert gp_acc.dtype == torch.float32 and gp_acc.shape[-1] == 576
-    lib.call("db1_conv3x3_implicit_wgrad", P(dy), P(x), P(gp_acc), n_patches, stream())
+    ws, wsn = _ws("db1_conv3x3_implicit_wgrad_workspace_bytes", (int(n_patches),), dy.device)   # fixed-order partial sums: bit-reproducible
+    lib.call("db1_conv3x3_implicit_wgrad", P(dy), P(x), P(gp_acc), n_patches, ws, wsn, stream())
 
 
 def groupnorm_gelu_nhwc_fwd(x, gamma, beta, y, mean, rstd, N, C, hw, groups=32, eps=1e-5):
@@ -513,12 +518,19 @@ def groupnorm_gelu_nhwc_fwd(x, gamma, beta, y, mean, rstd, N, C, hw, groups=32, 
 
 
 def groupnorm_gelu_nhwc_bwd(dy, x, gamma, beta, mean, rstd, dx, dgamma_acc, dbeta_acc, N, C, hw, groups=32):
+    ws, wsn = _ws("db1_groupnorm_gelu_nhwc_bwd_workspace_bytes", (int(N),), x.device)   # per-sample rows, summed in a fixed order (no atomics)
     lib.call("db1_groupnorm_gelu_nhwc_bwd", P(dy), P(x), P(gamma), P(beta), P(mean), P(rstd), P(dx), P(dgamma_acc), P(dbeta_acc),
-             N, C, hw, groups, dt_code(x), dt_code(gamma), stream())
+             N, C, hw, groups, dt_code(x), dt_code(gamma), ws, wsn, stream())
 
 
 def sumsq_acc(x, acc):
     _timed("sumsq", float(x.numel() * x.element_size()), lambda: lib.call("db1_sumsq_acc", P(x), P(acc), x.numel(), dt_code(x), stream()))
+
+
+def grad_norm_sq(x, acc):
+    """acc[0] = sum(x^2), deterministic (db1_grad_norm_sq: fixed-order partial sums, no atomics): what the engine's global-norm clip uses"""
+    ws, wsn = _ws("db1_grad_norm_sq_workspace_bytes", (x.numel(),), x.device)
+    _timed("sumsq", float(x.numel() * x.element_size()), lambda: lib.call("db1_grad_norm_sq", P(x), P(acc), x.numel(), dt_code(x), ws, wsn, stream()))
 
 
 def adam_step(p32, g, m, v, p_work, lr, beta1, beta2, eps, wd, adamw, step, gscale=1.0, clip=0.0, norm_sq=None):

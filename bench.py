@@ -216,6 +216,8 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DB1_BENCH_BATCH", 64)), help="sequences per GPU per step")
     ap.add_argument("--ga", type=int, default=1, help="gradient-accumulation micro-steps per optimizer step (the reference trains micro-batch 4 x GA 16, "
                                                       "scripts/evaluate/evaluate_rl_1.2B.sh:28-42): one timed step = GA x (fwd + bwd) + clip + Adam")
+    ap.add_argument("--graph", action="store_true", help="forward + backward of a micro-step as one hipGraph replay (bdm_db1_amd.GraphedTrainStep): what small "
+                                                         "micro-batches need (at 4 sequences the eager step is host-bound); no per-kernel timing in this mode")
     ap.add_argument("--layers", type=int, default=24, help="debug only: anything but 24 is not the benchmark config")
     ap.add_argument("--workload", default="text", choices=["text", "caption", "rl", "mixture"])
     ap.add_argument("--dropout", type=float, default=0.1, help="drop = embd_pdrop of the training step (the reference's defaults, src/config.py:123,161: 0.1)")
@@ -280,10 +282,19 @@ def main():
             v = t.vision_seq
             n_patches += v.shape[0] * v.shape[1] * (v.shape[3] // 16) * (v.shape[4] // 16)
 
+    gstep = None
+    if args.graph:
+        from bdm_db1_amd import GraphedTrainStep
+        gstep = GraphedTrainStep(engine, batch)
+        args.no_kernel_timing = True
+
     def step():
         for _ in range(args.ga):   # train.py:216-232: GA micro-steps of engine(x) -> backward -> step; the optimizer runs on the boundary
-            logits, loss = engine(batch)
-            engine.backward(loss)
+            if gstep is not None:
+                loss = gstep(batch)
+            else:
+                logits, loss = engine(batch)
+                engine.backward(loss)
             engine.step()
         return loss
 
@@ -320,7 +331,7 @@ def main():
         "config": {"workload": f"DB1-1.3B {args.workload} causal LM pre-training step (fwd+bwd+clip+Adam, training mode: dropout "
                                f"{args.dropout:g} on embeddings / attention / feed-forward outputs as the reference's defaults), seq_len 1024, "
                                f"{B} sequences/GPU/micro-step x {args.ga} micro-step(s) per optimizer step, random-init weights", "dropout": args.dropout, "n_layer": args.layers, "n_embed": 2048, "n_head": 16,
-                   "seq_len": L, "batch_per_gpu": B, "grad_accumulation": args.ga, "global_batch": B * world * args.ga, "parallelism": f"dp{world}",
+                   "seq_len": L, "batch_per_gpu": B, "grad_accumulation": args.ga, "micro_step_as_hipgraph": bool(args.graph), "global_batch": B * world * args.ga, "parallelism": f"dp{world}",
                    "attention_backward": {"forward": "nothing recomputed (the forward keeps its probabilities)", "scratch": "query side recomputes, P / dS through scratch",
                                           "recompute": "both sides recompute"}[model._probs_mode(B, L)],
                    "params": int(sum(int(np.prod(s)) for _, s, _ in model.arena.offsets.values()))},
@@ -384,6 +395,8 @@ def main():
         except Exception:
             pass
         out["kernels"] = ks
+    if gstep is not None:
+        gstep.close()
     if rank == 0 and world == 1 and not args.no_decode and args.layers == 24:
         out["decode"] = decode_leg(model, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -116,11 +116,13 @@ int db1_gemm_would_use_fast(int M, int N, int K, int dtA, int dtB, int dtC,
  * may be NULL) receives s for the backward.  mean/rstd: float32 [rows]. */
 /* Dropout (transformer_xl.py:229,262-269: on the attention / feed-forward output before the residual sum) is part of this kernel:
  * with drop_p > 0, s = alpha * x + dropout(r).  No mask is stored: keep decisions are a counter-based function (Philox4x32-10) of
- * (drop_seed, drop_step, drop_site, element index) -- see db1_dropout -- and the backward regenerates them. */
+ * (drop_seed, drop_step, drop_site, element index) -- see db1_dropout -- and the backward regenerates them.
+ * drop_step_dev (nullable, device): the step used is drop_step + *drop_step_dev, read when the kernel RUNS -- a captured hipGraph of a
+ * training micro-step (bdm_db1_amd.GraphedTrainStep) draws new masks at every replay by bumping that counter. */
 int db1_layernorm_residual_fwd(const void* x, const void* r, float alpha, const void* gamma, const void* beta,
                                void* y, void* s_out, float* mean, float* rstd,
                                int64_t rows, int d, float eps,
-                               float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step,
+                               float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
                                int dt, int dtParam, void* stream);
 /* ds = dL/ds (dtype dt); dr_out (nullable) = dL/dr = ds under the forward's keep decisions (== ds when drop_p = 0);
  * dgamma_acc / dbeta_acc: float32 [d], accumulated. */
@@ -128,7 +130,7 @@ int64_t db1_layernorm_residual_bwd_workspace_bytes(int64_t rows, int d, int dt);
 int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                                void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc,
                                int64_t rows, int d,
-                               float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step,
+                               float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
                                int dt, int dtParam, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ dropout
@@ -136,7 +138,7 @@ int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma,
  * keep(e) = [ u16(e) >= thr ] where the eight 16-bit uniforms of elements 8b .. 8b+7 are the 128 output bits of Philox4x32-10 on
  * counter (b lo, b hi, site, step) under key (seed lo, seed hi), low half-word first.  The same call is its own backward
  * (dx = dropout(dy) with the same seed / site / step).  n: a multiple of 8. */
-int db1_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint32_t site, uint32_t step, int dt, void* stream);
+int db1_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev, int dt, void* stream);
 
 /* ------------------------------------------------------------------ feed-forward activation
  * GEGLU: out[r, j] = z[r, j] * gelu_erf(z[r, n + j]) (activations.py:19-32); GELU/RELU: elementwise. */
@@ -310,16 +312,19 @@ int db1_conv_wgrad_unpermute(const float* gp, float* g_acc, int Cout, int Cin, i
 /* Implicit-GEMM 3x3 convolutions for the 64 -> 64 channel layers on 16x16 patches (channels-last bf16): no column matrix.
  *   fwd (sign = +1): y[pix, o] = sum_{tap,c} x[pix + s(tap), c] * w_op[o, tap*64 + c] + bias[o], w_op from db1_conv_weight_permute;
  *   data gradient (sign = -1): x := dy, w_op := db1_conv_weight_permute_t(weight)  ([c, tap*64 + o]), bias = NULL;
- *   wgrad: gp_acc[o, tap*64 + c] += sum_pix dy[pix, o] * x[pix + s(tap), c]   (float32 [64, 576], fp32 atomics over pixel ranges). */
+ *   wgrad: gp_acc[o, tap*64 + c] += sum_pix dy[pix, o] * x[pix + s(tap), c]   (float32 [64, 576]; the pixel ranges' partial sums are added
+ *          in a fixed order through the workspace -- or with fp32 atomics when none is given). */
 int db1_conv_weight_permute_t(const void* w, void* wp, int Cout, int Cin, int dtIn, int dtOut, void* stream);
 int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const void* bias, void* y, int64_t n_patches, int sign, int dtBias,
                              void* stream);
-int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, int64_t n_patches, void* stream);
+int64_t db1_conv3x3_implicit_wgrad_workspace_bytes(int64_t n_patches);   /* per-pixel-range partial sums: with them the result is bit-reproducible */
+int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, int64_t n_patches, void* ws, int64_t ws_bytes, void* stream);
 int db1_groupnorm_gelu_nhwc_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                                 int64_t N, int C, int hw, int groups, float eps, int dt, int dtParam, void* stream);
+int64_t db1_groupnorm_gelu_nhwc_bwd_workspace_bytes(int64_t N);   /* per-sample parameter-gradient rows, summed in a fixed order (without: fp32 atomics) */
 int db1_groupnorm_gelu_nhwc_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean,
                                 const float* rstd, void* dx, float* dgamma_acc, float* dbeta_acc,
-                                int64_t N, int C, int hw, int groups, int dt, int dtParam, void* stream);
+                                int64_t N, int C, int hw, int groups, int dt, int dtParam, void* ws, int64_t ws_bytes, void* stream);
 /* layout shuffles between GEMM output [N*p*p, C] ("NHWC") and [N, C, p, p] ("NCHW") */
 int db1_nhwc_to_nchw(const void* x, void* y, int64_t N, int C, int hw, int dt, void* stream);
 int db1_nchw_to_nhwc(const void* x, void* y, int64_t N, int C, int hw, int dt, void* stream);
@@ -333,6 +338,9 @@ int db1_groupnorm_gelu_bwd(const void* dy, const void* x, const void* gamma, con
 /* ------------------------------------------------------------------ optimizer
  * acc[0] += sum(x^2)  (global-norm clipping, train_config.py:211-215) */
 int db1_sumsq_acc(const void* x, float* acc, int64_t n, int dt, void* stream);
+/* the same sum without atomics (per-workgroup partials in the workspace, fixed-order final add); overwrite != 0: acc[0] = sum, else += */
+int64_t db1_sumsq_det_workspace_bytes(int64_t n);
+int db1_sumsq_det(const void* x, float* acc, int64_t n, int dt, int overwrite, void* ws, int64_t ws_bytes, void* stream);
 /* One fused Adam/AdamW step over a flat segment (DeepSpeed FusedAdam stand-in; torch.optim semantics).
  * g: gradients, float32 or (dtGrad = DB1_BF16) the bf16 copy the data-parallel engine all-reduces (train.py:231-232);
  * p32/m/v: float32 state; p_work (nullable): bf16 working copy written alongside.
@@ -355,8 +363,10 @@ int db1_mulaw_decode(const void* ids, float* out, int64_t n, int ids_are_int64, 
  * reference's forward / backward, sequencing the launches above (csrc/composite.hip), so that a host in any language drives the hot
  * path without re-implementing the Python orchestration.  bf16 activations; same conventions (caller-owned device pointers, (ws, ws_bytes)
  * scratch with a size query, asynchronous on `stream`, int status). */
-/* acc[0] = sum(g^2) over a flat gradient segment: the global-norm clip's reduction (train_config.py:211-215) */
-int db1_grad_norm_sq(const void* g, float* acc, int64_t n, int dt, void* stream);
+/* acc[0] = sum(g^2) over a flat gradient segment: the global-norm clip's reduction (train_config.py:211-215).  Deterministic: per-workgroup
+ * partial sums through the workspace, added in a fixed order (db1_sumsq_acc adds them with atomics). */
+int64_t db1_grad_norm_sq_workspace_bytes(int64_t n);
+int db1_grad_norm_sq(const void* g, float* acc, int64_t n, int dt, void* ws, int64_t ws_bytes, void* stream);
 /* backward of the tied head + masked CE (transformer_xl.py:593-613) from the (lse, sums) a previous db1_lmhead_ce_fwd left: the logits are
  * recomputed 16 384 rows at a time; dh [T, d] = d(loss * gscale) / dh, dW_acc [n_w_rows, d] (float32) = beta_dw * dW_acc + d(loss * gscale) / dW */
 int64_t db1_lmhead_ce_bwd_workspace_bytes(int64_t T, int n_w_rows, int d, int chunk_rows, int dt);

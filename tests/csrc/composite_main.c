@@ -50,10 +50,13 @@ int main(void) {
         double want = 0.0;
         for (int64_t i = 0; i < n; i++) { h[i] = (float)((i * 2654435761u % 2001) - 1000) * 1e-3f; want += (double)h[i] * h[i]; }
         float *d = NULL, *acc = NULL, got = -1.f;
+        void* nws = NULL;
+        const int64_t nws_b = db1_grad_norm_sq_workspace_bytes(n);
         CHECK_HIP(hipMalloc((void**)&d, n * 4));
         CHECK_HIP(hipMalloc((void**)&acc, 4));
+        CHECK_HIP(hipMalloc(&nws, nws_b));
         CHECK_HIP(hipMemcpy(d, h, n * 4, hipMemcpyHostToDevice));
-        CHECK_DB1(db1_grad_norm_sq(d, acc, n, 0 /* DB1_F32 */, st));
+        CHECK_DB1(db1_grad_norm_sq(d, acc, n, 0 /* DB1_F32 */, nws, nws_b, st));
         CHECK_HIP(hipStreamSynchronize(st));
         CHECK_HIP(hipMemcpy(&got, acc, 4, hipMemcpyDeviceToHost));
         if (fabs(got - want) > 1e-5 * want) { printf("grad_norm_sq: got %g want %g\n", got, want); return 4; }

@@ -518,3 +518,80 @@ def test_init_matches_reference_distribution(tag):
             assert abs((mx - mn) / std - (rmax - rmin) / rstd) < 0.18 * (rmax - rmin) / rstd, (n, (mx - mn) / std, (rmax - rmin) / rstd)
         else:               # small uniform tensors (convolution biases): inside the reference's bound
             assert mx <= rmax * 1.15 + 1e-6 and mn >= rmin * 1.15 - 1e-6, (n, mn, mx, rmin, rmax)
+
+
+def test_graphed_training_micro_steps_equal_eager_steps():
+    """bdm_db1_amd.GraphedTrainStep: forward + backward of a micro-step as a hipGraph replay (two graphs: first / accumulating micro-step of
+    an accumulation window, dropout step from a device counter) against the eager engine on the same batches: three optimizer steps of
+    two micro-steps with dropout 0.1 -- the losses and every parameter afterwards are bit-identical (same kernels, same masks)."""
+    from bdm_db1_amd import GraphedTrainStep, TransformerXL, initialize
+    from bdm_db1_amd.data import NLPTaskInput
+    cfg = dict(case_cfg("small_mixed"))
+    # (d = 512: the register-resident LayerNorm kernels -- the generic ones of other widths add their parameter gradients with atomics)
+    cfg.update(dict(n_embed=512, n_head=4, n_layer=2, n_position=256, mem_len=256, text_vocab_size=2000, drop=0.1, embd_pdrop=0.1))
+    params = make_params(cfg, 17)
+    rng = np.random.default_rng(5)
+    batches = []
+    for _ in range(6):
+        ids = rng.integers(0, 2000, (4, 257))
+        batches.append(NLPTaskInput(position_id=None, attention_mask=None, loss_mask=torch.ones(4, 256, device=DEV), label=torch.from_numpy(ids[:, 1:].copy()).to(DEV),
+                                    text_seq=torch.from_numpy(ids[:, :-1].copy()).to(DEV), text_len=None))
+
+    def run(graphed):
+        torch.manual_seed(99)   # -> the same dropout seed on both sides
+        model = TransformerXL(SimpleNamespace(**cfg), compute_dtype=torch.bfloat16)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+        eargs = SimpleNamespace(lr=2e-3, weight_decay=0.01, clip_grad=1.0, optimizer="adamw", keep_logits=False, fuse_head_loss=True, gradient_accumulation_steps=2)
+        engine, _, _, _ = initialize(eargs, model)
+        engine.train()
+        g = GraphedTrainStep(engine, [batches[0]]) if graphed else None
+        losses = []
+        for b in batches:
+            if g is not None:
+                loss = g([b])
+            else:
+                _, loss = engine([b])
+                engine.backward(loss)
+            engine.step()
+            losses.append(float(loss))
+        if g is not None:
+            g.close()
+            assert model._drop_step == 6
+        return losses, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1, (l0, l1)
+    assert len(set(round(x, 6) for x in l0)) == len(l0)      # different batches / masks every micro-step
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+
+
+def test_bf16_mixture_optimizer_step_is_bit_reproducible():
+    """a full optimizer step -- forward + backward of an RL + text + caption batch through the patch embedder (channels-last, implicit
+    convolutions), global-norm clip, AdamW, with dropout -- twice from the same state: identical loss, gradients, global norm and
+    parameters, bit for bit.  Round 3 removed the last float atomics of this path: the convolution weight gradients (fixed-order
+    partial sums), the GroupNorm parameter gradients, the 128-tile split-K of conv1's weight gradient, the global norm, short column sums."""
+    from bdm_db1_amd import TransformerXL, initialize, synth
+    cfg = synth.db1_config("1.3B", n_layer=2, n_embed=512, n_head=4, drop=0.1, embd_pdrop=0.1)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(7)
+        model = TransformerXL(cfg, compute_dtype=torch.bfloat16)
+        eargs = SimpleNamespace(lr=1e-3, weight_decay=0.01, clip_grad=1.0, optimizer="adamw", keep_logits=False, fuse_head_loss=True)
+        engine, _, _, _ = initialize(eargs, model)
+        engine.train()
+        batch = synth.mixture_batch(4, cfg.n_position, 3, DEV, cfg)
+        losses = []
+        for _step in range(2):
+            _, loss = engine(batch)
+            engine.backward(loss)
+            grads = model.arena.grad.clone()
+            engine.step()
+            losses.append(float(loss))
+        runs.append((losses, grads, float(engine._norm_sq), {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert runs[0][2] == runs[1][2]
+    bad = [n for n in model.arena.offsets if not torch.equal(model.arena.view(runs[0][1], n), model.arena.view(runs[1][1], n))]
+    assert not bad, bad
+    badp = [k for k in runs[0][3] if not torch.equal(runs[0][3][k], runs[1][3][k])]
+    assert not badp, badp

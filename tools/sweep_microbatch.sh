@@ -5,9 +5,9 @@ TAG=${TAG:-r03}
 E=$R/gpurun_out/sweep_$TAG
 mkdir -p $E
 cd $R
-for b in 4 8 16 32 64; do
+for b in ${SWEEP_BATCHES:-4 8 16 32 64}; do
   ga=$((64 / b))
-  timeout 600 python bench.py --batch $b --ga $ga --steps 4 --warmup 2 --no-cpu-baseline ${SWEEP_ARGS} > $E/${TAG}_bench_b${b}.json 2> $E/bench_b${b}.err </dev/null
+  timeout 600 python bench.py --batch $b --ga $ga --steps 4 --warmup 2 --no-cpu-baseline --no-decode ${SWEEP_ARGS} > $E/${TAG}_bench_b${b}.json 2> $E/bench_b${b}.err </dev/null
   python - <<P
 import json
 try:
