@@ -3,7 +3,7 @@
 Importing the package does not need a GPU; constructing a model or calling an op does, and raises
 if libdb1_hip.so or a gfx950 device is missing (there is no CPU fallback).
 """
-__all__ = ["TransformerXL", "initialize", "mpu", "GraphedMemoryStep", "GraphedTrainStep"]
+__all__ = ["TransformerXL", "initialize", "mpu", "GraphedMemoryStep", "GraphedRingStep", "RingMemory", "GraphedTrainStep"]
 
 
 def __getattr__(name):
@@ -16,6 +16,9 @@ def __getattr__(name):
     if name == "GraphedMemoryStep":
         from .decode import GraphedMemoryStep
         return GraphedMemoryStep
+    if name in ("GraphedRingStep", "RingMemory"):
+        from . import decode
+        return getattr(decode, name)
     if name == "GraphedTrainStep":
         from .graphed_train import GraphedTrainStep
         return GraphedTrainStep

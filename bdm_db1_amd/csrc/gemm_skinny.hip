@@ -36,16 +36,28 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs p) {
 #pragma unroll
     for (int t = 0; t < MT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-    for (int ks = ks0; ks < ks1; ks++) {
-        const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(wrow + ks * 64);
-        const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(wrow + ks * 64 + 8);
+    // The kernel is a latency problem (a workgroup streams only 64-256 KB of W): the W pieces of EIGHT k-steps (16 loads of 16 bytes per
+    // lane, 32 KB per workgroup) are requested before the first one is used, so a wave's share of K = 2048 is ONE round trip instead of
+    // two (unroll 4) -- and the loads are non-temporal: every byte of W is read once per call, by one workgroup.
+    constexpr int KB = 8;
+    for (int kb = ks0; kb < ks1; kb += KB) {
+        bf16x8_t b0[KB], b1[KB];
 #pragma unroll
-        for (int t = 0; t < MT; t++) {
-            const bf16x8_t a0 = xok[t] ? *reinterpret_cast<const bf16x8_t*>(xrow[t] + ks * 64) : zero;
-            const bf16x8_t a1 = xok[t] ? *reinterpret_cast<const bf16x8_t*>(xrow[t] + ks * 64 + 8) : zero;
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a0, acc[t], 0, 0, 0);  // swapped: D[n][m]
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a1, acc[t], 0, 0, 0);
+        for (int u = 0; u < KB; u++) {
+            const bool ok = kb + u < ks1;
+            b0[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wrow + (kb + u) * 64)) : zero;
+            b1[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wrow + (kb + u) * 64 + 8)) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < KB; u++) {
+            const bool ok = kb + u < ks1;
+#pragma unroll
+            for (int t = 0; t < MT; t++) {
+                const bf16x8_t a0 = (xok[t] && ok) ? *reinterpret_cast<const bf16x8_t*>(xrow[t] + (kb + u) * 64) : zero;
+                const bf16x8_t a1 = (xok[t] && ok) ? *reinterpret_cast<const bf16x8_t*>(xrow[t] + (kb + u) * 64 + 8) : zero;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[u], a0, acc[t], 0, 0, 0);  // swapped: D[n][m]
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[u], a1, acc[t], 0, 0, 0);
+            }
         }
     }
     if (wave > 0) {

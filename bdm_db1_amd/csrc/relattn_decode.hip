@@ -177,6 +177,234 @@ __global__ __launch_bounds__(128) void relattn_decode_merge_kernel(DecodeArgs p)
     p.out[((int64_t)b * p.q + i) * p.H * DEC_D + h * DEC_D + d] = f2bf(l > 0.f ? o / l : 0.f);
 }
 
+// ======================================================================================= ring variant (hipGraph-friendly inference)
+// The K / V of the memory live in a ring [B, cap, 2, H, D] (cap >= mlen + q): logical key j < mlen is ring row (start + j) % cap, the
+// q new keys / values are read from the packed projections of this call, qkv_new [B, q, 3, H, D], and copied into ring rows
+// (start + mlen + i) % cap by the workgroups that visit them -- so a call appends in place instead of concatenating 8 MB per layer, and
+// `start` is a DEVICE scalar (advanced by db1_ring_advance after the last layer): the same captured graph serves every call.
+// q + u and q + v are formed here from qkv_new (rounded to bf16 like db1_relattn_add_head_bias does).
+// SPLIT (q <= 16): the four waves of a workgroup are the four 32-key steps of a 128-key chunk (one partial per wave);
+// otherwise a wave is one of the four 16-query tiles and walks the chunk's steps itself (one partial per tile and chunk).
+#define DECR_KC 128
+struct DecodeRingArgs {
+    const bf16_t* qkv; const bf16_t* u; const bf16_t* vb; bf16_t* ring; const int* state; const bf16_t* R;
+    float* part; bf16_t* out;
+    int B, q, klen, mlen, H, shift, nd, nunit, cap;
+    float scale;
+};
+__device__ __forceinline__ bf16x8_t dec_add_bias(const bf16_t* q, const bf16_t* bias) {
+    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(q), b = *reinterpret_cast<const bf16x8_t*>(bias);
+    union { unsigned u[4]; bf16x8_t v; } o;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const float x0 = __uint_as_float((unsigned)(unsigned short)a[2 * t] << 16) + __uint_as_float((unsigned)(unsigned short)b[2 * t] << 16);
+        const float x1 = __uint_as_float((unsigned)(unsigned short)a[2 * t + 1] << 16) + __uint_as_float((unsigned)(unsigned short)b[2 * t + 1] << 16);
+        o.u[t] = dec_pk(x0, x1);
+    }
+    return o.v;
+}
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void relattn_decode_ring_kernel(DecodeRingArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = SPLIT ? 0 : wave * 16;
+    const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int a = lane & 15, g = lane >> 4;
+    const int HD = p.H * DEC_D;
+    {   // append: the new keys / values of this chunk enter the ring (all 256 threads; 32 sixteen-byte pieces per row and head)
+        const int start_ = p.state[0];
+        const int ja = chunk * DECR_KC > p.mlen ? chunk * DECR_KC : p.mlen, jb = (chunk + 1) * DECR_KC < p.klen ? (chunk + 1) * DECR_KC : p.klen;
+        const bf16_t* nk = p.qkv + (int64_t)b * p.q * 3 * HD + HD + h * DEC_D;
+        bf16_t* rg = p.ring + (int64_t)b * p.cap * 2 * HD + h * DEC_D;
+        for (int idx = threadIdx.x; idx < (jb - ja) * 32; idx += 256) {
+            const int j = ja + (idx >> 5), pc = idx & 31;          // piece 0..15: K, 16..31: V
+            int r = start_ + j;
+            r = r >= p.cap ? r - p.cap : r;
+            *reinterpret_cast<uint4*>(rg + (int64_t)r * 2 * HD + (pc >> 4) * HD + (pc & 15) * 8) =
+                *reinterpret_cast<const uint4*>(nk + (int64_t)(j - p.mlen) * 3 * HD + (pc >> 4) * HD + (pc & 15) * 8);
+        }
+    }
+    if (i0 >= p.q) return;  // waves are independent: no workgroup barrier below
+    char* Vs = smem + wave * DEC_WAVE_LDS;
+    float* Tw = reinterpret_cast<float*>(Vs + 32 * 256);
+    const int qi = i0 + a < p.q ? i0 + a : p.q - 1;  // rows beyond q repeat the last query (never stored)
+    const bf16_t* qrow = p.qkv + ((int64_t)b * p.q + qi) * 3 * HD + h * DEC_D + g * 8;
+    bf16x8_t fqu[4], fqv[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        fqu[ks] = dec_add_bias(qrow + ks * 32, p.u + h * DEC_D + g * 8 + ks * 32);
+        fqv[ks] = dec_add_bias(qrow + ks * 32, p.vb + h * DEC_D + g * 8 + ks * 32);
+    }
+    const int start = p.state[0];
+    bf16_t* ring = p.ring + (int64_t)b * p.cap * 2 * HD + h * DEC_D;        // row r: K at r * 2 HD, V at r * 2 HD + HD
+    const bf16_t* newkv = p.qkv + (int64_t)b * p.q * 3 * HD + HD + h * DEC_D;  // new row i: K at i * 3 HD, V at i * 3 HD + HD
+    auto krow = [&](int j) -> const bf16_t* {   // K row of logical key j (V: + HD); j clamped by the caller
+        if (j >= p.mlen) return newkv + (int64_t)(j - p.mlen) * 3 * HD;
+        int r = start + j;
+        r = r >= p.cap ? r - p.cap : r;
+        return ring + (int64_t)r * 2 * HD;
+    };
+    const bf16_t* Rg = p.R + h * DEC_D;
+    f32x4 acc_o[8];
+#pragma unroll
+    for (int db = 0; db < 8; db++) acc_o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_i = -1.0e30f, l_i = 0.f;
+    const int i = i0 + a;  // this lane's query
+    const int jc0 = chunk * DECR_KC;
+    for (int st = SPLIT ? wave : 0; st < (SPLIT ? wave + 1 : DECR_KC / 32); st++) {
+        const int j0 = jc0 + st * 32;
+        if (j0 >= p.klen) break;
+        if (j0 > i0 + 15 + p.mlen || j0 + 31 <= i0 - p.shift) continue;   // whole step outside the window of every query of the tile (wave-uniform)
+        // ---- stage V rows j0 .. j0+31 (rows past klen are clamped: their probabilities are exactly zero)
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int row = it * 4 + (lane >> 4), ch = lane & 15;
+            const int jr = j0 + row < p.klen ? j0 + row : p.klen - 1;
+            const bf16_t* src = krow(jr);
+            const uint4 val = *reinterpret_cast<const uint4*>(src + HD + ch * 8);
+            *reinterpret_cast<uint4*>(Vs + row * 256 + ch * 16) = val;
+        }
+        // ---- S^T[key][query] for the two 16-key blocks
+        f32x4 acc_s[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++) {
+            acc_s[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int jr = j0 + 16 * blk + a < p.klen ? j0 + 16 * blk + a : p.klen - 1;
+            const bf16_t* kr = krow(jr) + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+                acc_s[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(kr + ks * 32), fqu[ks], acc_s[blk], 0, 0, 0);
+        }
+        // ---- relative term: distances d_lo .. d_lo+47 with d_lo = mlen + i0 - j0 - 31  ->  Tw[dist][query]
+        const int d_lo = p.mlen + i0 - j0 - 31;
+#pragma unroll
+        for (int tb = 0; tb < 3; tb++) {
+            int dr = d_lo + 16 * tb + a;
+            dr = dr < 0 ? 0 : (dr > p.nd - 1 ? p.nd - 1 : dr);  // out-of-range distances belong to masked pairs
+            const bf16_t* rr = Rg + (int64_t)dr * HD + g * 8;
+            f32x4 acc_t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+                acc_t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(rr + ks * 32), fqv[ks], acc_t, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) Tw[(16 * tb + 4 * g + r) * 16 + a] = acc_t[r];
+        }
+        float s[8];
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int bcol = 16 * blk + 4 * g + r;  // key j0 + bcol
+                const int j = j0 + bcol;
+                const float v = (acc_s[blk][r] + Tw[(a - bcol + 31) * 16 + a]) * p.scale;
+                const bool vis = (j < p.klen) && (j <= i + p.mlen) && (j > i - p.shift) && (i < p.q);
+                s[blk * 4 + r] = vis ? v : -1.0e30f;
+            }
+        float mb = s[0];
+#pragma unroll
+        for (int t = 1; t < 8; t++) mb = fmaxf(mb, s[t]);
+        mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        const float m_new = fmaxf(m_i, mb);
+        const float alpha = __expf(m_i - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; t++) { s[t] = s[t] > -1.0e29f ? __expf(s[t] - m_new) : 0.f; rs += s[t]; }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_i = l_i * alpha + rs;
+        m_i = m_new;
+        union { unsigned u[4]; bf16x8_t v; } pb;
+#pragma unroll
+        for (int t = 0; t < 4; t++) pb.u[t] = dec_pk(s[2 * t], s[2 * t + 1]);
+#pragma unroll
+        for (int db = 0; db < 8; db++) {
+            const int t16 = lane & 15;
+            const char* base = Vs + (t16 >> 2) * 256 + (db * 16 + (t16 & 3) * 4) * 2;
+            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4_t, const_cast<char*>(base) + (4 * g) * 256));
+            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4_t, const_cast<char*>(base) + (16 + 4 * g) * 256));
+            const bf16x8_t vt = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc_o[db][r] *= alpha;
+            acc_o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb.v, acc_o[db], 0, 0, 0);
+        }
+    }
+    if (i < p.q) {
+        const int unit = SPLIT ? chunk * 4 + wave : chunk;
+        float* dst = p.part + ((((int64_t)b * p.H + h) * p.nunit + unit) * 64 + i) * (DEC_D + 2);
+#pragma unroll
+        for (int db = 0; db < 8; db++)
+            *reinterpret_cast<float2*>(dst + db * 16 + 4 * g) = make_float2(acc_o[db][0], acc_o[db][1]),
+            *reinterpret_cast<float2*>(dst + db * 16 + 4 * g + 2) = make_float2(acc_o[db][2], acc_o[db][3]);
+        if (g == 0) { dst[DEC_D] = m_i; dst[DEC_D + 1] = l_i; }
+    }
+}
+// one 128-thread block per (query, head, batch): the units' (m, l) first (independent loads, weights through LDS), then the weighted sum
+__global__ __launch_bounds__(128) void relattn_decode_merge2_kernel(const float* __restrict__ part, bf16_t* __restrict__ out, int q, int H, int nunit) {
+    __shared__ float wgt[64];
+    __shared__ float red[2];
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
+    const float* src = part + ((((int64_t)b * H + h) * nunit) * 64 + i) * (DEC_D + 2);
+    const int64_t cs = (int64_t)64 * (DEC_D + 2);
+    if (d < 64) {   // first wave: nunit <= 64 units
+        const float m = d < nunit ? src[d * cs + DEC_D] : -1.0e30f;
+        const float l = d < nunit ? src[d * cs + DEC_D + 1] : 0.f;
+        float mx = m;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float w = l > 0.f ? __expf(m - mx) : 0.f;
+        wgt[d] = w;
+        float ls = l * w;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, 64);
+        if (d == 0) red[0] = ls;
+    }
+    __syncthreads();
+    float o = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < nunit; c++) o += src[c * cs + d] * wgt[c];   // (units in order: deterministic)
+    const float l = red[0];
+    out[((int64_t)b * q + i) * H * DEC_D + h * DEC_D + d] = f2bf(l > 0.f ? o / l : 0.f);
+}
+__global__ void ring_advance_kernel(int* state, int q, int cap) { int s = state[0] + q; state[0] = s >= cap ? s - cap : s; }
+
+extern "C" int db1_ring_advance(int* state, int q, int cap, void* stream) {
+    if (!state || q < 0 || cap <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "ring_advance");
+    ring_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>(state, q, cap);
+    DB1_CHECK_LAUNCH("ring_advance");
+    return DB1_OK;
+}
+extern "C" int64_t db1_relattn_decode_ring_workspace_bytes(int B, int q, int klen, int H) {
+    (void)q;
+    return (int64_t)B * H * ((klen + 31) / 32) * 64 * (DEC_D + 2) * (int64_t)sizeof(float);
+}
+extern "C" int db1_relattn_decode_ring_fwd(const void* qkv_new, const void* u, const void* vb, void* kv_ring, const int* ring_state, int cap, const void* R,
+                                           int nd, void* out, int B, int q, int mlen, int H, int D, int shift, float scale, void* ws, int64_t ws_bytes,
+                                           void* stream) {
+    const int klen = mlen + q;
+    if (!db1_relattn_decode_supported(B, q, klen, H, D, DB1_BF16) || klen > 64 * 32)
+        DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_decode_ring: needs bf16, d_head = 128, 1 <= q <= 64, klen <= 2048 (got q=%d klen=%d D=%d)", q, klen, D);
+    if (cap < klen || nd < 1 || !R || !ring_state || !kv_ring || !u || !vb) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_decode_ring: ring capacity %d < klen %d, or null buffer", cap, klen);
+    if (!db1_aligned16(qkv_new) || !db1_aligned16(kv_ring) || !db1_aligned16(R) || !db1_aligned16(out) || !db1_aligned16(u) || !db1_aligned16(vb))
+        DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_decode_ring: operands must be 16-byte aligned");
+    DecodeRingArgs a;
+    a.qkv = (const bf16_t*)qkv_new; a.u = (const bf16_t*)u; a.vb = (const bf16_t*)vb; a.ring = (bf16_t*)kv_ring; a.state = ring_state; a.R = (const bf16_t*)R;
+    a.out = (bf16_t*)out; a.B = B; a.q = q; a.klen = klen; a.mlen = mlen; a.H = H; a.shift = shift; a.nd = nd; a.cap = cap; a.scale = scale;
+    const bool split = q <= 16;
+    const int nchunk = (klen + DECR_KC - 1) / DECR_KC;
+    a.nunit = split ? nchunk * 4 : nchunk;
+    DB1_NEED_WS(ws, ws_bytes, db1_relattn_decode_ring_workspace_bytes(B, q, klen, H), "relattn_decode_ring");
+    a.part = (float*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    if (split) {   // (every wave writes its unit, with l = 0 when it saw no visible key: the merge gives those weight 0)
+        relattn_decode_ring_kernel<true><<<dim3((unsigned)nchunk, (unsigned)H, (unsigned)B), 256, 4 * DEC_WAVE_LDS, st>>>(a);
+    } else relattn_decode_ring_kernel<false><<<dim3((unsigned)nchunk, (unsigned)H, (unsigned)B), 256, 4 * DEC_WAVE_LDS, st>>>(a);
+    DB1_CHECK_LAUNCH("relattn_decode_ring");
+    relattn_decode_merge2_kernel<<<dim3((unsigned)q, (unsigned)H, (unsigned)B), 128, 0, st>>>(a.part, a.out, q, H, a.nunit);
+    DB1_CHECK_LAUNCH("relattn_decode_merge2");
+    return DB1_OK;
+}
+
 extern "C" int db1_relattn_decode_supported(int B, int q, int klen, int H, int D, int dt) {
     return (dt == DB1_BF16 && D == DEC_D && B > 0 && H > 0 && q >= 1 && q <= 64 && klen >= q && B <= 65535 && H <= 65535) ? 1 : 0;
 }

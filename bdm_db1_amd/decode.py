@@ -76,3 +76,76 @@ class GraphedMemoryStep:
         self.ids.copy_(ids)
         self.graph.replay()
         return self.logits, self.mems
+
+
+class RingMemory:
+    """Transformer-XL memory for hipGraph-replayed inference: per layer the projected keys / values of the last ``mem_len`` tokens in a
+    ring [B, mem_len + 64, 2, H, D], appended IN PLACE by the attention launch of each call (db1_relattn_decode_ring_fwd), and a device
+    scalar with the ring's origin.  Pass it as ``mems`` (``model(x, compute_loss=False, mems=ring)`` returns it back as the new memory).
+    What it does not keep is the reference's memory CONTENT -- the hidden states (transformer_xl.py:470-504): a caller that reads or edits
+    ``mems[i]`` needs the list form (``model.init_mem``); evaluate_rl's loop only hands the memory back to the model."""
+
+    def __init__(self, model, batch_size: int):
+        if model.compute_dtype != torch.bfloat16 or not model.use_decode or model.d_head != 128 or not model.mem_len:
+            raise ValueError("RingMemory needs the bf16 K/V-cached decode path (d_head 128, mem_len > 0)")
+        self.model, self.B = model, batch_size
+        self.cap = int(model.mem_len) + 64
+        dev = model.dev
+        self.kv = [torch.zeros(batch_size, self.cap, 2, model.n_head, model.d_head, device=dev, dtype=torch.bfloat16) for _ in range(model.n_layer)]
+        self.state = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.reset()
+
+    def reset(self):
+        """a new episode: the keys / values of the zero memory (init_mem), origin 0"""
+        model, mlen = self.model, int(self.model.mem_len)
+        with torch.no_grad():
+            saved, model._dec_state = model._dec_state, None
+            dec = model._decode_begin(model.init_mem(self.B), self.B, 1, mlen)
+            model._dec_state = saved
+            for ring, kv in zip(self.kv, dec.kv):
+                ring[:, :mlen].copy_(kv.reshape(self.B, mlen, 2, model.n_head, model.d_head))
+            self.state.zero_()
+
+
+class GraphedRingStep:
+    """One inference call with memory (batch ``batch_size``, ``n_new`` new tokens) as ONE hipGraph replay over a RingMemory: nothing is
+    concatenated, copied or re-projected per call.  Several steps (e.g. the observation call and the 1-token calls of evaluate_rl) can
+    share one memory: ``GraphedRingStep(model, 1, 1, memory=obs_step.memory)``."""
+
+    def __init__(self, model, batch_size: int, n_new: int, memory: RingMemory = None, make_input=None):
+        from .data import NLPTaskInput
+        self.model, self.B, self.q = model, batch_size, n_new
+        self.memory = memory if memory is not None else RingMemory(model, batch_size)
+        assert self.memory.B == batch_size
+        dev = model.dev
+        self.ids = torch.zeros(batch_size, n_new, dtype=torch.long, device=dev)
+        make_input = make_input or (lambda ids: NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None))
+        self.x = make_input(self.ids)
+        saved_state = self.memory.state.clone()
+        saved_kv = None if memory is None else [k.clone() for k in self.memory.kv]
+        with torch.no_grad():   # eager warm-up (workspaces, the R table), then the capture
+            for _ in range(2):
+                model([self.x], compute_loss=False, mems=self.memory)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                logits, _, _ = model([self.x], compute_loss=False, mems=self.memory)
+        self.graph, self.logits = g, logits
+        self._version = model._wversion
+        if saved_kv is None:
+            self.memory.reset()
+        else:   # a shared memory keeps the state its owner left
+            for dst, src in zip(self.memory.kv, saved_kv):
+                dst.copy_(src)
+            self.memory.state.copy_(saved_state)
+
+    def reset_memory(self):
+        self.memory.reset()
+
+    def __call__(self, ids: torch.Tensor):
+        """ids [batch, n_new] -> (logits [batch, n_new, vocab] (static buffer, overwritten by the next call), the RingMemory)"""
+        if self.model._wversion != self._version:
+            raise RuntimeError("the weights changed after the graph was captured: build a new GraphedRingStep")
+        self.ids.copy_(ids)
+        self.graph.replay()
+        return self.logits, self.memory

@@ -771,6 +771,10 @@ class TransformerXL(nn.Module):
     def _attention_decode(self, qkv, i, B, L, mlen, shift, dec):
         H, D = self.n_head, self.d_head
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
+        if getattr(dec, "ring", None) is not None:   # K / V of the memory in a ring, appended in place by the attention launch (decode.RingMemory)
+            av = self._new(B, L, H, D)
+            ops.relattn_decode_ring_fwd(qkv, u, vb, dec.ring.kv[i], dec.ring.state, dec.R[i], av, B, L, mlen, H, D, shift, 1.0 / math.sqrt(D))
+            return av
         qu, qv = self._new(B, L, H, D), self._new(B, L, H, D)
         ops.relattn_add_head_bias(qkv, u, vb, qu, qv, B, L, L, H, D)
         old = dec.kv[i]
@@ -1053,7 +1057,12 @@ class TransformerXL(nn.Module):
                 dstep = self._drop_step
             if self.embd_pdrop > 0:
                 ops.dropout(h, h, self._drop_args(self.embd_pdrop, self.SITE_EMBED, dstep))                     # :545
-        mlen = mems[0].size(1) if mems is not None else 0
+        ring = mems if (mems is not None and not isinstance(mems, (list, tuple))) else None   # decode.RingMemory: K / V ring instead of hidden states
+        if ring is not None:
+            mems = None
+            mlen = int(self.mem_len)
+        else:
+            mlen = mems[0].size(1) if mems is not None else 0
         klen = L + mlen
         shift = self._window(L, mlen)
         # The reference builds a uint8 mask (1 = hidden, transformer_xl.py:551-567) and raises ValueError when NOTHING is hidden
@@ -1064,6 +1073,10 @@ class TransformerXL(nn.Module):
         if not (L > 1 or (self.same_length and shift <= L - 1)):
             raise ValueError("attention mask hides nothing (transformer_xl.py:177,205-206)")
         dec = self._decode_begin(mems, B, L, mlen) if (mems is not None and mlen > 0) else None
+        if ring is not None:
+            if not (self.use_decode and self.compute_dtype == torch.bfloat16 and ring.B == B and L <= 64 and mlen + L <= ring.cap):
+                raise ValueError("RingMemory needs the bf16 decode path, its own batch size and at most 64 new tokens per call")
+            dec = SimpleNamespace(ring=ring, R=self._decode_R(), kv=None, new_kv=[])
         R_in = self._sinusoid(klen) if dec is None else None
         if dstep is not None and self.embd_pdrop > 0:   # the position table goes through the same nn.Dropout (:575); the cached table stays intact
             R_drop = torch.empty_like(R_in)
@@ -1117,6 +1130,9 @@ class TransformerXL(nn.Module):
                     ctx.B, ctx.L, ctx.shift, ctx.dstep, ctx.dh_head = B, L, shift, dstep, None
                     self._ctx = ctx
         res = (lm_logits, loss)
+        if ring is not None:   # the ring was appended by the attention launches: only its origin moves
+            ops.ring_advance(ring.state, L, ring.cap)
+            return res + (ring,)
         if mems is not None:  # _update_mem (:487-504)
             end_idx = mlen + max(0, L)
             beg_idx = max(0, end_idx - self.mem_len)

@@ -412,6 +412,18 @@ def relattn_decode_fwd(qu, qv, k, v, R, out, B, q, klen, mlen, H, D, shift, scal
              B, q, klen, mlen, H, D, shift, float(scale), ws, wsn, stream())
 
 
+def relattn_decode_ring_fwd(qkv_new, u, vb, kv_ring, state, R, out, B, q, mlen, H, D, shift, scale):
+    """attention of q new tokens over a ring of cached K / V (db1_relattn_decode_ring_fwd): kv_ring [B, cap, 2, H, D], state int32[1]"""
+    cap = kv_ring.shape[1]
+    ws, wsn = _ws("db1_relattn_decode_ring_workspace_bytes", (B, q, mlen + q, H), out.device)
+    lib.call("db1_relattn_decode_ring_fwd", P(qkv_new), P(u), P(vb), P(kv_ring), P(state), cap, P(R), R.shape[0], P(out), B, q, mlen, H, D, shift,
+             float(scale), ws, wsn, stream())
+
+
+def ring_advance(state, q, cap):
+    lib.call("db1_ring_advance", P(state), int(q), int(cap), stream())
+
+
 def relattn_flash_supported(B, L, H, D, dtype) -> bool:
     return bool(lib.load().db1_relattn_flash_supported(B, L, H, D, dt_code(dtype)))
 

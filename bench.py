@@ -93,7 +93,7 @@ def decode_leg(model, dev, calls: int = 30):
     released evaluation runs -- on the model the training steps just used: ms per call as one hipGraph replay and eager, and the call
     against its roofline: it has to stream every bf16 decoder / head weight and the cached K / V of the memory once (algorithmic bytes)
     at the HBM rate."""
-    from bdm_db1_amd import GraphedMemoryStep
+    from bdm_db1_amd import GraphedMemoryStep, GraphedRingStep
     from bdm_db1_amd.data import NLPTaskInput
     was_training = model.training
     model.eval()
@@ -102,19 +102,21 @@ def decode_leg(model, dev, calls: int = 30):
     w_layer = (3 * d * d + d * d + di * d + d * (di // 2 if str(getattr(model, "activation_fn", "geglu")) == "geglu" else di)) * 2
     bytes_call = nl * (w_layer + 2 * mem * d * 2) + V * d * 2        # weights + K / V of the memory per layer + the tied head
     try:
-        step = GraphedMemoryStep(model, batch_size=1, n_new=1)
         ids = torch.randint(0, 32000, (1, 1), device=dev)
-        for _ in range(5):
-            step(ids)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(calls):
-            step(ids)
-        e1.record()
-        torch.cuda.synchronize()
-        ms_graph = e0.elapsed_time(e1) / calls
-        del step
+
+        def timed(step):
+            for _ in range(5):
+                step(ids)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(calls):
+                step(ids)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / calls
+        ms_graph = timed(GraphedRingStep(model, batch_size=1, n_new=1))            # K / V ring appended in place: the default graphed form
+        ms_graph_list = timed(GraphedMemoryStep(model, batch_size=1, n_new=1))     # the list-memory contract (hidden states copied per call)
         mems = model.init_mem(1)
         x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
         with torch.no_grad():
@@ -128,10 +130,10 @@ def decode_leg(model, dev, calls: int = 30):
         ms_eager = (time.perf_counter() - t0) / calls * 1e3
         gbps = bytes_call / (ms_graph * 1e-3) / 1e9
         out = {"workload": f"inference with Transformer-XL memory, batch 1, mem_len {mem}, 1 new token per call (evaluate_rl.py:157-266), bf16, K / V of the memory cached",
-               "ms_per_call": round(ms_graph, 4), "ms_per_call_eager": round(ms_eager, 4), "calls": calls, "tokens_per_s": round(1e3 / ms_graph, 1),
+               "ms_per_call": round(ms_graph, 4), "ms_per_call_list_memory_graph": round(ms_graph_list, 4), "ms_per_call_eager": round(ms_eager, 4), "calls": calls, "tokens_per_s": round(1e3 / ms_graph, 1),
                "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
                             "algorithmic_bytes_per_call": int(bytes_call),
-                            "kernel": "the whole call as one hipGraph replay (skinny GEMMs over the bf16 weights + relattn_decode over the cached K / V)"}}
+                            "kernel": "the whole call as one hipGraph replay over a K / V ring (skinny GEMMs over the bf16 weights + relattn_decode_ring)"}}
     except Exception as e:   # the decode leg must never take the bench line down
         out = {"ms_per_call": None, "error": repr(e)}
     model.train(was_training)

@@ -229,6 +229,17 @@ int db1_relattn_decode_fwd(const void* qu, const void* qv, const void* k, const 
                            int64_t kv_batch_stride, const void* R, int nd, void* out, int B, int q, int klen, int mlen, int H,
                            int D, int shift, float scale, void* ws, int64_t ws_bytes, void* stream);
 
+/* The same attention over a RING of cached keys / values (hipGraph-friendly inference: nothing is concatenated or copied per call):
+ * kv_ring [B, cap, 2, H, D] bf16, cap >= mlen + q; logical key j < mlen is ring row (ring_state[0] + j) % cap; the q new keys / values come
+ * from this call's packed projections qkv_new [B, q, 3, H, D] and are appended at rows (ring_state[0] + mlen + i) % cap by the same
+ * launch; q + r_w_bias / q + r_r_bias are formed inside (u, vb [H, D]).  ring_state is a DEVICE int (the row of logical key 0), advanced
+ * by db1_ring_advance(state, q, cap) after the last layer of a call -- so one captured graph serves every call.  klen <= 2048. */
+int64_t db1_relattn_decode_ring_workspace_bytes(int B, int q, int klen, int H);
+int db1_relattn_decode_ring_fwd(const void* qkv_new, const void* u, const void* vb, void* kv_ring, const int* ring_state, int cap, const void* R,
+                                int nd, void* out, int B, int q, int mlen, int H, int D, int shift, float scale, void* ws, int64_t ws_bytes,
+                                void* stream);
+int db1_ring_advance(int* state, int q, int cap, void* stream);
+
 /* ------------------------------------------------------------------ relative-position attention, materialised path
  * (fp32 parity gate, any head size).  Buffers S,T are float32 in [H][B][Lq][*] layout.
  * qu = q + u, qv = q + v_bias from the packed qkv activations [B, L, 3, H, D]  (transformer_xl.py:161,167). */

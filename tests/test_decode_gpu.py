@@ -123,3 +123,63 @@ def test_graphed_memory_step_matches_eager_calls():
             err = np.abs(got - eager[t]).max() / np.abs(eager[t]).max()
             assert err < 1e-6, f"pass {rep} call {t}: graph vs eager rel err {err:.3e}"
         step.reset_memory()
+
+
+@pytest.mark.parametrize("pre_lnorm", [False, True])
+def test_ring_memory_matches_the_kv_cached_path(pre_lnorm):
+    """RingMemory (keys / values of the memory in a ring, appended in place by db1_relattn_decode_ring_fwd, origin on the device) against
+    the K/V-cached list-memory path over an evaluate_rl-like call sequence with 2 sequences: multi-token observations (the tile-per-wave
+    form, q > 16), single tokens (the step-per-wave form), the memory sliding past mem_len and the ring wrapping (mem_len 40 + 64 rows)."""
+    from bdm_db1_amd import RingMemory, TransformerXL, synth
+    from bdm_db1_amd.data import NLPTaskInput
+    cfg = synth.db1_config("tiny", n_embed=256, n_head=2, n_layer=2, n_position=64, mem_len=40, pre_lnorm=pre_lnorm, fp16=True)
+    torch.manual_seed(3)
+    model = TransformerXL(cfg, device=torch.device(DEV), compute_dtype=torch.bfloat16)
+    model.eval()
+    rng = np.random.default_rng(0)
+    calls = [rng.integers(0, 32000, (2, q)) for q in (7, 1, 1, 22, 1, 30, 1, 1, 16, 17, 1, 40, 1, 1, 1, 9)]
+
+    def run(ring):
+        mems = RingMemory(model, 2) if ring else model.init_mem(2)
+        model._dec_state = None
+        outs = []
+        with torch.no_grad():
+            for ids in calls:
+                x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=torch.from_numpy(ids).to(DEV), text_len=None)
+                logits, _, mems = model([x], compute_loss=False, mems=mems)
+                outs.append(logits.float().cpu().numpy())
+        return outs
+    ref, got = run(False), run(True)
+    for step, (a, b) in enumerate(zip(got, ref)):
+        err = np.abs(a - b).max() / np.abs(b).max()
+        assert err < 1e-2, f"call {step} (q = {calls[step].shape[1]}): rel err {err:.3e}"   # same kernels' maths, different partial-sum grouping
+
+
+def test_graphed_ring_steps_share_a_memory():
+    """GraphedRingStep: an observation call (q = 22) and 1-token calls as two captured graphs over ONE RingMemory reproduce the eager
+    K/V-cached calls of the same token stream; reset_memory() starts a new episode"""
+    from bdm_db1_amd import GraphedRingStep, TransformerXL, synth
+    from bdm_db1_amd.data import NLPTaskInput
+    cfg = synth.db1_config("tiny", n_embed=256, n_head=2, n_layer=2, n_position=64, mem_len=40, fp16=True)
+    torch.manual_seed(5)
+    model = TransformerXL(cfg, device=torch.device(DEV), compute_dtype=torch.bfloat16)
+    model.eval()
+    rng = np.random.default_rng(1)
+    stream = []
+    for _ in range(5):   # five transitions: 22 observation tokens, then three single tokens
+        stream += [torch.from_numpy(rng.integers(0, 32000, (1, 22))).to(DEV)] + [torch.from_numpy(rng.integers(0, 32000, (1, 1))).to(DEV) for _ in range(3)]
+    mems, eager = model.init_mem(1), []
+    with torch.no_grad():
+        for ids in stream:
+            x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
+            logits, _, mems = model([x], compute_loss=False, mems=mems)
+            eager.append(logits.float().cpu().numpy())
+    obs = GraphedRingStep(model, batch_size=1, n_new=22)
+    one = GraphedRingStep(model, batch_size=1, n_new=1, memory=obs.memory)
+    for rep in range(2):
+        for t, ids in enumerate(stream):
+            logits, _ = (obs if ids.shape[1] == 22 else one)(ids)
+            got = logits.float().cpu().numpy()
+            err = np.abs(got - eager[t]).max() / np.abs(eager[t]).max()
+            assert err < 1e-2, f"pass {rep} call {t}: rel err {err:.3e}"
+        obs.reset_memory()

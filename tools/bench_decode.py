@@ -45,9 +45,11 @@ def timed(q, n, mems):
     return e0.elapsed_time(e1) / n, wall, mems
 
 
-for q in (q_first, 1):  # same calls as ONE hipGraph replay each (bdm_db1_amd/decode.py)
-    from bdm_db1_amd import GraphedMemoryStep
-    step = GraphedMemoryStep(model, batch_size=1, n_new=q)
+for q in (q_first, 1, -q_first, -1):  # same calls as ONE hipGraph replay each (bdm_db1_amd/decode.py); negative: the K / V ring form
+    from bdm_db1_amd import GraphedMemoryStep, GraphedRingStep
+    ring = q < 0
+    q = abs(q)
+    step = (GraphedRingStep if ring else GraphedMemoryStep)(model, batch_size=1, n_new=q)
     ids = torch.randint(0, 32000, (1, q), device=dev)
     for _ in range(3):
         step(ids)
@@ -57,7 +59,7 @@ for q in (q_first, 1):  # same calls as ONE hipGraph replay each (bdm_db1_amd/de
         step(ids)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    print(f"graphed q={q:3d} mem={step.mems[0].shape[1]}: {ms:8.3f} ms/call (wall)  {q / ms * 1e3:9.1f} tokens/s")
+    print(f"graphed{' ring' if ring else '     '} q={q:3d} mem={model.mem_len}: {ms:8.3f} ms/call (wall)  {q / ms * 1e3:9.1f} tokens/s")
     del step
 
 mems = model.init_mem(1)
