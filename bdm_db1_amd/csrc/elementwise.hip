@@ -3,6 +3,7 @@
 // global-norm, mu-law tokenizer.  All are one-pass (or L2-resident re-read) streaming kernels
 // with 16-byte vector accesses and wave-shuffle reductions; roofline = HBM bytes.
 #include "db1_common.h"
+#include "ln_row.h"
 
 // =====================================================================================
 // residual + LayerNorm      (reference: transformer_xl.py:231-238, 288-290)
@@ -161,31 +162,14 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const T* __restrict__ x
 #pragma unroll
             for (int j = 0; j < V; j++) a[k].v[j] = alpha * a[k].v[j];
     }
-    float sum = 0.f;
-#pragma unroll
-    for (int k = 0; k < NV; k++)
-#pragma unroll
-        for (int j = 0; j < V; j++) {
-            if (sizeof(T) == 2) a[k].v[j] = bf2f(f2bf(a[k].v[j]));  // s is a tensor of dtype T in the reference
-            sum += a[k].v[j];
-        }
-    const float mu = wave_sum(sum) / (float)d;
-    float sq = 0.f;
-#pragma unroll
-    for (int k = 0; k < NV; k++)
-#pragma unroll
-        for (int j = 0; j < V; j++) { const float c = a[k].v[j] - mu; sq += c * c; }
-    const float rs = rsqrtf(wave_sum(sq) / (float)d + eps);
+    float mu, rs;
+    ln_row_stats<T, NV>(a, d, eps, mu, rs);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    if (s_out) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-        const int i = (k * 64 + lane) * V;
-        if (s_out) a[k].store(s_out + row * d + i);
-        Vec16<T> o;
-#pragma unroll
-        for (int j = 0; j < V; j++) o.v[j] = (a[k].v[j] - mu) * rs * ldf(gamma + i + j) + ldf(beta + i + j);
-        o.store(y + row * d + i);
+        for (int k = 0; k < NV; k++) a[k].store(s_out + row * d + (k * 64 + lane) * V);
     }
+    ln_row_store<T, TP, NV>(a, mu, rs, gamma, beta, y + row * d, lane);
 }
 
 template <typename T, typename TP, int NV>

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(128) void relattn_decode_merge_kernel(DecodeArgs p)
 #define DECR_KC 128
 struct DecodeRingArgs {
     const bf16_t* qkv; const bf16_t* u; const bf16_t* vb; bf16_t* ring; const int* state; const bf16_t* R;
-    float* part; bf16_t* out;
+    float* part; bf16_t* out; unsigned* tickets;
     int B, q, klen, mlen, H, shift, nd, nunit, cap;
     float scale;
 };
@@ -203,6 +203,11 @@ __device__ __forceinline__ bf16x8_t dec_add_bias(const bf16_t* q, const bf16_t* 
     }
     return o.v;
 }
+__device__ __forceinline__ void dec_st_agent(float* p, float a, float b) {   // 8 bytes, write-through (sc1)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float dec_ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void relattn_decode_ring_kernel(DecodeRingArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -238,11 +243,14 @@ __global__ __launch_bounds__(256) void relattn_decode_ring_kernel(DecodeRingArgs
     const int start = p.state[0];
     bf16_t* ring = p.ring + (int64_t)b * p.cap * 2 * HD + h * DEC_D;        // row r: K at r * 2 HD, V at r * 2 HD + HD
     const bf16_t* newkv = p.qkv + (int64_t)b * p.q * 3 * HD + HD + h * DEC_D;  // new row i: K at i * 3 HD, V at i * 3 HD + HD
-    auto krow = [&](int j) -> const bf16_t* {   // K row of logical key j (V: + HD); j clamped by the caller
-        if (j >= p.mlen) return newkv + (int64_t)(j - p.mlen) * 3 * HD;
+    // K row of logical key j (V: + HD); j clamped by the caller.  A select, not a branch: with a divergent if / else around them the
+    // compiler issued the 28 loads of a step one round trip at a time (14.6 us per launch at q = 1, almost all of it memory latency)
+    auto krow = [&](int j) -> const bf16_t* {
         int r = start + j;
         r = r >= p.cap ? r - p.cap : r;
-        return ring + (int64_t)r * 2 * HD;
+        const int64_t off_ring = (int64_t)r * 2 * HD, off_new = (int64_t)(j - p.mlen) * 3 * HD;
+        const bf16_t* base = j >= p.mlen ? newkv : ring;
+        return base + (j >= p.mlen ? off_new : off_ring);
     };
     const bf16_t* Rg = p.R + h * DEC_D;
     f32x4 acc_o[8];
@@ -255,37 +263,51 @@ __global__ __launch_bounds__(256) void relattn_decode_ring_kernel(DecodeRingArgs
         const int j0 = jc0 + st * 32;
         if (j0 >= p.klen) break;
         if (j0 > i0 + 15 + p.mlen || j0 + 31 <= i0 - p.shift) continue;   // whole step outside the window of every query of the tile (wave-uniform)
-        // ---- stage V rows j0 .. j0+31 (rows past klen are clamped: their probabilities are exactly zero)
+        // ---- every global load of the step is requested before the first use: V rows j0 .. j0+31 (rows past klen are clamped: their
+        // probabilities are exactly zero), the two 16-key K blocks and the three 16-distance R blocks (d_lo = mlen + i0 - j0 - 31)
+        uint4 vreg[8];
+        bf16x8_t kreg[2][4], rreg[3][4];
 #pragma unroll
         for (int it = 0; it < 8; it++) {
             const int row = it * 4 + (lane >> 4), ch = lane & 15;
             const int jr = j0 + row < p.klen ? j0 + row : p.klen - 1;
-            const bf16_t* src = krow(jr);
-            const uint4 val = *reinterpret_cast<const uint4*>(src + HD + ch * 8);
-            *reinterpret_cast<uint4*>(Vs + row * 256 + ch * 16) = val;
+            vreg[it] = *reinterpret_cast<const uint4*>(krow(jr) + HD + ch * 8);
         }
-        // ---- S^T[key][query] for the two 16-key blocks
-        f32x4 acc_s[2];
 #pragma unroll
         for (int blk = 0; blk < 2; blk++) {
-            acc_s[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int jr = j0 + 16 * blk + a < p.klen ? j0 + 16 * blk + a : p.klen - 1;
             const bf16_t* kr = krow(jr) + g * 8;
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++)
-                acc_s[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(kr + ks * 32), fqu[ks], acc_s[blk], 0, 0, 0);
+            for (int ks = 0; ks < 4; ks++) kreg[blk][ks] = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
         }
-        // ---- relative term: distances d_lo .. d_lo+47 with d_lo = mlen + i0 - j0 - 31  ->  Tw[dist][query]
         const int d_lo = p.mlen + i0 - j0 - 31;
 #pragma unroll
         for (int tb = 0; tb < 3; tb++) {
             int dr = d_lo + 16 * tb + a;
             dr = dr < 0 ? 0 : (dr > p.nd - 1 ? p.nd - 1 : dr);  // out-of-range distances belong to masked pairs
             const bf16_t* rr = Rg + (int64_t)dr * HD + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) rreg[tb][ks] = *reinterpret_cast<const bf16x8_t*>(rr + ks * 32);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int row = it * 4 + (lane >> 4), ch = lane & 15;
+            *reinterpret_cast<uint4*>(Vs + row * 256 + ch * 16) = vreg[it];
+        }
+        // ---- S^T[key][query] for the two 16-key blocks
+        f32x4 acc_s[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++) {
+            acc_s[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) acc_s[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kreg[blk][ks], fqu[ks], acc_s[blk], 0, 0, 0);
+        }
+        // ---- relative term  ->  Tw[dist][query]
+#pragma unroll
+        for (int tb = 0; tb < 3; tb++) {
             f32x4 acc_t = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++)
-                acc_t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(rr + ks * 32), fqv[ks], acc_t, 0, 0, 0);
+            for (int ks = 0; ks < 4; ks++) acc_t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rreg[tb][ks], fqv[ks], acc_t, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; r++) Tw[(16 * tb + 4 * g + r) * 16 + a] = acc_t[r];
         }
@@ -329,14 +351,102 @@ __global__ __launch_bounds__(256) void relattn_decode_ring_kernel(DecodeRingArgs
             acc_o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb.v, acc_o[db], 0, 0, 0);
         }
     }
-    if (i < p.q) {
-        const int unit = SPLIT ? chunk * 4 + wave : chunk;
-        float* dst = p.part + ((((int64_t)b * p.H + h) * p.nunit + unit) * 64 + i) * (DEC_D + 2);
+    if (!SPLIT) {
+        if (i < p.q) {
+            float* dst = p.part + ((((int64_t)b * p.H + h) * p.nunit + chunk) * 64 + i) * (DEC_D + 2);
 #pragma unroll
-        for (int db = 0; db < 8; db++)
-            *reinterpret_cast<float2*>(dst + db * 16 + 4 * g) = make_float2(acc_o[db][0], acc_o[db][1]),
-            *reinterpret_cast<float2*>(dst + db * 16 + 4 * g + 2) = make_float2(acc_o[db][2], acc_o[db][3]);
-        if (g == 0) { dst[DEC_D] = m_i; dst[DEC_D + 1] = l_i; }
+            for (int db = 0; db < 8; db++)
+                *reinterpret_cast<float2*>(dst + db * 16 + 4 * g) = make_float2(acc_o[db][0], acc_o[db][1]),
+                *reinterpret_cast<float2*>(dst + db * 16 + 4 * g + 2) = make_float2(acc_o[db][2], acc_o[db][3]);
+            if (g == 0) { dst[DEC_D] = m_i; dst[DEC_D + 1] = l_i; }
+        }
+        return;
+    }
+    // ---- SPLIT: the four waves' partial results (one 32-key step each) are merged here, through LDS, into ONE unit per chunk (every wave
+    // reaches this point: i0 = 0 < q, and break / continue above only skip the step)
+    constexpr int OLD = DEC_D + 4;                       // floats per query row in LDS: O[128], m, l, pad
+    float* mine = reinterpret_cast<float*>(Vs);          // (the wave's own V stage / T scratch, 11 KB >= 16 rows x 132 floats: it is done with them)
+#pragma unroll
+    for (int db = 0; db < 8; db++) *reinterpret_cast<f32x4*>(mine + a * OLD + db * 16 + 4 * g) = acc_o[db];
+    if (g == 0) { mine[a * OLD + DEC_D] = m_i; mine[a * OLD + DEC_D + 1] = l_i; }
+    __syncthreads();
+    const bool inlaunch = p.tickets != nullptr;   // the merge over the chunks happens in this launch too: partials as write-through stores
+    {
+        const int qi = threadIdx.x & 15, dg = (threadIdx.x >> 4) * 8;
+        const float* w0p = reinterpret_cast<const float*>(smem) + qi * OLD;
+        float mw[4], lw[4], mx = -1.0e30f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            mw[w] = w0p[w * (DEC_WAVE_LDS / 4) + DEC_D]; lw[w] = w0p[w * (DEC_WAVE_LDS / 4) + DEC_D + 1];
+            mx = fmaxf(mx, mw[w]);
+        }
+        float lsum_ = 0.f, o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; w++) {   // (waves in order: deterministic)
+            const float wt = lw[w] > 0.f ? __expf(mw[w] - mx) : 0.f;
+            lsum_ += lw[w] * wt;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(w0p + w * (DEC_WAVE_LDS / 4) + dg), hi = *reinterpret_cast<const f32x4*>(w0p + w * (DEC_WAVE_LDS / 4) + dg + 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { o8[j] += lo[j] * wt; o8[4 + j] += hi[j] * wt; }
+        }
+        if (qi < p.q) {
+            float* dst = p.part + ((((int64_t)b * p.H + h) * p.nunit + chunk) * 64 + qi) * (DEC_D + 2);
+            if (inlaunch) {
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) dec_st_agent(dst + dg + j, o8[j], o8[j + 1]);
+                if (dg == 0) dec_st_agent(dst + DEC_D, mx, lsum_);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) *reinterpret_cast<float2*>(dst + dg + j) = make_float2(o8[j], o8[j + 1]);
+                if (dg == 0) { dst[DEC_D] = mx; dst[DEC_D + 1] = lsum_; }
+            }
+        }
+    }
+    if (!inlaunch) return;
+    // ---- the chunk that finishes last for this (batch, head) merges the units (ticket counter, zero on entry and left zero): one launch less
+    // per layer.  Same arithmetic as relattn_decode_merge2_kernel, two queries at a time (128 threads each).
+    // Hand-off (per-XCD L2s are not coherent, L1s never refreshed): write-through 8-byte stores above, every wave drains them, one relaxed
+    // agent-scope ticket per workgroup, and the merging workgroup reads the partials with L1-bypassing (sc1) loads.
+    __shared__ unsigned ticket_s;
+    __shared__ float wgt[2][64];
+    __shared__ float lsum[2];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) ticket_s = __hip_atomic_fetch_add(p.tickets + b * p.H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket_s != gridDim.x - 1) return;
+    if (threadIdx.x == 0) __hip_atomic_store(p.tickets + b * p.H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int half = threadIdx.x >> 7, d = threadIdx.x & 127;
+    const int64_t cs = (int64_t)64 * (DEC_D + 2);
+    for (int it = 0; it < (p.q + 1) / 2; it++) {
+        const int qi2 = it * 2 + half;
+        const bool valid = qi2 < p.q;
+        const float* src = p.part + ((((int64_t)b * p.H + h) * p.nunit) * 64 + (valid ? qi2 : 0)) * (DEC_D + 2);
+        if (d < 64) {   // first wave of the half: nunit <= 64 units
+            const float m = d < p.nunit ? dec_ld_agent(src + d * cs + DEC_D) : -1.0e30f;
+            const float l = d < p.nunit ? dec_ld_agent(src + d * cs + DEC_D + 1) : 0.f;
+            float mx = m;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            const float w = l > 0.f ? __expf(m - mx) : 0.f;
+            wgt[half][d] = w;
+            float ls = l * w;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, 64);
+            if (d == 0) lsum[half] = ls;
+        }
+        __syncthreads();
+        float o = 0.f;
+        for (int c0 = 0; c0 < p.nunit; c0 += 16) {   // 16 loads in flight (clamped index, zero weight beyond nunit); units in order: deterministic
+            float v[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) v[c] = dec_ld_agent(src + (c0 + c < p.nunit ? c0 + c : p.nunit - 1) * cs + d);
+#pragma unroll
+            for (int c = 0; c < 16; c++) o += v[c] * (c0 + c < p.nunit ? wgt[half][c0 + c] : 0.f);
+        }
+        const float l = lsum[half];
+        if (valid) p.out[((int64_t)b * p.q + qi2) * p.H * DEC_D + h * DEC_D + d] = f2bf(l > 0.f ? o / l : 0.f);
+        __syncthreads();
     }
 }
 // one 128-thread block per (query, head, batch): the units' (m, l) first (independent loads, weights through LDS), then the weighted sum
@@ -380,7 +490,7 @@ extern "C" int64_t db1_relattn_decode_ring_workspace_bytes(int B, int q, int kle
 }
 extern "C" int db1_relattn_decode_ring_fwd(const void* qkv_new, const void* u, const void* vb, void* kv_ring, const int* ring_state, int cap, const void* R,
                                            int nd, void* out, int B, int q, int mlen, int H, int D, int shift, float scale, void* ws, int64_t ws_bytes,
-                                           void* stream) {
+                                           void* tickets, void* stream) {
     const int klen = mlen + q;
     if (!db1_relattn_decode_supported(B, q, klen, H, D, DB1_BF16) || klen > 64 * 32)
         DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_decode_ring: needs bf16, d_head = 128, 1 <= q <= 64, klen <= 2048 (got q=%d klen=%d D=%d)", q, klen, D);
@@ -391,8 +501,9 @@ extern "C" int db1_relattn_decode_ring_fwd(const void* qkv_new, const void* u, c
     a.qkv = (const bf16_t*)qkv_new; a.u = (const bf16_t*)u; a.vb = (const bf16_t*)vb; a.ring = (bf16_t*)kv_ring; a.state = ring_state; a.R = (const bf16_t*)R;
     a.out = (bf16_t*)out; a.B = B; a.q = q; a.klen = klen; a.mlen = mlen; a.H = H; a.shift = shift; a.nd = nd; a.cap = cap; a.scale = scale;
     const bool split = q <= 16;
+    a.tickets = (B * H <= 2048) ? (unsigned*)tickets : nullptr;   // (the ticket buffer of db1_linear_decode_tickets_bytes)
     const int nchunk = (klen + DECR_KC - 1) / DECR_KC;
-    a.nunit = split ? nchunk * 4 : nchunk;
+    a.nunit = nchunk;   // (q <= 16: the four waves of a workgroup are merged inside it)
     DB1_NEED_WS(ws, ws_bytes, db1_relattn_decode_ring_workspace_bytes(B, q, klen, H), "relattn_decode_ring");
     a.part = (float*)ws;
     hipStream_t st = (hipStream_t)stream;
@@ -400,8 +511,10 @@ extern "C" int db1_relattn_decode_ring_fwd(const void* qkv_new, const void* u, c
         relattn_decode_ring_kernel<true><<<dim3((unsigned)nchunk, (unsigned)H, (unsigned)B), 256, 4 * DEC_WAVE_LDS, st>>>(a);
     } else relattn_decode_ring_kernel<false><<<dim3((unsigned)nchunk, (unsigned)H, (unsigned)B), 256, 4 * DEC_WAVE_LDS, st>>>(a);
     DB1_CHECK_LAUNCH("relattn_decode_ring");
-    relattn_decode_merge2_kernel<<<dim3((unsigned)q, (unsigned)H, (unsigned)B), 128, 0, st>>>(a.part, a.out, q, H, a.nunit);
-    DB1_CHECK_LAUNCH("relattn_decode_merge2");
+    if (!(split && a.tickets)) {
+        relattn_decode_merge2_kernel<<<dim3((unsigned)q, (unsigned)H, (unsigned)B), 128, 0, st>>>(a.part, a.out, q, H, a.nunit);
+        DB1_CHECK_LAUNCH("relattn_decode_merge2");
+    }
     return DB1_OK;
 }
 

@@ -77,6 +77,10 @@ class ParamArena:
             ops.cast(self.master, self.work)
 
 
+class _PendingLN(SimpleNamespace):
+    """a layer output whose closing residual LayerNorm has not been applied yet: LN(alpha * res + y) * gamma + beta (inference path)"""
+
+
 class _Ctx:
     pass
 
@@ -167,6 +171,8 @@ class TransformerXL(nn.Module):
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
         self._conv_ops = {}              # (weight name, weight version) -> tap-major GEMM operand
         self.use_decode = True           # inference with memory: K/V-cached path + fused decode attention when the shape allows
+        self.use_decode_fused = True     # ... and, for <= 64 new tokens, linear maps that finish with GEGLU / the residual LayerNorm (post-LN)
+        self.use_decode_ln_prologue = True   # ... <= 16 tokens: the residual LayerNorms ride on the way IN to the next linear map
         self._wversion = 0               # bumped whenever the weights change (invalidates the inference caches)
         self._dec_state = None           # K/V cache of the memory returned by the last forward (see _decode_begin)
         self._dec_R = None               # (version, [R_i = r_net_i(sinusoid(dist)) for dist < mem_len + 64])
@@ -768,6 +774,18 @@ class TransformerXL(nn.Module):
                 kv.append(qkv.view(B, mlen, 3, H, D)[:, :, 1:3].contiguous())
         return SimpleNamespace(kv=kv, R=self._decode_R(), new_kv=[])
 
+    def _decode_fused_ok(self, T, keep, dstep):
+        d, dff = self.d_model, self.d_ff
+        return (self.use_decode_fused and not keep and dstep is None and self.compute_dtype == torch.bfloat16 and self.activation_fn == "geglu" and
+                self.W("h.0.pos_ff.layer_norm.weight").dtype == self.W("h.0.pos_ff.layer_norm.bias").dtype and
+                ops.linear_decode_supported(T, d, d, False, True) and ops.linear_decode_supported(T, dff, d, True, False) and
+                ops.linear_decode_supported(T, d, dff, False, True))
+
+    def _decode_ln_prologue_ok(self, T):
+        d, dff = self.d_model, self.d_ff
+        return (self.use_decode_ln_prologue and ops.linear_decode_supported(T, 3 * d, d, False, False, True) and
+                ops.linear_decode_supported(T, dff, d, True, False, True))
+
     def _attention_decode(self, qkv, i, B, L, mlen, shift, dec):
         H, D = self.n_head, self.d_head
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
@@ -842,7 +860,7 @@ class TransformerXL(nn.Module):
         return dqkv, dR
 
     # ------------------------------------------------------------------ one decoder layer (post-LN; transformer_xl.py:112-353)
-    def _layer_fwd(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool, dec=None, dstep=None):
+    def _layer_fwd(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool, dec=None, dstep=None, pend=None):
         d, di, dff = self.d_model, self.d_inner, self.d_ff
         a = 1.0 if self.deepnorm_alpha is None else self.deepnorm_alpha
         p = f"h.{i}."
@@ -850,7 +868,10 @@ class TransformerXL(nn.Module):
         T = B * L
         if dec is not None:  # K/V-cached inference: only the new tokens are projected (identical maths: qkv_net has no bias)
             qkv = self._new(T, 3 * d)
-            ops.gemm(x, self.W(p + "dec_attn.qkv_net.weight").t(), qkv)
+            if pend is not None:   # the previous layer left its closing LayerNorm to this projection, which also stores the rows to x
+                ops.linear_decode(pend.y, self.W(p + "dec_attn.qkv_net.weight"), None, qkv, pre=(pend.res, pend.alpha, pend.gamma, pend.beta, pend.eps, x))
+            else:
+                ops.gemm(x, self.W(p + "dec_attn.qkv_net.weight").t(), qkv)
             av = self._attention_decode(qkv, i, B, L, mlen, shift, dec)
         else:
             if mem is not None:
@@ -873,6 +894,26 @@ class TransformerXL(nn.Module):
             R = self._new(R_in.shape[0], d)
             ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
             av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c, quv=quv)
+        if dec is not None and self._decode_fused_ok(T, keep, dstep):
+            # few new tokens: every launch is latency, so the linear maps do the layer's small follow-up work themselves (db1_linear_decode):
+            # GEGLU in the epilogue, and the residual LayerNorms either on the way IN to the next linear map (<= 16 tokens: no launch, no
+            # hand-off between workgroups; the layer's own closing LayerNorm is left to the next layer's qkv projection) or by the last
+            # workgroup on the way out.  9 launches per layer -> 5.
+            eps = self.layer_norm_epsilon
+            g1, b1 = self.W(p + "dec_attn.layer_norm.weight"), self.W(p + "dec_attn.layer_norm.bias")
+            g2, b2 = self.W(p + "pos_ff.layer_norm.weight"), self.W(p + "pos_ff.layer_norm.bias")
+            o, h1, act, f = self._new(T, d), self._new(T, d), self._new(T, dff), self._new(T, d)
+            if self._decode_ln_prologue_ok(T):
+                ops.linear_decode(av.view(T, d), self.W(p + "dec_attn.o_net.weight"), None, o)
+                ops.linear_decode(o, self.W(p + "pos_ff.CoreNet.0.weight"), self.W(p + "pos_ff.CoreNet.0.bias"), act, geglu=True,
+                                  pre=(x, a, g1, b1, eps, h1))
+                ops.linear_decode(act, self.W(p + "pos_ff.CoreNet.2.weight"), self.W(p + "pos_ff.CoreNet.2.bias"), f)
+                return _PendingLN(res=h1, y=f, alpha=a, gamma=g2, beta=b2, eps=eps), None
+            ops.linear_decode(av.view(T, d), self.W(p + "dec_attn.o_net.weight"), None, o, ln=(x, a, g1, b1, eps, h1))
+            ops.linear_decode(h1, self.W(p + "pos_ff.CoreNet.0.weight"), self.W(p + "pos_ff.CoreNet.0.bias"), act, geglu=True)
+            out = self._new(T, d)
+            ops.linear_decode(act, self.W(p + "pos_ff.CoreNet.2.weight"), self.W(p + "pos_ff.CoreNet.2.bias"), f, ln=(h1, a, g2, b2, eps, out))
+            return out, None
         o = self._new(T, d)
         ops.gemm(av.view(T, d), self.W(p + "dec_attn.o_net.weight").t(), o)
         h1 = self._new(T, d)
@@ -1085,10 +1126,17 @@ class TransformerXL(nn.Module):
         x = h.view(B * L, d)
         hids, lcs = [], []
         for i in range(self.n_layer):
+            kw = {}
+            if isinstance(x, _PendingLN):   # (inference, <= 16 new tokens) this layer's qkv projection normalises its input rows and stores them to x
+                kw["pend"], x = x, self._new(B * L, d)
             hids.append(x)
             layer_fwd = self._layer_fwd_prelnorm if self.pre_lnorm else self._layer_fwd
-            x, c = layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep, dec, dstep)
+            x, c = layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep, dec, dstep, **kw)
             lcs.append(c)
+        if isinstance(x, _PendingLN):
+            pend, x = x, self._new(B * L, d)
+            ops.layernorm_residual_fwd(pend.res, pend.y, pend.alpha, pend.gamma, pend.beta, x, None, self._new(B * L, dtype=torch.float32),
+                                       self._new(B * L, dtype=torch.float32), pend.eps)
         Wout = self.arena.view(self.arena.work, "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight",
                                full=True).view(self.vocab_pad, d)
         T = B * L

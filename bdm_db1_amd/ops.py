@@ -412,12 +412,54 @@ def relattn_decode_fwd(qu, qv, k, v, R, out, B, q, klen, mlen, H, D, shift, scal
              B, q, klen, mlen, H, D, shift, float(scale), ws, wsn, stream())
 
 
-def relattn_decode_ring_fwd(qkv_new, u, vb, kv_ring, state, R, out, B, q, mlen, H, D, shift, scale):
+_tickets = {}
+
+
+def decode_tickets(device) -> torch.Tensor:
+    """the ticket counters of the fused inference launches (db1_linear_decode_tickets_bytes): zero once, every launch leaves them zero.
+    One buffer per device: the inference path of a device runs on one stream at a time."""
+    t = _tickets.get(device)
+    if t is None:
+        t = torch.zeros(int(lib.load().db1_linear_decode_tickets_bytes()) // 4, dtype=torch.int32, device=device)
+        _tickets[device] = t
+    return t
+
+
+def relattn_decode_ring_fwd(qkv_new, u, vb, kv_ring, state, R, out, B, q, mlen, H, D, shift, scale, fused_merge=True):
     """attention of q new tokens over a ring of cached K / V (db1_relattn_decode_ring_fwd): kv_ring [B, cap, 2, H, D], state int32[1]"""
     cap = kv_ring.shape[1]
     ws, wsn = _ws("db1_relattn_decode_ring_workspace_bytes", (B, q, mlen + q, H), out.device)
     lib.call("db1_relattn_decode_ring_fwd", P(qkv_new), P(u), P(vb), P(kv_ring), P(state), cap, P(R), R.shape[0], P(out), B, q, mlen, H, D, shift,
-             float(scale), ws, wsn, stream())
+             float(scale), ws, wsn, P(decode_tickets(out.device)) if fused_merge else _vp(0), stream())
+
+
+def linear_decode_supported(M, N, K, geglu=False, ln=False, pre=False) -> bool:
+    return bool(lib.load().db1_linear_decode_supported(int(M), int(N), int(K), int(geglu), int(bool(ln)) | (2 if pre else 0)))
+
+
+def linear_decode(x, W, bias, y, geglu=False, ln=None, pre=None):
+    """y = x W^T + bias for M <= 64 rows (bf16), optionally through GEGLU (W [2N, K]); inside the same launch (db1_linear_decode)
+    pre = (res, alpha, gamma, beta, eps, out): the input rows are x_eff = LayerNorm(alpha * res + x) * gamma + beta, also stored to out;
+    ln  = (res, alpha, gamma, beta, eps, out): out = LayerNorm(alpha * res + y) * gamma + beta"""
+    M, K = x.shape
+    N = y.shape[1]
+    assert x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and W.is_contiguous() and W.shape == ((2 * N if geglu else N), K)
+    assert x.stride(1) == 1 and y.stride(1) == 1
+    ws, wsn = _ws("db1_linear_decode_workspace_bytes", (M, N, K, int(geglu)), y.device)
+    dtp = 0
+
+    def pack(t):
+        nonlocal dtp
+        if t is None:
+            return (_vp(0), 0, 1.0, _vp(0), _vp(0), 0.0, _vp(0), 0)
+        res, alpha, gamma, beta, eps, out = t
+        assert res.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and gamma.dtype == beta.dtype and res.stride(1) == 1 and out.stride(1) == 1
+        assert dtp in (0, dt_code(gamma.dtype) + 100)
+        dtp = dt_code(gamma.dtype) + 100
+        return (P(res), res.stride(0), float(alpha), P(gamma), P(beta), float(eps), P(out), out.stride(0))
+    a_pre, a_ln = pack(pre), pack(ln)
+    lib.call("db1_linear_decode", P(x), x.stride(0), P(W), P(bias), dt_code(bias.dtype) if bias is not None else 0, P(y), y.stride(0), M, N, K, int(geglu),
+             *a_pre, *a_ln, max(dtp - 100, 0), P(decode_tickets(y.device)), ws, wsn, stream())
 
 
 def ring_advance(state, q, cap):

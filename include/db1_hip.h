@@ -237,8 +237,33 @@ int db1_relattn_decode_fwd(const void* qu, const void* qv, const void* k, const 
 int64_t db1_relattn_decode_ring_workspace_bytes(int B, int q, int klen, int H);
 int db1_relattn_decode_ring_fwd(const void* qkv_new, const void* u, const void* vb, void* kv_ring, const int* ring_state, int cap, const void* R,
                                 int nd, void* out, int B, int q, int mlen, int H, int D, int shift, float scale, void* ws, int64_t ws_bytes,
-                                void* stream);
+                                void* tickets, void* stream);
 int db1_ring_advance(int* state, int q, int cap, void* stream);
+/* `tickets` (optional): db1_linear_decode_tickets_bytes() bytes, ZERO before the first launch and left zero by every launch that uses them.
+ * With it (and q <= 16) the key chunk that finishes last for a (batch, head) merges the partial results inside the attention launch. */
+
+/* ------------------------------------------------------------------ the inference layer's linear maps (M <= 64 new tokens), fused
+ * y[M, N] = x[M, K] . W^T + bias (bf16, W K-major like nn.Linear.weight, leading dimension K) as a stream over W, finishing the layer's
+ * small follow-up work inside the same launch:
+ *   geglu != 0: W is [2 N, K] (value rows, then gate rows), bias [2 N]; y = (x W_v^T + b_v) * gelu_erf(x W_g^T + b_g), both halves rounded
+ *               to bf16 first like the reference's z tensor (transformer_xl.py:262-269 with activations.py:19-32);
+ *   pre_out != NULL (M <= 16, K <= 2048, K % 256 == 0): the INPUT rows are normalised on the way in, x_eff = LayerNorm(pre_alpha * pre_res + x)
+ *               * pre_gamma + pre_beta (two passes in fp32 over the sum rounded to bf16, like db1_layernorm_residual_fwd; the row sums are
+ *               grouped differently, so the bf16 result can differ from that launch in the last place), stored to pre_out [M, K] as well --
+ *               the residual LayerNorm that closes the PREVIOUS sub-layer costs no launch and no inter-workgroup hand-off;
+ *   ln_out != NULL: after the last column group has stored y, ln_out[M, N] = LayerNorm(alpha * res + y) * gamma + beta (N = 512, 1024 or
+ *               2048; the arithmetic of db1_layernorm_residual_fwd on the stored bf16 y: equal results) -- for M > 16.
+ * K is split over workgroups when N alone gives too few of them; the partial tiles are added in split order by the last arrival
+ * (deterministic).  `tickets`: db1_linear_decode_tickets_bytes() bytes, zero before the first launch, left zero.
+ * db1_linear_decode_supported(..., ln): bit 0 = with ln_out, bit 1 = with pre_out. */
+int64_t db1_linear_decode_tickets_bytes(void);
+int64_t db1_linear_decode_workspace_bytes(int M, int N, int K, int geglu);
+int db1_linear_decode_supported(int M, int N, int K, int geglu, int ln);
+int db1_linear_decode(const void* x, int64_t ldx, const void* w, const void* bias, int dtBias, void* y, int64_t ldy, int M, int N, int K,
+                      int geglu, const void* pre_res, int64_t ld_pre_res, float pre_alpha, const void* pre_gamma, const void* pre_beta,
+                      float pre_eps, void* pre_out, int64_t ld_pre_out, const void* res, int64_t ld_res, float alpha, const void* gamma,
+                      const void* beta, float eps, void* ln_out, int64_t ld_out, int dtParam, void* tickets, void* ws, int64_t ws_bytes,
+                      void* stream);
 
 /* ------------------------------------------------------------------ relative-position attention, materialised path
  * (fp32 parity gate, any head size).  Buffers S,T are float32 in [H][B][Lq][*] layout.

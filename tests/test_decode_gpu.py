@@ -183,3 +183,111 @@ def test_graphed_ring_steps_share_a_memory():
             err = np.abs(got - eager[t]).max() / np.abs(eager[t]).max()
             assert err < 1e-2, f"pass {rep} call {t}: rel err {err:.3e}"
         obs.reset_memory()
+
+
+@pytest.mark.parametrize("M", [1, 5, 16, 22, 64])
+def test_linear_decode_equals_the_unfused_launches(M):
+    """db1_linear_decode at the DB1-1.3B layer shapes: the attention output projection + residual LayerNorm, the first feed-forward map through
+    GEGLU, the second one (split over K) + residual LayerNorm -- against db1_gemm / db1_ffn_act_fwd / db1_layernorm_residual_fwd.
+    The unsplit GEGLU launch is bit-equal; the ones split over K add their partial tiles in a fixed order (equal from run to run) and differ from
+    the single accumulation chain by fp32 rounding only; the LayerNorm tail equals the LayerNorm launch on the same y.  The ticket counters are zero again after every launch."""
+    from bdm_db1_amd import ops
+    d, dff, eps, alpha = 2048, 4096, 1e-5, 0.81
+    g = torch.Generator(device=DEV).manual_seed(M)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, device=DEV, generator=g) * sc).to(torch.bfloat16)
+    x, res = rnd(M, d), rnd(M, d)
+    Wo, W1, b1, W2, b2 = rnd(d, d, sc=0.03), rnd(2 * dff, d, sc=0.03), rnd(2 * dff, sc=0.5), rnd(d, dff, sc=0.03), rnd(d, sc=0.5)
+    gam, bet = rnd(d) + 1, rnd(d, sc=0.1)
+    new = lambda *s: torch.empty(*s, device=DEV, dtype=torch.bfloat16)
+    f32 = lambda *s: torch.empty(*s, device=DEV, dtype=torch.float32)
+
+    def unfused_ln(xin, W, bias, r):
+        y, out = new(M, W.shape[0]), new(M, W.shape[0])
+        ops.gemm(xin, W.t(), y, bias=bias)
+        ops.layernorm_residual_fwd(r, y, alpha, gam, bet, out, None, f32(M), f32(M), eps)
+        return y, out
+    def close(got, ref, what):
+        err = (got.float() - ref.float()).abs().max().item() / ref.float().abs().max().item()
+        assert err < 1e-2, f"{what}: rel err {err:.3e}"
+    # 1. o_net + LayerNorm (K = 2048 split over two workgroups per column group)
+    y_ref, h_ref = unfused_ln(x, Wo, None, res)
+    y, h = new(M, d), new(M, d)
+    ops.linear_decode(x, Wo, None, y, ln=(res, alpha, gam, bet, eps, h))
+    close(y, y_ref, "o_net"), close(h, h_ref, "o_net LayerNorm")
+    h_of_y = new(M, d)
+    ops.layernorm_residual_fwd(res, y, alpha, gam, bet, h_of_y, None, f32(M), f32(M), eps)
+    assert torch.equal(h, h_of_y)     # the LayerNorm tail is the LayerNorm launch's arithmetic on the y this launch stored
+    # 2. CoreNet.0 through GEGLU
+    z, a_ref = new(M, 2 * dff), new(M, dff)
+    ops.gemm(x, W1.t(), z, bias=b1)
+    ops.ffn_act_fwd(z, a_ref, "geglu")
+    act = new(M, dff)
+    ops.linear_decode(x, W1, b1, act, geglu=True)
+    assert torch.equal(act, a_ref)
+    # 3. CoreNet.2 (K = 4096: two workgroups per column group) + LayerNorm
+    f_ref, o_ref = unfused_ln(a_ref, W2, b2, res)
+    f, o = new(M, d), new(M, d)
+    ops.linear_decode(act, W2, b2, f, ln=(res, alpha, gam, bet, eps, o))
+    f2, o2 = new(M, d), new(M, d)
+    ops.linear_decode(act, W2, b2, f2, ln=(res, alpha, gam, bet, eps, o2))
+    assert torch.equal(f, f2) and torch.equal(o, o2)
+    close(f, f_ref, "CoreNet.2"), close(o, o_ref, "CoreNet.2 LayerNorm")
+    assert int(ops.decode_tickets(x.device).abs().sum().item()) == 0
+    if M <= 16:
+        # 4. the LayerNorm on the way IN: qkv = LN(alpha * res + x) W^T, and GEGLU(LN(.) W_1^T + b_1); the normalised rows are stored as well
+        hn_ref = new(M, d)
+        ops.layernorm_residual_fwd(res, x, alpha, gam, bet, hn_ref, None, f32(M), f32(M), eps)
+        Wq = rnd(3 * d, d, sc=0.03)
+        q_ref, q, hn = new(M, 3 * d), new(M, 3 * d), new(M, d)
+        ops.gemm(hn_ref, Wq.t(), q_ref)
+        ops.linear_decode(x, Wq, None, q, pre=(res, alpha, gam, bet, eps, hn))
+        close(hn, hn_ref, "input LayerNorm rows"), close(q, q_ref, "qkv after the input LayerNorm")
+        assert (hn.float() - hn_ref.float()).abs().max().item() <= 2.0 ** -6 * hn_ref.float().abs().max().item()   # a bf16 last place at most
+        q2 = new(M, 3 * d)
+        ops.gemm(hn, Wq.t(), q2)
+        assert torch.equal(q, q2)           # the projection used exactly the rows it stored
+        ops.ffn_act_fwd(z.copy_(torch.addmm(b1.float(), hn.float(), W1.float().t()).to(torch.bfloat16)), a_ref, "geglu")
+        hn2 = new(M, d)
+        ops.linear_decode(x, W1, b1, act, geglu=True, pre=(res, alpha, gam, bet, eps, hn2))
+        assert torch.equal(hn2, hn)
+        close(act, a_ref, "GEGLU after the input LayerNorm")
+
+
+def test_fused_inference_layer_equals_the_separate_launches():
+    """the model's inference path with the fused linear maps (use_decode_fused) against the same path with separate activation / LayerNorm
+    launches, over a ring memory: 1-token and multi-token calls, d_model = 512 (LayerNorm rows of one wave), with the residual LayerNorms on
+    the way in to the next linear map (<= 16 tokens) and on the way out, eager and as a graph"""
+    from bdm_db1_amd import GraphedRingStep, RingMemory, TransformerXL, synth
+    from bdm_db1_amd.data import NLPTaskInput
+    cfg = synth.db1_config("tiny", n_embed=512, n_head=4, n_layer=2, n_position=64, mem_len=40, fp16=True)
+    torch.manual_seed(11)
+    model = TransformerXL(cfg, device=torch.device(DEV), compute_dtype=torch.bfloat16)
+    model.eval()
+    assert model.d_head == 128 and model._decode_fused_ok(1, False, None)
+    rng = np.random.default_rng(4)
+    calls = [torch.from_numpy(rng.integers(0, 32000, (2, q))).to(DEV) for q in (7, 1, 1, 22, 1, 30, 1, 1, 16, 1)]
+
+    def run(fused, prologue=True):
+        model.use_decode_fused, model.use_decode_ln_prologue = fused, prologue
+        mems, outs = RingMemory(model, 2), []
+        with torch.no_grad():
+            for ids in calls:
+                x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
+                logits, _, mems = model([x], compute_loss=False, mems=mems)
+                outs.append(logits.float().cpu().numpy())
+        return outs
+    ref = run(False)
+    for prologue in (True, False):
+        got = run(True, prologue)
+        for step, (a, b) in enumerate(zip(got, ref)):
+            err = np.abs(a - b).max() / np.abs(b).max()
+            assert err < 1e-2, f"call {step} (LayerNorm on the way {'in' if prologue else 'out'}): rel err {err:.3e}"
+    model.use_decode_fused = model.use_decode_ln_prologue = True
+    one = GraphedRingStep(model, batch_size=2, n_new=1)
+    ids = calls[1]
+    first = one(ids)[0].float().cpu().numpy()
+    mems = RingMemory(model, 2)
+    with torch.no_grad():
+        x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
+        eager = model([x], compute_loss=False, mems=mems)[0].float().cpu().numpy()
+    assert np.array_equal(first, eager)
