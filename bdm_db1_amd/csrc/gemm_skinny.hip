@@ -142,6 +142,8 @@ struct SkinnyFusedArgs {
     const bf16_t* pre_res; const void* pre_gamma; const void* pre_beta; bf16_t* pre_out;
     int64_t ld_pre_res, ld_pre_out;
     float pre_alpha, pre_eps;
+    // the input rows are the MERGE of the decode attention's per-chunk partial results (PRO == -1): part [B*H][nunit][64][D + 2], row m = b * q + i
+    const float* att_part; int att_nunit, att_q, att_H;
 };
 
 // Hand-off between workgroups inside a launch (per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed): the data goes out
@@ -226,6 +228,72 @@ __global__ __launch_bounds__(256) void gemm_skinny_fused_kernel(SkinnyFusedArgs 
     for (int t = 0; t < MT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
     constexpr int KB = MT == 1 ? 8 : (MT == 2 ? 4 : 2);
+    if constexpr (PRO < 0) {
+        // The input rows (M <= 2) are the merge of the decode attention's chunk partials
+        // (relattn_decode.hip: O, max, sum per 128-key chunk; rows m = b * q + i): thread t owns columns 8 t .. 8 t + 7 = head t / 16, and weights the <= 12 units
+        // in chunk order -- the arithmetic of relattn_decode_merge2_kernel, in the shadow of the W stream instead of at the end of the
+        // attention launch behind a ticket (drain + atomic + two dependent reads: ~3 us per layer).
+        static_assert(MT == 1, "attention-merge prologue: one 16-row tile");
+        constexpr int MR = -PRO, XLD = 2048 + 8, NU = 12, DD = 128;
+        __shared__ __attribute__((aligned(16))) bf16_t xs[MR][XLD];
+        const int tcol = (int)threadIdx.x * 8;
+        const bool tin = tcol < p.K;
+        const int hh = tin ? tcol / DD : 0, d0 = tin ? tcol % DD : 0;
+        float4 olo[MR][NU], ohi[MR][NU];
+        float2 ml[MR][NU];
+#pragma unroll
+        for (int m = 0; m < MR; m++) {
+            const int bq = m < p.M ? m : 0, bb = bq / p.att_q, qi = bq % p.att_q;
+            const float* src = p.att_part + ((((int64_t)bb * p.att_H + hh) * p.att_nunit) * 64 + qi) * (DD + 2);
+#pragma unroll
+            for (int c = 0; c < NU; c++) {
+                const float* u = src + (int64_t)(c < p.att_nunit ? c : p.att_nunit - 1) * 64 * (DD + 2);
+                ml[m][c] = *reinterpret_cast<const float2*>(u + DD);
+                const float2 a0 = *reinterpret_cast<const float2*>(u + d0), a1 = *reinterpret_cast<const float2*>(u + d0 + 2);
+                const float2 a2 = *reinterpret_cast<const float2*>(u + d0 + 4), a3 = *reinterpret_cast<const float2*>(u + d0 + 6);
+                olo[m][c] = make_float4(a0.x, a0.y, a1.x, a1.y); ohi[m][c] = make_float4(a2.x, a2.y, a3.x, a3.y);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8_t b0[KB], b1[KB];
+#pragma unroll
+        for (int u = 0; u < KB; u++) {
+            const int ks = ks0 + u < ks1 ? ks0 + u : ks1 - 1;
+            b0[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wrow + ks * 64));
+            b1[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wrow + ks * 64 + 8));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MR; m++) {
+            float mx = -1.0e30f;
+#pragma unroll
+            for (int c = 0; c < NU; c++) mx = fmaxf(mx, c < p.att_nunit ? ml[m][c].x : -1.0e30f);
+            float l = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NU; c++) {
+                const float lc = c < p.att_nunit ? ml[m][c].y : 0.f;
+                const float wt = lc > 0.f ? __expf(ml[m][c].x - mx) : 0.f;
+                l += lc * wt;
+                o[0] += olo[m][c].x * wt; o[1] += olo[m][c].y * wt; o[2] += olo[m][c].z * wt; o[3] += olo[m][c].w * wt;
+                o[4] += ohi[m][c].x * wt; o[5] += ohi[m][c].y * wt; o[6] += ohi[m][c].z * wt; o[7] += ohi[m][c].w * wt;
+            }
+            Vec16<bf16_t> ov;
+#pragma unroll
+            for (int j = 0; j < 8; j++) ov.v[j] = l > 0.f ? o[j] / l : 0.f;
+            if (tin) ov.store(&xs[m][tcol]);
+        }
+        __syncthreads();
+        const bf16_t* xl = &xs[r < p.M && r < MR ? r : 0][g * 16];
+#pragma unroll
+        for (int u = 0; u < KB; u++) {
+            const bool ok = ks0 + u < ks1;
+            const int ks = ok ? ks0 + u : ks1 - 1;
+            const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xl + ks * 64), a1 = *reinterpret_cast<const bf16x8_t*>(xl + ks * 64 + 8);
+            const bf16x8_t w0 = ok ? b0[u] : zero, w1 = ok ? b1[u] : zero;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a0, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a1, acc[0], 0, 0, 0);
+        }
+    } else
     if constexpr (PRO > 0) {
         // The input rows are normalised on the way in (<= 16 rows, S == 1, the wave's share of K is one batch of <= KB k-steps).  The
         // workgroup does it cooperatively -- thread t owns columns 8 t .. 8 t + 7 of every row -- and leaves the bf16 rows in LDS, from where
@@ -435,7 +503,7 @@ extern "C" int64_t db1_linear_decode_workspace_bytes(int M, int N, int K, int ge
 }
 extern "C" int db1_linear_decode_supported(int M, int N, int K, int geglu, int ln) {   // ln: 0 none, 1 LayerNorm of the output rows, 2 of the input rows
     if (M < 1 || M > 64 || K % 64 || N % 16 || N < 16) return 0;
-    if (N / (geglu ? 8 : 16) + 1 > DB1_SKINNY_TICKETS) return 0;
+    if (((ln & 1) || (!(ln & 2) && skinny_fused_split(M, N, K, geglu) > 1)) && N / (geglu ? 8 : 16) + 1 > DB1_SKINNY_TICKETS) return 0;   // (tickets in use)
     if ((ln & 1) && N != 2048 && N != 1024 && N != 512) return 0;
     if ((ln & 2) && (M > 16 || K % 256 || K > 2048)) return 0;
     return 1;
@@ -483,5 +551,30 @@ extern "C" int db1_linear_decode(const void* x, int64_t ldx, const void* w, cons
 #undef SKF_MT
 #undef SKF
     DB1_CHECK_LAUNCH("linear_decode");
+    return DB1_OK;
+}
+
+
+// y[M, N] = merge(attention partials)[M, H * 128] . W^T: the output projection of the inference layer fed directly by the per-chunk partial
+// results of db1_relattn_decode_ring_fwd (called with out == NULL; q new tokens per sequence, B * q <= 2 rows, <= 12 chunks:
+// 120 registers of partials per row and thread)
+extern "C" int db1_linear_decode_attn_supported(int B, int q, int H, int D, int nunit, int N) {
+    return (B >= 1 && q >= 1 && B * q <= 2 && D == 128 && H * D <= 2048 && (H * D) % 256 == 0 && nunit >= 1 && nunit <= 12 && N % 16 == 0 && N >= 16 &&
+            N / 16 + 1 <= DB1_SKINNY_TICKETS) ? 1 : 0;
+}
+extern "C" int db1_linear_decode_attn(const float* attn_part, int nunit, int B, int q, int H, int D, const void* w, void* y, int64_t ldy, int N, void* stream) {
+    if (!db1_linear_decode_attn_supported(B, q, H, D, nunit, N))
+        DB1_FAIL(DB1_ERR_UNSUPPORTED, "linear_decode_attn: B=%d q=%d H=%d D=%d chunks=%d N=%d (needs B q <= 2, d_head = 128, H D <= 2048, <= 12 chunks)", B, q, H, D, nunit, N);
+    if (!attn_part || !w || !y) DB1_FAIL(DB1_ERR_BAD_SHAPE, "linear_decode_attn: null operand");
+    if (!db1_aligned16(attn_part) || !db1_aligned16(w) || !db1_aligned16(y) || (ldy % 8)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "linear_decode_attn: alignment");
+    SkinnyFusedArgs a = {};
+    a.x = (const bf16_t*)w;   // (never read: the rows come from attn_part)
+    a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.bias = nullptr; a.M = B * q; a.N = N; a.K = H * D; a.ldx = 0; a.ldw = a.K; a.ldy = ldy; a.S = 1;
+    a.att_part = attn_part; a.att_nunit = nunit; a.att_q = q; a.att_H = H;
+    const dim3 grid((unsigned)(N / 16), 1u);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.M == 1) gemm_skinny_fused_kernel<float, float, 1, false, -1><<<grid, 256, 0, st>>>(a);
+    else gemm_skinny_fused_kernel<float, float, 1, false, -2><<<grid, 256, 0, st>>>(a);
+    DB1_CHECK_LAUNCH("linear_decode_attn");
     return DB1_OK;
 }

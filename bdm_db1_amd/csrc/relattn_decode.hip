@@ -192,8 +192,7 @@ struct DecodeRingArgs {
     int B, q, klen, mlen, H, shift, nd, nunit, cap;
     float scale;
 };
-__device__ __forceinline__ bf16x8_t dec_add_bias(const bf16_t* q, const bf16_t* bias) {
-    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(q), b = *reinterpret_cast<const bf16x8_t*>(bias);
+__device__ __forceinline__ bf16x8_t dec_add_bias(const bf16x8_t a, const bf16x8_t b) {
     union { unsigned u[4]; bf16x8_t v; } o;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -216,6 +215,18 @@ __global__ __launch_bounds__(256) void relattn_decode_ring_kernel(DecodeRingArgs
     const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int a = lane & 15, g = lane >> 4;
     const int HD = p.H * DEC_D;
+    char* Vs = smem + wave * DEC_WAVE_LDS;
+    float* Tw = reinterpret_cast<float*>(Vs + 32 * 256);
+    const int qi = i0 + a < p.q ? i0 + a : p.q - 1;  // rows beyond q repeat the last query (never stored)
+    const bf16_t* qrow = p.qkv + ((int64_t)b * p.q + qi) * 3 * HD + h * DEC_D + g * 8;
+    // (requested before the append so that they travel while the ring origin arrives and the new rows are copied)
+    bf16x8_t qraw[4], uraw[4], vraw[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        qraw[ks] = *reinterpret_cast<const bf16x8_t*>(qrow + ks * 32);
+        uraw[ks] = *reinterpret_cast<const bf16x8_t*>(p.u + h * DEC_D + g * 8 + ks * 32);
+        vraw[ks] = *reinterpret_cast<const bf16x8_t*>(p.vb + h * DEC_D + g * 8 + ks * 32);
+    }
     {   // append: the new keys / values of this chunk enter the ring (all 256 threads; 32 sixteen-byte pieces per row and head)
         const int start_ = p.state[0];
         const int ja = chunk * DECR_KC > p.mlen ? chunk * DECR_KC : p.mlen, jb = (chunk + 1) * DECR_KC < p.klen ? (chunk + 1) * DECR_KC : p.klen;
@@ -230,15 +241,11 @@ __global__ __launch_bounds__(256) void relattn_decode_ring_kernel(DecodeRingArgs
         }
     }
     if (i0 >= p.q) return;  // waves are independent: no workgroup barrier below
-    char* Vs = smem + wave * DEC_WAVE_LDS;
-    float* Tw = reinterpret_cast<float*>(Vs + 32 * 256);
-    const int qi = i0 + a < p.q ? i0 + a : p.q - 1;  // rows beyond q repeat the last query (never stored)
-    const bf16_t* qrow = p.qkv + ((int64_t)b * p.q + qi) * 3 * HD + h * DEC_D + g * 8;
     bf16x8_t fqu[4], fqv[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
-        fqu[ks] = dec_add_bias(qrow + ks * 32, p.u + h * DEC_D + g * 8 + ks * 32);
-        fqv[ks] = dec_add_bias(qrow + ks * 32, p.vb + h * DEC_D + g * 8 + ks * 32);
+        fqu[ks] = dec_add_bias(qraw[ks], uraw[ks]);
+        fqv[ks] = dec_add_bias(qraw[ks], vraw[ks]);
     }
     const int start = p.state[0];
     bf16_t* ring = p.ring + (int64_t)b * p.cap * 2 * HD + h * DEC_D;        // row r: K at r * 2 HD, V at r * 2 HD + HD
@@ -494,14 +501,15 @@ extern "C" int db1_relattn_decode_ring_fwd(const void* qkv_new, const void* u, c
     const int klen = mlen + q;
     if (!db1_relattn_decode_supported(B, q, klen, H, D, DB1_BF16) || klen > 64 * 32)
         DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_decode_ring: needs bf16, d_head = 128, 1 <= q <= 64, klen <= 2048 (got q=%d klen=%d D=%d)", q, klen, D);
+    if (!out && q > 16) DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_decode_ring: partial results only (out == NULL) needs q <= 16");
     if (cap < klen || nd < 1 || !R || !ring_state || !kv_ring || !u || !vb) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_decode_ring: ring capacity %d < klen %d, or null buffer", cap, klen);
-    if (!db1_aligned16(qkv_new) || !db1_aligned16(kv_ring) || !db1_aligned16(R) || !db1_aligned16(out) || !db1_aligned16(u) || !db1_aligned16(vb))
+    if (!db1_aligned16(qkv_new) || !db1_aligned16(kv_ring) || !db1_aligned16(R) || (out && !db1_aligned16(out)) || !db1_aligned16(u) || !db1_aligned16(vb))
         DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_decode_ring: operands must be 16-byte aligned");
     DecodeRingArgs a;
     a.qkv = (const bf16_t*)qkv_new; a.u = (const bf16_t*)u; a.vb = (const bf16_t*)vb; a.ring = (bf16_t*)kv_ring; a.state = ring_state; a.R = (const bf16_t*)R;
     a.out = (bf16_t*)out; a.B = B; a.q = q; a.klen = klen; a.mlen = mlen; a.H = H; a.shift = shift; a.nd = nd; a.cap = cap; a.scale = scale;
     const bool split = q <= 16;
-    a.tickets = (B * H <= 2048) ? (unsigned*)tickets : nullptr;   // (the ticket buffer of db1_linear_decode_tickets_bytes)
+    a.tickets = (B * H <= 2048 && out) ? (unsigned*)tickets : nullptr;   // (the ticket buffer of db1_linear_decode_tickets_bytes)
     const int nchunk = (klen + DECR_KC - 1) / DECR_KC;
     a.nunit = nchunk;   // (q <= 16: the four waves of a workgroup are merged inside it)
     DB1_NEED_WS(ws, ws_bytes, db1_relattn_decode_ring_workspace_bytes(B, q, klen, H), "relattn_decode_ring");
@@ -511,7 +519,7 @@ extern "C" int db1_relattn_decode_ring_fwd(const void* qkv_new, const void* u, c
         relattn_decode_ring_kernel<true><<<dim3((unsigned)nchunk, (unsigned)H, (unsigned)B), 256, 4 * DEC_WAVE_LDS, st>>>(a);
     } else relattn_decode_ring_kernel<false><<<dim3((unsigned)nchunk, (unsigned)H, (unsigned)B), 256, 4 * DEC_WAVE_LDS, st>>>(a);
     DB1_CHECK_LAUNCH("relattn_decode_ring");
-    if (!(split && a.tickets)) {
+    if (out && !(split && a.tickets)) {
         relattn_decode_merge2_kernel<<<dim3((unsigned)q, (unsigned)H, (unsigned)B), 128, 0, st>>>(a.part, a.out, q, H, a.nunit);
         DB1_CHECK_LAUNCH("relattn_decode_merge2");
     }

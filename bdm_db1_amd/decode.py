@@ -143,9 +143,11 @@ class GraphedRingStep:
         self.memory.reset()
 
     def __call__(self, ids: torch.Tensor):
-        """ids [batch, n_new] -> (logits [batch, n_new, vocab] (static buffer, overwritten by the next call), the RingMemory)"""
+        """ids [batch, n_new] (or None / ``self.ids`` itself: the tokens are already in the static input buffer) ->
+        (logits [batch, n_new, vocab] (static buffer, overwritten by the next call), the RingMemory)"""
         if self.model._wversion != self._version:
             raise RuntimeError("the weights changed after the graph was captured: build a new GraphedRingStep")
-        self.ids.copy_(ids)
+        if ids is not None and ids.data_ptr() != self.ids.data_ptr():   # (a sampler that writes the next token into ``self.ids`` skips this copy)
+            self.ids.copy_(ids)
         self.graph.replay()
         return self.logits, self.memory

@@ -173,6 +173,7 @@ class TransformerXL(nn.Module):
         self.use_decode = True           # inference with memory: K/V-cached path + fused decode attention when the shape allows
         self.use_decode_fused = True     # ... and, for <= 64 new tokens, linear maps that finish with GEGLU / the residual LayerNorm (post-LN)
         self.use_decode_ln_prologue = True   # ... <= 16 tokens: the residual LayerNorms ride on the way IN to the next linear map
+        self.use_decode_attn_partials = True   # ... <= 2 tokens (ring memory): the output projection merges the attention's chunk partials
         self._wversion = 0               # bumped whenever the weights change (invalidates the inference caches)
         self._dec_state = None           # K/V cache of the memory returned by the last forward (see _decode_begin)
         self._dec_R = None               # (version, [R_i = r_net_i(sinusoid(dist)) for dist < mem_len + 64])
@@ -790,6 +791,10 @@ class TransformerXL(nn.Module):
         H, D = self.n_head, self.d_head
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
         if getattr(dec, "ring", None) is not None:   # K / V of the memory in a ring, appended in place by the attention launch (decode.RingMemory)
+            if getattr(dec, "partials", False):       # one or two new tokens: the output projection merges the chunk partials itself
+                part = self._new(ops.relattn_decode_ring_part_numel(B, L, mlen + L, H), dtype=torch.float32)
+                ops.relattn_decode_ring_fwd(qkv, u, vb, dec.ring.kv[i], dec.ring.state, dec.R[i], None, B, L, mlen, H, D, shift, 1.0 / math.sqrt(D), part=part)
+                return part
             av = self._new(B, L, H, D)
             ops.relattn_decode_ring_fwd(qkv, u, vb, dec.ring.kv[i], dec.ring.state, dec.R[i], av, B, L, mlen, H, D, shift, 1.0 / math.sqrt(D))
             return av
@@ -904,7 +909,10 @@ class TransformerXL(nn.Module):
             g2, b2 = self.W(p + "pos_ff.layer_norm.weight"), self.W(p + "pos_ff.layer_norm.bias")
             o, h1, act, f = self._new(T, d), self._new(T, d), self._new(T, dff), self._new(T, d)
             if self._decode_ln_prologue_ok(T):
-                ops.linear_decode(av.view(T, d), self.W(p + "dec_attn.o_net.weight"), None, o)
+                if getattr(dec, "partials", False):
+                    ops.linear_decode_attn(av, mlen + L, B, L, self.n_head, self.d_head, self.W(p + "dec_attn.o_net.weight"), o)
+                else:
+                    ops.linear_decode(av.view(T, d), self.W(p + "dec_attn.o_net.weight"), None, o)
                 ops.linear_decode(o, self.W(p + "pos_ff.CoreNet.0.weight"), self.W(p + "pos_ff.CoreNet.0.bias"), act, geglu=True,
                                   pre=(x, a, g1, b1, eps, h1))
                 ops.linear_decode(act, self.W(p + "pos_ff.CoreNet.2.weight"), self.W(p + "pos_ff.CoreNet.2.bias"), f)
@@ -1118,6 +1126,8 @@ class TransformerXL(nn.Module):
             if not (self.use_decode and self.compute_dtype == torch.bfloat16 and ring.B == B and L <= 64 and mlen + L <= ring.cap):
                 raise ValueError("RingMemory needs the bf16 decode path, its own batch size and at most 64 new tokens per call")
             dec = SimpleNamespace(ring=ring, R=self._decode_R(), kv=None, new_kv=[])
+            dec.partials = (self.use_decode_attn_partials and not self.pre_lnorm and self._decode_fused_ok(B * L, keep, dstep) and
+                            self._decode_ln_prologue_ok(B * L) and ops.linear_decode_attn_supported(B, L, self.n_head, self.d_head, mlen + L, d))
         R_in = self._sinusoid(klen) if dec is None else None
         if dstep is not None and self.embd_pdrop > 0:   # the position table goes through the same nn.Dropout (:575); the cached table stays intact
             R_drop = torch.empty_like(R_in)
@@ -1133,10 +1143,14 @@ class TransformerXL(nn.Module):
             layer_fwd = self._layer_fwd_prelnorm if self.pre_lnorm else self._layer_fwd
             x, c = layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep, dec, dstep, **kw)
             lcs.append(c)
+        head_pend = None
         if isinstance(x, _PendingLN):
             pend, x = x, self._new(B * L, d)
-            ops.layernorm_residual_fwd(pend.res, pend.y, pend.alpha, pend.gamma, pend.beta, x, None, self._new(B * L, dtype=torch.float32),
-                                       self._new(B * L, dtype=torch.float32), pend.eps)
+            if not compute_loss and ops.linear_decode_supported(B * L, self.vocab_pad, d, False, False, True):
+                head_pend = pend      # the vocabulary projection normalises its input rows itself (and stores them to x)
+            else:
+                ops.layernorm_residual_fwd(pend.res, pend.y, pend.alpha, pend.gamma, pend.beta, x, None, self._new(B * L, dtype=torch.float32),
+                                           self._new(B * L, dtype=torch.float32), pend.eps)
         Wout = self.arena.view(self.arena.work, "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight",
                                full=True).view(self.vocab_pad, d)
         T = B * L
@@ -1166,7 +1180,10 @@ class TransformerXL(nn.Module):
             self._ctx = ctx
         else:
             logits_pad = self._new(T, self.vocab_pad)
-            ops.gemm(x, Wout.t(), logits_pad, useful_flops=2.0 * T * V * d)   # (the padded vocabulary columns are not counted as work)
+            if head_pend is not None:
+                ops.linear_decode(head_pend.y, Wout, None, logits_pad, pre=(head_pend.res, head_pend.alpha, head_pend.gamma, head_pend.beta, head_pend.eps, x))
+            else:
+                ops.gemm(x, Wout.t(), logits_pad, useful_flops=2.0 * T * V * d)   # (the padded vocabulary columns are not counted as work)
             lm_logits = logits_pad.view(B, L, self.vocab_pad)[:, :, :V]
             if compute_loss:
                 ops.masked_ce_fwd(logits_pad, lab, msk, lse, sums, V)

@@ -425,12 +425,30 @@ def decode_tickets(device) -> torch.Tensor:
     return t
 
 
-def relattn_decode_ring_fwd(qkv_new, u, vb, kv_ring, state, R, out, B, q, mlen, H, D, shift, scale, fused_merge=True):
-    """attention of q new tokens over a ring of cached K / V (db1_relattn_decode_ring_fwd): kv_ring [B, cap, 2, H, D], state int32[1]"""
+def relattn_decode_ring_fwd(qkv_new, u, vb, kv_ring, state, R, out, B, q, mlen, H, D, shift, scale, fused_merge=True, part=None):
+    """attention of q new tokens over a ring of cached K / V (db1_relattn_decode_ring_fwd): kv_ring [B, cap, 2, H, D], state int32[1].
+    out None + part (a float tensor of relattn_decode_ring_part_numel elements): the per-chunk partial results only (for linear_decode_attn)"""
     cap = kv_ring.shape[1]
-    ws, wsn = _ws("db1_relattn_decode_ring_workspace_bytes", (B, q, mlen + q, H), out.device)
+    if part is not None:
+        ws, wsn = P(part), part.numel() * 4
+    else:
+        ws, wsn = _ws("db1_relattn_decode_ring_workspace_bytes", (B, q, mlen + q, H), qkv_new.device)
     lib.call("db1_relattn_decode_ring_fwd", P(qkv_new), P(u), P(vb), P(kv_ring), P(state), cap, P(R), R.shape[0], P(out), B, q, mlen, H, D, shift,
-             float(scale), ws, wsn, P(decode_tickets(out.device)) if fused_merge else _vp(0), stream())
+             float(scale), ws, wsn, P(decode_tickets(qkv_new.device)) if (fused_merge and out is not None) else _vp(0), stream())
+
+
+def relattn_decode_ring_part_numel(B, q, klen, H) -> int:
+    return int(lib.load().db1_relattn_decode_ring_workspace_bytes(int(B), int(q), int(klen), int(H))) // 4
+
+
+def linear_decode_attn_supported(B, q, H, D, klen, N) -> bool:
+    return bool(lib.load().db1_linear_decode_attn_supported(int(B), int(q), int(H), int(D), (int(klen) + 127) // 128, int(N)))
+
+
+def linear_decode_attn(part, klen, B, q, H, D, W, y):
+    """y = merge(part) W^T (db1_linear_decode_attn): part from relattn_decode_ring_fwd(out=None, part=...)"""
+    assert W.dtype == torch.bfloat16 and W.is_contiguous() and y.dtype == torch.bfloat16 and y.stride(1) == 1 and W.shape == (y.shape[1], H * D)
+    lib.call("db1_linear_decode_attn", P(part), (int(klen) + 127) // 128, B, q, H, D, P(W), P(y), y.stride(0), y.shape[1], stream())
 
 
 def linear_decode_supported(M, N, K, geglu=False, ln=False, pre=False) -> bool:

@@ -240,7 +240,8 @@ int db1_relattn_decode_ring_fwd(const void* qkv_new, const void* u, const void* 
                                 void* tickets, void* stream);
 int db1_ring_advance(int* state, int q, int cap, void* stream);
 /* `tickets` (optional): db1_linear_decode_tickets_bytes() bytes, ZERO before the first launch and left zero by every launch that uses them.
- * With it (and q <= 16) the key chunk that finishes last for a (batch, head) merges the partial results inside the attention launch. */
+ * With it (and q <= 16) the key chunk that finishes last for a (batch, head) merges the partial results inside the attention launch.
+ * out == NULL (q <= 16): no merge at all, the per-chunk partial results stay in ws for db1_linear_decode_attn. */
 
 /* ------------------------------------------------------------------ the inference layer's linear maps (M <= 64 new tokens), fused
  * y[M, N] = x[M, K] . W^T + bias (bf16, W K-major like nn.Linear.weight, leading dimension K) as a stream over W, finishing the layer's
@@ -257,6 +258,11 @@ int db1_ring_advance(int* state, int q, int cap, void* stream);
  * (deterministic).  `tickets`: db1_linear_decode_tickets_bytes() bytes, zero before the first launch, left zero.
  * db1_linear_decode_supported(..., ln): bit 0 = with ln_out, bit 1 = with pre_out. */
 int64_t db1_linear_decode_tickets_bytes(void);
+/* ... and the attention output projection fed by the attention's per-chunk partial results: db1_relattn_decode_ring_fwd with out == NULL
+ * (q <= 16) leaves [B*H][chunks = ceil(klen / 128)][64][D + 2] floats (unnormalised output, maximum, sum per query) in ITS workspace; this
+ * launch merges them on the way in (the arithmetic of the attention's own merge) and multiplies by W [N, H D].  B q <= 2 rows, <= 12 chunks. */
+int db1_linear_decode_attn_supported(int B, int q, int H, int D, int nunit, int N);
+int db1_linear_decode_attn(const float* attn_part, int nunit, int B, int q, int H, int D, const void* w, void* y, int64_t ldy, int N, void* stream);
 int64_t db1_linear_decode_workspace_bytes(int M, int N, int K, int geglu);
 int db1_linear_decode_supported(int M, int N, int K, int geglu, int ln);
 int db1_linear_decode(const void* x, int64_t ldx, const void* w, const void* bias, int dtBias, void* y, int64_t ldy, int M, int N, int K,

@@ -277,12 +277,13 @@ def test_fused_inference_layer_equals_the_separate_launches():
                 outs.append(logits.float().cpu().numpy())
         return outs
     ref = run(False)
-    for prologue in (True, False):
-        got = run(True, prologue)
+    for prologue in (True, False, None):
+        model.use_decode_attn_partials = prologue is not None      # (None: LayerNorm on the way in, attention with its own merge)
+        got = run(True, prologue is not False)
         for step, (a, b) in enumerate(zip(got, ref)):
             err = np.abs(a - b).max() / np.abs(b).max()
             assert err < 1e-2, f"call {step} (LayerNorm on the way {'in' if prologue else 'out'}): rel err {err:.3e}"
-    model.use_decode_fused = model.use_decode_ln_prologue = True
+    model.use_decode_fused = model.use_decode_ln_prologue = model.use_decode_attn_partials = True
     one = GraphedRingStep(model, batch_size=2, n_new=1)
     ids = calls[1]
     first = one(ids)[0].float().cpu().numpy()
@@ -291,3 +292,35 @@ def test_fused_inference_layer_equals_the_separate_launches():
         x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
         eager = model([x], compute_loss=False, mems=mems)[0].float().cpu().numpy()
     assert np.array_equal(first, eager)
+
+
+@pytest.mark.parametrize("B,q,mlen", [(1, 1, 1024), (2, 1, 300), (1, 2, 1000), (1, 1, 0)])
+def test_output_projection_merges_the_attention_partials(B, q, mlen):
+    """db1_relattn_decode_ring_fwd with out == NULL + db1_linear_decode_attn (the output projection merges the per-chunk partial results on
+    its way in) equals the attention with its own merge (in-launch by the last chunk, and as a separate launch) followed by the plain projection"""
+    from bdm_db1_amd import ops
+    H, D, cap = 16, 128, 1024 + 64
+    d = H * D
+    g = torch.Generator(device=DEV).manual_seed(B * 100 + q * 10 + mlen)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, device=DEV, generator=g) * sc).to(torch.bfloat16)
+    qkv, u, vb = rnd(B, q, 3, H, D), rnd(H, D, sc=0.3), rnd(H, D, sc=0.3)
+    ring0, R, W = rnd(B, cap, 2, H, D), rnd(cap, d), rnd(d, d, sc=0.03)
+    state = torch.tensor([777], dtype=torch.int32, device=DEV)
+    scale, shift = 1.0 / math.sqrt(D), mlen + q
+    outs = []
+    for mode in ("in-launch", "separate", "partials"):
+        ring = ring0.clone()
+        o = torch.empty(B * q, d, device=DEV, dtype=torch.bfloat16)
+        if mode == "partials":
+            assert ops.linear_decode_attn_supported(B, q, H, D, mlen + q, d)
+            part = torch.empty(ops.relattn_decode_ring_part_numel(B, q, mlen + q, H), device=DEV, dtype=torch.float32)
+            ops.relattn_decode_ring_fwd(qkv, u, vb, ring, state, R, None, B, q, mlen, H, D, shift, scale, part=part)
+            ops.linear_decode_attn(part, mlen + q, B, q, H, D, W, o)
+        else:
+            av = torch.empty(B, q, H, D, device=DEV, dtype=torch.bfloat16)
+            ops.relattn_decode_ring_fwd(qkv, u, vb, ring, state, R, av, B, q, mlen, H, D, shift, scale, fused_merge=mode == "in-launch")
+            ops.linear_decode(av.view(B * q, d), W, None, o)
+        outs.append((o, ring))
+    for o, ring in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and torch.equal(ring, outs[0][1])
+    assert int(ops.decode_tickets(qkv.device).abs().sum().item()) == 0

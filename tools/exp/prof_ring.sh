@@ -13,3 +13,4 @@ for r in csv.DictReader(open(sys.argv[1])):
 for k, v in sorted(d.items()):
     v.sort(); print(k, len(v), "median %.1f min %.1f" % (v[len(v)//2], v[0]))
 P
+python $R/tools/exp/trace_tail.py $(find /tmp/pr -name '*kernel_trace.csv' | head -1) ${TAILN:-135} > $R/gpurun_out/ring_trace_tail.txt
