@@ -183,8 +183,9 @@ __global__ __launch_bounds__(128) void relattn_decode_merge_kernel(DecodeArgs p)
 // (start + mlen + i) % cap by the workgroups that visit them -- so a call appends in place instead of concatenating 8 MB per layer, and
 // `start` is a DEVICE scalar (advanced by db1_ring_advance after the last layer): the same captured graph serves every call.
 // q + u and q + v are formed here from qkv_new (rounded to bf16 like db1_relattn_add_head_bias does).
-// SPLIT (q <= 16): the four waves of a workgroup are the four 32-key steps of a 128-key chunk (one partial per wave);
-// otherwise a wave is one of the four 16-query tiles and walks the chunk's steps itself (one partial per tile and chunk).
+// SPLIT (what the host launches): a workgroup = one 16-query tile x one 128-key chunk, its four waves are the chunk's four 32-key steps,
+// merged through LDS into one partial per (tile, chunk).  (The other form -- a wave is one of four 16-query tiles and walks the chunk's
+// steps itself -- took 38.6 us per launch at q = 22 against 8.8 us at q = 1: four dependent rounds of loads per wave.)
 #define DECR_KC 128
 struct DecodeRingArgs {
     const bf16_t* qkv; const bf16_t* u; const bf16_t* vb; bf16_t* ring; const int* state; const bf16_t* R;
@@ -206,13 +207,18 @@ __device__ __forceinline__ void dec_st_agent(float* p, float a, float b) {   // 
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float dec_ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void dec_ld_agent2(const float* p, float& a, float& b) {   // 8 bytes, L1-bypassing (sc1)
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __uint_as_float((unsigned)v); b = __uint_as_float((unsigned)(v >> 32));
+}
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void relattn_decode_ring_kernel(DecodeRingArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i0 = SPLIT ? 0 : wave * 16;
-    const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // SPLIT: blockIdx.x = chunk * (number of 16-query tiles) + tile -- every workgroup is ONE query tile against ONE 128-key chunk
+    const int nqt = SPLIT ? (p.q + 15) / 16 : 1;
+    const int i0 = SPLIT ? ((int)blockIdx.x % nqt) * 16 : wave * 16;
+    const int chunk = SPLIT ? (int)blockIdx.x / nqt : (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int a = lane & 15, g = lane >> 4;
     const int HD = p.H * DEC_D;
     char* Vs = smem + wave * DEC_WAVE_LDS;
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) void relattn_decode_ring_kernel(DecodeRingArgs
         const int ja = chunk * DECR_KC > p.mlen ? chunk * DECR_KC : p.mlen, jb = (chunk + 1) * DECR_KC < p.klen ? (chunk + 1) * DECR_KC : p.klen;
         const bf16_t* nk = p.qkv + (int64_t)b * p.q * 3 * HD + HD + h * DEC_D;
         bf16_t* rg = p.ring + (int64_t)b * p.cap * 2 * HD + h * DEC_D;
-        for (int idx = threadIdx.x; idx < (jb - ja) * 32; idx += 256) {
+        for (int idx = threadIdx.x; idx < ((!SPLIT || i0 == 0) ? (jb - ja) * 32 : 0); idx += 256) {   // (one query tile of the chunk copies)
             const int j = ja + (idx >> 5), pc = idx & 31;          // piece 0..15: K, 16..31: V
             int r = start_ + j;
             r = r >= p.cap ? r - p.cap : r;
@@ -396,8 +402,8 @@ __global__ __launch_bounds__(256) void relattn_decode_ring_kernel(DecodeRingArgs
 #pragma unroll
             for (int j = 0; j < 4; j++) { o8[j] += lo[j] * wt; o8[4 + j] += hi[j] * wt; }
         }
-        if (qi < p.q) {
-            float* dst = p.part + ((((int64_t)b * p.H + h) * p.nunit + chunk) * 64 + qi) * (DEC_D + 2);
+        if (i0 + qi < p.q) {
+            float* dst = p.part + ((((int64_t)b * p.H + h) * p.nunit + chunk) * 64 + i0 + qi) * (DEC_D + 2);
             if (inlaunch) {
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) dec_st_agent(dst + dg + j, o8[j], o8[j + 1]);
@@ -415,45 +421,46 @@ __global__ __launch_bounds__(256) void relattn_decode_ring_kernel(DecodeRingArgs
     // Hand-off (per-XCD L2s are not coherent, L1s never refreshed): write-through 8-byte stores above, every wave drains them, one relaxed
     // agent-scope ticket per workgroup, and the merging workgroup reads the partials with L1-bypassing (sc1) loads.
     __shared__ unsigned ticket_s;
-    __shared__ float wgt[2][64];
-    __shared__ float lsum[2];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) ticket_s = __hip_atomic_fetch_add(p.tickets + b * p.H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned* tk = p.tickets + ((int64_t)b * p.H + h) * nqt + i0 / 16;
+    if (threadIdx.x == 0) ticket_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (ticket_s != gridDim.x - 1) return;
-    if (threadIdx.x == 0) __hip_atomic_store(p.tickets + b * p.H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int half = threadIdx.x >> 7, d = threadIdx.x & 127;
-    const int64_t cs = (int64_t)64 * (DEC_D + 2);
-    for (int it = 0; it < (p.q + 1) / 2; it++) {
-        const int qi2 = it * 2 + half;
-        const bool valid = qi2 < p.q;
-        const float* src = p.part + ((((int64_t)b * p.H + h) * p.nunit) * 64 + (valid ? qi2 : 0)) * (DEC_D + 2);
-        if (d < 64) {   // first wave of the half: nunit <= 64 units
-            const float m = d < p.nunit ? dec_ld_agent(src + d * cs + DEC_D) : -1.0e30f;
-            const float l = d < p.nunit ? dec_ld_agent(src + d * cs + DEC_D + 1) : 0.f;
-            float mx = m;
+    if (ticket_s != gridDim.x / nqt - 1) return;
+    if (threadIdx.x == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {   // thread = (query qi of the tile, 8 output columns): all units' pieces are requested at once (<= 16 chunks: klen <= 2048), weighted in
+        // chunk order -- the arithmetic of relattn_decode_merge2_kernel, one round trip instead of one per row pair
+        constexpr int NU = 16;
+        const int qi = threadIdx.x & 15, dg = (threadIdx.x >> 4) * 8;
+        const bool valid = i0 + qi < p.q;
+        const float* src = p.part + ((((int64_t)b * p.H + h) * p.nunit) * 64 + (valid ? i0 + qi : i0)) * (DEC_D + 2);
+        const int64_t cs = (int64_t)64 * (DEC_D + 2);
+        float mlm[NU], mll[NU], ov[NU][8];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            const float w = l > 0.f ? __expf(m - mx) : 0.f;
-            wgt[half][d] = w;
-            float ls = l * w;
+        for (int c = 0; c < NU; c++) {
+            const float* u = src + (c < p.nunit ? c : p.nunit - 1) * cs;
+            dec_ld_agent2(u + DEC_D, mlm[c], mll[c]);
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, 64);
-            if (d == 0) lsum[half] = ls;
+            for (int j = 0; j < 8; j += 2) dec_ld_agent2(u + dg + j, ov[c][j], ov[c][j + 1]);
         }
-        __syncthreads();
-        float o = 0.f;
-        for (int c0 = 0; c0 < p.nunit; c0 += 16) {   // 16 loads in flight (clamped index, zero weight beyond nunit); units in order: deterministic
-            float v[16];
+        float mx = -1.0e30f;
 #pragma unroll
-            for (int c = 0; c < 16; c++) v[c] = dec_ld_agent(src + (c0 + c < p.nunit ? c0 + c : p.nunit - 1) * cs + d);
+        for (int c = 0; c < NU; c++) mx = fmaxf(mx, c < p.nunit ? mlm[c] : -1.0e30f);
+        float l = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < 16; c++) o += v[c] * (c0 + c < p.nunit ? wgt[half][c0 + c] : 0.f);
+        for (int c = 0; c < NU; c++) {
+            const float lc = c < p.nunit ? mll[c] : 0.f;
+            const float wt = lc > 0.f ? __expf(mlm[c] - mx) : 0.f;
+            l += lc * wt;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] += ov[c][j] * wt;
         }
-        const float l = lsum[half];
-        if (valid) p.out[((int64_t)b * p.q + qi2) * p.H * DEC_D + h * DEC_D + d] = f2bf(l > 0.f ? o / l : 0.f);
-        __syncthreads();
+        if (valid) {
+            uint4 w;
+            w.x = f2bf_pk(l > 0.f ? o[0] / l : 0.f, l > 0.f ? o[1] / l : 0.f); w.y = f2bf_pk(l > 0.f ? o[2] / l : 0.f, l > 0.f ? o[3] / l : 0.f);
+            w.z = f2bf_pk(l > 0.f ? o[4] / l : 0.f, l > 0.f ? o[5] / l : 0.f); w.w = f2bf_pk(l > 0.f ? o[6] / l : 0.f, l > 0.f ? o[7] / l : 0.f);
+            *reinterpret_cast<uint4*>(p.out + ((int64_t)b * p.q + i0 + qi) * p.H * DEC_D + h * DEC_D + dg) = w;
+        }
     }
 }
 // one 128-thread block per (query, head, batch): the units' (m, l) first (independent loads, weights through LDS), then the weighted sum
@@ -501,23 +508,20 @@ extern "C" int db1_relattn_decode_ring_fwd(const void* qkv_new, const void* u, c
     const int klen = mlen + q;
     if (!db1_relattn_decode_supported(B, q, klen, H, D, DB1_BF16) || klen > 64 * 32)
         DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_decode_ring: needs bf16, d_head = 128, 1 <= q <= 64, klen <= 2048 (got q=%d klen=%d D=%d)", q, klen, D);
-    if (!out && q > 16) DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_decode_ring: partial results only (out == NULL) needs q <= 16");
     if (cap < klen || nd < 1 || !R || !ring_state || !kv_ring || !u || !vb) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_decode_ring: ring capacity %d < klen %d, or null buffer", cap, klen);
     if (!db1_aligned16(qkv_new) || !db1_aligned16(kv_ring) || !db1_aligned16(R) || (out && !db1_aligned16(out)) || !db1_aligned16(u) || !db1_aligned16(vb))
         DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_decode_ring: operands must be 16-byte aligned");
     DecodeRingArgs a;
     a.qkv = (const bf16_t*)qkv_new; a.u = (const bf16_t*)u; a.vb = (const bf16_t*)vb; a.ring = (bf16_t*)kv_ring; a.state = ring_state; a.R = (const bf16_t*)R;
     a.out = (bf16_t*)out; a.B = B; a.q = q; a.klen = klen; a.mlen = mlen; a.H = H; a.shift = shift; a.nd = nd; a.cap = cap; a.scale = scale;
-    const bool split = q <= 16;
-    a.tickets = (B * H <= 2048 && out) ? (unsigned*)tickets : nullptr;   // (the ticket buffer of db1_linear_decode_tickets_bytes)
-    const int nchunk = (klen + DECR_KC - 1) / DECR_KC;
-    a.nunit = nchunk;   // (q <= 16: the four waves of a workgroup are merged inside it)
+    const bool split = true;   // (one workgroup per (query tile, chunk) for every q: the tile-per-wave form walked a chunk's four steps in sequence)
+    const int nchunk = (klen + DECR_KC - 1) / DECR_KC, nqt = (q + 15) / 16;
+    a.tickets = ((int64_t)B * H * nqt <= 2048 && out) ? (unsigned*)tickets : nullptr;   // (the ticket buffer of db1_linear_decode_tickets_bytes)
+    a.nunit = nchunk;   // (the four waves of a workgroup are merged inside it)
     DB1_NEED_WS(ws, ws_bytes, db1_relattn_decode_ring_workspace_bytes(B, q, klen, H), "relattn_decode_ring");
     a.part = (float*)ws;
     hipStream_t st = (hipStream_t)stream;
-    if (split) {   // (every wave writes its unit, with l = 0 when it saw no visible key: the merge gives those weight 0)
-        relattn_decode_ring_kernel<true><<<dim3((unsigned)nchunk, (unsigned)H, (unsigned)B), 256, 4 * DEC_WAVE_LDS, st>>>(a);
-    } else relattn_decode_ring_kernel<false><<<dim3((unsigned)nchunk, (unsigned)H, (unsigned)B), 256, 4 * DEC_WAVE_LDS, st>>>(a);
+    relattn_decode_ring_kernel<true><<<dim3((unsigned)(nchunk * nqt), (unsigned)H, (unsigned)B), 256, 4 * DEC_WAVE_LDS, st>>>(a);
     DB1_CHECK_LAUNCH("relattn_decode_ring");
     if (out && !(split && a.tickets)) {
         relattn_decode_merge2_kernel<<<dim3((unsigned)q, (unsigned)H, (unsigned)B), 128, 0, st>>>(a.part, a.out, q, H, a.nunit);

@@ -349,12 +349,27 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
 // as 16 rows x 64 B = one ds_read_b128 + one 16-byte-aligned global_store_dwordx4 per lane.  (The direct form -- 4-byte stores at
 // 2-byte-aligned addresses, four per lane and block -- cost 330 us of this kernel's 1330 at B = 64.)  Distances above the diagonal
 // (d < 0) are not stored; entries of the window nobody wrote are the ring's initial zeros, which is what dT holds there anyway.
-#define DTR_PITCH 144                          // bytes per ring row: 64 bf16 + 16
+#define DTR_PITCH 192                          // bytes per ring row: 64 bf16 + 64 (144: the window read 2-way, the 2-byte writes up to 4-way conflicted -- 20.6 % of the LDS cycles)
 #define Q2_OFF_D (2 * W16_STAGES * 8192)
 #define Q2_LDS (Q2_OFF_D + W16_WAVES * 16 * DTR_PITCH)
 typedef __attribute__((address_space(3))) unsigned short* lds_u16_ptr;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((address_space(3))) const u32x4_t* lds_u128_ptr;
+// (the p~ stream in and the dT stream out are touched once: non-temporal, so that they do not push the K / V tiles -- shared by the eight
+//  query tiles of a (batch, head) -- out of the XCD's L2; DB1_Q2_NT=0 at build time restores plain accesses)
+#ifndef DB1_Q2_NT
+#define DB1_Q2_NT 1   /* bit 0: loads (-0.7 %), bit 1: stores (+14 %: non-temporal stores are slow here) */
+#endif
+#if DB1_Q2_NT & 1
+#define Q2_NT_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define Q2_NT_LOAD(ptr) (*(ptr))
+#endif
+#if DB1_Q2_NT & 2
+#define Q2_NT_STORE(v, ptr) __builtin_nontemporal_store(v, ptr)
+#else
+#define Q2_NT_STORE(v, ptr) (*(ptr) = (v))
+#endif
 __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q2_kernel(FlashArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -404,10 +419,10 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q2_kernel(FlashArgs 
     if (jb_lo + 1 <= jb_hi) w16_stage_kv(sg, 1, wave);
     bf16x8_t ptq[2];   // p~ of the current / next block (slot = position in the loop & 1), m likewise
     float mq[2];
-    ptq[0] = *reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + jb_lo * sv_step);
+    ptq[0] = Q2_NT_LOAD(reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + jb_lo * sv_step));
     mq[0] = p.mblk[mrow + (int64_t)jb_lo * L];
     if (jb_lo + 1 <= jb_hi) {
-        ptq[1] = *reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + (jb_lo + 1) * sv_step);
+        ptq[1] = Q2_NT_LOAD(reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + (jb_lo + 1) * sv_step));
         mq[1] = p.mblk[mrow + (int64_t)(jb_lo + 1) * L];
     }
     f32x4 acc_dq[8];
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q2_kernel(FlashArgs 
         const float m2 = mq[par];
         if (pf) {   // block jb+2: K / V tiles (two LDS-DMA pieces), then its p~ image and maxima into the slot just read
             w16_stage_kv(sg, (stg + 2) % W16_STAGES, wave);
-            ptq[par] = *reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + (jb + 2) * sv_step);
+            ptq[par] = Q2_NT_LOAD(reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + (jb + 2) * sv_step));
             mq[par] = p.mblk[mrow + (int64_t)(jb + 2) * L];
         }
         int cur_sure = 0;
@@ -463,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q2_kernel(FlashArgs 
                     }
                 const int w0 = iw - j0 - 16;   // window start (a multiple of 16)
                 const u32x4_t win = *(lds_u128_ptr)(size_t)(drrow + (((unsigned)(w0 + 8 * (lane & 3)) & 63u) * 2));
-                if (w0 + 8 * (lane & 3) >= 0) *reinterpret_cast<u32x4_t*>(dtp + w0) = win;
+                if (w0 + 8 * (lane & 3) >= 0) Q2_NT_STORE(win, reinterpret_cast<u32x4_t*>(dtp + w0));
             }
             cur_sure = 2;   // f, the dT window
         }

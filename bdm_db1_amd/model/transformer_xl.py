@@ -171,7 +171,7 @@ class TransformerXL(nn.Module):
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
         self._conv_ops = {}              # (weight name, weight version) -> tap-major GEMM operand
         self.use_decode = True           # inference with memory: K/V-cached path + fused decode attention when the shape allows
-        self.use_decode_fused = True     # ... and, for <= 64 new tokens, linear maps that finish with GEGLU / the residual LayerNorm (post-LN)
+        self.use_decode_fused = True     # ... and, for <= 64 new tokens, linear maps as W streams that finish with GEGLU (post-LN)
         self.use_decode_ln_prologue = True   # ... <= 16 tokens: the residual LayerNorms ride on the way IN to the next linear map
         self.use_decode_attn_partials = True   # ... <= 2 tokens (ring memory): the output projection merges the attention's chunk partials
         self._wversion = 0               # bumped whenever the weights change (invalidates the inference caches)
@@ -917,10 +917,15 @@ class TransformerXL(nn.Module):
                                   pre=(x, a, g1, b1, eps, h1))
                 ops.linear_decode(act, self.W(p + "pos_ff.CoreNet.2.weight"), self.W(p + "pos_ff.CoreNet.2.bias"), f)
                 return _PendingLN(res=h1, y=f, alpha=a, gamma=g2, beta=b2, eps=eps), None
-            ops.linear_decode(av.view(T, d), self.W(p + "dec_attn.o_net.weight"), None, o, ln=(x, a, g1, b1, eps, h1))
+            # (17 .. 64 tokens: the LayerNorms as their own launches -- finishing them inside the linear map by the last workgroup to arrive,
+            #  ln= of ops.linear_decode, measured slower inside a graph than the launch boundary it saves)
+            stat = lambda: self._new(T, dtype=torch.float32)
+            ops.linear_decode(av.view(T, d), self.W(p + "dec_attn.o_net.weight"), None, o)
+            ops.layernorm_residual_fwd(x, o, a, g1, b1, h1, None, stat(), stat(), eps)
             ops.linear_decode(h1, self.W(p + "pos_ff.CoreNet.0.weight"), self.W(p + "pos_ff.CoreNet.0.bias"), act, geglu=True)
             out = self._new(T, d)
-            ops.linear_decode(act, self.W(p + "pos_ff.CoreNet.2.weight"), self.W(p + "pos_ff.CoreNet.2.bias"), f, ln=(h1, a, g2, b2, eps, out))
+            ops.linear_decode(act, self.W(p + "pos_ff.CoreNet.2.weight"), self.W(p + "pos_ff.CoreNet.2.bias"), f)
+            ops.layernorm_residual_fwd(h1, f, a, g2, b2, out, None, stat(), stat(), eps)
             return out, None
         o = self._new(T, d)
         ops.gemm(av.view(T, d), self.W(p + "dec_attn.o_net.weight").t(), o)

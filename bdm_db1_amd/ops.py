@@ -425,9 +425,11 @@ def decode_tickets(device) -> torch.Tensor:
     return t
 
 
-def relattn_decode_ring_fwd(qkv_new, u, vb, kv_ring, state, R, out, B, q, mlen, H, D, shift, scale, fused_merge=True, part=None):
+def relattn_decode_ring_fwd(qkv_new, u, vb, kv_ring, state, R, out, B, q, mlen, H, D, shift, scale, fused_merge=False, part=None):
     """attention of q new tokens over a ring of cached K / V (db1_relattn_decode_ring_fwd): kv_ring [B, cap, 2, H, D], state int32[1].
-    out None + part (a float tensor of relattn_decode_ring_part_numel elements): the per-chunk partial results only (for linear_decode_attn)"""
+    out None + part (a float tensor of relattn_decode_ring_part_numel elements): the per-chunk partial results only (for linear_decode_attn).
+    fused_merge: the chunk that finishes last merges inside the launch (ticket hand-off) instead of a second launch -- measured SLOWER inside
+    a graph (q = 1: 13.1 vs 9.3 us, q = 22: 23.9 vs 13.2 us: the drain + ticket + dependent reads cost more than a launch boundary), so off"""
     cap = kv_ring.shape[1]
     if part is not None:
         ws, wsn = P(part), part.numel() * 4
