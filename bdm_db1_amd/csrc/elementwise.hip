@@ -295,10 +295,17 @@ extern "C" int db1_layernorm_residual_fwd(const void* x, const void* r, float al
     return DB1_OK;
 }
 
-static const int LN_BWD_RPB = 32;  // rows per block of the fused backward = rows per partial-sum slot
+// rows per block of the fused backward = rows per partial-sum slot: 32 for the benchmark's 65 536 rows (2048 blocks); fewer for the
+// reference's micro-batch of 4 sequences (4096 rows gave 128 blocks: half the CUs, 40 us for a 10 us stream) so that >= 512 blocks exist
+static int ln_bwd_rpb(int64_t rows) {
+    int rpb = 32;
+    while (rpb > 4 && (rows + rpb - 1) / rpb < 512) rpb >>= 1;
+    return rpb;
+}
 extern "C" int64_t db1_layernorm_residual_bwd_workspace_bytes(int64_t rows, int d, int dt) {
     if (dt != DB1_BF16 || !ln_reg_nv<bf16_t>(d)) return 0;  // the generic kernels accumulate the parameter gradients directly
-    return ((rows + LN_BWD_RPB - 1) / LN_BWD_RPB) * 2 * (int64_t)d * (int64_t)sizeof(float);
+    const int rpb = ln_bwd_rpb(rows);
+    return ((rows + rpb - 1) / rpb) * 2 * (int64_t)d * (int64_t)sizeof(float);
 }
 extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                                           void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc, int64_t rows, int d,
@@ -313,7 +320,7 @@ extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const v
     if (!db1_aligned16(dy) || !db1_aligned16(s) || !db1_aligned16(ds)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "layernorm bwd: alignment");
     hipStream_t st = (hipStream_t)stream;
     if (dt == DB1_BF16 && ln_reg_nv<bf16_t>(d)) {  // fused one-pass backward (ds + parameter partials)
-        const int nv = ln_reg_nv<bf16_t>(d), rpb = LN_BWD_RPB;
+        const int nv = ln_reg_nv<bf16_t>(d), rpb = ln_bwd_rpb(rows);
         const int nblocks = (int)((rows + rpb - 1) / rpb);
         const bool params = dgamma_acc && dbeta_acc;
         float* ws = nullptr;

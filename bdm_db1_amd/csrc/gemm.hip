@@ -293,7 +293,7 @@ static GemmPlan gemm_plan(const GemmShape& g, bool aligned, int64_t ws_bytes) {
         const int64_t wg = pp_shape ? (int64_t)(M / 256) * (N / 256) * batch : (int64_t)(M / 256) * (N / TBN) * batch;
         int S = 0;
         for (int cand = 8; cand >= 2; cand >>= 1)
-            if (wg * cand <= 288 && (K / TBK) % cand == 0 && (K / TBK) / cand >= 32) { S = cand; break; }
+            if (wg * cand <= 288 && (K / TBK) % cand == 0 && (K / TBK) / cand >= 16) { S = cand; break; }   // (16: micro-batches of 4 sequences, K = 4096)
         // half a wave of 256x256 tiles (ff2 dW: 128) in two slices: nothing at K = 16 384, but 1184 -> 978 us at K = 65 536 (the 256x128
         // kernel it would otherwise take runs at 930 TFLOP/s, the ping-pong kernel at 1120 incl. the reduce)
         const bool half_wave = pp_shape && fb == 1 && wg > 96 && wg <= 128 && S == 2 && (K / TBK) / S >= 256;

@@ -66,7 +66,7 @@ def flash(B=16, L=1024, H=16, D=128):
 def gemm(B=16, L=1024):
     T, d = B * L, 2048
     torch.manual_seed(0)
-    shapes = [("qkv  NT", T, 3 * d, d), ("ff1  NT", T, 4 * d, d), ("ff2  NT", T, d, 2 * d), ("head NT", T, 33280, d)]
+    shapes = [("qkv  NT", T, 3 * d, d), ("o    NT", T, d, d), ("ff1  NT", T, 4 * d, d), ("ff2  NT", T, d, 2 * d), ("head NT", T, 33280, d)]
     for name, M, N, K in shapes:
         x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
         w = (torch.randn(N, K, device=DEV) * 0.02).to(torch.bfloat16)
