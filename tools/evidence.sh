@@ -21,7 +21,13 @@ DB1_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --batch 16 --steps 3 
 BENCH_ARGS="--no-cpu-baseline" bash tools/prof_step.sh
 cp gpurun_out/step_stats.csv $E/${TAG}_kernel_stats_short.csv
 cp $(ls gpurun_out/prof_step/*kernel_stats.csv | head -1) $E/${TAG}_bench_b64_kernel_stats.csv
+# the reference's own batch geometry: micro-batch 4 x gradient accumulation 16, eager and with the micro-step as a hipGraph
+timeout 600 python bench.py --batch 4 --ga 16 --steps 4 --warmup 2 --no-cpu-baseline --no-decode > $E/${TAG}_bench_b4_ga16.json 2> $E/bench_b4.err </dev/null
+timeout 600 python bench.py --batch 4 --ga 16 --graph --steps 4 --warmup 2 --no-cpu-baseline --no-decode > $E/${TAG}_bench_b4_ga16_graph.json 2> $E/bench_b4g.err </dev/null
 if [ "$1" = "pmc" ]; then
+  # PMC of the attention kernels (separate passes, no trace domains): matrix pipe, LDS conflicts, L2 hit rate, wave states
+  bash tools/pmc_run.sh relattn_flash "flash 64" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" > /dev/null 2>&1
+  cat gpurun_out/pmc_1.txt gpurun_out/pmc_2.txt gpurun_out/pmc_3.txt gpurun_out/pmc_4.txt > $E/${TAG}_pmc_flash_passes.txt 2>/dev/null
   timeout 1500 python tools/pmc_traffic.py $E/traffic > $E/traffic.log 2>&1 </dev/null
   cp $E/traffic/hbm_traffic_pmc.json $E/${TAG}_hbm_traffic_pmc.json 2>/dev/null
 fi
