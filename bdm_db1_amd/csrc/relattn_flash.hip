@@ -850,6 +850,174 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs
     store_acc_t16(acc_dv, 1.f, Ow, p.dv + (int64_t)b * p.dq_bs + (int64_t)kw * p.dq_rs + h * FA_D, p.dq_rs, lane);
 }
 
+// ======================================================================================= key side, 32 keys per wave (forward-stored p~)
+// relattn_flash_bwd_kv2_kernel<true> with a wave owning a whole 32-key block (two 16-key tiles) and a workgroup 256 keys: the A fragments
+// of a 32-query block -- dO^T and Qu^T through 32 transposing reads, the dO rows of dP through 8 ds_read_b128 -- are per wave, so they
+// now feed 48 MFMAs instead of 24 (the kernel is issue-bound: LDS reads were 44 of its ~130 instructions per wave-block).  A wave copies
+// the two images (query tiles 2 ib, 2 ib + 1) of ITS key block and reads both key halves' B fragments from them.  Needs L % 256 == 0.
+#define KV3_KEYS 256
+#define KV3_STAGES 4
+#define KV3_OFF_P 0                                   // [stage][8 key blocks][2 query tiles] images of 1 KiB
+#define KV3_OFF_QU (KV3_STAGES * 16384)
+#define KV3_OFF_DO (KV3_OFF_QU + KV3_STAGES * 8192)
+#define KV3_OFF_F (KV3_OFF_DO + KV3_STAGES * 8192)    // [stage][wave][64] floats: f [32 queries], delta [32 queries]
+#define KV3_LDS (KV3_OFF_F + KV3_STAGES * W16_WAVES * 256)
+__global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv3_kernel(FlashArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int kt, h, b;
+    if (!flash_wg_coords(p.L / KV3_KEYS, p.H, p.B, kt, h, b)) return;
+    const int H = p.H, L = p.L, HD = H * FA_D;
+    const int j0 = kt * KV3_KEYS, kw = j0 + 32 * wave;
+    const int a = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+    W16Lane ln;
+    w16_lane_init(ln, lds0, lds0, lane);   // the tr addresses of a [32][128] tile at LDS offset 0 (scratch addresses unused)
+    unsigned btr[2][2];   // [key half][k-slot group t]: queries kk(t, g) + (a >> 2), keys 16 half + 4 (a & 3) .. of this wave's key block
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int q = kk16(t, g) + (a >> 2), qtl = q >> 4, qa = q & 15;
+            const int tf = a & 1, gh = (a >> 1) & 1, gl = hf ^ tf;
+            const int c = (2 * gh + gl) * 16 + qa;
+            btr[hf][t] = lds0 + (wave * 2 + qtl) * 1024 + kv2_chunk_pos(c, qtl) * 16 + tf * 8;
+            W16_OPAQUE(btr[hf][t]);
+        }
+    const int ib_lo = j0 / FA_BK;
+    int ihi = j0 + KV3_KEYS - 1 + p.shift - 1;
+    if (ihi > L - 1) ihi = L - 1;
+    const int ib_hi = ihi / FA_BK;
+    const int srow = wave * 4 + (lane >> 4);
+    const int schunk = ((lane & 15) ^ swz_kv(srow)) << 3;
+    const bf16_t* quptr = p.qu + ((int64_t)b * L + ib_lo * FA_BK + srow) * HD + h * FA_D + schunk;
+    const bf16_t* doptr = p.dout + ((int64_t)b * L + ib_lo * FA_BK + srow) * HD + h * FA_D + schunk;
+    // this wave copies the images (key block j0 / 32 + wave, query tiles 2 ib and 2 ib + 1): adjacent in memory
+    const int64_t img = ((((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + wave) * (L / 16) + 2 * ib_lo) * 512;
+    const bf16_t* pptr0 = p.pt + img + kv2_chunk_pos(lane, 0) * 8;
+    const bf16_t* pptr1 = p.pt + img + 512 + kv2_chunk_pos(lane, 1) * 8;
+    const int64_t q_step = (int64_t)FA_BK * HD;
+    const float* fptr = lane < 32 ? p.fblk + (((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + wave) * L + ib_lo * FA_BK + lane
+                                  : p.delta + ((int64_t)b * H + h) * L + ib_lo * FA_BK + lane - 32;
+    unsigned fld[2];   // f of queries kk(t, g) .. + 3 (delta: + 128 bytes)
+#pragma unroll
+    for (int t = 0; t < 2; t++) { fld[t] = lds0 + KV3_OFF_F + wave * 256 + kk16(t, g) * 4; W16_OPAQUE(fld[t]); }
+    bf16x8_t fv[2][4];    // V of this lane's two keys (B operand of dP = dO.V^T)
+    {
+        const bf16_t* vg = p.v + (int64_t)b * p.kv_bs + h * FA_D;
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) fv[hf][ks] = *reinterpret_cast<const bf16x8_t*>(vg + (int64_t)(kw + 16 * hf + a) * p.kv_rs + ks * 32 + g * 8);
+    }
+    constexpr int NP = 5;   // requests per wave and block
+    auto stage = [&](int stg) __attribute__((always_inline)) {
+        const unsigned dstf = __builtin_amdgcn_readfirstlane(lds0 + KV3_OFF_F + stg * (W16_WAVES * 256) + wave * 256);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(fptr), "s"(dstf) : "memory");
+        fptr += FA_BK;
+        glds16(pptr0, lds0 + KV3_OFF_P + stg * 16384 + wave * 2048);
+        glds16(pptr1, lds0 + KV3_OFF_P + stg * 16384 + wave * 2048 + 1024);
+        glds16(quptr, lds0 + KV3_OFF_QU + stg * 8192 + wave * 1024);
+        glds16(doptr, lds0 + KV3_OFF_DO + stg * 8192 + wave * 1024);
+        pptr0 += 1024; pptr1 += 1024; quptr += q_step; doptr += q_step;   // the next 32 queries: two images further
+    };
+    stage(0);
+    if (ib_lo + 1 <= ib_hi) stage(1);
+    if (ib_lo + 2 <= ib_hi) stage(2);
+    f32x4 acc_dk[2][8], acc_dv[2][8];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+        for (int db = 0; db < 8; db++) { zero4(acc_dk[hf][db]); zero4(acc_dv[hf][db]); }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // (the V fragments; as a builtin so that hipcc's own bookkeeping sees them retired)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto block = [&](auto STG, int ib) __attribute__((always_inline)) {
+        constexpr int stg = decltype(STG)::value;
+        const int i0q = ib * FA_BK;
+        if (ib + 3 <= ib_hi) stage((stg + 3) % KV3_STAGES);
+        if (!(i0q + 31 < kw || i0q >= kw + 31 + p.shift)) {  // some (i, j) of this block pair is visible
+            bf16x8_t pb[2], sb[2];
+            // dP[query][key] = dO.V^T: the dO rows of a 16-query tile (A operand) are read once for both key tiles
+            f32x4 adp[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                bf16x8_t dor[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) dor[ks] = lds_ld128(ln.rowf[t][ks] + KV3_OFF_DO + stg * 8192);
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    zero4(adp[hf][t]);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) adp[hf][t] = MFMA16(dor[ks], fv[hf][ks], adp[hf][t]);
+                }
+            }
+            f32x4 f4[2], d4[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                f4[t] = *(lds_f32x4_ptr)(size_t)(fld[t] + stg * (W16_WAVES * 256));
+                d4[t] = *(lds_f32x4_ptr)(size_t)(fld[t] + stg * (W16_WAVES * 256) + 128);
+            }
+            const bool edge = i0q < kw + 31 || i0q + 31 >= kw + p.shift;
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                const bf16x8_t pt = lds_tr_pair(btr[hf][0] + KV3_OFF_P + stg * 16384, btr[hf][1] + KV3_OFF_P + stg * 16384);
+                float pf32[8], ds32[8];
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        pf32[t * 4 + r] = __uint_as_float((unsigned)(unsigned short)pt[t * 4 + r] << 16) * f4[t][r];
+                        ds32[t * 4 + r] = pf32[t * 4 + r] * (adp[hf][t][r] - d4[t][r]) * p.scale;
+                    }
+                pb[hf] = pack8(pf32);
+                sb[hf] = pack8(ds32);
+                if (edge) {
+                    // diagonal / window-edge pairs: a 16 x 32 tile without any visible pair was never written by the forward -- select, do
+                    // not multiply (the bytes there are arbitrary)
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int i = i0q + kk16(t, g) + r, j = kw + 16 * hf + a;
+                            const bool keep = (j <= i) && (j > i - p.shift);
+                            pb[hf][t * 4 + r] = keep ? pb[hf][t * 4 + r] : (short)0;
+                            sb[hf][t * 4 + r] = keep ? sb[hf][t * 4 + r] : (short)0;
+                        }
+                }
+            }
+#pragma unroll
+            for (int db = 0; db < 8; db++) {
+                const bf16x8_t dot = lds_tr_pair(ln.tr[0][db] + KV3_OFF_DO + stg * 8192, ln.tr[1][db] + KV3_OFF_DO + stg * 8192);
+                const bf16x8_t qut = lds_tr_pair(ln.tr[0][db] + KV3_OFF_QU + stg * 8192, ln.tr[1][db] + KV3_OFF_QU + stg * 8192);
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    acc_dv[hf][db] = MFMA16(dot, pb[hf], acc_dv[hf][db]);   // dV^T[d][key] += dO^T . P
+                    acc_dk[hf][db] = MFMA16(qut, sb[hf], acc_dk[hf][db]);   // dK^T[d][key] += Qu^T . dS
+                }
+            }
+        }
+        // block ib+1 must have landed: everything but the pieces of the (up to two) later blocks already requested
+        if (ib + 3 <= ib_hi) w16_vmcnt<2 * NP>(); else if (ib + 2 <= ib_hi) w16_vmcnt<NP>(); else w16_vmcnt<0>();
+        __syncthreads();
+    };
+    for (int ib = ib_lo; ib <= ib_hi; ib += 4) {
+        block(std::integral_constant<int, 0>{}, ib);
+        if (ib + 1 <= ib_hi) block(std::integral_constant<int, 1>{}, ib + 1);
+        if (ib + 2 <= ib_hi) block(std::integral_constant<int, 2>{}, ib + 2);
+        if (ib + 3 <= ib_hi) block(std::integral_constant<int, 3>{}, ib + 3);
+    }
+    bf16_t* Ow = reinterpret_cast<bf16_t*>(smem + wave * W16_TW_BYTES);   // (every wave is past the final barrier: the stages are free)
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+        store_acc_t16(acc_dk[hf], 1.f, Ow, p.dk + (int64_t)b * p.dq_bs + (int64_t)(kw + 16 * hf) * p.dq_rs + h * FA_D, p.dq_rs, lane);
+        store_acc_t16(acc_dv[hf], 1.f, Ow, p.dv + (int64_t)b * p.dq_bs + (int64_t)(kw + 16 * hf) * p.dq_rs + h * FA_D, p.dq_rs, lane);
+    }
+}
+
 // ======================================================================================= host side
 extern "C" int db1_relattn_flash_fwd2_launch(const FlashArgs* a, void* stream);   // relattn_flash_fwd2.hip (8 waves x 16 rows)
 extern "C" int db1_relattn_flash_fwd3_launch(const FlashArgs* a, void* stream);   // relattn_flash_fwd3.hip (4 waves x 32 rows: the default)
@@ -925,6 +1093,7 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
         hipFuncSetAttribute((const void*)relattn_flash_bwd_kv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KV2_LDS);
         hipFuncSetAttribute((const void*)relattn_flash_bwd_kv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KV2_LDS_F);
         hipFuncSetAttribute((const void*)relattn_flash_bwd_q2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q2_LDS);
+        hipFuncSetAttribute((const void*)relattn_flash_bwd_kv3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV3_LDS);
     });
     const dim3 grid(flash_grid(L / FA_BQ, H, B));
     if ((probs == nullptr) != (mblk == nullptr) || !db1_aligned16(probs)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_flash_bwd: probs and mblk go together, probs 16-byte aligned");
@@ -935,6 +1104,12 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
         a.fblk = reinterpret_cast<float*>(ws);
         relattn_flash_bwd_q2_kernel<<<grid, 512, Q2_LDS, s>>>(a);
         DB1_CHECK_LAUNCH("relattn_flash_bwd_q2");
+        static const bool kv3_on = [] { const char* e = getenv("DB1_FLASH_KV3"); return !e || atoi(e) != 0; }();
+        if (kv3_on && (L % KV3_KEYS) == 0) {   // a wave = 32 keys
+            relattn_flash_bwd_kv3_kernel<<<dim3(flash_grid(L / KV3_KEYS, H, B)), 512, KV3_LDS, s>>>(a);
+            DB1_CHECK_LAUNCH("relattn_flash_bwd_kv3");
+            return DB1_OK;
+        }
         relattn_flash_bwd_kv2_kernel<true><<<grid, 512, KV2_LDS_F, s>>>(a);
         DB1_CHECK_LAUNCH("relattn_flash_bwd_kv2");
         return DB1_OK;
