@@ -855,6 +855,10 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs
 // of a 32-query block -- dO^T and Qu^T through 32 transposing reads, the dO rows of dP through 8 ds_read_b128 -- are per wave, so they
 // now feed 48 MFMAs instead of 24 (the kernel is issue-bound: LDS reads were 44 of its ~130 instructions per wave-block).  A wave copies
 // the two images (query tiles 2 ib, 2 ib + 1) of ITS key block and reads both key halves' B fragments from them.  Needs L % 256 == 0.
+// 1734 -> 1652 us for the backward pair at B = 64.  (The same move on the query side -- 32 queries per wave, 256 per workgroup, V / K^T
+// fragments feeding 32 MFMAs -- was built, is correct, and is 4 % SLOWER, 1658 -> 1718 us: the causal triangle leaves the low-query waves of
+// a 256-query workgroup idle at the barriers of the late key blocks (82 % useful wave-blocks against 92 %), and twice the (batch, head)
+// pairs are in flight per XCD.  Removed again.)
 #define KV3_KEYS 256
 #define KV3_STAGES 4
 #define KV3_OFF_P 0                                   // [stage][8 key blocks][2 query tiles] images of 1 KiB
