@@ -66,11 +66,15 @@ class ParamArena:
         self.exp_avg_sq: Optional[torch.Tensor] = None
 
     def view(self, buf: torch.Tensor, name: str, full: bool = False) -> torch.Tensor:
-        off, shape, alloc = self.offsets[name]
-        if full:
-            return buf[off:off + alloc]
-        n = int(np.prod(shape))
-        return buf[off:off + n].view(*shape)
+        # (views are cached per buffer: building one costs ~10 us of host time, and an inference layer asks for a dozen per call)
+        key = (buf.data_ptr(), buf.dtype, buf.numel(), name, full)
+        cache = self.__dict__.setdefault("_view_cache", {})
+        v = cache.get(key)
+        if v is None:
+            off, shape, alloc = self.offsets[name]
+            v = buf[off:off + alloc] if full else buf[off:off + int(np.prod(shape))].view(*shape)
+            cache[key] = v
+        return v
 
     def sync_work(self):
         if self.work is not self.master:
