@@ -1091,7 +1091,7 @@ class TransformerXL(nn.Module):
     def forward(self, tasks_input: Sequence, compute_loss: bool = True, mems=None):
         """transformer_xl.py:506-619.  Runs on ``self.dev`` whatever the caller's current device is (streams, workspaces and the
         per-device kernel attributes all follow the current device)."""
-        with torch.cuda.device(self.dev):
+        with torch.cuda.device(self.dev), ops.stream_scope():
             return self._forward(tasks_input, compute_loss, mems)
 
     def _forward(self, tasks_input: Sequence, compute_loss: bool = True, mems=None):
@@ -1221,7 +1221,7 @@ class TransformerXL(nn.Module):
         """Accumulate d(loss * grad_scale)/d(params) of the last forward into the gradient arena.
         ``layer_done_hook(name)`` fires as soon as a layer's gradients are final (used by the data-parallel
         engine to start that layer's bucket all-reduce while earlier layers are still in backward)."""
-        with torch.cuda.device(self.dev):
+        with torch.cuda.device(self.dev), ops.stream_scope():
             return self._backward(grad_scale, layer_done_hook)
 
     def _backward(self, grad_scale, layer_done_hook):

@@ -31,7 +31,30 @@ def P(t: Optional[torch.Tensor]):
     return _vp(t.data_ptr())
 
 
+_scope_stream = None   # (raw handle, c_void_p) of the stream a model call runs on, while it runs
+
+
+class stream_scope:
+    """``with ops.stream_scope():`` around a model forward / backward: the current stream is looked up ONCE (torch.cuda.current_stream()
+    costs ~7 us of host time and every launch asks for it: a quarter of the host time of an eager inference call).  Nothing inside may
+    switch streams -- the model's own code never does."""
+
+    def __enter__(self):
+        global _scope_stream
+        self.prev = _scope_stream
+        h = torch.cuda.current_stream().cuda_stream
+        _scope_stream = (h, _vp(h))
+        return self
+
+    def __exit__(self, *exc):
+        global _scope_stream
+        _scope_stream = self.prev
+        return False
+
+
 def stream():
+    if _scope_stream is not None:
+        return _scope_stream[1]
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
@@ -48,7 +71,8 @@ class _Workspace:
     def get(self, nbytes: int, device):
         if nbytes <= 0:
             return _vp(0), 0
-        key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+        key = (device.index if device.index is not None else torch.cuda.current_device(),
+               _scope_stream[0] if _scope_stream is not None else torch.cuda.current_stream(device).cuda_stream)
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
