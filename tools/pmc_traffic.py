@@ -20,7 +20,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(out_dir, ctr.lower())
     subprocess.run(["rm", "-rf", d])
     cmd = ["timeout", "600", "rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing", "--no-decode"]   # (hipGraph replays under counter collection abort the queue)
     with open(os.path.join(out_dir, ctr.lower() + ".log"), "w") as lf:
         subprocess.run(cmd, cwd="/tmp", env=env, stdin=subprocess.DEVNULL, stdout=lf, stderr=subprocess.STDOUT)
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -46,7 +46,7 @@ gemm = [(k, v) for k, v in kernels.items() if k.startswith("gemm_bf16_")]
 tot_l = sum(v["launches"] for _, v in gemm)
 res = {
     "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
-              "--no-kernel-timing` (default batch, recorded in batch_per_gpu); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request; "
+              "--no-kernel-timing --no-decode` (default batch, recorded in batch_per_gpu); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request; "
               "calibrated on adam_kernel: 16 B/param read, 14 B/param written, and on ce_fwd: T x vocab_pad x 2 B read)",
     "kernels": kernels,
     "tile_gemm_avg_bytes_per_launch": round(sum(v["hbm_side_bytes_per_launch"] * v["launches"] for _, v in gemm) / tot_l) if tot_l else None,
