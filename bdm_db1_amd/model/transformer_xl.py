@@ -138,8 +138,10 @@ class TransformerXL(nn.Module):
         # regenerated in the backward: no mask tensors.  The reference's released configuration has dropattn = 0 (config.py:167).
         self.embd_pdrop = float(g("embd_pdrop", 0.0) or 0.0)
         self.drop_p = float(g("drop", 0.0) or 0.0)
-        if float(g("dropattn", 0.0) or 0.0) != 0.0:
-            raise NotImplementedError("dropattn != 0: attention-probability dropout is not implemented (the reference trains with dropattn = 0)")
+        # dropattn (:211; 0 in the released configuration, config.py:167): dropout on the attention probabilities.  Supported through the
+        # MATERIALISED attention path only (the probabilities exist there as a tensor; the flash kernels do not draw masks) -- correct and
+        # pinned to the oracle, not fast.
+        self.dropattn = float(g("dropattn", 0.0) or 0.0)
         rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
         self.dropout_seed = ((torch.initial_seed() * 0x9E3779B97F4A7C15) + rank) & 0xFFFFFFFFFFFFFFFF   # every data-parallel rank draws its own masks
         self._drop_step = 0                # bumped by every training forward: a new mask per micro-step
@@ -701,11 +703,13 @@ class TransformerXL(nn.Module):
         ops.relattn_softmax_fwd(AC, T, None, H, B, Lq, Lk, nd, mlen, shift, 1.0 / math.sqrt(D))
         return AC, T, qu, qv
 
-    def _attention_fwd(self, qkv, R, i, B, Lq, Lk, mlen, shift, c: Optional[_Ctx], quv=None):
+    def _attention_fwd(self, qkv, R, i, B, Lq, Lk, mlen, shift, c: Optional[_Ctx], quv=None, dstep=None):
         H, D = self.n_head, self.d_head
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
         av = self._new(B, Lq, H, D)
-        flash = (self.use_flash and mlen == 0 and Lq == Lk and shift >= 1 and ops.relattn_flash_supported(B, Lq, H, D, self.compute_dtype))
+        pdrop = self._drop_args(self.dropattn, 4 * i + 2, dstep)     # dropout on the probabilities: materialised path only
+        flash = (self.use_flash and mlen == 0 and Lq == Lk and shift >= 1 and ops.relattn_flash_supported(B, Lq, H, D, self.compute_dtype) and
+                 pdrop is ops.NO_DROP)
         assert quv is None or flash
         if flash:
             if quv is not None:  # written by the projection's epilogue (db1_gemm_nt_headbias)
@@ -723,6 +727,8 @@ class TransformerXL(nn.Module):
                 c.lse, c.qu, c.qv, c.probs, c.mblk = lse, qu, qv, probs, mblk
         else:
             Pm, _, _, _ = self._attn_probs(qkv, R, u, vb, B, Lq, Lk, mlen, shift)
+            if pdrop is not ops.NO_DROP:
+                ops.dropout(Pm, Pm, pdrop)            # (:211; [H, B, Lq, Lk] element order; the backward regenerates the mask)
             qkv5 = qkv.view(B, Lk, 3, H, D)
             ops.gemm_batched(Pm, qkv5[:, :, 2].permute(2, 0, 1, 3), av.permute(2, 0, 1, 3))
         if c is not None:
@@ -812,7 +818,7 @@ class TransformerXL(nn.Module):
         dec.new_kv.append(kv_all[:, max(0, klen - self.mem_len):])
         return av
 
-    def _attention_bwd(self, dav, c: _Ctx, i, B, L, shift):
+    def _attention_bwd(self, dav, c: _Ctx, i, B, L, shift, dstep=None):
         """returns dqkv [B*L, 3d] and dR [L, d]; accumulates du / dv_bias"""
         H, D, d = self.n_head, self.d_head, self.d_model
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
@@ -844,7 +850,13 @@ class TransformerXL(nn.Module):
             Pm, T, qu, qv = self._attn_probs(qkv, R, u, vb, B, L, L, 0, shift)
             dP = self._new(H, B, L, L, dtype=torch.float32)
             ops.gemm_batched(dav4.permute(2, 0, 1, 3), qkv5[:, :, 2].permute(2, 0, 3, 1), dP)
-            ops.gemm_batched(Pm.transpose(2, 3), dav4.permute(2, 0, 1, 3), dqkv5[:, :, 2].permute(2, 0, 1, 3))          # dV
+            Pd = Pm
+            pdrop = self._drop_args(self.dropattn, 4 * i + 2, dstep)
+            if pdrop is not ops.NO_DROP:   # the forward's dropped probabilities again (counter-based mask), and the gradient through that dropout
+                Pd = torch.empty_like(Pm)
+                ops.dropout(Pm, Pd, pdrop)
+                ops.dropout(dP, dP, pdrop)
+            ops.gemm_batched(Pd.transpose(2, 3), dav4.permute(2, 0, 1, 3), dqkv5[:, :, 2].permute(2, 0, 1, 3))          # dV
             dT = T
             ops.relattn_softmax_bwd(Pm, dP, dT, H, B, L, L, nd, 0, shift, scale)
             dS = dP
@@ -893,7 +905,7 @@ class TransformerXL(nn.Module):
             quv = None
             Wqkv = self.W(p + "dec_attn.qkv_net.weight")
             if (mem is None and shift >= 1 and self.use_flash and self.use_flash_bwd and self.compute_dtype == torch.bfloat16 and
-                    self.use_headbias_epilogue and ops.relattn_flash_supported(B, L, self.n_head, self.d_head, self.compute_dtype) and
+                    not (self.dropattn > 0 and dstep is not None) and self.use_headbias_epilogue and ops.relattn_flash_supported(B, L, self.n_head, self.d_head, self.compute_dtype) and
                     ops.gemm_nt_headbias_supported(T, 3 * d, d, d)):
                 # q + r_w_bias and q + r_r_bias leave the projection's accumulators directly (the q columns of qkv stay unwritten)
                 quv = (self._new(B, L, self.n_head, self.d_head), self._new(B, L, self.n_head, self.d_head))
@@ -902,7 +914,7 @@ class TransformerXL(nn.Module):
                 ops.gemm(xin, Wqkv.t(), qkv)
             R = self._new(R_in.shape[0], d)
             ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
-            av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c, quv=quv)
+            av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c, quv=quv, dstep=dstep)
         if dec is not None and self._decode_fused_ok(T, keep, dstep):
             # few new tokens: every launch is latency, so the linear maps do the layer's small follow-up work themselves (db1_linear_decode):
             # GEGLU in the epilogue, and the residual LayerNorms either on the way IN to the next linear map (<= 16 tokens: no launch, no
@@ -977,7 +989,7 @@ class TransformerXL(nn.Module):
         else:
             R = self._new(R_in.shape[0], d)
             ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
-            av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c)
+            av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c, dstep=dstep)
         o = self._new(T, d)
         ops.gemm(av.view(T, d), self.W(p + "dec_attn.o_net.weight").t(), o)
         if dstep is not None and self.drop_p > 0:
@@ -1031,7 +1043,7 @@ class TransformerXL(nn.Module):
         ops.gemm(do.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=self._gb)
         dav = self._new(T, d)
         ops.gemm(do, W(p + "dec_attn.o_net.weight"), dav)
-        dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift)
+        dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift, dstep)
         ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=self._gb)
         ops.gemm(dqkv.t(), c.hin, G(p + "dec_attn.qkv_net.weight"), beta=self._gb)
         dhin = self._new(T, d)
@@ -1074,7 +1086,7 @@ class TransformerXL(nn.Module):
         ops.gemm(do.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=self._gb)
         dav = self._new(T, d)
         ops.gemm(do, W(p + "dec_attn.o_net.weight"), dav)
-        dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift)
+        dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift, dstep)
         ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=self._gb)
         ops.gemm(dqkv.t(), c.x, G(p + "dec_attn.qkv_net.weight"), beta=self._gb)
         ops.gemm(dqkv, W(p + "dec_attn.qkv_net.weight"), ds1, beta=a)        # dx = a*ds1 + dqkv Wqkv (in place over ds1)

@@ -159,7 +159,7 @@ def attention_mask_dense(cfg: OracleConfig, qlen: int, mlen: int) -> Array:
 # --------------------------------------------------------------------------------------
 # relative-position attention (RelPartialLearnableMultiHeadAttn, transformer_xl.py:112-243)
 # --------------------------------------------------------------------------------------
-def relattn_core_fwd(q, k, v, R, u, vb, masked, scale, mlen=0):
+def relattn_core_fwd(q, k, v, R, u, vb, masked, scale, mlen=0, pscale=None):
     """q:(B,Lq,H,D) k,v:(B,Lk,H,D) R:(n_dist,H,D) indexed by distance, u,vb:(H,D).
 
     score[i,j] = ((q_i+u).k_j + (q_i+vb).R[mlen+i-j]) * scale, masked_fill(-1e30),
@@ -183,17 +183,21 @@ def relattn_core_fwd(q, k, v, R, u, vb, masked, scale, mlen=0):
     S = S - S.max(-1, keepdims=True)
     P = np.exp(S)
     P = P / P.sum(-1, keepdims=True)
-    out = (P @ v.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3)
-    return out, (P, dist, mlen, masked)
+    Pd = P if pscale is None else P * pscale       # self.dropatt(attn_prob) (transformer_xl.py:211): pscale = keep / (1 - p), shape (B,H,Lq,Lk)
+    out = (Pd @ v.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3)
+    return out, (P, dist, mlen, masked, pscale)
 
 
 def relattn_core_bwd(dout, q, k, v, R, u, vb, scale, cache):
-    P, dist, mlen, masked = cache
+    P, dist, mlen, masked, pscale = cache
     B, Lq, H, D = q.shape
     Lk = k.shape[1]
     do = dout.transpose(0, 2, 1, 3)                # (B,H,Lq,D)
     dP = do @ v.transpose(0, 2, 3, 1)
-    dv = (P.transpose(0, 1, 3, 2) @ do).transpose(0, 2, 1, 3)
+    Pd = P if pscale is None else P * pscale
+    if pscale is not None:
+        dP = dP * pscale                            # gradient through the dropout on the probabilities
+    dv = (Pd.transpose(0, 1, 3, 2) @ do).transpose(0, 2, 1, 3)
     dS = P * (dP - (P * dP).sum(-1, keepdims=True)) * scale
     # masked_fill passes no gradient to the scores it overwrites: only matters for a row whose keys are ALL hidden (its P is
     # uniform, not zero -- e.g. same_length with mem_len = 0); elsewhere P, hence dS, is already exactly zero there
@@ -397,7 +401,7 @@ SITE_EMBED, SITE_POS = 0xE0000000, 0xE0000001
 
 
 def site_of(layer: int, which: int) -> int:
-    """which: 0 = attention output (:229), 1 = feed-forward output (:269)"""
+    """which: 0 = attention output (:229), 1 = feed-forward output (:269), 2 = attention probabilities (:211, element order [H, B, Lq, Lk])"""
     return layer * 4 + which
 
 
@@ -649,7 +653,11 @@ class OracleModel:
         R = (R_in @ P[pre + "dec_attn.r_net.weight"].T).reshape(-1, H, D)
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
         scale = 1.0 / math.sqrt(D)
-        av, ac = relattn_core_fwd(q, k, v, R, u, vb, masked, scale, mlen)
+        pscale = None
+        if self._dropout is not None and cfg.dropattn > 0:   # mask drawn over the device's [H, B, Lq, Lk] element order
+            pscale = dropout_scale(B * H * L * Lk, cfg.dropattn, self._dropout["seed"], site_of(i, 2), self._dropout["step"]) \
+                .reshape(H, B, L, Lk).transpose(1, 0, 2, 3).astype(self.dtype)
+        av, ac = relattn_core_fwd(q, k, v, R, u, vb, masked, scale, mlen, pscale)
         av2 = av.reshape(B, L, H * D)
         o = av2 @ P[pre + "dec_attn.o_net.weight"].T
         o, c["drop_o"] = self._drop(o, cfg.drop, site_of(i, 0))                 # :229

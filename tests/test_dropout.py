@@ -47,10 +47,11 @@ def test_philox_known_answers_and_mask_statistics():
     assert np.all(O.dropout_scale(64, 0.0, 1, 2, 3) == 1.0)
 
 
-@pytest.mark.parametrize("pre_lnorm", [False, True])
-def test_oracle_gradients_under_dropout_match_finite_differences(pre_lnorm):
+@pytest.mark.parametrize("pre_lnorm,dropattn", [(False, 0.0), (True, 0.0), (False, 0.2), (True, 0.2)])
+def test_oracle_gradients_under_dropout_match_finite_differences(pre_lnorm, dropattn):
+    """(dropattn > 0: dropout on the attention probabilities too, transformer_xl.py:211)"""
     cfg = dict(case_cfg("small_window"), n_embed=32, n_head=2, n_position=16, mem_len=16, text_vocab_size=50, num_continuous_bin=8, num_discrete_values=8,
-               drop=0.25, embd_pdrop=0.2, pre_lnorm=pre_lnorm)
+               drop=0.25, embd_pdrop=0.2, dropattn=dropattn, pre_lnorm=pre_lnorm)
     params = {k: v.astype(np.float64) for k, v in make_params(cfg, 5).items()}
     rng = np.random.default_rng(3)
     ids = rng.integers(0, 50, (2, 17))
@@ -196,6 +197,34 @@ def test_model_with_dropout_matches_oracle_fp32(name):
     _, loss_eval = model(to_inputs(tasks))
     _, ref_eval, _ = oracle.forward([O.TaskBatch(**t) for t in tasks])
     assert abs(float(loss_eval) - ref_eval) < 2e-5 * max(1.0, abs(ref_eval))   # eval mode: no dropout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small_prelnorm", "small_flags", "small_window"])
+def test_model_with_attention_dropout_matches_oracle_fp32(name):
+    """dropattn = 0.1 on top of drop / embd_pdrop = 0.1 (the reference's nn.Dropout on attn_prob, transformer_xl.py:211; 0 in the released
+    configuration): the model takes the materialised attention path, draws the mask over the [H, B, Lq, Lk] probabilities and regenerates it
+    in the backward; loss, logits and every parameter gradient against the oracle under the same mask function"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_model_gpu import to_inputs, rel_err
+    cfg, model, oracle, seed = _build(name, dict(drop=0.1, embd_pdrop=0.1, dropattn=0.1), torch.float32)
+    tasks = make_batch(name, cfg, seed)
+    model.train()
+    logits, loss = model(to_inputs(tasks))
+    ref_logits, ref_loss, _ = oracle.forward([O.TaskBatch(**t) for t in tasks], dropout={"seed": model.dropout_seed, "step": 1})
+    assert rel_err(logits, ref_logits) < 1e-4 and abs(float(loss) - ref_loss) < 2e-5 * max(1.0, abs(ref_loss))
+    model.arena.grad.zero_()
+    model.backward()
+    ref_grads = oracle.backward()
+    worst = max((rel_err(model.G(n), g), n) for n, g in ref_grads.items())
+    assert worst[0] < 1e-3, worst
+    cfg0, model0, oracle0, _ = _build(name, dict(drop=0.1, embd_pdrop=0.1), torch.float32)
+    model0.train()
+    model0.dropout_seed = model.dropout_seed
+    _, loss0 = model0(to_inputs(tasks))
+    assert abs(float(loss0) - float(loss)) > 1e-5            # the probability masks really bite
 
 
 @pytest.mark.gpu

@@ -60,7 +60,7 @@ def test_flash_forward_matches_oracle(B, L, H, shift):
     D = 128
     qkv, R, u, vb = make_inputs(B, L, H, D, seed=L + shift)
     scale = 1.0 / math.sqrt(D)
-    out_ref, (Pm, _, _, _) = O.relattn_core_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], R, u, vb, masked_for(L, shift), scale)
+    out_ref, (Pm, _, _, _, _) = O.relattn_core_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], R, u, vb, masked_for(L, shift), scale)
     QKV, Rd, U, VB = dev16(qkv), dev16(R), dev16(u), dev16(vb)
     qu, qv = torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16), torch.empty(B, L, H, D, device=DEV, dtype=torch.bfloat16)
     ops.relattn_add_head_bias(QKV, U, VB, qu, qv, B, L, L, H, D)
