@@ -215,7 +215,10 @@ extern "C" int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const v
 
 static int ci_wgrad_ksplit(int64_t n_patches) {
     const int64_t nk = n_patches * (CI_HW / TBK);
-    int ks = 128;                                        // 5 column tiles x 128 pixel ranges = 640 workgroups
+    // 5 column tiles x ks pixel ranges workgroups, two per CU (64 KB of LDS each): 102 ranges = 510 workgroups are ONE round of the 512
+    // slots (128 ranges = 640 left a second round a quarter full); DB1_CONV_WGRAD_KS overrides (A/B)
+    static const int env_ks = [] { const char* e = getenv("DB1_CONV_WGRAD_KS"); return e ? atoi(e) : 0; }();
+    int ks = env_ks > 0 ? env_ks : 102;
     while (ks > 1 && nk / ks < 8) ks >>= 1;
     return ks;
 }
