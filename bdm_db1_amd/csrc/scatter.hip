@@ -19,46 +19,86 @@ __global__ __launch_bounds__(256) void scatter_keys_kernel(const int64_t* __rest
     idx[t] = (unsigned)t;
 }
 
-// one workgroup per sorted position; only the first position of a run works: it walks the run (tokens in ascending order) and owns the
-// table row.  The four waves split the columns (64 * V each per sweep) and the walk is batched eight tokens at a time -- eight index
-// loads, then their row loads, then the adds in token order -- so that a long run (the 22 local-position rows of an RL batch take
-// ~3 000 tokens each) is a stream, not a chain of dependent round trips.
+// one workgroup per sorted position; only the first position of a run works: it owns the table row.  The four waves split the columns
+// (64 * V each per sweep) and the walk is batched sixteen tokens at a time -- the index loads, then their row loads, then the adds in token
+// order -- so that a run is a stream, not a chain of dependent round trips.  Long runs (the 22 local-position rows of an RL batch take
+// ~3 000 tokens each: one workgroup per row streamed 12 MB at 10 GB/s, 1.3 ms) are cut at the multiples of SC_CHUNK sorted positions: the
+// part of a run inside a later chunk is summed by that chunk's own workgroup into a partial row (scatter_chunk_kernel, launched first),
+// and the owner adds its own head part, then the partial rows in chunk order.  The cut points depend on the sorted order only: same
+// inputs -> same bits.
+#define SC_CHUNK 256
+#define SC_PART_MAX_D 8192      // the workspace holds partial rows for d up to this (larger d: the owner walks its whole run)
+template <typename T, int BATCH>
+__device__ __forceinline__ void sc_sum_range(const T* __restrict__ dout, int64_t ld, const unsigned* __restrict__ keys, const unsigned* __restrict__ idx,
+                                             unsigned key, int64_t q, int64_t qend, int c, float (&acc)[Vec16<T>::N]) {
+    constexpr int V = Vec16<T>::N;
+    bool more = true;
+    while (more) {
+        unsigned rows[BATCH];
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {          // (wave-uniform: every lane reads the same keys)
+            const bool in = q + u < qend && keys[q + u] == key;
+            rows[u] = in ? idx[q + u] : 0u;
+            cnt += in ? 1 : 0;
+        }
+        Vec16<T> v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; u++)
+            if (u < cnt) v[u].load(dout + (int64_t)rows[u] * ld + c);
+#pragma unroll
+        for (int u = 0; u < BATCH; u++)
+            if (u < cnt) {
+#pragma unroll
+                for (int j = 0; j < V; j++) acc[j] += v[u].v[j];
+            }
+        q += cnt;
+        more = cnt == BATCH;
+    }
+}
+// chunk ch >= 1 whose first position continues a run: partial[ch][:] = sum of that run's tokens inside the chunk, in token order
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_chunk_kernel(const T* __restrict__ dout, int64_t ld, const unsigned* __restrict__ keys,
+                                                            const unsigned* __restrict__ idx, float* __restrict__ part, int64_t n, int d) {
+    constexpr int V = Vec16<T>::N;
+    const int64_t ch = (int64_t)blockIdx.x + 1, p = ch * SC_CHUNK;
+    const unsigned key = keys[p];
+    if (key == SC_INVALID || keys[p - 1] != key) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t qend = p + SC_CHUNK < n ? p + SC_CHUNK : n;
+    for (int c = (wave * 64 + lane) * V; c < d; c += 4 * 64 * V) {
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j] = 0.f;
+        sc_sum_range<T, 16>(dout, ld, keys, idx, key, p, qend, c, acc);
+#pragma unroll
+        for (int j = 0; j < V; j += 4) *reinterpret_cast<float4*>(part + ch * d + c + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_runs_kernel(const T* __restrict__ dout, int64_t ld, const unsigned* __restrict__ keys,
-                                                           const unsigned* __restrict__ idx, float* __restrict__ dtable, int64_t n, int d) {
-    constexpr int V = Vec16<T>::N, BATCH = 8;
+                                                           const unsigned* __restrict__ idx, float* __restrict__ dtable, const float* __restrict__ part,
+                                                           int64_t n, int d) {
+    constexpr int V = Vec16<T>::N;
     const int64_t p = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned key = keys[p];
     if (key == SC_INVALID || (p > 0 && keys[p - 1] == key)) return;
     float* trow = dtable + (int64_t)key * d;
+    const int64_t head_end = part ? ((p / SC_CHUNK + 1) * SC_CHUNK < n ? (p / SC_CHUNK + 1) * SC_CHUNK : n) : n;   // (no partials: the whole run)
     for (int c = (wave * 64 + lane) * V; c < d; c += 4 * 64 * V) {
         float acc[V];
 #pragma unroll
         for (int j = 0; j < V; j++) acc[j] = 0.f;
-        int64_t q = p;
-        bool more = true;
-        while (more) {
-            unsigned rows[BATCH];
-            int cnt = 0;
+        sc_sum_range<T, 16>(dout, ld, keys, idx, key, p, head_end, c, acc);
+        if (part) {
+            for (int64_t ch = p / SC_CHUNK + 1; ch * SC_CHUNK < n && keys[ch * SC_CHUNK] == key; ch++) {   // the run's later chunks, in order
 #pragma unroll
-            for (int u = 0; u < BATCH; u++) {          // (wave-uniform: every lane reads the same keys)
-                const bool in = q + u < n && keys[q + u] == key;
-                rows[u] = in ? idx[q + u] : 0u;
-                cnt += in ? 1 : 0;
-            }
-            Vec16<T> v[BATCH];
-#pragma unroll
-            for (int u = 0; u < BATCH; u++)
-                if (u < cnt) v[u].load(dout + (int64_t)rows[u] * ld + c);
-#pragma unroll
-            for (int u = 0; u < BATCH; u++)
-                if (u < cnt) {
-#pragma unroll
-                    for (int j = 0; j < V; j++) acc[j] += v[u].v[j];
+                for (int j = 0; j < V; j += 4) {
+                    const float4 o = *reinterpret_cast<const float4*>(part + ch * d + c + j);
+                    acc[j] += o.x; acc[j + 1] += o.y; acc[j + 2] += o.z; acc[j + 3] += o.w;
                 }
-            q += cnt;
-            more = cnt == BATCH;
+            }
         }
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
@@ -75,9 +115,10 @@ static int64_t sc_sort_temp_bytes(int64_t n) {
     (void)rocprim::radix_sort_pairs(nullptr, tb, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (size_t)n, 0, 32, (hipStream_t)0, false);
     return (int64_t)tb;
 }
+static int64_t sc_part_bytes(int64_t n) { return sc_al(((n + SC_CHUNK - 1) / SC_CHUNK) * (int64_t)SC_PART_MAX_D * (int64_t)sizeof(float)); }
 extern "C" int64_t db1_embed_scatter_add_workspace_bytes(int64_t n_tokens) {
     if (n_tokens <= 0) return 0;
-    return 4 * sc_al(n_tokens * 4) + sc_al(sc_sort_temp_bytes(n_tokens));
+    return 4 * sc_al(n_tokens * 4) + sc_al(sc_sort_temp_bytes(n_tokens)) + sc_part_bytes(n_tokens);
 }
 
 int db1_scatter_add_impl(const void* dout, const int64_t* ids, float* dtable_acc, int64_t n_tokens, int d, int64_t ld_dout, int64_t n_table_rows, int dt,
@@ -93,13 +134,19 @@ int db1_scatter_add_impl(const void* dout, const int64_t* ids, float* dtable_acc
     unsigned* keys_out = (unsigned*)((char*)ws + seg);
     unsigned* idx_in = (unsigned*)((char*)ws + 2 * seg);
     unsigned* idx_out = (unsigned*)((char*)ws + 3 * seg);
-    void* temp = (char*)ws + 4 * seg;
-    size_t tb = (size_t)(ws_bytes - 4 * seg);
+    float* part = d <= SC_PART_MAX_D ? (float*)((char*)ws + 4 * seg) : nullptr;      // [chunk][d] partial rows of the runs that cross chunk boundaries
+    void* temp = (char*)ws + 4 * seg + sc_part_bytes(n_tokens);
+    size_t tb = (size_t)(ws_bytes - 4 * seg - sc_part_bytes(n_tokens));
     scatter_keys_kernel<<<(unsigned)((n_tokens + 255) / 256), 256, 0, st>>>(ids, keys_in, idx_in, n_tokens, n_table_rows);
     DB1_CHECK_LAUNCH(who);
     if (rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, idx_in, idx_out, (size_t)n_tokens, 0, 32, st, false) != hipSuccess)
         DB1_FAIL(DB1_ERR_HIP, "%s: radix sort", who);
-    DB1_DISPATCH_DT(dt, T, (scatter_runs_kernel<T><<<(unsigned)n_tokens, 256, 0, st>>>((const T*)dout, ld_dout, keys_out, idx_out, dtable_acc, n_tokens, d)));
+    const int64_t nchunk = (n_tokens + SC_CHUNK - 1) / SC_CHUNK;
+    if (part && nchunk > 1) {
+        DB1_DISPATCH_DT(dt, T, (scatter_chunk_kernel<T><<<(unsigned)(nchunk - 1), 256, 0, st>>>((const T*)dout, ld_dout, keys_out, idx_out, part, n_tokens, d)));
+        DB1_CHECK_LAUNCH(who);
+    }
+    DB1_DISPATCH_DT(dt, T, (scatter_runs_kernel<T><<<(unsigned)n_tokens, 256, 0, st>>>((const T*)dout, ld_dout, keys_out, idx_out, dtable_acc, part, n_tokens, d)));
     DB1_CHECK_LAUNCH(who);
     return DB1_OK;
 }

@@ -176,7 +176,7 @@ int db1_embed_gather_fwd(const void* table, const int64_t* ids, void* out, int64
 /* dtable_acc[ids[t], :] += dout[t, :]; ids outside [0, n_table_rows) are skipped, as they read zeros in the forward.  Deterministic: no
  * float atomics -- the tokens are ordered by table row with a stable device radix sort and every table row is written by the one wave
  * that adds its tokens in token order.  d and ld_dout: multiples of 16 bytes. */
-int64_t db1_embed_scatter_add_workspace_bytes(int64_t n_tokens);   /* sort keys / values + the sort's own scratch */
+int64_t db1_embed_scatter_add_workspace_bytes(int64_t n_tokens);   /* sort keys / values + the sort's own scratch + partial rows of long runs (d <= 8192) */
 int db1_embed_scatter_add_bwd(const void* dout, const int64_t* ids, float* dtable_acc, int64_t n_tokens, int d,
                               int64_t ld_dout, int64_t n_table_rows, int dt, void* ws, int64_t ws_bytes, void* stream);
 /* RL sequence assembly (transformer_xl.py:621-660): rows with ids >= 0 take word_table[ids];
