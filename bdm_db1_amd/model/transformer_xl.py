@@ -19,6 +19,7 @@ There is no CPU or torch-op fallback: without libdb1_hip.so or without a gfx950 
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -176,6 +177,7 @@ class TransformerXL(nn.Module):
         self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
         self._conv_ops = {}              # (weight name, weight version) -> tap-major GEMM operand
+        self.use_proj_cl = os.environ.get("DB1_PROJ_CL", "1") != "0"   # channels-last patch embedder: projection against a column-permuted weight copy (no activation shuffles)
         self.use_decode = True           # inference with memory: K/V-cached path + fused decode attention when the shape allows
         self.use_decode_fused = True     # ... and, for <= 64 new tokens, linear maps as W streams that finish with GEGLU (post-LN)
         self.use_decode_ln_prologue = True   # ... <= 16 tokens: the residual LayerNorms ride on the way IN to the next linear map
@@ -422,6 +424,26 @@ class TransformerXL(nn.Module):
             self._conv_ops[key] = wp
         return self._conv_ops[key]
 
+    def _proj_operand_cl(self):
+        """the patch projection weight [d, 64 * hw] with its columns in (pixel, channel) order, per weight version: the channels-last
+        convolution output [N * hw, 64] IS [N, hw * 64], so the projection (and its data gradient) needs no layout shuffle of the
+        activations -- a 67 MB copy of the weight per optimizer step instead of two passes over [N, 16 384] per batch"""
+        wname = "vision_encoder.patch_embeddings.projection.weight"
+        hw, d = self.patch_size * self.patch_size, self.d_model
+        if self._graph_static:
+            key = (wname + "^cl", "static")
+            if key not in self._conv_ops:
+                self._conv_ops[key] = torch.empty(d, hw * 64, device=self.dev, dtype=self.compute_dtype)
+            ops.nchw_to_nhwc(self.W(wname), self._conv_ops[key], d, 64, hw)
+            return self._conv_ops[key]
+        key = (wname + "^cl", self._wversion)
+        if key not in self._conv_ops:
+            self._conv_ops = {k: v for k, v in self._conv_ops.items() if k[1] in (self._wversion, "static")}
+            wp = torch.empty(d, hw * 64, device=self.dev, dtype=self.compute_dtype)
+            ops.nchw_to_nhwc(self.W(wname), wp, d, 64, hw)
+            self._conv_ops[key] = wp
+        return self._conv_ops[key]
+
     def _conv_operand_t_cl(self, wname):
         """data-gradient operand [c_in, tap*64 + c_out] of a 64 -> 64 conv weight, per weight version"""
         if self._graph_static:
@@ -490,9 +512,13 @@ class TransformerXL(nn.Module):
         ops.groupnorm_gelu_nhwc_fwd(c.c2, self.W(pe + "residual_path.3.weight"), self.W(pe + "residual_path.3.bias"), a1, c.m1, c.r1, N, 64, hw)
         c3, c.cols3 = self._conv3x3_fwd_cl(a1, pe + "residual_path.5.weight", pe + "residual_path.5.bias", N, 64)
         ops.add(c.c1, c3, c3)                                  # residual
-        c.y = self._new(N, 64 * hw)                            # (c, y, x) flattening = the projection weight's layout
-        ops.nhwc_to_nchw(c3, c.y, N, 64, hw)
         emb = self._new(N, d)
+        if self.use_proj_cl:
+            c.y, c.y_cl = c3.view(N, hw * 64), True             # (y, x, c) flattening against the column-permuted projection weight
+            ops.gemm(c.y, self._proj_operand_cl().t(), emb, bias=self.W(pe + "projection.bias"))
+            return emb, N
+        c.y, c.y_cl = self._new(N, 64 * hw), False             # (c, y, x) flattening = the projection weight's layout
+        ops.nhwc_to_nchw(c3, c.y, N, 64, hw)
         ops.gemm(c.y, self.W(pe + "projection.weight").view(d, 64 * hw).t(), emb, bias=self.W(pe + "projection.bias"))
         return emb, N
 
@@ -585,6 +611,19 @@ class TransformerXL(nn.Module):
         pe = "vision_encoder.patch_embeddings."
         ops.embed_scatter_add(demb, c.row_ids, self.G("vision_encoder.row_position_embeddings.weight"))
         ops.embed_scatter_add(demb, c.col_ids, self.G("vision_encoder.col_position_embeddings.weight"))
+        if c.cl and getattr(c, "y_cl", False):
+            # the weight gradient comes out with (pixel, channel) columns: shuffled back per weight row and added (fp32, two passes over 134 MB),
+            # the data gradient [N, hw * 64] is channels-last already
+            gp = torch.empty(d, hw * 64, device=self.dev, dtype=torch.float32)
+            ops.gemm(demb.t(), c.y, gp)
+            gpt = torch.empty(d, 64 * hw, device=self.dev, dtype=torch.float32)
+            ops.nhwc_to_nchw(gp, gpt, d, 64, hw)
+            gw = self.G(pe + "projection.weight").view(d, 64 * hw)
+            ops.add(gpt, gw, gw)
+            ops.colsum_acc(demb, self.G(pe + "projection.bias"))
+            dy_nhwc = self._new(N * hw, 64)
+            ops.gemm(demb, self._proj_operand_cl(), dy_nhwc.view(N, hw * 64))
+            return self._vision_bwd_cl(dy_nhwc, c, N)
         ops.gemm(demb.t(), c.y, self.G(pe + "projection.weight").view(d, 64 * hw), beta=1.0)
         ops.colsum_acc(demb, self.G(pe + "projection.bias"))
         dy = self._new(N, 64 * hw)
