@@ -894,15 +894,18 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv3_kernel(FlashArgs
     const int ib_hi = ihi / FA_BK;
     const int srow = wave * 4 + (lane >> 4);
     const int schunk = ((lane & 15) ^ swz_kv(srow)) << 3;
-    const bf16_t* quptr = p.qu + ((int64_t)b * L + ib_lo * FA_BK + srow) * HD + h * FA_D + schunk;
-    const bf16_t* doptr = p.dout + ((int64_t)b * L + ib_lo * FA_BK + srow) * HD + h * FA_D + schunk;
+    // The query blocks are walked DOWNWARDS from the last one: the four key tiles of a (batch, head) -- co-resident on one XCD -- then start on
+    // the same block at the same time and stay in step, so its Qu / dO tiles are fetched from HBM once instead of once per key tile (walking
+    // up, tile kt starts at block 8 kt: no two tiles ever touch a block at the same time -- L2 hit rate 21 %, 3.25 GB per launch at 4.7 TB/s).
+    const bf16_t* quptr = p.qu + ((int64_t)b * L + ib_hi * FA_BK + srow) * HD + h * FA_D + schunk;
+    const bf16_t* doptr = p.dout + ((int64_t)b * L + ib_hi * FA_BK + srow) * HD + h * FA_D + schunk;
     // this wave copies the images (key block j0 / 32 + wave, query tiles 2 ib and 2 ib + 1): adjacent in memory
-    const int64_t img = ((((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + wave) * (L / 16) + 2 * ib_lo) * 512;
+    const int64_t img = ((((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + wave) * (L / 16) + 2 * ib_hi) * 512;
     const bf16_t* pptr0 = p.pt + img + kv2_chunk_pos(lane, 0) * 8;
     const bf16_t* pptr1 = p.pt + img + 512 + kv2_chunk_pos(lane, 1) * 8;
     const int64_t q_step = (int64_t)FA_BK * HD;
-    const float* fptr = lane < 32 ? p.fblk + (((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + wave) * L + ib_lo * FA_BK + lane
-                                  : p.delta + ((int64_t)b * H + h) * L + ib_lo * FA_BK + lane - 32;
+    const float* fptr = lane < 32 ? p.fblk + (((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + wave) * L + ib_hi * FA_BK + lane
+                                  : p.delta + ((int64_t)b * H + h) * L + ib_hi * FA_BK + lane - 32;
     unsigned fld[2];   // f of queries kk(t, g) .. + 3 (delta: + 128 bytes)
 #pragma unroll
     for (int t = 0; t < 2; t++) { fld[t] = lds0 + KV3_OFF_F + wave * 256 + kk16(t, g) * 4; W16_OPAQUE(fld[t]); }
@@ -920,16 +923,16 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv3_kernel(FlashArgs
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(fptr), "s"(dstf) : "memory");
-        fptr += FA_BK;
+        fptr -= FA_BK;
         glds16(pptr0, lds0 + KV3_OFF_P + stg * 16384 + wave * 2048);
         glds16(pptr1, lds0 + KV3_OFF_P + stg * 16384 + wave * 2048 + 1024);
         glds16(quptr, lds0 + KV3_OFF_QU + stg * 8192 + wave * 1024);
         glds16(doptr, lds0 + KV3_OFF_DO + stg * 8192 + wave * 1024);
-        pptr0 += 1024; pptr1 += 1024; quptr += q_step; doptr += q_step;   // the next 32 queries: two images further
+        pptr0 -= 1024; pptr1 -= 1024; quptr -= q_step; doptr -= q_step;   // the previous 32 queries: two images back
     };
     stage(0);
-    if (ib_lo + 1 <= ib_hi) stage(1);
-    if (ib_lo + 2 <= ib_hi) stage(2);
+    if (ib_hi - 1 >= ib_lo) stage(1);
+    if (ib_hi - 2 >= ib_lo) stage(2);
     f32x4 acc_dk[2][8], acc_dv[2][8];
 #pragma unroll
     for (int hf = 0; hf < 2; hf++)
@@ -942,7 +945,7 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv3_kernel(FlashArgs
     auto block = [&](auto STG, int ib) __attribute__((always_inline)) {
         constexpr int stg = decltype(STG)::value;
         const int i0q = ib * FA_BK;
-        if (ib + 3 <= ib_hi) stage((stg + 3) % KV3_STAGES);
+        if (ib - 3 >= ib_lo) stage((stg + 3) % KV3_STAGES);
         if (!(i0q + 31 < kw || i0q >= kw + 31 + p.shift)) {  // some (i, j) of this block pair is visible
             bf16x8_t pb[2], sb[2];
             // dP[query][key] = dO.V^T: the dO rows of a 16-query tile (A operand) are read once for both key tiles
@@ -1005,14 +1008,14 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv3_kernel(FlashArgs
             }
         }
         // block ib+1 must have landed: everything but the pieces of the (up to two) later blocks already requested
-        if (ib + 3 <= ib_hi) w16_vmcnt<2 * NP>(); else if (ib + 2 <= ib_hi) w16_vmcnt<NP>(); else w16_vmcnt<0>();
+        if (ib - 3 >= ib_lo) w16_vmcnt<2 * NP>(); else if (ib - 2 >= ib_lo) w16_vmcnt<NP>(); else w16_vmcnt<0>();
         __syncthreads();
     };
-    for (int ib = ib_lo; ib <= ib_hi; ib += 4) {
+    for (int ib = ib_hi; ib >= ib_lo; ib -= 4) {
         block(std::integral_constant<int, 0>{}, ib);
-        if (ib + 1 <= ib_hi) block(std::integral_constant<int, 1>{}, ib + 1);
-        if (ib + 2 <= ib_hi) block(std::integral_constant<int, 2>{}, ib + 2);
-        if (ib + 3 <= ib_hi) block(std::integral_constant<int, 3>{}, ib + 3);
+        if (ib - 1 >= ib_lo) block(std::integral_constant<int, 1>{}, ib - 1);
+        if (ib - 2 >= ib_lo) block(std::integral_constant<int, 2>{}, ib - 2);
+        if (ib - 3 >= ib_lo) block(std::integral_constant<int, 3>{}, ib - 3);
     }
     bf16_t* Ow = reinterpret_cast<bf16_t*>(smem + wave * W16_TW_BYTES);   // (every wave is past the final barrier: the stages are free)
 #pragma unroll
