@@ -49,6 +49,16 @@ class GraphedTrainStep:
             for n in _tensor_fields(t):
                 setattr(st, n, getattr(t, n).to(dev).clone())
             self.static.append(st)
+        # vision position ids: in training mode the reference draws them per step on the host (vision_embedding.py:150-169) -- a host-side
+        # draw + copy cannot be captured, so a task that does not carry them gets static device tensors the graph reads, refilled with a
+        # fresh draw before every replay
+        self._vis = []
+        for st in self.static:
+            geo = self._vision_geometry(st)
+            if geo is not None and getattr(st, "vision_row_ids", None) is None:
+                r, c = model._vision_position_ids(geo[1], geo[2], geo[0])
+                st.vision_row_ids, st.vision_col_ids = r.to(dev), c.to(dev)
+                self._vis.append((st, geo))
         self._fields = [_tensor_fields(t) for t in self.static]
         # the dropout step counter moves to the device; it continues the eager engine's count
         self.step_dev = torch.full((1,), int(model._drop_step), dtype=torch.int32, device=dev)
@@ -80,16 +90,35 @@ class GraphedTrainStep:
         model._grad_fresh = True
         model._ctx = None
 
+    def _vision_geometry(self, t):
+        img = getattr(t, "vision_seq", None)
+        if img is None:
+            img = getattr(t, "img_seq", None)
+        if img is None or not torch.is_tensor(img) or img.dim() < 3:
+            return None
+        p = self.model.patch_size
+        n_img = 1
+        for s_ in img.shape[:-3]:
+            n_img *= int(s_)
+        return n_img, img.shape[-2] // p, img.shape[-1] // p
+
     def __call__(self, batch: Sequence):
         """one micro-step: returns the loss (a static device scalar, overwritten by the next call); follow it with ``engine.step()``"""
         eng, model = self.engine, self.model
         assert len(batch) == len(self.static)
         for st, t, names in zip(self.static, batch, self._fields):
             for n in names:
-                src = getattr(t, n)
+                src = getattr(t, n, None)
                 dst = getattr(st, n)
+                if src is None:          # (the position ids this object supplies itself, below)
+                    continue
                 if src.data_ptr() != dst.data_ptr():
                     dst.copy_(src, non_blocking=True)
+        for st, geo in self._vis:
+            if not any(getattr(t, "vision_row_ids", None) is not None for t in batch if self._vision_geometry(t) == geo):
+                r, c = model._vision_position_ids(geo[1], geo[2], geo[0])
+                st.vision_row_ids.copy_(r, non_blocking=True)
+                st.vision_col_ids.copy_(c, non_blocking=True)
         boundary = eng.is_gradient_accumulation_boundary()
         if eng.dp_world > 1 and boundary:
             # the bucket all-reduces are launched from inside this backward: eager, on the same device counter

@@ -595,3 +595,50 @@ def test_bf16_mixture_optimizer_step_is_bit_reproducible():
     assert not bad, bad
     badp = [k for k in runs[0][3] if not torch.equal(runs[0][3][k], runs[1][3][k])]
     assert not badp, badp
+
+
+def test_graphed_training_with_vision_batches():
+    """GraphedTrainStep on an RL + text + caption batch: the vision position ids -- drawn per step on the host by the reference's training
+    mode (vision_embedding.py:150-169), which a capture cannot contain -- are static device inputs of the graph, refilled with a fresh draw
+    before every replay; with ids supplied by the caller the graphed micro-step reproduces the eager one bit for bit"""
+    from bdm_db1_amd import GraphedTrainStep, TransformerXL, initialize, synth
+    cfg = synth.db1_config("1.3B", n_layer=2, n_embed=512, n_head=4, drop=0.1, embd_pdrop=0.1)
+
+    def build():
+        torch.manual_seed(7)
+        model = TransformerXL(cfg, compute_dtype=torch.bfloat16)
+        engine, _, _, _ = initialize(SimpleNamespace(lr=1e-3, weight_decay=0.01, clip_grad=1.0, optimizer="adamw", keep_logits=False, fuse_head_loss=True), model)
+        engine.train()
+        return model, engine
+    model, engine = build()
+    batch = synth.mixture_batch(4, cfg.n_position, 3, DEV, cfg)
+    g = GraphedTrainStep(engine, batch)
+    assert g._vis, "the mixture batch has image tasks without explicit position ids"
+    st = g._vis[0][0]
+    loss_a = float(g(batch)); ids_a = st.vision_row_ids.clone()
+    engine.step()
+    loss_b = float(g(batch)); ids_b = st.vision_row_ids.clone()
+    engine.step()
+    assert np.isfinite(loss_a) and np.isfinite(loss_b) and not torch.equal(ids_a, ids_b)      # a fresh draw per micro-step
+    g.close()
+    # caller-supplied ids: graph == eager
+    torch.manual_seed(3)
+    fixed = []
+    for t in batch:
+        geo = g._vision_geometry(t)
+        if geo is not None:
+            r, c = model._vision_position_ids(geo[1], geo[2], geo[0])
+            t.vision_row_ids, t.vision_col_ids = r.to(DEV), c.to(DEV)
+            fixed.append(t)
+    assert fixed
+    res = []
+    for graphed in (False, True):
+        model, engine = build()
+        if graphed:
+            gs = GraphedTrainStep(engine, batch)
+            loss = gs(batch)
+        else:
+            _, loss = engine(batch)
+            engine.backward(loss)
+        res.append((float(loss), model.arena.grad.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
