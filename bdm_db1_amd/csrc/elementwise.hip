@@ -1096,6 +1096,92 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, const int6
     }
 }
 
+// Forward and backward of a row in ONE pass (the chunked head + loss sweep, lmhead_ce.hip): the row of logits (<= 256 x 8 x CE_MAXV
+// elements: 34 816) stays in the registers of its workgroup between the (max, sum-exp) reduction and the gradient, so the chunk of logits
+// is read once and written once instead of read twice and written once (3.3 -> 2.2 GB per 16 384-row chunk at the DB1 vocabulary).  Same
+// arithmetic as ce_fwd_kernel + ce_bwd_kernel, expression for expression: lse, the per-token losses and dlogits are bit-equal.
+#define CE_MAXV 17
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(T* logits, const int64_t* __restrict__ labels, const float* __restrict__ mask,
+                                                         float* __restrict__ lse, const float* __restrict__ norm, float* __restrict__ tok_loss,
+                                                         int V, int64_t ld, float gscale) {
+    __shared__ float sm[4];
+    constexpr int VN = Vec16<T>::N;
+    const int64_t t = blockIdx.x;
+    T* row = logits + t * ld;
+    const int tid = threadIdx.x;
+    uint4 raw[CE_MAXV];    // the row as loaded (16 bytes per piece: half the registers of the unpacked form -> twice the rows in flight per CU)
+#pragma unroll
+    for (int k = 0; k < CE_MAXV; k++) {   // (unconditional, at a clamped address: loads inside a branch are waited for one by one)
+        const int c = (k * 256 + tid) * VN;
+        raw[k] = *reinterpret_cast<const uint4*>(row + (c < ld ? c : (int)ld - VN));
+    }
+    auto unpack = [&](int k, float (&x)[VN]) {
+        Vec16<T> a;
+        a.load(reinterpret_cast<const T*>(&raw[k]));
+#pragma unroll
+        for (int j = 0; j < VN; j++) x[j] = a.v[j];
+    };
+    float m = -3.0e38f, s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CE_MAXV; k++) {
+        const int c = (k * 256 + tid) * VN;
+        if (c < V) {
+            float x[VN];
+            unpack(k, x);
+#pragma unroll
+            for (int j = 0; j < VN; j++) x[j] = (c + j >= V) ? -3.0e38f : x[j];   // padded vocabulary columns
+            float vm = x[0];
+#pragma unroll
+            for (int j = 1; j < VN; j++) vm = fmaxf(vm, x[j]);
+            if (vm > m) { s *= __expf(m - vm); m = vm; }
+#pragma unroll
+            for (int j = 0; j < VN; j++) s += __expf(x[j] - m);
+        }
+    }
+    const float M = block_max256(m, sm);
+    const float S = block_sum256(s * __expf(m - M), sm);
+    const float l = M + logf(S);
+    const int64_t yl = labels[t];
+    const int y = (yl >= 0 && yl < V) ? (int)yl : -1;
+    const float mk = y >= 0 ? mask[t] : 0.f;
+    if (tid == 0) {
+        lse[t] = l;
+        tok_loss[t] = mk * (y >= 0 ? l - ldf(row + y) : 0.f);     // (read before any thread overwrites the row: see the barrier below)
+    }
+    __syncthreads();
+    const float w = mk / norm[1] * gscale;
+#pragma unroll
+    for (int k = 0; k < CE_MAXV; k++) {
+        const int c = (k * 256 + tid) * VN;
+        if (c < ld) {
+            float x[VN];
+            unpack(k, x);
+            Vec16<T> o;
+#pragma unroll
+            for (int j = 0; j < VN; j++) o.v[j] = (c + j < V) ? w * (__expf(x[j] - l) - (c + j == y ? 1.f : 0.f)) : 0.f;
+            o.store(row + c);
+        }
+    }
+}
+// dlogits in place + lse + sums[0] += sum(mask * nll), sums[1] += sum(mask); norm[1] = the loss normaliser (sum(mask) over ALL rows of the step)
+extern "C" int db1_masked_ce_fwd_bwd_supported(int V, int64_t ld, int dt) {
+    const int VN = dt == DB1_F32 ? 4 : 8;
+    return (db1_dt_ok(dt) && V > 0 && ld >= V && ld % VN == 0 && ld <= (int64_t)256 * VN * CE_MAXV) ? 1 : 0;
+}
+extern "C" int db1_masked_ce_fwd_bwd(void* logits, const int64_t* labels, const float* mask, float* lse, float* sums, const float* norm,
+                                     int64_t T_, int V, int64_t ld, float gscale, int dt, void* ws_, int64_t ws_bytes, void* stream) {
+    if (!db1_masked_ce_fwd_bwd_supported(V, ld, dt) || !db1_aligned16(logits)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "masked_ce_fwd_bwd: V=%d ld=%lld (rows of at most %d elements, 16-byte aligned)", V, (long long)ld, 256 * 8 * CE_MAXV);
+    if (T_ <= 0 || !labels || !mask || !lse || !sums || !norm) DB1_FAIL(DB1_ERR_BAD_SHAPE, "masked_ce_fwd_bwd: shape / null buffer");
+    DB1_NEED_WS(ws_, ws_bytes, T_ * (int64_t)sizeof(float), "masked_ce_fwd_bwd");
+    float* tok_loss = (float*)ws_;
+    DB1_DISPATCH_DT(dt, T, (ce_fwd_bwd_kernel<T><<<(unsigned)T_, 256, 0, (hipStream_t)stream>>>((T*)logits, labels, mask, lse, norm, tok_loss, V, ld, gscale)));
+    DB1_CHECK_LAUNCH("masked_ce_fwd_bwd");
+    ce_sum_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(tok_loss, mask, sums, T_);
+    DB1_CHECK_LAUNCH("masked_ce_fwd_bwd sum");
+    return DB1_OK;
+}
+
 extern "C" int64_t db1_masked_ce_fwd_workspace_bytes(int64_t T_) { return T_ * (int64_t)sizeof(float); }  // per-token losses
 extern "C" int db1_masked_ce_fwd(const void* logits, const int64_t* labels, const float* mask, float* lse, float* sums,
                                  int64_t T_, int V, int64_t ld, int dt, void* ws_, int64_t ws_bytes, void* stream) {

@@ -73,14 +73,22 @@ static int lmhead_sweep(const void* h, const void* W, const int64_t* labels, con
                                   gws, p.gemm_b, stream);                                                        // logits = h W^T
         if (rc) return rc;
         if (hipMemsetAsync(chunk2, 0, 2 * sizeof(float), st) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "%s: memset", who);
-        rc = db1_masked_ce_fwd(logits, labels + r0, mask + r0, lse + r0, chunk2, rows, V, n_w_rows, dt, cws, p.ce_b, stream);
-        if (rc) return rc;
-        lmhead_add_loss_kernel<<<1, 1, 0, st>>>(chunk2, acc2);
-        DB1_CHECK_LAUNCH("lmhead chunk loss");
-        if (!train) continue;
-        // dlogits in place (normaliser = sum(mask) over all rows = acc2[1]), then its two products before the next chunk overwrites it
-        rc = db1_masked_ce_bwd(logits, labels + r0, mask + r0, lse + r0, acc2, logits, rows, V, n_w_rows, gscale, dt, stream);
-        if (rc) return rc;
+        if (train && db1_masked_ce_fwd_bwd_supported(V, n_w_rows, dt)) {
+            // loss and dlogits (in place; normaliser = sum(mask) over all rows = acc2[1]) from ONE pass over the chunk: the row stays in registers
+            rc = db1_masked_ce_fwd_bwd(logits, labels + r0, mask + r0, lse + r0, chunk2, acc2, rows, V, n_w_rows, gscale, dt, cws, p.ce_b, stream);
+            if (rc) return rc;
+            lmhead_add_loss_kernel<<<1, 1, 0, st>>>(chunk2, acc2);
+            DB1_CHECK_LAUNCH("lmhead chunk loss");
+        } else {
+            rc = db1_masked_ce_fwd(logits, labels + r0, mask + r0, lse + r0, chunk2, rows, V, n_w_rows, dt, cws, p.ce_b, stream);
+            if (rc) return rc;
+            lmhead_add_loss_kernel<<<1, 1, 0, st>>>(chunk2, acc2);
+            DB1_CHECK_LAUNCH("lmhead chunk loss");
+            if (!train) continue;
+            // dlogits in place (normaliser = sum(mask) over all rows = acc2[1]), then its two products before the next chunk overwrites it
+            rc = db1_masked_ce_bwd(logits, labels + r0, mask + r0, lse + r0, acc2, logits, rows, V, n_w_rows, gscale, dt, stream);
+            if (rc) return rc;
+        }
         rc = db1_gemm_strided(logits, hc, dW_acc, nullptr, n_w_rows, d, rows, dt, dt, DB1_F32, 0, 1, n_w_rows, d, 1, d, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1.f,
                               r0 == 0 ? beta_dw : 1.f, gws, p.gemm_b, stream);                                   // dW (+)= dlogits^T h
         if (rc) return rc;

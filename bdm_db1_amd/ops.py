@@ -392,6 +392,13 @@ def masked_ce_bwd(logits2d, labels, mask, lse, sums, dlogits2d, V, gscale=1.0):
                             dt_code(logits2d), stream()))
 
 
+def masked_ce_fwd_bwd(logits2d, labels, mask, lse, sums, norm, V, gscale=1.0):
+    """lse, sums += (loss, mask) and logits2d overwritten by dlogits in ONE pass (db1_masked_ce_fwd_bwd); norm[1] = the loss normaliser"""
+    T, ld = logits2d.shape[0], logits2d.stride(0)
+    ws, wsn = _ws("db1_masked_ce_fwd_workspace_bytes", (T,), logits2d.device)
+    lib.call("db1_masked_ce_fwd_bwd", P(logits2d), P(labels), P(mask), P(lse), P(sums), P(norm), T, V, ld, float(gscale), dt_code(logits2d), ws, wsn, stream())
+
+
 def lmhead_ce(h2d, W, labels, mask, lse, sums, V, dh=None, dW_acc=None, beta_dw=1.0, gscale=1.0, chunk_rows=0):
     """tied head + masked CE without the logits tensor (db1_lmhead_ce_fwd / _fwd_bwd): ``dh`` and ``dW_acc`` given -> the training sweep"""
     T, d = h2d.shape

@@ -202,6 +202,13 @@ int db1_masked_ce_fwd(const void* logits, const int64_t* labels, const float* ma
                       int64_t T, int V, int64_t ld, int dt, void* ws, int64_t ws_bytes, void* stream);
 int db1_masked_ce_bwd(const void* logits, const int64_t* labels, const float* mask, const float* lse, const float* sums,
                       void* dlogits, int64_t T, int V, int64_t ld, float gscale, int dt, void* stream);
+/* both in ONE pass over the rows (each row stays in the registers of its workgroup: ld <= 34 816 elements in bf16, 17 408 in fp32): lse,
+ * sums[0] += sum(mask * nll), sums[1] += sum(mask), and logits overwritten by dlogits = mask / norm[1] * gscale * (softmax - onehot);
+ * norm[1] = the loss normaliser (a device float pair like `sums`).  Bit-equal to db1_masked_ce_fwd followed by db1_masked_ce_bwd.
+ * ws: db1_masked_ce_fwd_workspace_bytes(T). */
+int db1_masked_ce_fwd_bwd_supported(int V, int64_t ld, int dt);
+int db1_masked_ce_fwd_bwd(void* logits, const int64_t* labels, const float* mask, float* lse, float* sums, const float* norm,
+                          int64_t T, int V, int64_t ld, float gscale, int dt, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ tied LM head + masked cross-entropy, chunked over the token rows
  * (transformer_xl.py:593-613).  The (T x vocabulary) logits tensor is never materialised: chunk_rows rows of logits at a time

@@ -619,6 +619,13 @@ def test_masked_ce(ops, dtype, V, ld):
     ref[:, :V] = p * (mask / mask.sum())[:, None]
     close(dl, ref, 3e-6 if dtype == "f32" else 6e-3, name="dlogits")
     assert float(dl[:, V:].abs().max()) == 0.0 if ld > V else True
+    # both in one pass over the rows (the row stays in registers; what the chunked head + loss sweep runs): bit-equal to the pair above
+    if ops.lib.load().db1_masked_ce_fwd_bwd_supported(V, ld, ops.dt_code(buf)):
+        buf2, lse2, sums2 = buf.clone(), torch.empty(T, device=DEV), torch.zeros(2, device=DEV)
+        ops.masked_ce_fwd_bwd(buf2, torch.from_numpy(labels).to(DEV), dev(mask), lse2, sums2, sums, V, gscale=1.0)
+        assert torch.equal(lse2, lse) and torch.equal(sums2, sums) and torch.equal(buf2, dl)
+    else:
+        assert dtype == "f32" and ld > 17408 or dtype == "f32"
 
 
 # ------------------------------------------------------------------------------- optimizer
