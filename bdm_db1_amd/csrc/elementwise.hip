@@ -4,6 +4,9 @@
 // with 16-byte vector accesses and wave-shuffle reductions; roofline = HBM bytes.
 #include "db1_common.h"
 #include "ln_row.h"
+#ifndef DB1_ACT_UNROLL
+#define DB1_ACT_UNROLL 2   /* rows in flight per thread of the activation kernels (tools/exp/act_unroll.sh) */
+#endif
 
 // =====================================================================================
 // residual + LayerNorm      (reference: transformer_xl.py:231-238, 288-290)
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const T* __restrict__ z, T
     if (c >= n) return;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
     const int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
-#pragma unroll 2
+#pragma unroll DB1_ACT_UNROLL
     for (int64_t r = r0; r < r1; r++) {
         Vec16<T> a, o;
         a.load(z + r * ld + c);
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const T* __restrict__
     float s1[V], s2[V];
 #pragma unroll
     for (int j = 0; j < V; j++) { s1[j] = 0.f; s2[j] = 0.f; }
-#pragma unroll 2
+#pragma unroll DB1_ACT_UNROLL
     for (int64_t r = r0; r < r1; r++) {
         Vec16<T> a, g, o;
         a.load(z + r * ld + c);
