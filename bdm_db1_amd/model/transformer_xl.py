@@ -511,12 +511,21 @@ class TransformerXL(nn.Module):
         c.m1, c.r1 = self._new(N * 32, dtype=torch.float32), self._new(N * 32, dtype=torch.float32)
         ops.groupnorm_gelu_nhwc_fwd(c.c2, self.W(pe + "residual_path.3.weight"), self.W(pe + "residual_path.3.bias"), a1, c.m1, c.r1, N, 64, hw)
         c3, c.cols3 = self._conv3x3_fwd_cl(a1, pe + "residual_path.5.weight", pe + "residual_path.5.bias", N, 64)
+        if self.use_proj_cl:
+            # (y, x, c) flattening against the column-permuted projection weight.  The patch count of a mixed batch is whatever the data gives
+            # (4116, 20 680 ...): rows are padded with zeros to a multiple of 256 so that the K = 16 384 projection and its two gradients take
+            # the 256 x 256 kernels (the 128-tile / generic kernels ran them at 0.24 PFLOP/s) -- the residual add writes into the padded buffer
+            Np = _round_up(N, 256) if N >= 512 else N
+            ypad = self._new(Np * hw, 64)
+            ops.add(c.c1, c3, ypad[:N * hw])                   # residual
+            if Np > N:
+                ypad[N * hw:].zero_()
+            c.y, c.y_cl, c.Np = ypad.view(Np, hw * 64), True, Np
+            emb_pad = self._new(Np, d)
+            ops.gemm(c.y, self._proj_operand_cl().t(), emb_pad, bias=self.W(pe + "projection.bias"))
+            return emb_pad[:N], N
         ops.add(c.c1, c3, c3)                                  # residual
         emb = self._new(N, d)
-        if self.use_proj_cl:
-            c.y, c.y_cl = c3.view(N, hw * 64), True             # (y, x, c) flattening against the column-permuted projection weight
-            ops.gemm(c.y, self._proj_operand_cl().t(), emb, bias=self.W(pe + "projection.bias"))
-            return emb, N
         c.y, c.y_cl = self._new(N, 64 * hw), False             # (c, y, x) flattening = the projection weight's layout
         ops.nhwc_to_nchw(c3, c.y, N, 64, hw)
         ops.gemm(c.y, self.W(pe + "projection.weight").view(d, 64 * hw).t(), emb, bias=self.W(pe + "projection.bias"))
@@ -614,16 +623,22 @@ class TransformerXL(nn.Module):
         if c.cl and getattr(c, "y_cl", False):
             # the weight gradient comes out with (pixel, channel) columns: shuffled back per weight row and added (fp32, two passes over 134 MB),
             # the data gradient [N, hw * 64] is channels-last already
+            Np = c.Np
+            dpad = demb
+            if Np > N:                                             # zero rows for the padded patches
+                dpad = self._new(Np, d)
+                dpad[:N].copy_(demb)
+                dpad[N:].zero_()
             gp = torch.empty(d, hw * 64, device=self.dev, dtype=torch.float32)
-            ops.gemm(demb.t(), c.y, gp)
+            ops.gemm(dpad.t(), c.y, gp)
             gpt = torch.empty(d, 64 * hw, device=self.dev, dtype=torch.float32)
             ops.nhwc_to_nchw(gp, gpt, d, 64, hw)
             gw = self.G(pe + "projection.weight").view(d, 64 * hw)
             ops.add(gpt, gw, gw)
             ops.colsum_acc(demb, self.G(pe + "projection.bias"))
-            dy_nhwc = self._new(N * hw, 64)
-            ops.gemm(demb, self._proj_operand_cl(), dy_nhwc.view(N, hw * 64))
-            return self._vision_bwd_cl(dy_nhwc, c, N)
+            dy_nhwc = self._new(Np * hw, 64)
+            ops.gemm(dpad, self._proj_operand_cl(), dy_nhwc.view(Np, hw * 64))
+            return self._vision_bwd_cl(dy_nhwc[:N * hw], c, N)
         ops.gemm(demb.t(), c.y, self.G(pe + "projection.weight").view(d, 64 * hw), beta=1.0)
         ops.colsum_acc(demb, self.G(pe + "projection.bias"))
         dy = self._new(N, 64 * hw)
