@@ -243,7 +243,7 @@ extern "C" int db1_patch_embed_bwd(const void* demb, const void* const* weights,
     CK(db1_nchw_to_nhwc(dyn, t1, s.N, 64, hw, bf, stream));                                // t1 = dy (channels-last): gradient of the residual sum
     // conv3 (residual_path.5): weight / bias gradients, data gradient
     if (hipMemsetAsync(gp, 0, 64 * 576 * 4, st) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "patch_embed_bwd: memset");
-    CK(db1_conv3x3_implicit_wgrad(t1, a1, gp, s.N, gws, gws_b, stream));
+    CK(db1_conv3x3_implicit_wgrad(t1, a1, gp, nullptr, s.N, gws, gws_b, stream));
     CK(db1_conv_wgrad_unpermute(gp, grads[8], 64, 64, 576, stream));
     CK(db1_colsum_acc(t1, grads[9], s.rows, 64, 64, bf, gws, gws_b, stream));
     CK(db1_conv_weight_permute_t(weights[8], wt, 64, 64, bf, bf, stream));
@@ -251,7 +251,7 @@ extern "C" int db1_patch_embed_bwd(const void* demb, const void* const* weights,
     CK(db1_groupnorm_gelu_nhwc_bwd(t2, c2, weights[6], weights[7], m1, r1, t3, grads[6], grads[7], s.N, 64, hw, 32, bf, bf, gws, gws_b, stream));   // t3 = dc2
     // conv2 (residual_path.2)
     if (hipMemsetAsync(gp, 0, 64 * 576 * 4, st) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "patch_embed_bwd: memset");
-    CK(db1_conv3x3_implicit_wgrad(t3, a0, gp, s.N, gws, gws_b, stream));
+    CK(db1_conv3x3_implicit_wgrad(t3, a0, gp, nullptr, s.N, gws, gws_b, stream));
     CK(db1_conv_wgrad_unpermute(gp, grads[4], 64, 64, 576, stream));
     CK(db1_colsum_acc(t3, grads[5], s.rows, 64, 64, bf, gws, gws_b, stream));
     CK(db1_conv_weight_permute_t(weights[4], wt, 64, 64, bf, bf, stream));

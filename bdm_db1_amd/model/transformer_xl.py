@@ -477,12 +477,12 @@ class TransformerXL(nn.Module):
         wp = self._conv_operand_cl(wname, Cin)
         gp = torch.zeros(64, wp.shape[1], device=self.dev, dtype=torch.float32)
         implicit = Cin == 64 and cols.shape[1] == 64  # `cols` is the conv input
-        if implicit:
-            ops.conv3x3_implicit_wgrad(dy, cols, gp, N)
+        if implicit:   # (the bias gradient -- column sums of dy -- comes out of the same kernel)
+            ops.conv3x3_implicit_wgrad(dy, cols, gp, N, gbias_acc=self.G(bname))
         else:
             ops.gemm(dy.t(), cols, gp, beta=1.0)
+            ops.colsum_acc(dy, self.G(bname))
         ops.conv_wgrad_unpermute(gp, self.G(wname), 64, Cin)
-        ops.colsum_acc(dy, self.G(bname))
         if not need_dx:
             return None
         if implicit:

@@ -611,10 +611,10 @@ def conv3x3_implicit_fwd(x, w_op, bias, y, n_patches, sign=1):
     lib.call("db1_conv3x3_implicit_fwd", P(x), P(w_op), P(bias), P(y), n_patches, sign, dt_code(bias) if bias is not None else 0, stream())
 
 
-def conv3x3_implicit_wgrad(dy, x, gp_acc, n_patches):
+def conv3x3_implicit_wgrad(dy, x, gp_acc, n_patches, gbias_acc=None):
     assert gp_acc.dtype == torch.float32 and gp_acc.shape[-1] == 576
     ws, wsn = _ws("db1_conv3x3_implicit_wgrad_workspace_bytes", (int(n_patches),), dy.device)   # fixed-order partial sums: bit-reproducible
-    lib.call("db1_conv3x3_implicit_wgrad", P(dy), P(x), P(gp_acc), n_patches, ws, wsn, stream())
+    lib.call("db1_conv3x3_implicit_wgrad", P(dy), P(x), P(gp_acc), P(gbias_acc), n_patches, ws, wsn, stream())
 
 
 def groupnorm_gelu_nhwc_fwd(x, gamma, beta, y, mean, rstd, N, C, hw, groups=32, eps=1e-5):

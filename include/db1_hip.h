@@ -367,7 +367,8 @@ int db1_conv_weight_permute_t(const void* w, void* wp, int Cout, int Cin, int dt
 int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const void* bias, void* y, int64_t n_patches, int sign, int dtBias,
                              void* stream);
 int64_t db1_conv3x3_implicit_wgrad_workspace_bytes(int64_t n_patches);   /* per-pixel-range partial sums: with them the result is bit-reproducible */
-int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, int64_t n_patches, void* ws, int64_t ws_bytes, void* stream);
+int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, float* gbias_acc /* optional [64]: += column sums of dy (the bias gradient) */,
+                               int64_t n_patches, void* ws, int64_t ws_bytes, void* stream);
 int db1_groupnorm_gelu_nhwc_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                                 int64_t N, int C, int hw, int groups, float eps, int dt, int dtParam, void* stream);
 int64_t db1_groupnorm_gelu_nhwc_bwd_workspace_bytes(int64_t N);   /* per-sample parameter-gradient rows, summed in a fixed order (without: fp32 atomics) */

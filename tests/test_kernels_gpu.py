@@ -894,5 +894,11 @@ def test_implicit_3x3_convolutions(ops):
     gw_ref = (dy.T @ cols).reshape(64, C, 9).transpose(0, 2, 1).reshape(64, 576)       # tap-major columns
     g0 = rng.standard_normal((64, 576)).astype(np.float32)
     gp = dev(g0)
-    ops.conv3x3_implicit_wgrad(dev16(dy), X, gp, N)
+    b0 = rng.standard_normal(64).astype(np.float32)
+    gb = dev(b0)
+    ops.conv3x3_implicit_wgrad(dev16(dy), X, gp, N, gbias_acc=gb)
     close(gp, g0 + gw_ref, 1e-5, name="implicit conv wgrad")
+    close(gb, b0 + dy.sum(0), 1e-5, name="implicit conv bias gradient (column sums of dy from the same kernel)")
+    gp2, gb2 = dev(g0), dev(b0)
+    ops.conv3x3_implicit_wgrad(dev16(dy), X, gp2, N, gbias_acc=gb2)
+    assert torch.equal(gp2, gp) and torch.equal(gb2, gb)       # fixed-order partial sums: bit-reproducible
