@@ -27,6 +27,7 @@ struct ConvArgs {
     int64_t n_patches;
     int sign, ksplit;
     float* part;          // wgrad: per-pixel-range partial sums [ksplit][64][576] (deterministic mode), or null (fp32 atomics onto y)
+    const bf16_t* res;    // fwd: optional residual [n_patches * 256, 64] added in the epilogue (y = conv + bias + res)
     float* gbias;         // wgrad: optional bias gradient [64] (accumulated): column sums of dY from the A fragments the kernel holds anyway
     float* part_bias;     // ... its partial sums [ksplit][64] in the deterministic mode
 };
@@ -97,6 +98,27 @@ __global__ __launch_bounds__(256, 2) void conv_implicit_kernel(ConvArgs p) {
         cur ^= 1;
     }
     bf16_t* Y = (bf16_t*)p.y + pix0 * CI_C;
+    if (p.res) {   // (the residual sum of the block, vision_embedding.py:84: one pass over two [pixels, 64] tensors less than a separate add)
+        const bf16_t* Rr = p.res + pix0 * CI_C;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int m = wave * 64 + i * 16 + (lane & 15), n = j * 16 + (lane >> 4) * 4;
+                const uint2 rv = *reinterpret_cast<const uint2*>(Rr + (int64_t)m * CI_C + n);
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (p.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] += ldf((const TBIAS*)p.bias + n + r);
+                }
+                v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+                v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+                uint2 o;
+                o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]);
+                *reinterpret_cast<uint2*>(Y + (int64_t)m * CI_C + n) = o;
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -220,14 +242,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------- host side
+extern "C" int db1_conv3x3_implicit_fwd_res(const void* x, const void* w_op, const void* bias, const void* res, void* y, int64_t n_patches, int sign,
+                                            int dtBias, void* stream);
 extern "C" int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const void* bias, void* y, int64_t n_patches, int sign, int dtBias,
                                         void* stream) {
+    return db1_conv3x3_implicit_fwd_res(x, w_op, bias, nullptr, y, n_patches, sign, dtBias, stream);
+}
+extern "C" int db1_conv3x3_implicit_fwd_res(const void* x, const void* w_op, const void* bias, const void* res, void* y, int64_t n_patches, int sign,
+                                            int dtBias, void* stream) {
+    if (res && !db1_aligned16(res)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "conv3x3_implicit_fwd: residual must be 16-byte aligned");
     if (n_patches <= 0 || (sign != 1 && sign != -1)) DB1_FAIL(DB1_ERR_BAD_SHAPE, "conv3x3_implicit_fwd: n_patches=%lld sign=%d", (long long)n_patches, sign);
     if (!x || !w_op || !y || !db1_aligned16(x) || !db1_aligned16(w_op) || !db1_aligned16(y)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "conv3x3_implicit_fwd: operands must be 16-byte aligned");
     if (n_patches > 8000000) DB1_FAIL(DB1_ERR_BAD_SHAPE, "conv3x3_implicit_fwd: too many patches");
     ConvArgs a;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w_op; a.y = y; a.bias = bias; a.n_patches = n_patches; a.sign = sign; a.ksplit = 1; a.part = nullptr;
-    a.gbias = nullptr; a.part_bias = nullptr;
+    a.gbias = nullptr; a.part_bias = nullptr; a.res = (const bf16_t*)res;
     static Db1PerDeviceOnce attr_once;
     attr_once.run([] {
         hipFuncSetAttribute((const void*)conv_implicit_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CI_STAGE_BYTES);
@@ -262,7 +291,7 @@ extern "C" int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* 
     a.ksplit = ks;
     // with the workspace: per-range partial sums + a fixed-order reduce (bit-reproducible); without: fp32 atomics onto gp_acc
     a.part = (ws && ws_bytes >= db1_conv3x3_implicit_wgrad_workspace_bytes(n_patches) && db1_aligned16(ws)) ? (float*)ws : nullptr;
-    a.gbias = gbias_acc;
+    a.gbias = gbias_acc; a.res = nullptr;
     a.part_bias = (a.part && gbias_acc) ? a.part + (int64_t)ks * (CI_C * 9 * CI_C) : nullptr;
     static Db1PerDeviceOnce attr_once;
     attr_once.run([] { hipFuncSetAttribute((const void*)conv_wgrad_implicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); });

@@ -177,6 +177,7 @@ class TransformerXL(nn.Module):
         self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
         self._conv_ops = {}              # (weight name, weight version) -> tap-major GEMM operand
+        self.use_conv_res_epilogue = os.environ.get("DB1_CONV_RES", "1") != "0"   # residual sum of the patch block in the last convolution's epilogue
         self.use_proj_cl = os.environ.get("DB1_PROJ_CL", "1") != "0"   # channels-last patch embedder: projection against a column-permuted weight copy (no activation shuffles)
         self.use_decode = True           # inference with memory: K/V-cached path + fused decode attention when the shape allows
         self.use_decode_fused = True     # ... and, for <= 64 new tokens, linear maps as W streams that finish with GEGLU (post-LN)
@@ -459,15 +460,17 @@ class TransformerXL(nn.Module):
             self._conv_ops[key] = wt
         return self._conv_ops[key]
 
-    def _conv3x3_fwd_cl(self, x_cl, wname, bname, N, Cin):
+    def _conv3x3_fwd_cl(self, x_cl, wname, bname, N, Cin, out=None, res=None):
         """returns (output [N*256, 64], what the backward needs: the input itself for the implicit 64-channel convs, else the
-        column matrix)"""
+        column matrix); ``out`` / ``res``: write into this buffer / add this residual in the epilogue (implicit convolutions only)"""
         hw = self.patch_size * self.patch_size
         wp = self._conv_operand_cl(wname, Cin)
-        out = self._new(N * hw, 64)
         if Cin == 64 and self.use_implicit_conv:  # implicit GEMM: the shifted pixels are gathered by the LDS-DMA, no column matrix
-            ops.conv3x3_implicit_fwd(x_cl, wp, self.W(bname), out, N, sign=1)
+            out = self._new(N * hw, 64) if out is None else out
+            ops.conv3x3_implicit_fwd(x_cl, wp, self.W(bname), out, N, sign=1, res=res)
             return out, x_cl
+        assert out is None and res is None
+        out = self._new(N * hw, 64)
         cols = self._new(N * hw, wp.shape[1])
         ops.im2col3x3_nhwc(x_cl, cols, N, Cin, self.patch_size)
         ops.gemm(cols, wp.t(), out, bias=self.W(bname))
@@ -510,6 +513,17 @@ class TransformerXL(nn.Module):
         a1 = self._new(N * hw, 64)
         c.m1, c.r1 = self._new(N * 32, dtype=torch.float32), self._new(N * 32, dtype=torch.float32)
         ops.groupnorm_gelu_nhwc_fwd(c.c2, self.W(pe + "residual_path.3.weight"), self.W(pe + "residual_path.3.bias"), a1, c.m1, c.r1, N, 64, hw)
+        if self.use_proj_cl and self.use_implicit_conv and self.use_conv_res_epilogue:
+            # the last convolution adds the residual in its epilogue and writes straight into the projection's (row-padded) operand
+            Np = _round_up(N, 256) if N >= 512 else N
+            ypad = self._new(Np * hw, 64)
+            _, c.cols3 = self._conv3x3_fwd_cl(a1, pe + "residual_path.5.weight", pe + "residual_path.5.bias", N, 64, out=ypad[:N * hw], res=c.c1)
+            if Np > N:
+                ypad[N * hw:].zero_()
+            c.y, c.y_cl, c.Np = ypad.view(Np, hw * 64), True, Np
+            emb_pad = self._new(Np, d)
+            ops.gemm(c.y, self._proj_operand_cl().t(), emb_pad, bias=self.W(pe + "projection.bias"))
+            return emb_pad[:N], N
         c3, c.cols3 = self._conv3x3_fwd_cl(a1, pe + "residual_path.5.weight", pe + "residual_path.5.bias", N, 64)
         if self.use_proj_cl:
             # (y, x, c) flattening against the column-permuted projection weight.  The patch count of a mixed batch is whatever the data gives

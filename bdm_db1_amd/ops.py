@@ -606,8 +606,12 @@ def conv_weight_permute_t(w, wp, Cout, Cin):
     lib.call("db1_conv_weight_permute_t", P(w), P(wp), Cout, Cin, dt_code(w), dt_code(wp), stream())
 
 
-def conv3x3_implicit_fwd(x, w_op, bias, y, n_patches, sign=1):
+def conv3x3_implicit_fwd(x, w_op, bias, y, n_patches, sign=1, res=None):
     """64 -> 64 channel 3x3 conv on 16x16 patches, channels-last bf16, no column matrix (sign=-1: data gradient)"""
+    if res is not None:   # y = conv + bias + res
+        assert res.dtype == torch.bfloat16 and res.is_contiguous()
+        lib.call("db1_conv3x3_implicit_fwd_res", P(x), P(w_op), P(bias), P(res), P(y), n_patches, sign, dt_code(bias) if bias is not None else 0, stream())
+        return
     lib.call("db1_conv3x3_implicit_fwd", P(x), P(w_op), P(bias), P(y), n_patches, sign, dt_code(bias) if bias is not None else 0, stream())
 
 

@@ -366,6 +366,9 @@ int db1_conv_wgrad_unpermute(const float* gp, float* g_acc, int Cout, int Cin, i
 int db1_conv_weight_permute_t(const void* w, void* wp, int Cout, int Cin, int dtIn, int dtOut, void* stream);
 int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const void* bias, void* y, int64_t n_patches, int sign, int dtBias,
                              void* stream);
+/* same with a residual [n_patches * 256, 64] (bf16) added in the epilogue: y = conv + bias + res (the residual block's closing sum) */
+int db1_conv3x3_implicit_fwd_res(const void* x, const void* w_op, const void* bias, const void* res, void* y, int64_t n_patches, int sign,
+                                 int dtBias, void* stream);
 int64_t db1_conv3x3_implicit_wgrad_workspace_bytes(int64_t n_patches);   /* per-pixel-range partial sums: with them the result is bit-reproducible */
 int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, float* gbias_acc /* optional [64]: += column sums of dy (the bias gradient) */,
                                int64_t n_patches, void* ws, int64_t ws_bytes, void* stream);
