@@ -241,6 +241,66 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------- conv1 (3 -> 64)
+// The first convolution of the patch embedder (vision_embedding.py:44-50: 3 input channels, K = 27 padded to 32) as ONE streaming kernel per
+// patch: the 1.5 KB of pixels go to LDS, every lane gathers the 8 column-matrix entries of its (pixel, k-group) -- that 16-byte piece IS the
+// MFMA A fragment and is also stored as the column matrix the weight gradient contracts over -- and one v_mfma_f32_16x16x32_bf16 per
+// (16 pixels x 16 outputs) finishes the contraction.  Reads 1.5 KB, writes 16 + 32 KB per patch; it replaces a scalar im2col (27 two-byte
+// stores per pixel), a zero-padding pass and a K = 32 GEMM on the generic strided kernel: 3.3 ms -> ~0.7 ms at 60 160 patches.
+template <typename TBIAS>
+__global__ __launch_bounds__(256) void conv1_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const void* bias,
+                                                          bf16_t* __restrict__ cols, bf16_t* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) bf16_t px[CI_HW * 3 + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t pix0 = (int64_t)blockIdx.x * CI_HW;
+    if (tid < CI_HW * 3 / 8) *reinterpret_cast<uint4*>(px + tid * 8) = *reinterpret_cast<const uint4*>(x + pix0 * 3 + tid * 8);
+    const int xm = lane & 15, g = lane >> 4;
+    int off[8];          // LDS element offset of entry j relative to the pixel's own first channel, or a large negative marker for the zero padding k >= 27
+    int dyj[8], dxj[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int k = 8 * g + j, tap = k / 3, c = k - 3 * tap;
+        dyj[j] = k < 27 ? tap / 3 - 1 : 100;
+        dxj[j] = tap % 3 - 1;
+        off[j] = (dyj[j] * 16 + dxj[j]) * 3 + c;
+    }
+    bf16x8_t bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) bfr[j] = *reinterpret_cast<const bf16x8_t*>(wp + (j * 16 + xm) * 32 + 8 * g);
+    __syncthreads();
+    bf16_t* Y = y + pix0 * CI_C;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int yr = wave * 4 + i, pix = yr * 16 + xm;       // this lane's pixel of the tile = patch row yr
+        bf16x8_t af;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int yy = yr + dyj[j], xx = xm + dxj[j];
+            const bool in = yy >= 0 && yy < 16 && xx >= 0 && xx < 16;
+            const short v = (short)px[in ? pix * 3 + off[j] : 0];
+            af[j] = in ? v : (short)0;
+        }
+        *reinterpret_cast<bf16x8_t*>(cols + (pix0 + pix) * 32 + 8 * g) = af;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc, 0, 0, 0);  // swapped: D[n][m]
+            store_frag<bf16_t, TBIAS>(acc, Y, CI_C, pix, j * 16 + g * 4, 1.f, 0.f, bias);
+        }
+    }
+}
+extern "C" int db1_conv1_fused_fwd(const void* x, const void* w_op, const void* bias, void* cols, void* y, int64_t n_patches, int dtBias, void* stream) {
+    if (n_patches <= 0 || n_patches > 8000000) DB1_FAIL(DB1_ERR_BAD_SHAPE, "conv1_fused_fwd: n_patches=%lld", (long long)n_patches);
+    if (!x || !w_op || !cols || !y || !db1_aligned16(x) || !db1_aligned16(w_op) || !db1_aligned16(cols) || !db1_aligned16(y))
+        DB1_FAIL(DB1_ERR_BAD_ALIGN, "conv1_fused_fwd: operands must be 16-byte aligned");
+    if (bias && !db1_dt_ok(dtBias)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "conv1_fused_fwd: bias dtype");
+    hipStream_t st = (hipStream_t)stream;
+    if (bias && dtBias == DB1_BF16) conv1_fused_kernel<bf16_t><<<(unsigned)n_patches, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w_op, bias, (bf16_t*)cols, (bf16_t*)y);
+    else conv1_fused_kernel<float><<<(unsigned)n_patches, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w_op, bias, (bf16_t*)cols, (bf16_t*)y);
+    DB1_CHECK_LAUNCH("conv1_fused_fwd");
+    return DB1_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------- host side
 extern "C" int db1_conv3x3_implicit_fwd_res(const void* x, const void* w_op, const void* bias, const void* res, void* y, int64_t n_patches, int sign,
                                             int dtBias, void* stream);

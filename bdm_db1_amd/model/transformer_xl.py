@@ -177,6 +177,7 @@ class TransformerXL(nn.Module):
         self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
         self._conv_ops = {}              # (weight name, weight version) -> tap-major GEMM operand
+        self.use_conv1_fused = os.environ.get("DB1_CONV1_FUSED", "1") != "0"      # 3 -> 64 channel convolution as one streaming kernel
         self.use_conv_res_epilogue = os.environ.get("DB1_CONV_RES", "1") != "0"   # residual sum of the patch block in the last convolution's epilogue
         self.use_proj_cl = os.environ.get("DB1_PROJ_CL", "1") != "0"   # channels-last patch embedder: projection against a column-permuted weight copy (no activation shuffles)
         self.use_decode = True           # inference with memory: K/V-cached path + fused decode attention when the shape allows
@@ -471,6 +472,10 @@ class TransformerXL(nn.Module):
             return out, x_cl
         assert out is None and res is None
         out = self._new(N * hw, 64)
+        if Cin == 3 and wp.shape[1] == 32 and hw == 256 and self.use_conv1_fused:   # one streaming kernel: column matrix + convolution
+            cols = self._new(N * hw, 32)
+            ops.conv1_fused_fwd(x_cl, wp, self.W(bname), cols, out, N)
+            return out, cols
         cols = self._new(N * hw, wp.shape[1])
         ops.im2col3x3_nhwc(x_cl, cols, N, Cin, self.patch_size)
         ops.gemm(cols, wp.t(), out, bias=self.W(bname))

@@ -615,6 +615,12 @@ def conv3x3_implicit_fwd(x, w_op, bias, y, n_patches, sign=1, res=None):
     lib.call("db1_conv3x3_implicit_fwd", P(x), P(w_op), P(bias), P(y), n_patches, sign, dt_code(bias) if bias is not None else 0, stream())
 
 
+def conv1_fused_fwd(x_cl, w_op, bias, cols, y, n_patches):
+    """3 -> 64 channel 3x3 conv on 16x16 patches + its column matrix in one kernel (db1_conv1_fused_fwd)"""
+    assert x_cl.dtype == torch.bfloat16 and w_op.shape == (64, 32) and cols.shape[1] == 32 and y.shape[1] == 64
+    lib.call("db1_conv1_fused_fwd", P(x_cl), P(w_op), P(bias), P(cols), P(y), n_patches, dt_code(bias) if bias is not None else 0, stream())
+
+
 def conv3x3_implicit_wgrad(dy, x, gp_acc, n_patches, gbias_acc=None):
     assert gp_acc.dtype == torch.float32 and gp_acc.shape[-1] == 576
     ws, wsn = _ws("db1_conv3x3_implicit_wgrad_workspace_bytes", (int(n_patches),), dy.device)   # fixed-order partial sums: bit-reproducible

@@ -369,6 +369,10 @@ int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const void* bias, 
 /* same with a residual [n_patches * 256, 64] (bf16) added in the epilogue: y = conv + bias + res (the residual block's closing sum) */
 int db1_conv3x3_implicit_fwd_res(const void* x, const void* w_op, const void* bias, const void* res, void* y, int64_t n_patches, int sign,
                                  int dtBias, void* stream);
+/* The 3 -> 64 channel convolution of 16x16 patches (channels-last bf16 [n_patches*256, 3]) in one streaming kernel: y [n_patches*256, 64] =
+ * conv + bias and, beside it, the column matrix cols [n_patches*256, 32] (tap-major, k = tap*3 + c, zero for k >= 27) that the weight
+ * gradient contracts over; w_op [64, 32] as db1_conv_weight_permute leaves it. */
+int db1_conv1_fused_fwd(const void* x, const void* w_op, const void* bias, void* cols, void* y, int64_t n_patches, int dtBias, void* stream);
 int64_t db1_conv3x3_implicit_wgrad_workspace_bytes(int64_t n_patches);   /* per-pixel-range partial sums: with them the result is bit-reproducible */
 int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, float* gbias_acc /* optional [64]: += column sums of dy (the bias gradient) */,
                                int64_t n_patches, void* ws, int64_t ws_bytes, void* stream);

@@ -902,3 +902,27 @@ def test_implicit_3x3_convolutions(ops):
     gp2, gb2 = dev(g0), dev(b0)
     ops.conv3x3_implicit_wgrad(dev16(dy), X, gp2, N, gbias_acc=gb2)
     assert torch.equal(gp2, gp) and torch.equal(gb2, gb)       # fixed-order partial sums: bit-reproducible
+
+
+def test_conv1_fused_kernel_equals_im2col_plus_gemm(ops):
+    """db1_conv1_fused_fwd (3 -> 64 channels on 16 x 16 patches, channels-last): its column matrix is bit-equal to db1_im2col3x3_nhwc's and its
+    output equals the K = 32 GEMM over that matrix up to the bf16 rounding of the result"""
+    rng = np.random.default_rng(21)
+    N = 37
+    x = dev16(rng.standard_normal((N * 256, 3)))
+    w = dev16(rng.standard_normal((64, 3, 3, 3)) * 0.2)
+    bias = dev16(rng.standard_normal(64) * 0.1)
+    wp = torch.empty(64, 32, device=DEV, dtype=torch.bfloat16)
+    ops.conv_weight_permute(w, wp, 64, 3)
+    cols_ref = torch.empty(N * 256, 32, device=DEV, dtype=torch.bfloat16)
+    ops.im2col3x3_nhwc(x, cols_ref, N, 3, 16)
+    y_ref = torch.empty(N * 256, 64, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(cols_ref, wp.t(), y_ref, bias=bias)
+    cols = torch.full((N * 256, 32), 7.0, device=DEV, dtype=torch.bfloat16)
+    y = torch.empty(N * 256, 64, device=DEV, dtype=torch.bfloat16)
+    ops.conv1_fused_fwd(x, wp, bias, cols, y, N)
+    assert torch.equal(cols, cols_ref)
+    err = (y.float() - y_ref.float()).abs().max().item() / y_ref.float().abs().max().item()
+    assert err < 1e-2, err
+    ref64 = cols_ref.double() @ wp.double().t() + bias.double()
+    assert (y.double() - ref64).abs().max().item() <= (y_ref.double() - ref64).abs().max().item() * 1.5 + 1e-3
