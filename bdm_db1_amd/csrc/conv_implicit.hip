@@ -333,7 +333,7 @@ static int ci_wgrad_ksplit(int64_t n_patches) {
     const int64_t nk = n_patches * (CI_HW / TBK);
     // 5 column tiles x ks pixel ranges workgroups, two per CU (64 KB of LDS each): 102 ranges = 510 workgroups are ONE round of the 512
     // slots (128 ranges = 640 left a second round a quarter full); DB1_CONV_WGRAD_KS overrides (A/B)
-    static const int env_ks = [] { const char* e = getenv("DB1_CONV_WGRAD_KS"); return e ? atoi(e) : 0; }();
+    const int env_ks = db1_knob(DB1_KNOB_CONV_WGRAD_KS, 0);   // A/B knob
     int ks = env_ks > 0 ? env_ks : 102;
     while (ks > 1 && nk / ks < 8) ks >>= 1;
     return ks;

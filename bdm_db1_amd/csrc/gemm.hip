@@ -211,15 +211,9 @@ static thread_local int g_force_generic = 0;
 static thread_local int g_tile_pref = 0;      // 0: measured heuristics; 128 / 256 / 512 / 1024: pin that tile kernel
 extern "C" void db1_test_gemm_force_generic(int on) { g_force_generic = on; }
 extern "C" void db1_test_gemm_tile_override(int tile) { g_tile_pref = tile; }
-// read-once process configuration for A/B measurements (immutable after the first GEMM call)
-struct GemmEnv {
-    int tile, splitk;
-    GemmEnv() {
-        const char* e = getenv("DB1_GEMM_TILE"); tile = e ? atoi(e) : 0;
-        const char* k = getenv("DB1_GEMM_SPLITK"); splitk = k ? atoi(k) : 1;   // DB1_GEMM_SPLITK=0 disables the workspace split-K
-    }
-};
-static const GemmEnv& gemm_env() { static const GemmEnv e; return e; }
+// A/B knobs (thread-local, test header): pin one tile kernel / disable the workspace split-K
+struct GemmEnv { int tile, splitk; };
+static GemmEnv gemm_env() { return GemmEnv{db1_knob(DB1_KNOB_GEMM_TILE, 0), db1_knob(DB1_KNOB_GEMM_SPLITK, 1)}; }
 
 // ---- the dispatcher's decision, separated from the launch so that the workspace query, the kernel-choice query and the call agree
 enum { GK_GENERIC = 0, GK_TILE128 = 1, GK_TILE256 = 2, GK_PP = 3, GK_PP32 = 4, GK_W4 = 5, GK_SKINNY = 6, GK_SPLITK = 16, GK_TAIL = 32 };

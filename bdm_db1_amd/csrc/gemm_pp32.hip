@@ -211,8 +211,7 @@ int db1_gemm_pp32_launch(const GemmTileArgs& t_in, int fa, int fb, int dtC, int 
     t.tiles_n = t.N / 256;
     t.ksplit = 1;
     dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch);
-    static int ns = -1;  // DB1_GEMM_PP32_STAGES=4|5 (A/B measurements)
-    if (ns < 0) { const char* e = getenv("DB1_GEMM_PP32_STAGES"); ns = e ? atoi(e) : 4; }   /* read once */  // measured: 4 stages (128 KiB) beat 5 (160 KiB) on every shape
+    const int ns = db1_knob(DB1_KNOB_PP32_STAGES, 4);   // A/B knob (4 | 5); measured: 4 stages (128 KiB) beat 5 (160 KiB) on every shape
 #define FORMS(NS_)                                                                            \
     if (fa == 0 && fb == 0) launch_pp32<true, true, NS_>(t, dtC, dtBias, grid, st);           \
     else if (fa == 0 && fb == 1) launch_pp32<true, false, NS_>(t, dtC, dtBias, grid, st);     \

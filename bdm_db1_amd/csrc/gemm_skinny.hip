@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_fused_kernel(SkinnyFusedArgs 
 extern "C" int64_t db1_linear_decode_tickets_bytes(void) { return (int64_t)DB1_SKINNY_TICKETS * 4; }
 static int skinny_fused_split(int M, int N, int K, int geglu) {
     (void)M;
-    static const int mode = [] { const char* e = getenv("DB1_LINEAR_DECODE_SPLITK"); return e ? atoi(e) : -1; }();   // 0 / 1: never split
+    const int mode = db1_knob(DB1_KNOB_LINEAR_DECODE_SPLITK, -1);   // A/B knob; 0 / 1: never split
     if (geglu || mode == 0 || mode == 1) return 1;
     const int groups = N / 16, ksteps = K / 64;
     int S = 1;

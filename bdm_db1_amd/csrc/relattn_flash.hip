@@ -1061,7 +1061,7 @@ extern "C" int db1_relattn_flash_fwd(const void* qu, const void* qv, const void*
         hipFuncSetAttribute((const void*)relattn_flash_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W16_FWD_LDS);
     });
     // plain causal window + kept probabilities (the training configuration): the hand-scheduled loop of relattn_flash_fwd2.hip
-    static const bool fwd2_off = getenv("DB1_FLASH_FWD2") && atoi(getenv("DB1_FLASH_FWD2")) == 0;   // A/B switch, read once
+    const bool fwd2_off = db1_knob(DB1_KNOB_FLASH_FWD2, 1) == 0;   // A/B knob
     if (probs && shift >= L && !fwd2_off && g_fwd2_on) return g_fwd2_on == 2 ? db1_relattn_flash_fwd2_launch(&a, stream) : db1_relattn_flash_fwd3_launch(&a, stream);
     if (probs) relattn_flash_fwd_kernel<true><<<dim3(flash_grid(L / FA_BQ, H, B)), 512, W16_FWD_LDS, (hipStream_t)stream>>>(a);
     else relattn_flash_fwd_kernel<false><<<dim3(flash_grid(L / FA_BQ, H, B)), 512, W16_FWD_LDS, (hipStream_t)stream>>>(a);
@@ -1111,7 +1111,7 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
         a.fblk = reinterpret_cast<float*>(ws);
         relattn_flash_bwd_q2_kernel<<<grid, 512, Q2_LDS, s>>>(a);
         DB1_CHECK_LAUNCH("relattn_flash_bwd_q2");
-        static const bool kv3_on = [] { const char* e = getenv("DB1_FLASH_KV3"); return !e || atoi(e) != 0; }();
+        const bool kv3_on = db1_knob(DB1_KNOB_FLASH_KV3, 1) != 0;   // A/B knob
         if (kv3_on && (L % KV3_KEYS) == 0) {   // a wave = 32 keys
             relattn_flash_bwd_kv3_kernel<<<dim3(flash_grid(L / KV3_KEYS, H, B)), 512, KV3_LDS, s>>>(a);
             DB1_CHECK_LAUNCH("relattn_flash_bwd_kv3");

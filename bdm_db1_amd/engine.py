@@ -213,7 +213,8 @@ class DB1Engine:
                      "global_steps": self.global_steps, "micro_steps": self.micro_steps,
                      # the dropout stream (counter-based Philox on (seed, site, step)): a resumed run continues it instead of replaying the
                      # masks of the first iterations
-                     "dropout": {"seed": int(self.module.dropout_seed), "step": int(self.module._drop_step)}}
+                     "dropout": {"seed": int(self.module.dropout_seed),
+                                 "step": int(self.module._drop_step_dev.item()) if self.module._drop_step_dev is not None else int(self.module._drop_step)}}
             state.update(client_state or {})
             torch.save(state, os.path.join(path, "mp_rank_00_model_states.pt"))
             with open(os.path.join(save_dir, "latest"), "w") as f:
@@ -248,6 +249,8 @@ class DB1Engine:
             if rank == 0:   # (the other ranks keep their own seed: seed + rank at construction; the step counter is common)
                 self.module.dropout_seed = int(state["dropout"]["seed"])
             self.module._drop_step = int(state["dropout"]["step"])
+            if self.module._drop_step_dev is not None:   # a hipGraph-captured step is active (graphed_train.py): its device counter follows
+                self.module._drop_step_dev.fill_(int(self.module._drop_step))
         client = {k: v for k, v in state.items() if k not in ("module", "optimizer", "lr_scheduler", "dropout")}
         return path, client
 

@@ -41,6 +41,8 @@ class GraphedTrainStep:
         model = engine.module
         if not model.training or model.keep_logits or not model.fuse_head_loss:
             raise ValueError("GraphedTrainStep captures the training micro-step with the fused head + loss (engine.train(), keep_logits=False)")
+        if engine.micro_steps % engine.gradient_accumulation_steps() != 0:
+            raise ValueError("GraphedTrainStep must be built on a gradient-accumulation boundary: its warm-up clears the gradient accumulators")
         self.engine, self.model = engine, model
         dev = model.dev
         self.static: List = []
@@ -125,12 +127,17 @@ class GraphedTrainStep:
             self.step_dev.add_(1)
             _, loss = model(self.static)
             eng.backward(loss)
+            model._drop_step += 1      # host mirror of the device counter (what engine.save_checkpoint stores)
             return loss
         fresh = bool(model._grad_fresh)
         self.graphs[fresh].replay()
         model._grad_fresh = False
         model._drop_step += 1          # (host mirror of the device counter: checkpoints / a later switch back to eager steps)
         return self.loss[fresh]
+
+    def resync_dropout_step(self):
+        """after engine.load_checkpoint(): the device counter follows the restored host counter"""
+        self.step_dev.fill_(int(self.model._drop_step))
 
     def close(self):
         """back to eager steps: the dropout counter returns to the host"""

@@ -73,8 +73,29 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.db1_is_experiment_build() and os.environ.get("DB1_ALLOW_EXPERIMENT") != "1":
+        raise Db1Error(f"{LIB_PATH} was compiled with -DDB1_EXPERIMENT (timing ablations with wrong results by construction, tools/exp): "
+                       "rebuild without DB1_EXTRA_HIPCC_FLAGS, or set DB1_ALLOW_EXPERIMENT=1 in the experiment script")
     _lib = lib
     return lib
+
+
+# A/B knobs of the dispatchers (include/db1_hip_test.h: db1_test_set_knob; thread-local in the library, never read from the environment by
+# the library itself).  Tuning scripts under tools/ keep their old switches by calling this once: DB1_W4=0 python tools/exp_w4.py ...
+KNOB_ENV = {"DB1_GEMM_TILE": "gemm_tile", "DB1_GEMM_SPLITK": "gemm_splitk", "DB1_GEMM_PP32_STAGES": "pp32_stages",
+            "DB1_LINEAR_DECODE_SPLITK": "linear_decode_splitk", "DB1_W4": "w4", "DB1_FLASH_FWD2": "flash_fwd2", "DB1_FLASH_KV3": "flash_kv3",
+            "DB1_CONV_WGRAD_KS": "conv_wgrad_ks"}
+
+
+def set_knob(name: str, value: int):
+    call("db1_test_set_knob", name.encode(), int(value))
+
+
+def apply_env_knobs():
+    """(tools / tests only) forward the DB1_* A/B environment switches of the calling script to the CURRENT thread's knobs"""
+    for env, knob in KNOB_ENV.items():
+        if env in os.environ:
+            set_knob(knob, int(os.environ[env]))
 
 
 def declared_symbols() -> List[str]:

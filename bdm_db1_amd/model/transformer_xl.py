@@ -67,9 +67,14 @@ class ParamArena:
         self.exp_avg_sq: Optional[torch.Tensor] = None
 
     def view(self, buf: torch.Tensor, name: str, full: bool = False) -> torch.Tensor:
-        # (views are cached per buffer: building one costs ~10 us of host time, and an inference layer asks for a dozen per call)
-        key = (buf.data_ptr(), buf.dtype, buf.numel(), name, full)
-        cache = self.__dict__.setdefault("_view_cache", {})
+        # (views are cached per buffer: building one costs ~10 us of host time, and an inference layer asks for a dozen per call.  The
+        # cache belongs to the buffer OBJECT -- an attribute of the tensor itself -- so a reallocated arena buffer (dtype / device move, a
+        # rebuilt engine) takes its views with it when it is freed instead of being kept alive by a stale entry here)
+        cache = buf.__dict__.get("_db1_views")
+        if cache is None:
+            cache = {}
+            buf._db1_views = cache
+        key = (name, full)
         v = cache.get(key)
         if v is None:
             off, shape, alloc = self.offsets[name]
@@ -1192,7 +1197,7 @@ class TransformerXL(nn.Module):
         h = embs[0] if len(embs) == 1 else torch.cat(embs, dim=0)  # concat on the batch dim (:541-545): data movement only
         B, L, _ = h.shape
         dstep = None
-        if self.training and mems is None and (self.drop_p > 0 or self.embd_pdrop > 0):
+        if self.training and mems is None and (self.drop_p > 0 or self.embd_pdrop > 0 or self.dropattn > 0):
             if self._drop_step_dev is not None:      # graph mode: step = 0 + the device counter (bumped by the captured graph itself)
                 dstep = 0
             else:

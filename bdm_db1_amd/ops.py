@@ -4,6 +4,8 @@ Python or in torch ops here, and nothing falls back to torch when a call fails."
 from __future__ import annotations
 
 import ctypes
+import os
+import threading
 from typing import Optional
 
 import torch
@@ -31,30 +33,38 @@ def P(t: Optional[torch.Tensor]):
     return _vp(t.data_ptr())
 
 
-_scope_stream = None   # (raw handle, c_void_p) of the stream a model call runs on, while it runs
+_tls = threading.local()   # .scope = (raw handle, c_void_p, device index) of the stream a model call runs on, while it runs -- per host thread
+_DEBUG_STREAM = bool(int(os.environ.get("DB1_DEBUG_STREAM", "0")))
+
+
+def _scope():
+    return getattr(_tls, "scope", None)
 
 
 class stream_scope:
     """``with ops.stream_scope():`` around a model forward / backward: the current stream is looked up ONCE (torch.cuda.current_stream()
     costs ~7 us of host time and every launch asks for it: a quarter of the host time of an eager inference call).  Nothing inside may
-    switch streams -- the model's own code never does."""
+    switch streams or devices -- the model's own code never does; ``DB1_DEBUG_STREAM=1`` checks every launch against torch's current
+    stream.  The scope is thread-local (one host thread per GPU / rank is the contract of include/db1_hip.h; two threads driving two
+    models never see each other's stream or scratch buffer)."""
 
     def __enter__(self):
-        global _scope_stream
-        self.prev = _scope_stream
+        self.prev = _scope()
         h = torch.cuda.current_stream().cuda_stream
-        _scope_stream = (h, _vp(h))
+        _tls.scope = (h, _vp(h), torch.cuda.current_device())
         return self
 
     def __exit__(self, *exc):
-        global _scope_stream
-        _scope_stream = self.prev
+        _tls.scope = self.prev
         return False
 
 
 def stream():
-    if _scope_stream is not None:
-        return _scope_stream[1]
+    sc = _scope()
+    if sc is not None:
+        if _DEBUG_STREAM and (torch.cuda.current_device() != sc[2] or torch.cuda.current_stream().cuda_stream != sc[0]):
+            raise lib.Db1Error("the current stream / device changed inside an ops.stream_scope()")
+        return sc[1]
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
@@ -72,7 +82,7 @@ class _Workspace:
         if nbytes <= 0:
             return _vp(0), 0
         key = (device.index if device.index is not None else torch.cuda.current_device(),
-               _scope_stream[0] if _scope_stream is not None else torch.cuda.current_stream(device).cuda_stream)
+               _scope()[0] if _scope() is not None else torch.cuda.current_stream(device).cuda_stream)
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)

@@ -228,6 +228,32 @@ def test_model_with_attention_dropout_matches_oracle_fp32(name):
 
 
 @pytest.mark.gpu
+def test_model_with_attention_dropout_only_matches_oracle_fp32():
+    """dropattn = 0.2 with drop = embd_pdrop = 0: the dropout step must still be created, the materialised attention path taken
+    and the probability masks applied -- loss, logits and gradients against the oracle under the same mask function, and the masks bite"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_model_gpu import to_inputs, rel_err
+    name = "small_window"
+    cfg, model, oracle, seed = _build(name, dict(drop=0.0, embd_pdrop=0.0, dropattn=0.2), torch.float32)
+    tasks = make_batch(name, cfg, seed)
+    model.train()
+    logits, loss = model(to_inputs(tasks))
+    assert model._drop_step == 1
+    ref_logits, ref_loss, _ = oracle.forward([O.TaskBatch(**t) for t in tasks], dropout={"seed": model.dropout_seed, "step": 1})
+    assert rel_err(logits, ref_logits) < 1e-4 and abs(float(loss) - ref_loss) < 2e-5 * max(1.0, abs(ref_loss))
+    model.arena.grad.zero_()
+    model.backward()
+    ref_grads = oracle.backward()
+    worst = max((rel_err(model.G(n), g), n) for n, g in ref_grads.items())
+    assert worst[0] < 1e-3, worst
+    model.eval()
+    _, loss_eval = model(to_inputs(tasks))
+    assert abs(float(loss_eval) - float(loss)) > 1e-5        # the probability masks really bite in train mode
+
+
+@pytest.mark.gpu
 def test_model_with_dropout_bf16_close_to_oracle():
     """bf16 path (register-resident LayerNorm kernels with the fused masks need d in {512, 1024, 2048}: d = 512 here).
     Stated tolerance: logits 3e-2 of max |logit|, loss 2e-2 abs, gradients 6e-2 of each tensor's max."""

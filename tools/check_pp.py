@@ -4,6 +4,7 @@ os.environ.setdefault("DB1_GEMM_TILE", "512")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bdm_db1_amd import ops
+from bdm_db1_amd import lib; lib.apply_env_knobs()   # DB1_* A/B switches of this script -> the library's thread-local knobs
 torch.manual_seed(0)
 bad = 0
 for (M, N, K) in [(256, 256, 64), (512, 768, 128), (512, 256, 320), (768, 512, 1024)]:

@@ -1,6 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bdm_db1_amd import ops
+from bdm_db1_amd import lib; lib.apply_env_knobs()   # DB1_* A/B switches of this script -> the library's thread-local knobs
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60160
 dy = torch.randn(n * 256, 64, device="cuda").bfloat16(); x = torch.randn(n * 256, 64, device="cuda").bfloat16()
 gp = torch.zeros(64, 576, device="cuda")

@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(__file__)); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 from bdm_db1_amd import ops
+from bdm_db1_amd import lib; lib.apply_env_knobs()   # DB1_* A/B switches of this script -> the library's thread-local knobs
 from bench_kernels import timeit
 
 DEV = "cuda"
