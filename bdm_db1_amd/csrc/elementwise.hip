@@ -509,6 +509,12 @@ __global__ __launch_bounds__(64 * CSR_WAVES) void colsum_part_reduce_strided_ker
     colsum_part_reduce_body(part, out, nchunks, cols, pitch);
 }
 
+int db1_colsum_part_reduce_launch(const float* part, float* out, int nchunks, int cols, hipStream_t st) {   // (gemm_geglu.hip)
+    colsum_part_reduce_kernel<<<(cols + 63) / 64, 64 * CSR_WAVES, 0, st>>>(part, out, nchunks, cols);
+    DB1_CHECK_LAUNCH("colsum_part_reduce");
+    return DB1_OK;
+}
+
 static inline unsigned grid_for(int64_t work_items) {
     int64_t b = (work_items + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;  // 16 blocks per CU, grid-stride beyond

@@ -33,6 +33,13 @@ struct GemmTileArgs {
     int split_n;
     void* Cu; void* Cv; const void* bias_u; const void* bias_v;
     int64_t ld_uv;
+    // GEGLU epilogues of the 4-wave kernel (gemm_w4.hip; 0 = off).  Forward (NT, db1_gemm_nt_geglu): B = W1 [2 dff, K], C = z [M, 2 dff] and
+    // Cact = z[:, :dff] * gelu(z[:, dff:]) [M, dff] leave the same accumulators.  Backward (NN, db1_gemm_nn_geglu_bwd): the product is
+    // dact [M, dff] = dy W2; the epilogue reads Zin = z and writes C = dz [M, 2 dff] plus the column sums of dz per 128-row block to colpart.
+    int geglu_dff = 0;
+    void* Cact = nullptr; int64_t ld_act = 0;
+    const bf16_t* Zin = nullptr; int64_t ld_z = 0;
+    float* colpart = nullptr;
 };
 
 // ---- staging of one 16 KiB operand (sub-)tile = 16 wave-instructions of 1 KiB, PIECES per wave (wave w takes w*PIECES ..)
@@ -216,5 +223,8 @@ int db1_gemm_pp_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBia
 bool db1_gemm_w4_supported(const GemmTileArgs& t, int fa, int fb, int dtC, int batch);
 int db1_gemm_w4_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);
 int db1_gemm_pp32_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);
+bool db1_gemm_w4_geglu_supported(int M, int dff, int K, int64_t lda, int64_t ldw, int64_t ldz, int64_t ld_other, bool fwd);
+int db1_gemm_w4_geglu_fwd_launch(const GemmTileArgs& t, int dtBias, hipStream_t st);
+int db1_gemm_w4_geglu_bwd_launch(const GemmTileArgs& t, hipStream_t st);
 int db1_gemm_skinny_launch(const bf16_t* x, const bf16_t* w, void* y, const void* bias, int M, int N, int K, int64_t ldx, int64_t ldw,
                            int64_t ldy, float alpha, float beta, int dtC, int dtBias, hipStream_t st);

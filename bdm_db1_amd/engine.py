@@ -47,6 +47,8 @@ class GradSync:
         assert stage is None or (stage.numel() == flat_grad.numel() and cast is not None)
         self.handles = []
         self.launched = set()
+        self.time_waits = False    # bench.py --gpus N: HIP-event pairs around the waits of finish() = the exposed communication
+        self.wait_events = []
 
     @property
     def reduced(self) -> torch.Tensor:
@@ -68,8 +70,15 @@ class GradSync:
         """launch whatever was not launched by a hook, then wait for everything"""
         for n in self.order:
             self.launch(n)
+        ev = None
+        if self.time_waits and self.handles and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for h in self.handles:
             h.wait()
+        if ev is not None:
+            ev[1].record()
+            self.wait_events.append(ev)
         self.handles = []
         self.launched = set()
 
@@ -194,6 +203,21 @@ class DB1Engine:
         self.module.mark_weights_changed()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step(1)
+
+    @property
+    def time_comm(self) -> bool:
+        return self.sync.time_waits
+
+    @time_comm.setter
+    def time_comm(self, on: bool):
+        self.sync.time_waits = bool(on)
+
+    def exposed_comm_ms(self) -> float:
+        """total time the compute stream spent waiting for bucket all-reduces since time_comm was switched on (synchronises)"""
+        torch.cuda.synchronize(self.module.device)
+        ms = float(sum(a.elapsed_time(b) for a, b in self.sync.wait_events))
+        self.sync.wait_events = []
+        return ms
 
     def get_global_grad_norm(self) -> float:
         """host-synchronising convenience (not used in the step path)"""

@@ -179,6 +179,7 @@ class TransformerXL(nn.Module):
         self.flash_probs_budget = 0.25   # "forward" only while the kept probabilities of all layers fit in this fraction of the device memory, else "scratch"
         self._probs_mode_cache = {}
         self.use_headbias_epilogue = True  # q + r_w_bias / q + r_r_bias written by the qkv projection's epilogue (large bf16 batches)
+        self.use_geglu_epilogue = os.environ.get("DB1_GEGLU_EPI", "1") != "0"   # GEGLU and its backward inside the feed-forward GEMMs' epilogues (large bf16 batches)
         self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
         self._conv_ops = {}              # (weight name, weight version) -> tap-major GEMM operand
@@ -1028,10 +1029,7 @@ class TransformerXL(nn.Module):
         ops.layernorm_residual_fwd(x, o, a, self.W(p + "dec_attn.layer_norm.weight"), self.W(p + "dec_attn.layer_norm.bias"),
                                    h1, o if keep else None, m1, r1, self.layer_norm_epsilon,
                                    drop=self._drop_args(self.drop_p, 4 * i, dstep))  # s1 = a x + dropout(o) overwrites o
-        z = self._new(T, di)
-        ops.gemm(h1, self.W(p + "pos_ff.CoreNet.0.weight").t(), z, bias=self.W(p + "pos_ff.CoreNet.0.bias"))
-        act = self._new(T, dff)
-        ops.ffn_act_fwd(z, act, self.activation_fn)
+        z, act = self._ff1_fwd(h1, p, T)
         f = self._new(T, d)
         ops.gemm(act, self.W(p + "pos_ff.CoreNet.2.weight").t(), f, bias=self.W(p + "pos_ff.CoreNet.2.bias"))
         out = self._new(T, d)
@@ -1043,6 +1041,33 @@ class TransformerXL(nn.Module):
             c.x, c.qkv, c.R, c.av, c.s1, c.m1, c.r1 = x, qkv, R, av, o, m1, r1
             c.h1, c.z, c.act, c.s2, c.m2, c.r2 = h1, z, act, f, m2, r2
         return out, c
+
+    # ---- PositionwiseFF halves with the activation inside the GEMM where the shape allows (db1_gemm_nt_geglu / db1_gemm_nn_geglu_bwd: the
+    # "bias + GEGLU" epilogue of SURVEY 8b; otherwise the same arithmetic as separate launches)
+    def _ff1_fwd(self, x, p, T):
+        """z = x W1^T + b1, act = GEGLU(z)  (transformer_xl.py:264-266, activations.py:19-32)"""
+        d, di, dff = self.d_model, self.d_inner, self.d_ff
+        z, act = self._new(T, di), self._new(T, dff)
+        W1, b1 = self.W(p + "pos_ff.CoreNet.0.weight"), self.W(p + "pos_ff.CoreNet.0.bias")
+        if self.use_geglu_epilogue and self.activation_fn == "geglu" and ops.gemm_nt_geglu_fused(T, dff, d, self.compute_dtype):
+            ops.gemm_nt_geglu(x, W1, b1, z, act)
+        else:
+            ops.gemm(x, W1.t(), z, bias=b1)
+            ops.ffn_act_fwd(z, act, self.activation_fn)
+        return z, act
+
+    def _ff2_dgrad(self, df, z, p, T):
+        """dz from df = d(loss)/d(CoreNet output): dact = df W2, through the activation; accumulates the first bias's gradient"""
+        d, di, dff = self.d_model, self.d_inner, self.d_ff
+        dz = self._new(T, di)
+        W2, gb1 = self.W(p + "pos_ff.CoreNet.2.weight"), self.G(p + "pos_ff.CoreNet.0.bias")
+        if self.use_geglu_epilogue and self.activation_fn == "geglu" and ops.gemm_nn_geglu_bwd_fused(T, dff, d, self.compute_dtype):
+            ops.gemm_nn_geglu_bwd(df, W2, z, dz, gb1)
+        else:
+            dact = self._new(T, dff)
+            ops.gemm(df, W2, dact)
+            ops.ffn_act_bwd_bias(z, dact, dz, gb1, self.activation_fn)
+        return dz
 
     # ---- pre-LN ordering of the same kernels (config default `--pre-lnorm True`; transformer_xl.py:126-137,231-233,277-282)
     def _layer_fwd_prelnorm(self, i, x, R_in, B, L, mlen, shift, mem, keep: bool, dec=None, dstep=None):
@@ -1078,10 +1103,7 @@ class TransformerXL(nn.Module):
         m2, r2 = self._new(T, dtype=torch.float32), self._new(T, dtype=torch.float32)
         ops.layernorm_residual_fwd(h1, None, 1.0, self.W(p + "pos_ff.layer_norm.weight"), self.W(p + "pos_ff.layer_norm.bias"),
                                    fin, None, m2, r2, self.layer_norm_epsilon)
-        z = self._new(T, di)
-        ops.gemm(fin, self.W(p + "pos_ff.CoreNet.0.weight").t(), z, bias=self.W(p + "pos_ff.CoreNet.0.bias"))
-        act = self._new(T, dff)
-        ops.ffn_act_fwd(z, act, self.activation_fn)
+        z, act = self._ff1_fwd(fin, p, T)
         out = self._new(T, d)
         ops.gemm(act, self.W(p + "pos_ff.CoreNet.2.weight").t(), out, bias=self.W(p + "pos_ff.CoreNet.2.bias"))
         if dstep is not None and self.drop_p > 0:
@@ -1103,10 +1125,7 @@ class TransformerXL(nn.Module):
             ops.dropout(dout, df, self._drop_args(self.drop_p, 4 * i + 1, dstep))
         ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=self._gb)
         ops.colsum_acc(df, G(p + "pos_ff.CoreNet.2.bias"))
-        dact = self._new(T, dff)
-        ops.gemm(df, W(p + "pos_ff.CoreNet.2.weight"), dact)
-        dz = self._new(T, di)
-        ops.ffn_act_bwd_bias(c.z, dact, dz, G(p + "pos_ff.CoreNet.0.bias"), self.activation_fn)
+        dz = self._ff2_dgrad(df, c.z, p, T)
         ops.gemm(dz.t(), c.fin, G(p + "pos_ff.CoreNet.0.weight"), beta=self._gb)
         dfin = self._new(T, d)
         ops.gemm(dz, W(p + "pos_ff.CoreNet.0.weight"), dfin)
@@ -1148,10 +1167,7 @@ class TransformerXL(nn.Module):
                                    dr_out=df if dropping else None, drop=self._drop_args(self.drop_p, 4 * i + 1, dstep))
         ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=self._gb)
         ops.colsum_acc(df, G(p + "pos_ff.CoreNet.2.bias"))
-        dact = self._new(T, dff)
-        ops.gemm(df, W(p + "pos_ff.CoreNet.2.weight"), dact)
-        dz = self._new(T, di)
-        ops.ffn_act_bwd_bias(c.z, dact, dz, G(p + "pos_ff.CoreNet.0.bias"), self.activation_fn)
+        dz = self._ff2_dgrad(df, c.z, p, T)
         ops.gemm(dz.t(), c.h1, G(p + "pos_ff.CoreNet.0.weight"), beta=self._gb)
         ops.gemm(dz, W(p + "pos_ff.CoreNet.0.weight"), ds2, beta=a)          # dh1 = a*ds2 + dz W1   (in place over ds2)
         dh1 = ds2

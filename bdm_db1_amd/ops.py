@@ -154,6 +154,11 @@ def _timed(family: str, work: float, run):
         run()
 
 
+def marker(tag: int):
+    """an empty kernel named db1_marker_kernel on the current stream (include/db1_hip_test.h): cuts a kernel trace to a region"""
+    lib.call("db1_test_marker", int(tag), stream())
+
+
 def _tri_fraction(M: int, K: int, mode: int, period: int, tm: int = 256, tk: int = 64) -> float:
     """share of the k-tiles a tile GEMM executes under a structural-zero hint for A (db1_gemm_strided_tri): a k-tile is skipped when
     it is zero for EVERY row of the m-tile (mode 1: k > m; mode 2: (k mod period) < m)"""
@@ -317,6 +322,39 @@ def ffn_act_bwd_bias(z, dout, dz, dbias_acc, act: str):
     ws, wsn = _ws("db1_ffn_act_bwd_bias_workspace_bytes", (rows, n, ACT_CODES[act]), z.device)
     _timed("ffn_act_bwd", float((z.numel() + dout.numel() + dz.numel()) * z.element_size()),
            lambda: lib.call("db1_ffn_act_bwd_bias", P(z), P(dout), P(dz), P(dbias_acc), rows, n, ACT_CODES[act], dt_code(z), ws, wsn, stream()))
+
+
+def gemm_nt_geglu_fused(M: int, dff: int, K: int, dtype, lda=None, ldw=None, ldz=None, ldact=None) -> bool:
+    """does db1_gemm_nt_geglu run the activation inside the GEMM's epilogue at this shape (else: separate launches)"""
+    return bool(lib.load().db1_gemm_nt_geglu_fused(M, dff, K, dt_code(dtype), lda or K, ldw or K, ldz or 2 * dff, ldact or dff))
+
+
+def gemm_nn_geglu_bwd_fused(M: int, dff: int, K: int, dtype, lddy=None, ldw=None, ldz=None, lddz=None) -> bool:
+    return bool(lib.load().db1_gemm_nn_geglu_bwd_fused(M, dff, K, dt_code(dtype), lddy or K, ldw or dff, ldz or 2 * dff, lddz or 2 * dff))
+
+
+def gemm_nt_geglu(x, w1, bias, z, act):
+    """z = x w1^T + bias  [M, 2 dff]   and   act = z[:, :dff] * gelu(z[:, dff:])  [M, dff]   (PositionwiseFF's first half, one launch where fused)"""
+    M, K = x.shape
+    dff = act.shape[1]
+    assert w1.shape == (2 * dff, K) and z.shape == (M, 2 * dff) and x.stride(1) == 1 and w1.stride(1) == 1 and z.stride(1) == 1 and act.stride(1) == 1
+    assert bias is None or bias.dtype == x.dtype
+    ws, wsn = _ws("db1_gemm_workspace_bytes", (M, 2 * dff, K, dt_code(x), dt_code(w1), dt_code(z), x.stride(0), 1, 1, w1.stride(0), z.stride(0), 1, 1, 1), x.device)
+    _timed("gemm", 2.0 * M * 2 * dff * K,
+           lambda: lib.call("db1_gemm_nt_geglu", P(x), P(w1), P(bias), P(z), P(act), M, dff, K, x.stride(0), w1.stride(0), z.stride(0), act.stride(0),
+                            dt_code(x), ws, wsn, stream()))
+
+
+def gemm_nn_geglu_bwd(dy, w2, z, dz, dbias_acc):
+    """dz = GEGLU'(z) applied to dact = dy w2 (w2 [K, dff] row-major; dact is never stored); dbias_acc [2 dff] fp32 += column sums of dz"""
+    M, K = dy.shape
+    dff = w2.shape[1]
+    assert w2.shape[0] == K and z.shape == (M, 2 * dff) and dz.shape == (M, 2 * dff) and dbias_acc.dtype == torch.float32 and dbias_acc.numel() == 2 * dff
+    assert dy.stride(1) == 1 and w2.stride(1) == 1 and z.stride(1) == 1 and dz.stride(1) == 1
+    ws, wsn = _ws("db1_gemm_nn_geglu_bwd_workspace_bytes", (M, dff, K, dt_code(dy), dy.stride(0), w2.stride(0), z.stride(0), dz.stride(0)), dy.device)
+    _timed("gemm", 2.0 * M * dff * K,
+           lambda: lib.call("db1_gemm_nn_geglu_bwd", P(dy), P(w2), P(z), P(dz), P(dbias_acc), M, dff, K, dy.stride(0), w2.stride(0), z.stride(0), dz.stride(0),
+                            dt_code(dy), ws, wsn, stream()))
 
 
 def colsum_acc(x2d, out_acc):

@@ -21,6 +21,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+FAMILY_NOTE = ("bf16 MFMA tile GEMM family gemm_bf16_{w4,w4n,pp,pp32,tile256,tile}_kernel + splitk_reduce_kernel: every tile-GEMM launch of the timed steps "
+               "(decoder layers incl. the batched dR contraction and split-K reduces, and the three head products of the chunked head + loss sweep with its "
+               "ce_fwd_bwd / ce_sum kernels), rank 0; FLOPs = executed work: the vocabulary pad of the head and k-tiles skipped as structural zeros are not counted")
 FLOP_PER_TOKEN = 6_899_036_160       # fwd+bwd, DB1-1.3B, L=1024, causal-counted attention (SURVEY.md 8d / BASELINE.md 4)
 FLOP_PER_PATCH = 317_227_008         # image-patch embedder fwd+bwd
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak, MI355X_MICROARCH.md
@@ -33,56 +36,75 @@ HBM_PEAK_GBPS = 8000.0               # HBM3E peak, MI355X_MICROARCH.md
 REFERENCE_CPU_TOKENS_PER_S_8_CORES = 56.0
 
 
-def cpu_baseline(repeats: int = 3):
-    """The CPU oracle (oracle/db1_oracle.py, NumPy + OpenBLAS, fp32) timed on this box's host cores on a bounded sample of the SAME
-    workload: DB1-1.3B geometry, ONE 1024-token sequence, forward + backward through k = 1 and k = 2 of the 24 decoder layers plus
-    the tied head and loss, each measured ``repeats`` times after one untimed run (median taken); tokens/s is extrapolated to 24
-    layers from the per-layer difference.  Reported baseline only (rank 0, N = 1)."""
+def _oracle_params(O, rng, d, H, k, vocab):
+    f = np.float32
+    params = {"r_w_bias": (rng.standard_normal((H, d // H)) * 0.02).astype(f), "r_r_bias": (rng.standard_normal((H, d // H)) * 0.02).astype(f),
+              "word_embedding.weight": (rng.standard_normal((vocab, d)) * 0.02).astype(f)}
+    for i in range(k):
+        p = f"h.{i}."
+        params[p + "dec_attn.qkv_net.weight"] = (rng.standard_normal((3 * d, d)) * 0.02).astype(f)
+        params[p + "dec_attn.o_net.weight"] = (rng.standard_normal((d, d)) * 0.02).astype(f)
+        params[p + "dec_attn.r_net.weight"] = (rng.standard_normal((d, d)) * 0.02).astype(f)
+        params[p + "pos_ff.CoreNet.0.weight"] = (rng.standard_normal((4 * d, d)) * 0.02).astype(f)
+        params[p + "pos_ff.CoreNet.0.bias"] = np.zeros(4 * d, f)
+        params[p + "pos_ff.CoreNet.2.weight"] = (rng.standard_normal((d, 2 * d)) * 0.02).astype(f)
+        params[p + "pos_ff.CoreNet.2.bias"] = np.zeros(d, f)
+        for ln in ("dec_attn.layer_norm", "pos_ff.layer_norm"):
+            params[p + ln + ".weight"], params[p + ln + ".bias"] = np.ones(d, f), np.zeros(d, f)
+    return params
+
+
+def _time_oracle(O, cfg, params, ids, repeats):
+    model = O.OracleModel(cfg, params, dtype=np.float32)
+    task = O.TaskBatch(kind="nlp", text_seq=ids[:, :-1], label=ids[:, 1:], loss_mask=np.ones((ids.shape[0], ids.shape[1] - 1), np.float32))
+    ts = []
+    for r in range(repeats + 1):   # the first run pays first-touch page faults and BLAS thread start-up: not timed
+        t0 = time.perf_counter()
+        model.forward([task])
+        model.backward()
+        if r:
+            ts.append(time.perf_counter() - t0)
+    return ts
+
+
+def cpu_baseline(repeats: int = 5):
+    """The CPU oracle (oracle/db1_oracle.py, NumPy + OpenBLAS, fp32) timed on this box's host cores, SURVEY 8d's recipe (median of 5 after
+    one untimed run): (1) BASELINE config 1 -- DB1-tiny (2 layers, d = 128, 4 heads) on 8 x 256 tokens, forward + loss + backward, whole;
+    (2) a bounded sample of the benchmarked workload -- DB1-1.3B geometry, ONE 1024-token sequence (config 2 at B = 1), forward + backward
+    through k = 1 and k = 2 of the 24 decoder layers plus the tied head and loss; tokens/s is extrapolated to 24 layers from the per-layer
+    difference.  Reported baseline only (rank 0, N = 1)."""
     from oracle import db1_oracle as O
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count() or 1
-    d, H, L = 2048, 16, 1024
+    fmt = lambda v: "/".join(f"{x:.2f}" for x in v)
     rng = np.random.default_rng(0)
+    # ---- config 1: DB1-tiny, 8 x 256 tokens (seed 0), the whole model
+    cfg_t = O.OracleConfig(n_embed=128, n_layer=2, n_head=4, n_position=256, mem_len=256)
+    ts_t = _time_oracle(O, cfg_t, _oracle_params(O, rng, 128, 4, 2, cfg_t.total_vocab_size), rng.integers(0, 32000, (8, 257)), repeats)
+    tiny = {"value": round(8 * 256 / float(np.median(ts_t)), 1), "unit": "tokens/s", "seconds": [round(x, 3) for x in ts_t],
+            "sample": "BASELINE config 1: DB1-tiny (2 layers, d 128, 4 heads, vocabulary 33 025), 8 x 256 tokens, fwd + loss + bwd, fp32, median of "
+                      f"{repeats} after one untimed run"}
+    # ---- config 2 at B = 1: DB1-1.3B geometry
+    d, H, L = 2048, 16, 1024
     med, runs = {}, {}
     for k in (1, 2):
         cfg = O.OracleConfig(n_embed=d, n_layer=k, n_head=H, n_position=L, mem_len=L)
-        params = {}
-        f = np.float32
-        params["r_w_bias"], params["r_r_bias"] = (rng.standard_normal((H, d // H)) * 0.02).astype(f), (rng.standard_normal((H, d // H)) * 0.02).astype(f)
-        params["word_embedding.weight"] = (rng.standard_normal((cfg.total_vocab_size, d)) * 0.02).astype(f)
-        for i in range(k):
-            p = f"h.{i}."
-            params[p + "dec_attn.qkv_net.weight"] = (rng.standard_normal((3 * d, d)) * 0.02).astype(f)
-            params[p + "dec_attn.o_net.weight"] = (rng.standard_normal((d, d)) * 0.02).astype(f)
-            params[p + "dec_attn.r_net.weight"] = (rng.standard_normal((d, d)) * 0.02).astype(f)
-            params[p + "pos_ff.CoreNet.0.weight"] = (rng.standard_normal((4 * d, d)) * 0.02).astype(f)
-            params[p + "pos_ff.CoreNet.0.bias"] = np.zeros(4 * d, f)
-            params[p + "pos_ff.CoreNet.2.weight"] = (rng.standard_normal((d, 2 * d)) * 0.02).astype(f)
-            params[p + "pos_ff.CoreNet.2.bias"] = np.zeros(d, f)
-            for ln in ("dec_attn.layer_norm", "pos_ff.layer_norm"):
-                params[p + ln + ".weight"], params[p + ln + ".bias"] = np.ones(d, f), np.zeros(d, f)
-        model = O.OracleModel(cfg, params, dtype=np.float32)
-        ids = rng.integers(0, 32000, (1, L + 1))
-        task = O.TaskBatch(kind="nlp", text_seq=ids[:, :-1], label=ids[:, 1:], loss_mask=np.ones((1, L), np.float32))
-        ts = []
-        for r in range(repeats + 1):   # the first run pays first-touch page faults and BLAS thread start-up: not timed
-            t0 = time.perf_counter()
-            model.forward([task])
-            model.backward()
-            if r:
-                ts.append(time.perf_counter() - t0)
-        runs[k], med[k] = ts, float(np.median(ts))
+        runs[k] = _time_oracle(O, cfg, _oracle_params(O, rng, d, H, k, cfg.total_vocab_size), rng.integers(0, 32000, (1, L + 1)), repeats)
+        med[k] = float(np.median(runs[k]))
     per_layer = max(med[2] - med[1], 1e-9)
     fixed = max(med[1] - per_layer, 0.0)
     full = fixed + 24 * per_layer
-    fmt = lambda v: "/".join(f"{x:.2f}" for x in v)
     return {"value": round(L / full, 2), "unit": "tokens/s", "cores": int(threads), "kind": "port",
             "sample": f"DB1-1.3B geometry, 1 sequence x 1024 tokens, fwd+bwd, fp32 NumPy/OpenBLAS oracle; 1 and 2 decoder layers + tied head, "
                       f"median of {repeats} timed runs each after one untimed run ({fmt(runs[1])} s; {fmt(runs[2])} s), extrapolated to 24 layers "
-                      f"({full:.1f} s/sequence); {os.cpu_count()} logical CPUs on the box, {threads} BLAS threads",
+                      f"({full:.1f} s/sequence); {os.cpu_count()} logical CPUs on the box, {threads} BLAS threads.  Why {threads} threads do not beat the "
+                      f"reference's 8-core figure: at ONE sequence the layer's GEMMs are 1024-row products (34 GFLOP per layer, forward) that OpenBLAS "
+                      f"cannot spread over more than a few dozen cores, and the attention part runs per (head) as 16 batched 1024 x 1024 x 128 products "
+                      f"plus NumPy elementwise passes over [16, 1024, 1024] fp32 tensors that are single-threaded and memory-bound",
+            "tiny_config1": tiny,
             "reference_torch_cpu": {"value": REFERENCE_CPU_TOKENS_PER_S_8_CORES, "unit": "tokens/s", "cores": 8,
                                     "note": "the reference's own torch-CPU forward+backward at the same geometry, timed by the survey in its "
                                             "container (SURVEY.md section 6); context only, not re-timed on this box"}}
@@ -142,6 +164,62 @@ def decode_leg(model, dev, calls: int = 30):
         out = {"ms_per_call": None, "error": repr(e)}
     model.train(was_training)
     return out
+
+
+def mixture_leg(engine, model, dev, cfg, B, L, seed, steps: int = 5, warmup: int = 2):
+    """BASELINE config 5 / north_star's target workload on the SAME model and engine, right after the text steps: the mixed-modal
+    pre-training step (50 % RL-trajectory rows with image-patch observations, 25 % text, 25 % caption; synth.mixture_batch) -- forward +
+    backward + clip + Adam, ``steps`` timed steps after ``warmup`` untimed ones, bracketed by device synchronisation like the main leg."""
+    from bdm_db1_amd import synth
+    try:
+        batch = synth.mixture_batch(B, L, seed, dev, cfg)
+        n_patches = 0
+        for t in batch:
+            if getattr(t, "img_seq", None) is not None:
+                n_patches += t.img_seq.shape[0] * (t.img_seq.shape[2] // 16) * (t.img_seq.shape[3] // 16)
+            if getattr(t, "vision_seq", None) is not None:
+                v = t.vision_seq
+                n_patches += v.shape[0] * v.shape[1] * (v.shape[3] // 16) * (v.shape[4] // 16)
+
+        def step():
+            _, loss = engine(batch)
+            engine.backward(loss)
+            engine.step()
+            return loss
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        flops = B * L * FLOP_PER_TOKEN + n_patches * FLOP_PER_PATCH
+        return {"workload": f"DB1-1.3B mixed-modal pre-training step (BASELINE config 5 stand-in: {batch[0].tensor_seq.shape[0]} RL-trajectory rows with 3x64x80 "
+                            f"observation frames, {batch[1].text_seq.shape[0]} text rows, {batch[2].text_seq.shape[0]} caption rows with one 3x224x224 image each), "
+                            f"seq_len {L}, {B} sequences/GPU, same model / engine / dropout as the text steps",
+                "tokens_per_s": round(B * L / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "image_patches_per_step": int(n_patches),
+                "pct_mfma_peak_step": round(100.0 * flops / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 2), "final_loss": round(float(loss), 4),
+                "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)}
+    except Exception as e:   # the mixture leg must never take the bench line down
+        return {"tokens_per_s": None, "error": repr(e)}
+
+
+def rocprof_crosscheck(family_kernels_note: str):
+    """the newest committed per-kernel table of a rocprofv3 kernel trace cut to the timed steps of THIS command (tools/prof_step.sh ->
+    tools/prof_table.py -> profiles/r*_step_table.json): the same GEMM-family fraction, computed from the profiler's kernel durations"""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_table.json")))
+    if not cands:
+        return None
+    try:
+        rec = json.load(open(cands[-1]))
+        fam = rec["families"]["gemm"]
+        return {"frac": fam["frac"], "achieved": fam["achieved"], "ms_per_step": fam["ms_per_step"], "source": os.path.relpath(cands[-1], ROOT),
+                "note": "rocprofv3 --kernel-trace of an earlier run of this command on another box of the pool, cut to the timed steps by marker kernels; "
+                        "the same kernels as `frac`: " + family_kernels_note}
+    except Exception:
+        return None
 
 
 def self_launch(n: int) -> int:
@@ -230,6 +308,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the inference-with-memory leg after the timed steps")
+    ap.add_argument("--no-mixture", action="store_true", help="skip the mixed-modal leg (5 steps of the mixture workload on the same model) after the timed steps")
     ap.add_argument("--no-flash", action="store_true")
     ap.add_argument("--flash-probs", choices=["forward", "scratch", "recompute"], default="forward",
                     help="A/B: what the flash backward recomputes (nothing: the forward keeps p~ per layer / the query side only / both sides)")
@@ -314,16 +393,29 @@ def main():
     fence()
     timer = None if args.no_kernel_timing else ops.KernelTimer()
     ops.set_gemm_timer(timer)
+    engine.time_comm = world > 1          # event pairs around the wait for the bucket all-reduces (GradSync.finish): the exposed communication
+    ops.marker(1)                         # empty marker kernels: tools/prof_table.py cuts a rocprofv3 kernel trace to the timed steps
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    ops.marker(2)
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     ops.set_gemm_timer(None)
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dt, dp_info = dt_local, None
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        ts = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(ts, torch.tensor([dt_local], device=dev, dtype=torch.float64))
+        per_rank = [float(t.item()) for t in ts]
+        dt = max(per_rank)                                    # the job is as slow as its slowest rank
+        exposed = torch.tensor([engine.exposed_comm_ms()], device=dev, dtype=torch.float64)
+        dist.all_reduce(exposed, op=dist.ReduceOp.MAX)
+        dp_info = {"ms_per_step_per_rank": [round(t / args.steps * 1e3, 3) for t in per_rank],
+                   "ms_per_step_min": round(min(per_rank) / args.steps * 1e3, 3), "ms_per_step_max": round(max(per_rank) / args.steps * 1e3, 3),
+                   "exposed_comm_ms_per_step_max": round(float(exposed.item()) / args.steps, 3),
+                   "note": "exposed communication = time the compute stream waits in GradSync.finish for bucket all-reduces that were launched from the "
+                           "backward (HIP events around the waits, max over ranks); gradients cross xGMI in bf16, 25 per-layer buckets + embeddings"}
+    engine.time_comm = False
     loss_v = float(loss)
 
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2**30
@@ -345,9 +437,18 @@ def main():
         "final_loss": round(loss_v, 4),
         "peak_hbm_gib": round(peak_gb, 1),
     }
+    if dp_info is not None:
+        out["data_parallel"] = dp_info
     summ = timer.summary() if timer is not None else {}
     if "gemm" in summ:
+        # the dominant kernel family = EVERY bf16 tile-GEMM launch of the step: the decoder layers' products and the three head products of
+        # the chunked head + loss sweep (db1_lmhead_ce_fwd_bwd sequences them with its loss kernel behind ONE C call, so that call is timed
+        # as a whole: the ~2 ms per step of ce_fwd_bwd_kernel / ce_sum_kernel ride along, on both sides of the cross-check)
         ms, flops, launches = summ["gemm"]
+        ms_dec, flops_dec, launches_dec = ms, flops, launches
+        if "lmhead_ce" in summ:
+            hms, hflops, hn = summ["lmhead_ce"]
+            ms, flops, launches = ms + hms, flops + hflops, launches + hn
         ach = flops / (ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
         try:  # HBM-side bytes per tile-GEMM launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
@@ -363,15 +464,23 @@ def main():
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
                            "traffic_source": traffic_src,
-                           "kernel": "bf16 MFMA tile GEMM family gemm_bf16_{w4,pp,pp32,tile256,tile}_kernel (every tile-GEMM launch of the timed steps incl. the batched dR contraction and split-K reduces, rank 0); FLOPs = executed work: the vocabulary pad of the head and k-tiles skipped as structural zeros are not counted",
+                           "kernel": FAMILY_NOTE,
                            "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
                            "flop_per_launch_avg": round(flops / launches),
-                           "kernel_time_share_of_step": round(ms / (dt * 1e3), 4)}
+                           "flop_per_step": round(flops / args.steps), "ms_per_step": round(ms / args.steps, 3),
+                           "kernel_time_share_of_step": round(ms / (dt * 1e3), 4),
+                           "decoder_layers_only": {"achieved": round(flops_dec / (ms_dec * 1e-3) / 1e12, 1), "frac": round(flops_dec / (ms_dec * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                                   "launches": launches_dec, "ms_per_step": round(ms_dec / args.steps, 3)},
+                           "rocprof": rocprof_crosscheck(FAMILY_NOTE) if args.workload == "text" and B == 64 and args.ga == 1 else None}
+        out["roofline"]["rocprof_frac"] = out["roofline"]["rocprof"]["frac"] if out["roofline"]["rocprof"] else None
+        # work per step of every timed family (FLOPs or bytes): what tools/prof_table.py divides the profiler's kernel durations into
+        out["work_per_step"] = {fam: w / args.steps for fam, (_, w, _) in summ.items()}
         # the other kernels of the step against THEIR rooflines: algorithmic FLOPs or bytes / HIP-event time on the launch stream
         ks = {}
         for fam, (fms, work, n) in sorted(summ.items()):
             if fam == "gemm" or fms <= 0:
                 continue
+            # (lmhead_ce stays listed on its own as well: it is part of the roofline family above)
             mfma = fam.startswith("flash") or fam == "lmhead_ce"
             rate = work / (fms * 1e-3) / (1e12 if mfma else 1e9)
             peak = MFMA_BF16_PEAK_TFLOPS if mfma else HBM_PEAK_GBPS
@@ -403,6 +512,8 @@ def main():
         out["kernels"] = ks
     if gstep is not None:
         gstep.close()
+    if rank == 0 and world == 1 and not args.no_mixture and args.workload == "text" and args.ga == 1 and gstep is None:
+        out["mixture"] = mixture_leg(engine, model, dev, cfg, B, L, seed + 100)
     if rank == 0 and world == 1 and not args.no_decode and args.layers == 24:
         out["decode"] = decode_leg(model, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

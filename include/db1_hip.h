@@ -106,6 +106,20 @@ int db1_gemm_nn(const void* A, const void* B, void* C, const void* bias, int M, 
                 int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* ws, int64_t ws_bytes, void* stream);
 int db1_gemm_tn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
                 int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* ws, int64_t ws_bytes, void* stream);
+/* The "bias + GEGLU" epilogue of the feed-forward GEMMs (PositionwiseFF, transformer_xl.py:246-292; GEGLU = a * gelu_erf(b),
+ * activations.py:19-32).  Forward: Z[M, 2 dff] = A[M, K] * W1[2 dff, K]^T + bias AND ACT[M, dff] = Z[:, :dff] * gelu(Z[:, dff:]) from the
+ * same accumulators (ACT is computed from the ROUNDED Z, i.e. it equals db1_ffn_act_fwd on the stored Z bit for bit).  Backward:
+ * dact = dY[M, K] * W2[K, dff] is never stored; the epilogue reads Z and writes dZ[M, 2 dff] = (dact * gelu(g), dact * v * gelu'(g)) and
+ * dbias_acc[2 dff] (fp32) += the column sums of the stored dZ, added in a fixed order (the same arithmetic per element as db1_gemm_nn +
+ * db1_ffn_act_bwd_bias).  Large bf16 shapes run fused inside the 4-wave tile GEMM (..._fused() says which: 1 = fused, the separate
+ * activation passes over Z disappear); every other shape / dtype runs the equivalent separate launches.  dt: operands, Z, ACT, bias. */
+int db1_gemm_nt_geglu_fused(int M, int dff, int K, int dt, int64_t lda, int64_t ldw, int64_t ldz, int64_t ldact);
+int db1_gemm_nt_geglu(const void* A, const void* W1, const void* bias, void* Z, void* ACT, int M, int dff, int K,
+                      int64_t lda, int64_t ldw, int64_t ldz, int64_t ldact, int dt, void* ws, int64_t ws_bytes, void* stream);
+int db1_gemm_nn_geglu_bwd_fused(int M, int dff, int K, int dt, int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz);
+int64_t db1_gemm_nn_geglu_bwd_workspace_bytes(int M, int dff, int K, int dt, int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz);
+int db1_gemm_nn_geglu_bwd(const void* dY, const void* W2, const void* Z, void* dZ, float* dbias_acc, int M, int dff, int K,
+                          int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz, int dt, void* ws, int64_t ws_bytes, void* stream);
 /* which kernel db1_gemm_strided would pick: 0 = strided fp32-MFMA, 1 = bf16 MFMA tile kernel */
 int db1_gemm_would_use_fast(int M, int N, int K, int dtA, int dtB, int dtC,
                             int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs, int64_t c_cs);

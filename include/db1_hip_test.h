@@ -25,7 +25,8 @@ void db1_test_flash_fwd2(int on);
 /* A/B knobs of the dispatchers for measurements: THREAD-LOCAL (they affect calls made afterwards by the same host thread), unset by
  * default; the library never reads the environment.  Names: "gemm_tile" (128 | 256 | 512 | 1024: pin one tile kernel), "gemm_splitk" (0: no
  * workspace split-K), "pp32_stages" (4 | 5), "linear_decode_splitk" (0 | 1: never split), "w4" (0: the 8-wave GEMM kernels, 2: 4-wave for NT
- * only), "flash_fwd2" (0: the compiled flash-forward loop), "flash_kv3" (0: 16 keys per wave in the key-side backward), "conv_wgrad_ks".
+ * only), "flash_fwd2" (0: the compiled flash-forward loop), "flash_kv3" (0: 16 keys per wave in the key-side backward), "conv_wgrad_ks",
+ * "geglu_epi" (0: db1_gemm_nt_geglu / db1_gemm_nn_geglu_bwd run as separate GEMM + activation launches at every shape).
  * Returns 0, or DB1_ERR_BAD_SHAPE for an unknown name. */
 int db1_test_set_knob(const char* name, int value);
 void db1_test_clear_knobs(void);

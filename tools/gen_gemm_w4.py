@@ -119,7 +119,7 @@ class Gen:
                 out.append(f"v_mov_b32 v{b}, {rd}")
                 out += [f"v_xor_b32 v{b + f}, {f << 5}, v{b}" for f in range(1, 8)]
                 out += [f"v_add_u32 v{b + 8 + f}, 0x10000, v{b + f}" for f in range(8)]
-        for op, (v0, st) in enumerate((("%[voffa]", "%[pstepa]"), ("%[voffb]", "%[pstepb]"))):
+        for op, (v0, st, sub) in enumerate((("%[voffa]", "%[pstepa]", "%[suba]"), ("%[voffb]", "%[pstepb]", "%[subb]"))):
             b = VOFF + op * 8
             out.append(f"v_mov_b32 v{b}, {v0}")
             for it in range(1, 4):
@@ -127,8 +127,9 @@ class Gen:
                 if not self.km[op] and it == 2:
                     out.append(f"v_xor_b32 v{b + it}, 0x80, v{b + it}")   # k-rows 8..15 of a 16-row group: chunk index ^ 8
             if self.km[op]:
-                out.append(f"s_lshl_b32 s76, {st}, 4")                    # the second 128 rows: 16 pieces of 8 rows
-                out += [f"v_add_u32 v{b + 4 + it}, s76, v{b + it}" for it in range(4)]
+                # the second sub-tile of 128 rows: byte distance as an operand (normally 16 pieces of 8 rows = 128 rows further on; the
+                # GEGLU-epilogue NT kernel interleaves value and gate rows of W and places its sub-tiles 64 rows apart, gemm_w4.hip)
+                out += [f"v_add_u32 v{b + 4 + it}, {sub}, v{b + it}" for it in range(4)]
             else:
                 out += [f"v_add_u32 v{b + 4 + it}, 0x100, v{b + it}" for it in range(4)]   # 128 rows = 256 bytes further along the k-row
         for t in range(2):
