@@ -288,9 +288,14 @@ static GemmPlan gemm_plan(const GemmShape& g, bool aligned, int64_t ws_bytes) {
         int S = 0;
         for (int cand = 8; cand >= 2; cand >>= 1)
             if (wg * cand <= 288 && (K / TBK) % cand == 0 && (K / TBK) / cand >= 16) { S = cand; break; }   // (16: micro-batches of 4 sequences, K = 4096)
-        // half a wave of 256x256 tiles (ff2 dW: 128) in two slices: nothing at K = 16 384, but 1184 -> 978 us at K = 65 536 (the 256x128
-        // kernel it would otherwise take runs at 930 TFLOP/s, the ping-pong kernel at 1120 incl. the reduce)
-        const bool half_wave = pp_shape && fb == 1 && wg > 96 && wg <= 128 && S == 2 && (K / TBK) / S >= 256;
+        // half a wave of 256x256 tiles (128 of them) in two slices.  Round 1 measured the weight gradients of 64-sequence batches (ff2 dW: nothing
+        // at K = 16 384, 1184 -> 978 us at K = 65 536).  Round 4, micro-batches of 4 sequences (T = 4096, tools/bench_kernels.py gemm 4, 4-wave
+        // kernels): the data gradients with long contractions gain most -- dqkv NN K = 6144: 112 -> 92 us, dff1 NN K = 8192: 163 -> 119 us --, ff2 dW
+        // TN K = 4096: 91 -> 80 us, ff2 NT K = 4096: equal, and K = 2048 (o_net NT / NN) LOSES 15-20 % (16 k-tiles per slice do not pay for the
+        // second prologue + the reduce).  Rule: >= 32 k-tiles per slice when B is M-major, >= 48 when both operands are K-major.
+        const int hw_min = db1_knob(DB1_KNOB_GEMM_HALFWAVE, 0);   // A/B knob: > 0 = this many k-tiles per slice for every layout
+        const int hw_need = hw_min > 0 ? hw_min : (fb == 1 ? 32 : 48);
+        const bool half_wave = pp_shape && wg > 96 && wg <= 128 && S == 2 && (K / TBK) / S >= hw_need;
         // three quarters of a wave (qkv dW: 192 tiles) in four slices = three whole waves: 1310-1324 -> 1196-1221 us at K = 65 536 with
         // the 4-wave kernel (with the 8-wave kernels this gained 2 %)
         const bool three_quarters = pp_shape && fb == 1 && wg == 192 && (K / TBK) % 4 == 0 && (K / TBK) / 4 >= 128;

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from bdm_db1_amd import ops  # noqa: E402
+from bdm_db1_amd import ops, lib  # noqa: E402
+lib.apply_env_knobs()
 
 DEV = "cuda"
 
