@@ -175,22 +175,19 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const T* __restrict__ x
     ln_row_store<T, TP, NV>(a, mu, rs, gamma, beta, y + row * d, lane);
 }
 
-// CS: also the column sums of the branch gradient as STORED (dr_out when the branch was dropped, else ds): the gradient of the bias that was
-// added in front of the residual sum (the second feed-forward bias) from the same registers -- a third partial row per block
-template <typename T, typename TP, int NV, bool CS = false>
+template <typename T, typename TP, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ s, const TP* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ ds,
                                                            float* __restrict__ part, int64_t rows, int d, int rows_per_block,
                                                            T* __restrict__ dr_out, Db1Drop drp) {
     constexpr int V = Vec16<T>::N;
-    constexpr int NP = CS ? 3 : 2;
-    __shared__ float red[NP * 64 * V * NV];
+    __shared__ float red[2 * 64 * V * NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float gam[NV][V], ag[NV][V], ab[NV][V], ac[CS ? NV : 1][V];
+    float gam[NV][V], ag[NV][V], ab[NV][V];
 #pragma unroll
     for (int k = 0; k < NV; k++)
 #pragma unroll
-        for (int j = 0; j < V; j++) { gam[k][j] = ldf(gamma + (k * 64 + lane) * V + j); ag[k][j] = 0.f; ab[k][j] = 0.f; if (CS) ac[k][j] = 0.f; }
+        for (int j = 0; j < V; j++) { gam[k][j] = ldf(gamma + (k * 64 + lane) * V + j); ag[k][j] = 0.f; ab[k][j] = 0.f; }
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     for (int64_t row = r0 + wave; row < r1; row += 4) {
@@ -222,10 +219,6 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const T* __restrict__
                 if (drp.thr) db1_drop_apply<V>(drp, row * d + (k * 64 + lane) * V, o.v);
                 o.store(dr_out + row * d + (k * 64 + lane) * V);
             }
-            if (CS) {
-#pragma unroll
-                for (int j = 0; j < V; j++) ac[k][j] += sizeof(T) == 2 ? bf2f(f2bf(o.v[j])) : o.v[j];   // what was stored
-            }
         }
     }
     if (!part) return;
@@ -237,34 +230,32 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const T* __restrict__
 #pragma unroll
                 for (int j = 0; j < V; j++) {
                     const int c = (k * 64 + lane) * V + j;
-                    if (w == 0) { red[c] = ag[k][j]; red[d + c] = ab[k][j]; if (CS) red[2 * d + c] = ac[k][j]; }
-                    else { red[c] += ag[k][j]; red[d + c] += ab[k][j]; if (CS) red[2 * d + c] += ac[k][j]; }
+                    if (w == 0) { red[c] = ag[k][j]; red[d + c] = ab[k][j]; }
+                    else { red[c] += ag[k][j]; red[d + c] += ab[k][j]; }
                 }
         }
         __syncthreads();
     }
-    float* dst = part + (int64_t)blockIdx.x * NP * d;
-    for (int c = threadIdx.x; c < NP * d; c += 256) dst[c] = red[c];
+    float* dst = part + (int64_t)blockIdx.x * 2 * d;
+    for (int c = threadIdx.x; c < 2 * d; c += 256) dst[c] = red[c];
 }
 // 64 columns per workgroup; wave w adds the partial rows w, w+16, ... in order, then the 16 wave sums are added in wave order
 // (4 waves per workgroup left each wave a chain of nblocks / 4 dependent loads: 35 us per call, latency-bound)
 #define LNR_WAVES 16
-__global__ __launch_bounds__(64 * LNR_WAVES) void ln_param_reduce_kernel(const float* __restrict__ part, float* dgamma, float* dbeta, int nblocks, int d,
-                                                                          float* dcol = nullptr) {
+__global__ __launch_bounds__(64 * LNR_WAVES) void ln_param_reduce_kernel(const float* __restrict__ part, float* dgamma, float* dbeta, int nblocks, int d) {
     __shared__ float red[LNR_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;  // < np * d (d is a multiple of 64 here)
-    const int np = dcol ? 3 : 2;
+    const int c = blockIdx.x * 64 + lane;  // < 2 * d (d is a multiple of 64 here)
     float acc = 0.f;
 #pragma unroll 8
-    for (int b = wave; b < nblocks; b += LNR_WAVES) acc += part[(int64_t)b * np * d + c];
+    for (int b = wave; b < nblocks; b += LNR_WAVES) acc += part[(int64_t)b * 2 * d + c];
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0) {
         float t = red[0][lane];
 #pragma unroll
         for (int w = 1; w < LNR_WAVES; w++) t += red[w][lane];
-        if (c < d) dgamma[c] += t; else if (c < 2 * d) dbeta[c - d] += t; else dcol[c - 2 * d] += t;
+        if (c < d) dgamma[c] += t; else dbeta[c - d] += t;
     }
 }
 template <typename T> static int ln_reg_nv(int d) {  // NV such that d == 64 * V * NV, or 0
@@ -319,38 +310,10 @@ extern "C" int64_t db1_layernorm_residual_bwd_workspace_bytes(int64_t rows, int 
     const int rpb = ln_bwd_rpb(rows);
     return ((rows + rpb - 1) / rpb) * 2 * (int64_t)d * (int64_t)sizeof(float);
 }
-extern "C" int64_t db1_layernorm_residual_bwd_colsum_workspace_bytes(int64_t rows, int d, int dt) {
-    if (dt != DB1_BF16 || !ln_reg_nv<bf16_t>(d)) return db1_colsum_acc_workspace_bytes(rows, d);   // the separate column-sum pass
-    const int rpb = ln_bwd_rpb(rows);
-    return ((rows + rpb - 1) / rpb) * 3 * (int64_t)d * (int64_t)sizeof(float);
-}
-static int ln_bwd_impl(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd, void* ds, void* dr_out, float* dgamma_acc,
-                       float* dbeta_acc, float* dcol_acc, int64_t rows, int d, float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step,
-                       const uint32_t* drop_step_dev, int dt, int dtParam, void* ws_, int64_t ws_bytes, void* stream);
 extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                                           void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc, int64_t rows, int d,
                                           float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev, int dt,
                                           int dtParam, void* ws_, int64_t ws_bytes, void* stream) {
-    return ln_bwd_impl(dy, s, gamma, mean, rstd, ds, dr_out, dgamma_acc, dbeta_acc, nullptr, rows, d, drop_p, drop_seed, drop_site, drop_step, drop_step_dev, dt,
-                       dtParam, ws_, ws_bytes, stream);
-}
-extern "C" int db1_layernorm_residual_bwd_colsum(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
-                                                 void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc, float* dcol_acc, int64_t rows, int d,
-                                                 float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
-                                                 int dt, int dtParam, void* ws_, int64_t ws_bytes, void* stream) {
-    if (!dcol_acc || !dgamma_acc || !dbeta_acc) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd (column sums): null accumulator");
-    if (dt == DB1_BF16 && ln_reg_nv<bf16_t>(d))
-        return ln_bwd_impl(dy, s, gamma, mean, rstd, ds, dr_out, dgamma_acc, dbeta_acc, dcol_acc, rows, d, drop_p, drop_seed, drop_site, drop_step, drop_step_dev,
-                           dt, dtParam, ws_, ws_bytes, stream);
-    // other widths / fp32: the plain backward, then the column sums of the branch gradient as a separate pass (same result)
-    int rc = ln_bwd_impl(dy, s, gamma, mean, rstd, ds, dr_out, dgamma_acc, dbeta_acc, nullptr, rows, d, drop_p, drop_seed, drop_site, drop_step, drop_step_dev, dt,
-                         dtParam, nullptr, 0, stream);
-    if (rc) return rc;
-    return db1_colsum_acc(dr_out ? dr_out : ds, dcol_acc, rows, d, d, dt, ws_, ws_bytes, stream);
-}
-static int ln_bwd_impl(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd, void* ds, void* dr_out, float* dgamma_acc,
-                       float* dbeta_acc, float* dcol_acc, int64_t rows, int d, float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step,
-                       const uint32_t* drop_step_dev, int dt, int dtParam, void* ws_, int64_t ws_bytes, void* stream) {
     if (drop_p < 0.f || drop_p >= 1.f) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd: dropout p=%g", (double)drop_p);
     if (dr_out && !db1_aligned16(dr_out)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "layernorm bwd: dr_out alignment");
     const Db1Drop drp = db1_drop_make(drop_p, drop_seed, drop_site, drop_step, drop_step_dev);
@@ -365,18 +328,17 @@ static int ln_bwd_impl(const void* dy, const void* s, const void* gamma, const f
         const bool params = dgamma_acc && dbeta_acc;
         float* ws = nullptr;
         if (params) {
-            DB1_NEED_WS(ws_, ws_bytes, dcol_acc ? db1_layernorm_residual_bwd_colsum_workspace_bytes(rows, d, dt) : db1_layernorm_residual_bwd_workspace_bytes(rows, d, dt), "layernorm bwd");
+            DB1_NEED_WS(ws_, ws_bytes, db1_layernorm_residual_bwd_workspace_bytes(rows, d, dt), "layernorm bwd");
             ws = (float*)ws_;
         }
-#define LN_BWD_F(TP, NV, CS) ln_bwd_fused_kernel<bf16_t, TP, NV, CS><<<nblocks, 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)s, (const TP*)gamma, mean, rstd, (bf16_t*)ds, ws, rows, d, rpb, (bf16_t*)dr_out, drp)
-#define LN_BWD_NV(TP, CS) do { if (nv == 1) LN_BWD_F(TP, 1, CS); else if (nv == 2) LN_BWD_F(TP, 2, CS); else LN_BWD_F(TP, 4, CS); } while (0)
-        if (dcol_acc) { if (dtParam == DB1_BF16) LN_BWD_NV(bf16_t, true); else LN_BWD_NV(float, true); }
-        else { if (dtParam == DB1_BF16) LN_BWD_NV(bf16_t, false); else LN_BWD_NV(float, false); }
+#define LN_BWD_F(TP, NV) ln_bwd_fused_kernel<bf16_t, TP, NV><<<nblocks, 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)s, (const TP*)gamma, mean, rstd, (bf16_t*)ds, ws, rows, d, rpb, (bf16_t*)dr_out, drp)
+#define LN_BWD_NV(TP) do { if (nv == 1) LN_BWD_F(TP, 1); else if (nv == 2) LN_BWD_F(TP, 2); else LN_BWD_F(TP, 4); } while (0)
+        if (dtParam == DB1_BF16) LN_BWD_NV(bf16_t); else LN_BWD_NV(float);
 #undef LN_BWD_NV
 #undef LN_BWD_F
         DB1_CHECK_LAUNCH("layernorm bwd (fused)");
         if (params) {
-            ln_param_reduce_kernel<<<(dcol_acc ? 3 : 2) * d / 64, 64 * LNR_WAVES, 0, st>>>(ws, dgamma_acc, dbeta_acc, nblocks, d, dcol_acc);
+            ln_param_reduce_kernel<<<2 * d / 64, 64 * LNR_WAVES, 0, st>>>(ws, dgamma_acc, dbeta_acc, nblocks, d);
             DB1_CHECK_LAUNCH("layernorm bwd param reduce");
         }
         return DB1_OK;

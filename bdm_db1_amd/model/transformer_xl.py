@@ -1162,12 +1162,11 @@ class TransformerXL(nn.Module):
         # the forward's keep decisions (df, written by the same kernel from the same registers)
         ds2 = self._new(T, d)
         df = self._new(T, d) if dropping else ds2
-        # (the second feed-forward bias's gradient = column sums of df: from the LayerNorm backward's own registers, no pass over df)
         ops.layernorm_residual_bwd(dout, c.s2, W(p + "pos_ff.layer_norm.weight"), c.m2, c.r2, ds2,
                                    G(p + "pos_ff.layer_norm.weight"), G(p + "pos_ff.layer_norm.bias"),
-                                   dr_out=df if dropping else None, drop=self._drop_args(self.drop_p, 4 * i + 1, dstep),
-                                   dcol_acc=G(p + "pos_ff.CoreNet.2.bias"))
+                                   dr_out=df if dropping else None, drop=self._drop_args(self.drop_p, 4 * i + 1, dstep))
         ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=self._gb)
+        ops.colsum_acc(df, G(p + "pos_ff.CoreNet.2.bias"))
         dz = self._ff2_dgrad(df, c.z, p, T)
         ops.gemm(dz.t(), c.h1, G(p + "pos_ff.CoreNet.0.weight"), beta=self._gb)
         ops.gemm(dz, W(p + "pos_ff.CoreNet.0.weight"), ds2, beta=a)          # dh1 = a*ds2 + dz W1   (in place over ds2)

@@ -295,21 +295,11 @@ def layernorm_residual_fwd(x, r, alpha, gamma, beta, y, s_out, mean, rstd, eps, 
                             rows, d, float(eps), float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), _drop_dev(drop), dt_code(x), dt_code(gamma), stream()))
 
 
-def layernorm_residual_bwd(dy, s, gamma, mean, rstd, ds, dgamma_acc, dbeta_acc, dr_out=None, drop=NO_DROP, dcol_acc=None):
-    """``dr_out``: gradient of the (dropped) residual input r = ds under the forward's keep decisions; None when nothing was dropped.
-    ``dcol_acc`` [d] fp32: += column sums of that branch gradient as stored (the gradient of a bias added in front of the residual sum)"""
+def layernorm_residual_bwd(dy, s, gamma, mean, rstd, ds, dgamma_acc, dbeta_acc, dr_out=None, drop=NO_DROP):
+    """``dr_out``: gradient of the (dropped) residual input r = ds under the forward's keep decisions; None when nothing was dropped"""
     rows, d = dy.numel() // dy.shape[-1], dy.shape[-1]
-    nbytes = float(rows * d * dy.element_size() * (3 + (dr_out is not None)))   # dy, s in; ds [, dr] out
-    if dcol_acc is not None:
-        assert dcol_acc.dtype == torch.float32 and dcol_acc.numel() == d
-        ws, wsn = _ws("db1_layernorm_residual_bwd_colsum_workspace_bytes", (rows, d, dt_code(dy)), dy.device)
-        _timed("layernorm_bwd", nbytes,
-               lambda: lib.call("db1_layernorm_residual_bwd_colsum", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dr_out), P(dgamma_acc), P(dbeta_acc),
-                                P(dcol_acc), rows, d, float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), _drop_dev(drop), dt_code(dy), dt_code(gamma),
-                                ws, wsn, stream()))
-        return
     ws, wsn = _ws("db1_layernorm_residual_bwd_workspace_bytes", (rows, d, dt_code(dy)), dy.device)
-    _timed("layernorm_bwd", nbytes,
+    _timed("layernorm_bwd", float(rows * d * dy.element_size() * (3 + (dr_out is not None))),   # dy, s in; ds [, dr] out
            lambda: lib.call("db1_layernorm_residual_bwd", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dr_out), P(dgamma_acc), P(dbeta_acc),
                             rows, d, float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), _drop_dev(drop), dt_code(dy), dt_code(gamma), ws, wsn, stream()))
 

@@ -146,14 +146,6 @@ int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma,
                                int64_t rows, int d,
                                float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
                                int dt, int dtParam, void* ws, int64_t ws_bytes, void* stream);
-/* the same, and dcol_acc[d] (fp32) += the column sums of the branch gradient AS STORED (dr_out when the branch was dropped, else ds): the gradient
- * of a bias added in front of the residual sum (PositionwiseFF's second bias, transformer_xl.py:268) from the same pass instead of a separate
- * db1_colsum_acc over that tensor; fixed summation order.  dgamma_acc / dbeta_acc / dcol_acc must all be given. */
-int64_t db1_layernorm_residual_bwd_colsum_workspace_bytes(int64_t rows, int d, int dt);
-int db1_layernorm_residual_bwd_colsum(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
-                                      void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc, float* dcol_acc, int64_t rows, int d,
-                                      float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
-                                      int dt, int dtParam, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ dropout
  * y[e] = x[e] * keep(e) * 65536 / (65536 - thr),  thr = round(p * 65536)   (nn.Dropout, transformer_xl.py:409,545,575; y may alias x).

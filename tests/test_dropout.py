@@ -141,19 +141,6 @@ def test_layernorm_residual_with_fused_dropout(dtype, d):
     assert np.abs(dr.double().cpu().numpy() - dsq * mask).max() <= (1e-6 if dtype == "f32" else 8e-3) * np.abs(dsq).max()
     assert np.array_equal(dr.double().cpu().numpy() == 0, (mask == 0) | (dsq == 0))
     assert np.abs(dg.double().cpu().numpy() - (dy * xh).sum(0)).max() <= tol * np.abs((dy * xh).sum(0)).max() + 1e-6
-    # the variant that also hands back the column sums of the stored branch gradient (the bias in front of the residual sum): same ds / dr /
-    # parameter gradients, dcol == column sums of dr exactly as stored (fp32 summation order aside); and of ds when nothing is dropped
-    ds2, dr2 = torch.empty_like(ds), torch.empty_like(dr)
-    dg2, db2, dc2 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV), torch.full((d,), 0.5, device=DEV)
-    ops.layernorm_residual_bwd(_dev(dy, td), s, _dev(gam, td), mean, rstd, ds2, dg2, db2, dr_out=dr2, drop=drop, dcol_acc=dc2)
-    assert torch.equal(ds2, ds) and torch.equal(dr2, dr)
-    assert torch.allclose(dg2, dg, rtol=1e-5, atol=1e-6) and torch.allclose(db2, db, rtol=1e-5, atol=1e-6)
-    want = dr.double().sum(0).cpu().numpy() + 0.5
-    assert np.abs(dc2.double().cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
-    dc3 = torch.zeros(d, device=DEV)
-    ops.layernorm_residual_bwd(_dev(dy, td), s, _dev(gam, td), mean, rstd, ds2, dg2, db2, dcol_acc=dc3)
-    want = ds2.double().sum(0).cpu().numpy()
-    assert np.abs(dc3.double().cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max() + 1e-6
 
 
 def _build(name, over, dtype):
