@@ -9,10 +9,8 @@ timeout 900 python bench.py > $E/${TAG}_bench_default.json 2> $E/bench_default.e
 for w in caption rl mixture; do
   timeout 600 python bench.py --workload $w --no-cpu-baseline > $E/${TAG}_bench_${w}.json 2> $E/bench_$w.err </dev/null
 done
-# what the flash backward recomputes: same box, same commit
-for m in scratch recompute; do
-  timeout 600 python bench.py --flash-probs $m --no-cpu-baseline --steps 6 --warmup 2 > $E/${TAG}_bench_flash_${m}.json 2> $E/bench_flash_$m.err </dev/null
-done
+# the GEGLU epilogues of the feed-forward GEMMs against the separate activation passes: same box, same commit
+DB1_GEGLU_EPI=0 timeout 600 python bench.py --no-cpu-baseline --no-decode --no-mixture --steps 6 --warmup 2 > $E/${TAG}_bench_geglu_unfused.json 2> $E/bench_geglu_unfused.err </dev/null
 timeout 600 python tools/bench_kernels.py flash 64 > $E/${TAG}_flash_kernels.txt 2> $E/flash_kernels.err </dev/null
 timeout 600 python tools/bench_decode.py > $E/${TAG}_decode.txt 2> $E/decode.err </dev/null
 # the multi-rank path on this 1-GPU box: two ranks share the GPU, gloo instead of RCCL (which refuses two ranks on one device)
@@ -21,9 +19,11 @@ DB1_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --batch 16 --steps 3 
 BENCH_ARGS="--no-cpu-baseline" bash tools/prof_step.sh
 cp gpurun_out/step_stats.csv $E/${TAG}_kernel_stats_short.csv
 cp $(ls gpurun_out/prof_step/*kernel_stats.csv | head -1) $E/${TAG}_bench_b64_kernel_stats.csv
+cp gpurun_out/step_table.json $E/${TAG}_step_table.json; cp gpurun_out/step_table.txt $E/${TAG}_step_table.txt
 # the reference's own batch geometry: micro-batch 4 x gradient accumulation 16, eager and with the micro-step as a hipGraph
 timeout 600 python bench.py --batch 4 --ga 16 --steps 4 --warmup 2 --no-cpu-baseline --no-decode > $E/${TAG}_bench_b4_ga16.json 2> $E/bench_b4.err </dev/null
 timeout 600 python bench.py --batch 4 --ga 16 --graph --steps 4 --warmup 2 --no-cpu-baseline --no-decode > $E/${TAG}_bench_b4_ga16_graph.json 2> $E/bench_b4g.err </dev/null
+timeout 600 python bench.py --batch 8 --ga 8 --graph --steps 4 --warmup 2 --no-cpu-baseline --no-decode > $E/${TAG}_bench_b8_ga8_graph.json 2> $E/bench_b8g.err </dev/null
 if [ "$1" = "pmc" ]; then
   # PMC of the attention kernels (separate passes, no trace domains): matrix pipe, LDS conflicts, L2 hit rate, wave states
   bash tools/pmc_run.sh relattn_flash "flash 64" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" > /dev/null 2>&1
