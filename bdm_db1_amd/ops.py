@@ -120,10 +120,14 @@ class KernelTimer:
     kernel is launched on; nothing is synchronised until ``summary()``.  ``work`` is the ALGORITHMIC work of the launch: FLOPs actually
     executed for the MFMA-bound families ("gemm", "flash_fwd", "flash_bwd"), bytes for the HBM-bound kernels."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.rec = {}   # family -> [event pairs, summed work, launches]
+        self.only = None if only is None else set(only)   # time these families only (the others run uninstrumented)
 
     def wrap(self, family: str, work: float, fn):
+        if self.only is not None and family not in self.only:
+            fn()
+            return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
