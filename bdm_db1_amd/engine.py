@@ -107,6 +107,10 @@ class DB1Engine:
             ga = max(1, glob // (micro * self.dp_world)) if (micro and glob) else 1
         self._ga = int(ga)
         model.loss_grad_scale = 1.0 / self._ga
+        # gradient accumulation with the weight gradients formed ONCE per optimizer step (model.WgradStash: the operands of all micro-steps are
+        # kept -- 57 KB per token -- and dW = dy^T x runs over K = ga * T rows on the boundary micro-step): opt-in, `defer_wgrad=True`
+        self.defer_wgrad = bool(g("defer_wgrad", False)) and self._ga > 1
+        model.wgrad_defer_ga = self._ga if self.defer_wgrad else 0
         self.micro_steps = 0
         self.global_steps = 0
         self.beta1, self.beta2 = float(g("adam_beta1", 0.9)), float(g("adam_beta2", 0.999))
@@ -140,6 +144,7 @@ class DB1Engine:
 
     # ---- what the reference's drivers call
     def __call__(self, *a, **k):
+        self.module._wg_slot = self.micro_steps % self._ga
         return self.module(*a, **k)
 
     def __getattr__(self, name):  # attribute passthrough (model.init_mem, evaluate_rl.py:344)
@@ -171,7 +176,7 @@ class DB1Engine:
         per-layer buckets are all-reduced while the backward of the earlier layers is still running."""
         boundary = self.is_gradient_accumulation_boundary()
         hook = self.sync.launch if (boundary and self.overlap_comm and self.dp_world > 1) else None
-        self.module.backward(grad_scale=1.0 / self._ga, layer_done_hook=hook)
+        self.module.backward(grad_scale=1.0 / self._ga, layer_done_hook=hook, flush_wgrads=boundary)
         return loss
 
     def step(self):

@@ -75,20 +75,29 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):
             for _ in range(2):
                 self.step_dev.add_(1)
+                model._wg_slot = 0
                 _, loss = model(self.static)
-                model.backward(grad_scale=model.loss_grad_scale, layer_done_hook=None)
+                model.backward(grad_scale=model.loss_grad_scale, layer_done_hook=None, flush_wgrads=False)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         model.zero_grad()
         self.step_dev.fill_(int(model._drop_step))
-        for fresh in (True, False):
-            model._grad_fresh = fresh
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.step_dev.add_(1)
-                _, loss = model(self.static)
-                model.backward(grad_scale=model.loss_grad_scale, layer_done_hook=None)
-            self.graphs[fresh], self.loss[fresh] = g, loss
+        # one graph per (first / accumulating micro-step) -- and, with deferred weight gradients (engine option defer_wgrad), per micro-step
+        # of the accumulation window: each writes its operands into its own rows of the stash.  All graphs share one memory pool (they never
+        # run at the same time), so their intermediate buffers cost what one micro-step costs.
+        self.defer = bool(getattr(engine, "defer_wgrad", False)) and model.wgrad_defer_ga > 1
+        self.pool = torch.cuda.graph_pool_handle()
+        slots = range(engine.gradient_accumulation_steps()) if self.defer else (0,)
+        for slot in slots:
+            for fresh in ((True,) if (self.defer and slot == 0) else ((False,) if self.defer else (True, False))):
+                model._grad_fresh = fresh
+                model._wg_slot = slot
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.pool):
+                    self.step_dev.add_(1)
+                    _, loss = model(self.static)
+                    model.backward(grad_scale=model.loss_grad_scale, layer_done_hook=None, flush_wgrads=False)
+                self.graphs[(fresh, slot)], self.loss[(fresh, slot)] = g, loss
         model._grad_fresh = True
         model._ctx = None
 
@@ -125,15 +134,28 @@ class GraphedTrainStep:
         if eng.dp_world > 1 and boundary:
             # the bucket all-reduces are launched from inside this backward: eager, on the same device counter
             self.step_dev.add_(1)
+            model._wg_slot = eng.micro_steps % eng.gradient_accumulation_steps()
             _, loss = model(self.static)
             eng.backward(loss)
             model._drop_step += 1      # host mirror of the device counter (what engine.save_checkpoint stores)
             return loss
         fresh = bool(model._grad_fresh)
-        self.graphs[fresh].replay()
+        slot = eng.micro_steps % eng.gradient_accumulation_steps() if self.defer else 0
+        key = (fresh, slot)
+        if key not in self.graphs:
+            raise RuntimeError(f"GraphedTrainStep: no captured graph for micro-step {slot} of the window with fresh={fresh}: with deferred weight gradients the "
+                               "first micro-step of a window must follow an optimizer step (or zero_grad) and the others must not")
+        if self.defer:
+            st = model.wgrad_stash
+            st.slot = slot
+            if slot == 0:
+                st.beta = 0.0 if fresh else 1.0
+        self.graphs[key].replay()
         model._grad_fresh = False
         model._drop_step += 1          # (host mirror of the device counter: checkpoints / a later switch back to eager steps)
-        return self.loss[fresh]
+        if self.defer and boundary:    # the stashed weight gradients of the whole window: K = ga * T, outside the graph
+            model.flush_deferred_wgrads()
+        return self.loss[key]
 
     def resync_dropout_step(self):
         """after engine.load_checkpoint(): the device counter follows the restored host counter"""

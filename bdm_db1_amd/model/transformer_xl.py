@@ -87,6 +87,36 @@ class ParamArena:
             ops.cast(self.master, self.work)
 
 
+class WgradStash:
+    """Operands of the weight-gradient products of every decoder layer, kept for ALL micro-steps of an optimizer step (gradient
+    accumulation): for each of the four big linear maps of a layer its input x and its output gradient dy, [ga * T, width] each, micro-step
+    k in rows [k T, (k + 1) T).  The weight gradients are then formed ONCE per optimizer step, dW = dy^T x over K = ga * T rows, instead of
+    ga times over K = T with a read-modify-write of the fp32 accumulator each time: at the reference's geometry (micro-batch 4 x 1024 tokens,
+    16 micro-steps, scripts/evaluate/evaluate_rl_1.2B.sh:28-42) those K = 4096 products are a quarter of the step and run at half the rate of
+    the K = 65 536 ones.  57 KB per token: 90 GB of the 288 at 16 x 4096 tokens -- memory this part has and the reference's GPUs did not."""
+    KINDS = ("qkv", "o", "ff1", "ff2")
+
+    def __init__(self, model, T: int, ga: int):
+        d, di, dff = model.d_model, model.d_inner, model.d_ff
+        self.T, self.ga, self.n_layer = T, ga, model.n_layer
+        xw = {"qkv": d, "o": d, "ff1": d, "ff2": dff}
+        yw = {"qkv": 3 * d, "o": d, "ff1": di, "ff2": d}
+        new = lambda w: torch.empty(ga * T, w, device=model.dev, dtype=model.compute_dtype)
+        self.x = [{k: new(xw[k]) for k in self.KINDS} for _ in range(model.n_layer)]
+        self.dy = [{k: new(yw[k]) for k in self.KINDS} for _ in range(model.n_layer)]
+        self.slot = 0            # micro-step of the accumulation window the next forward / backward belongs to (set by the engine)
+        self.beta = 0.0          # beta of the flush: 0 when the gradient arena was fresh at slot 0
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for L in (self.x, self.dy) for dct in L for t in dct.values())
+
+    def xs(self, i: int, kind: str) -> torch.Tensor:
+        return self.x[i][kind][self.slot * self.T:(self.slot + 1) * self.T]
+
+    def dys(self, i: int, kind: str) -> torch.Tensor:
+        return self.dy[i][kind][self.slot * self.T:(self.slot + 1) * self.T]
+
+
 class _PendingLN(SimpleNamespace):
     """a layer output whose closing residual LayerNorm has not been applied yet: LN(alpha * res + y) * gamma + beta (inference path)"""
 
@@ -179,6 +209,9 @@ class TransformerXL(nn.Module):
         self.flash_probs_budget = 0.25   # "forward" only while the kept probabilities of all layers fit in this fraction of the device memory, else "scratch"
         self._probs_mode_cache = {}
         self.use_headbias_epilogue = True  # q + r_w_bias / q + r_r_bias written by the qkv projection's epilogue (large bf16 batches)
+        self.wgrad_stash: Optional[WgradStash] = None   # gradient accumulation: weight gradients formed once per optimizer step (engine option defer_wgrad)
+        self.wgrad_defer_ga = 0          # > 1: training forwards stash the weight-gradient operands of this many micro-steps (set by the engine)
+        self._wg_slot = 0                # micro-step index inside the accumulation window (set by the engine before every forward)
         self.use_geglu_epilogue = os.environ.get("DB1_GEGLU_EPI", "1") != "0"   # GEGLU and its backward inside the feed-forward GEMMs' epilogues (large bf16 batches)
         self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
@@ -782,10 +815,10 @@ class TransformerXL(nn.Module):
         ops.relattn_softmax_fwd(AC, T, None, H, B, Lq, Lk, nd, mlen, shift, 1.0 / math.sqrt(D))
         return AC, T, qu, qv
 
-    def _attention_fwd(self, qkv, R, i, B, Lq, Lk, mlen, shift, c: Optional[_Ctx], quv=None, dstep=None):
+    def _attention_fwd(self, qkv, R, i, B, Lq, Lk, mlen, shift, c: Optional[_Ctx], quv=None, dstep=None, av_out=None):
         H, D = self.n_head, self.d_head
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
-        av = self._new(B, Lq, H, D)
+        av = self._new(B, Lq, H, D) if av_out is None else av_out.view(B, Lq, H, D)
         pdrop = self._drop_args(self.dropattn, 4 * i + 2, dstep)     # dropout on the probabilities: materialised path only
         flash = (self.use_flash and mlen == 0 and Lq == Lk and shift >= 1 and ops.relattn_flash_supported(B, Lq, H, D, self.compute_dtype) and
                  pdrop is ops.NO_DROP)
@@ -897,14 +930,14 @@ class TransformerXL(nn.Module):
         dec.new_kv.append(kv_all[:, max(0, klen - self.mem_len):])
         return av
 
-    def _attention_bwd(self, dav, c: _Ctx, i, B, L, shift, dstep=None):
+    def _attention_bwd(self, dav, c: _Ctx, i, B, L, shift, dstep=None, dqkv_out=None):
         """returns dqkv [B*L, 3d] and dR [L, d]; accumulates du / dv_bias"""
         H, D, d = self.n_head, self.d_head, self.d_model
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
         qkv, R = c.qkv, c.R
         nd = R.shape[0]
         scale = 1.0 / math.sqrt(D)
-        dqkv = self._new(B * L, 3 * d)
+        dqkv = self._new(B * L, 3 * d) if dqkv_out is None else dqkv_out
         dqkv5 = dqkv.view(B, L, 3, H, D)
         qkv5 = qkv.view(B, L, 3, H, D)
         dav4 = dav.view(B, L, H, D)
@@ -966,6 +999,11 @@ class TransformerXL(nn.Module):
         p = f"h.{i}."
         c = _Ctx() if keep else None
         T = B * L
+        st = self._stash(T, keep) if (dec is None and mem is None) else None   # deferred weight gradients: inputs of the four linear maps live in the stash
+        if st is not None and x.data_ptr() != st.xs(i, "qkv").data_ptr():     # (layer 0: the embedding output; later layers were written there directly)
+            sx = st.xs(i, "qkv")
+            sx.copy_(x)
+            x = sx
         if dec is not None:  # K/V-cached inference: only the new tokens are projected (identical maths: qkv_net has no bias)
             qkv = self._new(T, 3 * d)
             if pend is not None:   # the previous layer left its closing LayerNorm to this projection, which also stores the rows to x
@@ -993,7 +1031,7 @@ class TransformerXL(nn.Module):
                 ops.gemm(xin, Wqkv.t(), qkv)
             R = self._new(R_in.shape[0], d)
             ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
-            av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c, quv=quv, dstep=dstep)
+            av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c, quv=quv, dstep=dstep, av_out=None if st is None else st.xs(i, "o"))
         if dec is not None and self._decode_fused_ok(T, keep, dstep):
             # few new tokens: every launch is latency, so the linear maps do the layer's small follow-up work themselves (db1_linear_decode):
             # GEGLU in the epilogue, and the residual LayerNorms either on the way IN to the next linear map (<= 16 tokens: no launch, no
@@ -1024,15 +1062,15 @@ class TransformerXL(nn.Module):
             return out, None
         o = self._new(T, d)
         ops.gemm(av.view(T, d), self.W(p + "dec_attn.o_net.weight").t(), o)
-        h1 = self._new(T, d)
+        h1 = self._new(T, d) if st is None else st.xs(i, "ff1")
         m1, r1 = self._new(T, dtype=torch.float32), self._new(T, dtype=torch.float32)
         ops.layernorm_residual_fwd(x, o, a, self.W(p + "dec_attn.layer_norm.weight"), self.W(p + "dec_attn.layer_norm.bias"),
                                    h1, o if keep else None, m1, r1, self.layer_norm_epsilon,
                                    drop=self._drop_args(self.drop_p, 4 * i, dstep))  # s1 = a x + dropout(o) overwrites o
-        z, act = self._ff1_fwd(h1, p, T)
+        z, act = self._ff1_fwd(h1, p, T, act=None if st is None else st.xs(i, "ff2"))
         f = self._new(T, d)
         ops.gemm(act, self.W(p + "pos_ff.CoreNet.2.weight").t(), f, bias=self.W(p + "pos_ff.CoreNet.2.bias"))
-        out = self._new(T, d)
+        out = self._new(T, d) if (st is None or i + 1 >= self.n_layer) else st.xs(i + 1, "qkv")   # the next layer's input, where its weight gradient will look for it
         m2, r2 = self._new(T, dtype=torch.float32), self._new(T, dtype=torch.float32)
         ops.layernorm_residual_fwd(h1, f, a, self.W(p + "pos_ff.layer_norm.weight"), self.W(p + "pos_ff.layer_norm.bias"),
                                    out, f if keep else None, m2, r2, self.layer_norm_epsilon,
@@ -1042,12 +1080,20 @@ class TransformerXL(nn.Module):
             c.h1, c.z, c.act, c.s2, c.m2, c.r2 = h1, z, act, f, m2, r2
         return out, c
 
+    def _stash(self, T: int, keep: bool) -> Optional[WgradStash]:
+        """the weight-gradient stash when this training forward / backward uses it (post-LN layers, bf16 or fp32, matching token count)"""
+        st = self.wgrad_stash
+        if st is None or not keep or not self.training or self.pre_lnorm or st.T != T or self.wgrad_defer_ga <= 1:
+            return None
+        return st
+
     # ---- PositionwiseFF halves with the activation inside the GEMM where the shape allows (db1_gemm_nt_geglu / db1_gemm_nn_geglu_bwd: the
     # "bias + GEGLU" epilogue of SURVEY 8b; otherwise the same arithmetic as separate launches)
-    def _ff1_fwd(self, x, p, T):
+    def _ff1_fwd(self, x, p, T, act=None):
         """z = x W1^T + b1, act = GEGLU(z)  (transformer_xl.py:264-266, activations.py:19-32)"""
         d, di, dff = self.d_model, self.d_inner, self.d_ff
-        z, act = self._new(T, di), self._new(T, dff)
+        z = self._new(T, di)
+        act = self._new(T, dff) if act is None else act
         W1, b1 = self.W(p + "pos_ff.CoreNet.0.weight"), self.W(p + "pos_ff.CoreNet.0.bias")
         if self.use_geglu_epilogue and self.activation_fn == "geglu" and ops.gemm_nt_geglu_fused(T, dff, d, self.compute_dtype):
             ops.gemm_nt_geglu(x, W1, b1, z, act)
@@ -1056,10 +1102,10 @@ class TransformerXL(nn.Module):
             ops.ffn_act_fwd(z, act, self.activation_fn)
         return z, act
 
-    def _ff2_dgrad(self, df, z, p, T):
+    def _ff2_dgrad(self, df, z, p, T, dz=None):
         """dz from df = d(loss)/d(CoreNet output): dact = df W2, through the activation; accumulates the first bias's gradient"""
         d, di, dff = self.d_model, self.d_inner, self.d_ff
-        dz = self._new(T, di)
+        dz = self._new(T, di) if dz is None else dz
         W2, gb1 = self.W(p + "pos_ff.CoreNet.2.weight"), self.G(p + "pos_ff.CoreNet.0.bias")
         if self.use_geglu_epilogue and self.activation_fn == "geglu" and ops.gemm_nn_geglu_bwd_fused(T, dff, d, self.compute_dtype):
             ops.gemm_nn_geglu_bwd(df, W2, z, dz, gb1)
@@ -1151,40 +1197,74 @@ class TransformerXL(nn.Module):
         ops.add(dx, dh1, dx)
         return dx
 
-    def _layer_bwd(self, i, dout, c: _Ctx, R_in, B, L, shift, dstep=None):
+    def _layer_bwd(self, i, dout, c: _Ctx, R_in, B, L, shift, dstep=None, flush=True):
         d, di, dff = self.d_model, self.d_inner, self.d_ff
         a = 1.0 if self.deepnorm_alpha is None else self.deepnorm_alpha
         p = f"h.{i}."
         T = B * L
         W, G = self.W, self.G
         dropping = dstep is not None and self.drop_p > 0
+        st = self._stash(T, True)   # deferred weight gradients: the four output gradients go to the stash, their products run once per optimizer step
         # ---- feed-forward.  s2 = a h1 + dropout(f): the residual branch takes ds2 as it is, the feed-forward branch takes it under
         # the forward's keep decisions (df, written by the same kernel from the same registers)
         ds2 = self._new(T, d)
-        df = self._new(T, d) if dropping else ds2
-        ops.layernorm_residual_bwd(dout, c.s2, W(p + "pos_ff.layer_norm.weight"), c.m2, c.r2, ds2,
+        if st is not None:
+            df = st.dys(i, "ff2")
+        else:
+            df = self._new(T, d) if dropping else ds2
+        ops.layernorm_residual_bwd(dout, c.s2, W(p + "pos_ff.layer_norm.weight"), c.m2, c.r2, ds2 if (dropping or st is None) else df,
                                    G(p + "pos_ff.layer_norm.weight"), G(p + "pos_ff.layer_norm.bias"),
                                    dr_out=df if dropping else None, drop=self._drop_args(self.drop_p, 4 * i + 1, dstep))
-        ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=self._gb)
+        if st is not None and not dropping:
+            ds2.copy_(df)                # (nothing dropped: df = ds2; the stash keeps it, the in-place dh1 below needs its own copy)
+        if st is None:
+            ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=self._gb)
         ops.colsum_acc(df, G(p + "pos_ff.CoreNet.2.bias"))
-        dz = self._ff2_dgrad(df, c.z, p, T)
-        ops.gemm(dz.t(), c.h1, G(p + "pos_ff.CoreNet.0.weight"), beta=self._gb)
+        dz = self._ff2_dgrad(df, c.z, p, T, dz=None if st is None else st.dys(i, "ff1"))
+        if st is None:
+            ops.gemm(dz.t(), c.h1, G(p + "pos_ff.CoreNet.0.weight"), beta=self._gb)
         ops.gemm(dz, W(p + "pos_ff.CoreNet.0.weight"), ds2, beta=a)          # dh1 = a*ds2 + dz W1   (in place over ds2)
         dh1 = ds2
         # ---- attention
         ds1 = self._new(T, d)
-        do = self._new(T, d) if dropping else ds1
-        ops.layernorm_residual_bwd(dh1, c.s1, W(p + "dec_attn.layer_norm.weight"), c.m1, c.r1, ds1,
+        if st is not None:
+            do = st.dys(i, "o")
+        else:
+            do = self._new(T, d) if dropping else ds1
+        ops.layernorm_residual_bwd(dh1, c.s1, W(p + "dec_attn.layer_norm.weight"), c.m1, c.r1, ds1 if (dropping or st is None) else do,
                                    G(p + "dec_attn.layer_norm.weight"), G(p + "dec_attn.layer_norm.bias"),
                                    dr_out=do if dropping else None, drop=self._drop_args(self.drop_p, 4 * i, dstep))
-        ops.gemm(do.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=self._gb)
+        if st is not None and not dropping:
+            ds1.copy_(do)
+        if st is None:
+            ops.gemm(do.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=self._gb)
         dav = self._new(T, d)
         ops.gemm(do, W(p + "dec_attn.o_net.weight"), dav)
-        dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift, dstep)
+        dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift, dstep, dqkv_out=None if st is None else st.dys(i, "qkv"))
         ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=self._gb)
-        ops.gemm(dqkv.t(), c.x, G(p + "dec_attn.qkv_net.weight"), beta=self._gb)
+        if st is None:
+            ops.gemm(dqkv.t(), c.x, G(p + "dec_attn.qkv_net.weight"), beta=self._gb)
         ops.gemm(dqkv, W(p + "dec_attn.qkv_net.weight"), ds1, beta=a)        # dx = a*ds1 + dqkv Wqkv (in place over ds1)
+        if st is not None and flush:
+            self._flush_layer_wgrads(i, st)
         return ds1
+
+    def _flush_layer_wgrads(self, i: int, st: WgradStash):
+        """the four weight gradients of layer i over every micro-step stashed so far: dW = dy^T x, K = (slot + 1) * T rows"""
+        p = f"h.{i}."
+        n = (st.slot + 1) * st.T
+        for kind, name in (("ff2", "pos_ff.CoreNet.2.weight"), ("ff1", "pos_ff.CoreNet.0.weight"), ("o", "dec_attn.o_net.weight"),
+                           ("qkv", "dec_attn.qkv_net.weight")):
+            ops.gemm(st.dy[i][kind][:n].t(), st.x[i][kind][:n], self.G(p + name), beta=st.beta)
+
+    def flush_deferred_wgrads(self):
+        """(a hipGraph-captured boundary micro-step stashes like the others; the products then run here, outside the graph)"""
+        st = self.wgrad_stash
+        if st is None:
+            return
+        with torch.cuda.device(self.dev), ops.stream_scope():
+            for i in reversed(range(self.n_layer)):
+                self._flush_layer_wgrads(i, st)
 
     # ------------------------------------------------------------------ public API
     def init_mem(self, batch_size):
@@ -1249,6 +1329,14 @@ class TransformerXL(nn.Module):
             ops.dropout(R_in, R_drop, self._drop_args(self.embd_pdrop, self.SITE_POS, dstep))
             R_in = R_drop
         x = h.view(B * L, d)
+        if self.wgrad_defer_ga > 1 and keep and self.training and not self.pre_lnorm and mems is None:
+            st = self.wgrad_stash
+            if st is None or st.T != B * L or st.ga != self.wgrad_defer_ga:
+                self.wgrad_stash = None          # (free the old buffers first)
+                st = self.wgrad_stash = WgradStash(self, B * L, self.wgrad_defer_ga)
+            if not 0 <= self._wg_slot < st.ga:
+                raise RuntimeError(f"weight-gradient stash: micro-step {self._wg_slot} of an accumulation window of {st.ga}")
+            st.slot = self._wg_slot
         hids, lcs = [], []
         for i in range(self.n_layer):
             kw = {}
@@ -1323,20 +1411,24 @@ class TransformerXL(nn.Module):
             res = res + (new_mems,)
         return res
 
-    def backward(self, grad_scale: float = 1.0, layer_done_hook=None):
+    def backward(self, grad_scale: float = 1.0, layer_done_hook=None, flush_wgrads: bool = True):
         """Accumulate d(loss * grad_scale)/d(params) of the last forward into the gradient arena.
         ``layer_done_hook(name)`` fires as soon as a layer's gradients are final (used by the data-parallel
-        engine to start that layer's bucket all-reduce while earlier layers are still in backward)."""
+        engine to start that layer's bucket all-reduce while earlier layers are still in backward).
+        ``flush_wgrads`` (only with a ``wgrad_stash``): form the stashed weight gradients in this backward (the last micro-step of an
+        accumulation window); False on the other micro-steps."""
         with torch.cuda.device(self.dev), ops.stream_scope():
-            return self._backward(grad_scale, layer_done_hook)
+            return self._backward(grad_scale, layer_done_hook, flush_wgrads)
 
-    def _backward(self, grad_scale, layer_done_hook):
+    def _backward(self, grad_scale, layer_done_hook, flush_wgrads=True):
         ctx = self._ctx
         if ctx is None:
             raise RuntimeError("backward() without a preceding forward(compute_loss=True)")
         self._ctx = None
         self._gb = 0.0 if self._grad_fresh else 1.0   # beta of the weight-gradient GEMMs: write on a fresh arena, accumulate otherwise
         self._grad_fresh = False
+        if self.wgrad_stash is not None and self.wgrad_stash.slot == 0:
+            self.wgrad_stash.beta = self._gb          # the flush of this accumulation window writes (fresh arena) or accumulates
         d, V = self.d_model, self.total_vocab_size
         B, L = ctx.B, ctx.L
         T = B * L
@@ -1355,7 +1447,10 @@ class TransformerXL(nn.Module):
             ops.gemm(dlogits, Wout, dh, useful_flops=2.0 * T * V * d)
             del dlogits
         for i in reversed(range(self.n_layer)):
-            dh = (self._layer_bwd_prelnorm if self.pre_lnorm else self._layer_bwd)(i, dh, ctx.lcs[i], ctx.R_in, B, L, ctx.shift, ctx.dstep)
+            if self.pre_lnorm:
+                dh = self._layer_bwd_prelnorm(i, dh, ctx.lcs[i], ctx.R_in, B, L, ctx.shift, ctx.dstep)
+            else:
+                dh = self._layer_bwd(i, dh, ctx.lcs[i], ctx.R_in, B, L, ctx.shift, ctx.dstep, flush=flush_wgrads)
             ctx.lcs[i] = None
             if layer_done_hook is not None:
                 layer_done_hook(f"h.{i}")

@@ -305,6 +305,8 @@ def main():
                                                       "scripts/evaluate/evaluate_rl_1.2B.sh:28-42): one timed step = GA x (fwd + bwd) + clip + Adam")
     ap.add_argument("--graph", action="store_true", help="forward + backward of a micro-step as one hipGraph replay (bdm_db1_amd.GraphedTrainStep): what small "
                                                          "micro-batches need (at 4 sequences the eager step is host-bound); no per-kernel timing in this mode")
+    ap.add_argument("--no-defer-wgrad", action="store_true", help="with --ga > 1: form the weight gradients per micro-step (K = micro-batch tokens, fp32 accumulate) instead of "
+                                                                  "once per optimizer step from the stashed operands of all micro-steps (bdm_db1_amd WgradStash)")
     ap.add_argument("--layers", type=int, default=24, help="debug only: anything but 24 is not the benchmark config")
     ap.add_argument("--workload", default="text", choices=["text", "caption", "rl", "mixture"])
     ap.add_argument("--dropout", type=float, default=0.1, help="drop = embd_pdrop of the training step (the reference's defaults, src/config.py:123,161: 0.1)")
@@ -349,7 +351,7 @@ def main():
     model.use_flash = not args.no_flash
     model.flash_probs_mode = args.flash_probs
     eargs = SimpleNamespace(lr=1e-4, weight_decay=0.01, clip_grad=1.0, optimizer="adam", keep_logits=False, fuse_head_loss=not args.materialise_logits,
-                            gradient_accumulation_steps=args.ga)
+                            gradient_accumulation_steps=args.ga, defer_wgrad=args.ga > 1 and not args.no_defer_wgrad)
     engine, _, _, _ = initialize(eargs, model, mpu=mpu if world > 1 else None)
     engine.train()
     B, L = args.batch, cfg.n_position
@@ -443,7 +445,7 @@ def main():
         "config": {"workload": f"DB1-1.3B {args.workload} causal LM pre-training step (fwd+bwd+clip+Adam, training mode: dropout "
                                f"{args.dropout:g} on embeddings / attention / feed-forward outputs as the reference's defaults), seq_len 1024, "
                                f"{B} sequences/GPU/micro-step x {args.ga} micro-step(s) per optimizer step, random-init weights", "dropout": args.dropout, "n_layer": args.layers, "n_embed": 2048, "n_head": 16,
-                   "seq_len": L, "batch_per_gpu": B, "grad_accumulation": args.ga, "micro_step_as_hipgraph": bool(args.graph), "global_batch": B * world * args.ga, "parallelism": f"dp{world}",
+                   "seq_len": L, "batch_per_gpu": B, "grad_accumulation": args.ga, "micro_step_as_hipgraph": bool(args.graph), "weight_gradients": ("once per optimizer step from the stashed operands of all micro-steps" if getattr(engine, "defer_wgrad", False) else "per micro-step"), "global_batch": B * world * args.ga, "parallelism": f"dp{world}",
                    "attention_backward": {"forward": "nothing recomputed (the forward keeps its probabilities)", "scratch": "query side recomputes, P / dS through scratch",
                                           "recompute": "both sides recompute"}[model._probs_mode(B, L)],
                    "params": int(sum(int(np.prod(s)) for _, s, _ in model.arena.offsets.values()))},
@@ -487,12 +489,6 @@ def main():
                                                    "launches": launches_dec, "ms_per_step": round(ms_dec / args.steps, 3)},
                            "geglu_epilogues": bool(getattr(model, "use_geglu_epilogue", False)), "geglu_note": GEGLU_NOTE,
                            "rocprof": rocprof_crosscheck(FAMILY_NOTE) if args.workload == "text" and B == 64 and args.ga == 1 else None}
-        out["roofline"]["rocprof_frac"] = out["roofline"]["rocprof"]["frac"] if out["roofline"]["rocprof"] else None
-        # work per step of every timed family (FLOPs or bytes): what tools/prof_table.py divides the profiler's kernel durations into
-        out["work_per_step"] = {fam: w / rest_steps for fam, (_, w, _) in rest.items()}
-        out["work_per_step"].update({fam: w / args.steps for fam, (_, w, _) in summ.items()})
-        out["kernels_note"] = (f"`kernels`: every other kernel family against its own roofline, HIP events on {rest_steps} extra steps run after the timed region "
-                               "(an event pair around each of a step's ~700 launches costs the step ~0.7 %; inside the timed region only the roofline family carries them)")
         # the other kernels of the step against THEIR rooflines: algorithmic FLOPs or bytes / HIP-event time on the launch stream
         ks = {}
         rest = timer_rest.summary() if timer_rest is not None else {}
@@ -529,6 +525,12 @@ def main():
                                         "hbm_source": os.path.relpath(cands[-1], ROOT)})
         except Exception:
             pass
+        out["roofline"]["rocprof_frac"] = out["roofline"]["rocprof"]["frac"] if out["roofline"]["rocprof"] else None
+        # work per step of every timed family (FLOPs or bytes): what tools/prof_table.py divides the profiler's kernel durations into
+        out["work_per_step"] = {fam: w / rest_steps for fam, (_, w, _) in rest.items()}
+        out["work_per_step"].update({fam: w / args.steps for fam, (_, w, _) in summ.items()})
+        out["kernels_note"] = (f"`kernels`: every other kernel family against its own roofline, HIP events on {rest_steps} extra steps run after the timed region "
+                               "(an event pair around each of a step's ~700 launches costs the step ~0.7 %; inside the timed region only the roofline family carries them)")
         out["kernels"] = ks
     if gstep is not None:
         gstep.close()

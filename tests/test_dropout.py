@@ -249,8 +249,10 @@ def test_model_with_attention_dropout_only_matches_oracle_fp32():
     worst = max((rel_err(model.G(n), g), n) for n, g in ref_grads.items())
     assert worst[0] < 1e-3, worst
     model.eval()
-    _, loss_eval = model(to_inputs(tasks))
-    assert abs(float(loss_eval) - float(loss)) > 1e-5        # the probability masks really bite in train mode
+    logits_eval, _ = model(to_inputs(tasks))
+    # the probability masks really bite in train mode (on the logits: the loss of this near-uniform tiny model barely moves, and which way
+    # depends on the seed the test session happens to have set)
+    assert rel_err(logits, logits_eval.float().cpu().numpy()) > 1e-3
 
 
 @pytest.mark.gpu
