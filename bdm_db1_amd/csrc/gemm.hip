@@ -216,7 +216,7 @@ struct GemmEnv { int tile, splitk; };
 static GemmEnv gemm_env() { return GemmEnv{db1_knob(DB1_KNOB_GEMM_TILE, 0), db1_knob(DB1_KNOB_GEMM_SPLITK, 1)}; }
 
 // ---- the dispatcher's decision, separated from the launch so that the workspace query, the kernel-choice query and the call agree
-enum { GK_GENERIC = 0, GK_TILE128 = 1, GK_TILE256 = 2, GK_PP = 3, GK_PP32 = 4, GK_W4 = 5, GK_SKINNY = 6, GK_SPLITK = 16, GK_TAIL = 32 };
+enum { GK_GENERIC = 0, GK_TILE128 = 1, GK_TILE256 = 2, GK_PP = 3, GK_PP32 = 4, GK_W4 = 5, GK_SKINNY = 6, GK_W4N = 7, GK_SPLITK = 16, GK_TAIL = 32 };
 struct GemmPlan {
     int kind = GK_GENERIC;   // GK_* of the kernel that runs the contraction (for GK_TAIL: of the main part)
     int fa = 0, fb = 0;
@@ -282,6 +282,15 @@ static GemmPlan gemm_plan(const GemmShape& g, bool aligned, int64_t ws_bytes) {
             return pl;
         }
     }
+    // 256 x 128 tiles of the 4-wave kernel (gemm_w4.hip, NJ = 4): outputs whose 256 x 256 tiling fills at most half a wave of workgroups while
+    // the 256 x 128 tiling fills a whole one -- micro-batches of 4 sequences: o_net, ff2, the data gradients (knob "w4n": 0 off; 1 before
+    // the half-wave split-K; 2 after it; 3 = 1 + the last-wave rule below: the default)
+    const int w4n_mode = db1_knob(DB1_KNOB_W4N, 3);
+    const bool w4n_shape = w4n_mode && tile_pref == 0 && (M % 256) == 0 && (N % 128) == 0 && g.c_cs == 1 && g_tri_mode == 0 &&
+                           db1_gemm_w4n_supported(t, fa, fb, g.dtC, (int)batch);
+    const int64_t wg256 = (int64_t)(M / 256) * ((N + 255) / 256) * batch, wg128 = (int64_t)(M / 256) * (N / 128) * batch;
+    const bool w4n_half = w4n_shape && wg256 > 96 && wg256 <= 128 && wg128 >= 192;
+    if (w4n_half && w4n_mode == 1) { pl.kind = GK_W4N; return pl; }
     // deterministic split-K (see splitk_reduce_kernel): only when the big-tile kernels would leave most CUs idle
     if (tile_pref == 0 && splitk_on && g.batch1 == 1 && (pp_shape || (t256_shape && fb == 1)) && g.c_cs == 1) {
         const int64_t wg = pp_shape ? (int64_t)(M / 256) * (N / 256) * batch : (int64_t)(M / 256) * (N / TBN) * batch;
@@ -309,6 +318,13 @@ static GemmPlan gemm_plan(const GemmShape& g, bool aligned, int64_t ws_bytes) {
             pl.kind = (pp_shape ? big(u, (int)batch * S, fb == 1) : GK_TILE256) | GK_SPLITK;
             return pl;
         }
+    }
+    if (w4n_half) { pl.kind = GK_W4N; return pl; }
+    // ... and outputs whose LAST wave of 256 x 256 workgroups is mostly empty (qkv at 4 sequences: 384 tiles = 1.5 waves): by the fill of the
+    // last wave, with the 256 x 128 kernel priced at 0.85 of the 256 x 256 one per FLOP (knob "w4n" >= 3; measured below)
+    if (w4n_shape && w4n_mode >= 3 && wg256 >= 160 && wg256 < 1024) {
+        const double e256 = (double)wg256 / (256.0 * ((wg256 + 255) / 256)), e128 = (double)wg128 / (256.0 * ((wg128 + 255) / 256));
+        if (0.85 * e128 > e256) { pl.kind = GK_W4N; return pl; }
     }
     if (pp_shape && tile_pref == 1024) { pl.kind = big(t, (int)batch, true); return pl; }
     if (pp_shape && (tile_pref == 512 || (tile_pref == 0 && (int64_t)(M / 256) * (N / 256) * batch >= 160))) {
@@ -428,6 +444,7 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
         const bool k32 = tile_pref == 1024 || (tile_pref == 0 && fb == 1);
         return k32 ? db1_gemm_pp32_launch(t, fa, fb, dtC, dtBias, (int)batch, st) : db1_gemm_pp_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
     }
+    if (base == GK_W4N) return db1_gemm_w4n_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
     if (base == GK_TILE256) return db1_gemm_tile256_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
     t.ksplit = pl.ksplit;
     dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch, (unsigned)t.ksplit);

@@ -222,6 +222,8 @@ int db1_gemm_tile256_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int 
 int db1_gemm_pp_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);
 bool db1_gemm_w4_supported(const GemmTileArgs& t, int fa, int fb, int dtC, int batch);
 int db1_gemm_w4_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);
+bool db1_gemm_w4n_supported(const GemmTileArgs& t, int fa, int fb, int dtC, int batch);
+int db1_gemm_w4n_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);
 int db1_gemm_pp32_launch(const GemmTileArgs& t, int fa, int fb, int dtC, int dtBias, int batch, hipStream_t st);
 bool db1_gemm_w4_geglu_supported(int M, int dff, int K, int64_t lda, int64_t ldw, int64_t ldz, int64_t ld_other, bool fwd);
 int db1_gemm_w4_geglu_fwd_launch(const GemmTileArgs& t, int dtBias, hipStream_t st);

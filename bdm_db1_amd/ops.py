@@ -720,7 +720,7 @@ def mulaw_decode(ids, out, is_action, num_bins=1024, mu=100.0, M=256.0, oob_flag
              float(M), P(oob_flag), stream())
 
 
-GEMM_KERNELS = {0: "strided-fp32", 1: "tile128", 2: "tile256", 3: "pp-k64", 4: "pp-k32", 5: "w4", 6: "skinny"}
+GEMM_KERNELS = {0: "strided-fp32", 1: "tile128", 2: "tile256", 3: "pp-k64", 4: "pp-k32", 5: "w4", 6: "skinny", 7: "w4n"}
 
 
 def gemm_kernel_choice(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, beta: float = 0.0, ws_bytes: int = -1):

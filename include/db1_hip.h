@@ -80,7 +80,7 @@ int64_t db1_gemm_workspace_bytes(int M, int N, int K, int dtA, int dtB, int dtC,
                                  int batch0, int batch1);
 /* which kernel db1_gemm_strided takes for this product given ws_bytes of workspace (-1: as much as it wants):
  * 0 strided fp32-MFMA, 1 128x128 tile, 2 256x128 tile, 3 / 4 256x256 8-wave (k64 x 2 / k32 x 4), 5 256x256 4-wave hand-scheduled,
- * 6 skinny W-streaming; +16 split-K through the workspace; +32 the last partial wave of tile rows runs as a second call */
+ * 6 skinny W-streaming, 7 256x128 4-wave hand-scheduled; +16 split-K through the workspace; +32 the last partial wave of tile rows runs as a second call */
 int db1_gemm_kernel_choice(int M, int N, int K, int dtA, int dtB, int dtC,
                            int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs, int64_t c_cs,
                            int batch0, int batch1, float beta, int64_t ws_bytes);

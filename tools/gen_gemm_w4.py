@@ -35,17 +35,26 @@ def EARLY():
 
 
 class Gen:
-    def __init__(self, a_kmajor, b_kmajor):
+    """nj = 8: 256 x 256 workgroup tile (wave tile 128 x 128).  nj = 4: 256 x 128 (wave tile 128 x 64: the two waves of a tile row share ONE
+    128-column B sub-tile and take its fragments 0-3 / 4-7) -- for outputs whose 256 x 256 tiling leaves half the CUs idle (micro-batches of
+    4 sequences: o_net, ff2, the data gradients).  Same LDS image, same register map, same accumulator numbering a[4 (8 i + j)] (j < nj): the
+    k-tile is 8 nj MFMAs per fragment set instead of 64, 8 + nj fragment reads, 8 + nj LDS-DMA requests."""
+
+    def __init__(self, a_kmajor, b_kmajor, nj=8):
         self.km = (a_kmajor, b_kmajor)
+        self.nj = nj
+        self.ns = 8 * nj          # MFMA slots per fragment set
+        self.nr = 8 + nj          # fragment reads per set
+        self.nd = 8 + nj          # LDS-DMA requests per k-tile
 
     def mfma(self, fs, slot):
-        i, j = slot >> 3, slot & 7
+        i, j = slot // self.nj, slot % self.nj
         c = 4 * (8 * i + j)
         return f"v_mfma_f32_16x16x32_bf16 a[{c}:{c + 3}], v[{FB[fs] + 4 * j}:{FB[fs] + 4 * j + 3}], v[{FA[fs] + 4 * i}:{FA[fs] + 4 * i + 3}], a[{c}:{c + 3}]"
 
     def frag_read(self, fs, stage, ks, n):
-        """n = 0..15: A fragments 0-7 then B fragments 0-7 of (stage, ks) into set fs; 1 or 2 instructions"""
-        op, f = n >> 3, n & 7
+        """n = 0 .. 7 + nj: A fragments 0-7 then B fragments 0 .. nj - 1 of (stage, ks) into set fs; 1 or 2 instructions"""
+        op, f = (0, n) if n < 8 else (1, n - 8)
         dst = (FA[fs] if op == 0 else FB[fs]) + 4 * f
         if self.km[op]:
             return [f"ds_read_b128 v[{dst}:{dst + 3}], v{RD[op] + stage * 2 + ks} offset:{f * 2048}"]
@@ -53,7 +62,7 @@ class Gen:
         return [f"ds_read_b64_tr_b16 v[{dst}:{dst + 1}], v{a} offset:{ks * 8192}", f"ds_read_b64_tr_b16 v[{dst + 2}:{dst + 3}], v{a} offset:{ks * 8192 + 1024}"]
 
     def dma(self, stage, d):
-        """d = 0..15: (operand, sub-tile, piece); returns (m0 setup, load)"""
+        """d = 0 .. 7 + nj: (operand, sub-tile, piece): A's two sub-tiles, then B's two (nj = 8) or one (nj = 4); returns (m0 setup, load)"""
         op, sub, it = d >> 3, (d >> 2) & 1, d & 3
         imm = stage * 65536 + (op * 2 + sub) * 16384 + it * 1024
         ptr = "s[72:73]" if op == 0 else "s[74:75]"
@@ -70,37 +79,43 @@ class Gen:
         # spacing 5 / 6 / 7: 11.92 / 11.80 / 11.53 (2 or 3: 13.1 -- the requests must not queue up); reads from 40: 11.43; A 17 or 23,
         # B 35: worse; B 43: same; W4_EARLY=7 (seven A fragments of the next ks-1 set read at the end of the previous half, barrier A after
         # slot 13-19): 11.48-11.71, no gain.  (W4_* environment variables: for such experiments only.)
-        A, B, RD = (int(os.environ.get(k, d)) for k, d in (("W4_A", 19), ("W4_B", 39), ("W4_RD", 40)))
-        SPF = float(os.environ.get("W4_SP", 7))
-        # DMA d: M0 setup after global slot A + 1 + SP * d, load one slot later (global slot = P0 slot, or 64 + P1 slot)
+        if self.nj == 8:
+            A, B, RD = (int(os.environ.get(k, d)) for k, d in (("W4_A", 19), ("W4_B", 39), ("W4_RD", 40)))
+            SPF = float(os.environ.get("W4_SP", 7))
+        else:   # 32 slots per fragment set: the same order of events at half the distances (12 reads, 12 requests per k-tile)
+            A, B, RD = (int(os.environ.get(k, d)) for k, d in (("W4N_A", 13), ("W4N_B", 18), ("W4N_RD", 19)))
+            SPF = float(os.environ.get("W4N_SP", 4))
+        NS, NR, ND = self.ns, self.nr, self.nd
+        # DMA d: M0 setup after global slot A + 1 + SP * d, load one slot later (global slot = P0 slot, or NS + P1 slot)
         ev = {}
         if do_dma:
-            for d in range(16):
+            for d in range(ND):
                 g = A + 1 + int(SPF * d) + woff
                 ev.setdefault(g, []).append(self.dma(stage, d)[0])
                 ev.setdefault(g + 1, []).append(self.dma(stage, d)[1])
-            ev.setdefault(A + 1 + int(SPF * 15) + woff + 1, []).extend(self.ptr_step())
-            assert A + 1 + int(SPF * 15) + woff + 1 < 128
-        before_b = sum(1 for d in range(16) if A + 1 + int(SPF * d) + woff + 1 <= 64 + B) if do_dma else 0   # loads of k-tile t+2 already issued at barrier B
-        E = EARLY()
+            ev.setdefault(A + 1 + int(SPF * (ND - 1)) + woff + 1, []).extend(self.ptr_step())
+            assert A + 1 + int(SPF * (ND - 1)) + woff + 1 < 2 * NS
+        before_b = sum(1 for d in range(ND) if A + 1 + int(SPF * d) + woff + 1 <= NS + B) if do_dma else 0   # loads of k-tile t+2 already issued at barrier B
+        E = EARLY() if self.nj == 8 else 0
+        assert RD + NR <= NS
         out = []
-        for slot in range(64):  # ---- P0
+        for slot in range(NS):  # ---- P0
             out.append(self.mfma(0, slot))
-            if slot < 16 - E:
+            if slot < NR - E:
                 out += self.frag_read(1, stage, 1, slot + E)
             if slot == A:
                 out += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
             out += ev.get(slot, [])
         pending = 0
-        for slot in range(64):  # ---- P1
+        for slot in range(NS):  # ---- P1
             out.append(self.mfma(1, slot))
-            out += ev.get(64 + slot, [])
+            out += ev.get(NS + slot, [])
             if do_next and slot == B:
                 out += [f"s_waitcnt vmcnt({before_b})", "s_barrier"]
-            if do_next and RD <= slot < RD + 16:
+            if do_next and RD <= slot < RD + NR:
                 out += self.frag_read(0, stage ^ 1, 0, slot - RD)
-            if do_next and RD + 16 <= slot < RD + 16 + E:   # the first E A-fragments of (t+1, ks 1): A fragment i of F1 was last used in slot 8 i + 7
-                i = slot - RD - 16
+            if do_next and RD + NR <= slot < RD + NR + E:   # the first E A-fragments of (t+1, ks 1): A fragment i of F1 was last used in slot 8 i + 7
+                i = slot - RD - NR
                 assert slot >= 8 * i + 8
                 r = self.frag_read(1, stage ^ 1, 1, i)
                 pending += len(r)
@@ -126,6 +141,8 @@ class Gen:
                 out.append(f"v_add_u32 v{b + it}, {st}, v{b + it - 1}")
                 if not self.km[op] and it == 2:
                     out.append(f"v_xor_b32 v{b + it}, 0x80, v{b + it}")   # k-rows 8..15 of a 16-row group: chunk index ^ 8
+            if op == 1 and self.nj == 4:
+                continue                                                   # one B sub-tile only
             if self.km[op]:
                 # the second sub-tile of 128 rows: byte distance as an operand (normally 16 pieces of 8 rows = 128 rows further on; the
                 # GEGLU-epilogue NT kernel interleaves value and gate rows of W and places its sub-tiles 64 rows apart, gemm_w4.hip)
@@ -133,13 +150,13 @@ class Gen:
             else:
                 out += [f"v_add_u32 v{b + 4 + it}, 0x100, v{b + it}" for it in range(4)]   # 128 rows = 256 bytes further along the k-row
         for t in range(2):
-            for d in range(16):
+            for d in range(self.nd):
                 m0set, ld = self.dma(t, d)
                 out += [m0set, "s_nop 0", ld]
             out += self.ptr_step()
-        out += [f"v_accvgpr_write_b32 a{n}, 0" for n in range(256)]   # (while the first two k-tiles are on their way)
-        out += ["s_waitcnt vmcnt(16)", "s_barrier"]
-        for n in range(16):
+        out += [f"v_accvgpr_write_b32 a{4 * (8 * i + j) + r}, 0" for i in range(8) for j in range(self.nj) for r in range(4)]   # (while the first two k-tiles are on their way)
+        out += [f"s_waitcnt vmcnt({self.nd})", "s_barrier"]
+        for n in range(self.nr):
             out += self.frag_read(0, 0, 0, n)
         for n in range(EARLY()):
             out += self.frag_read(1, 0, 1, n)
@@ -183,3 +200,4 @@ if __name__ == "__main__":
     d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bdm_db1_amd", "csrc")
     for name, ak, bk in (("nt", True, True), ("nn", True, False), ("tn", False, False)):
         Gen(ak, bk).emit(os.path.join(d, f"gemm_w4_loop_{name}.inc"))
+        Gen(ak, bk, nj=4).emit(os.path.join(d, f"gemm_w4n_loop_{name}.inc"))
