@@ -290,7 +290,7 @@ static GemmPlan gemm_plan(const GemmShape& g, bool aligned, int64_t ws_bytes) {
                            db1_gemm_w4n_supported(t, fa, fb, g.dtC, (int)batch);
     const int64_t wg256 = (int64_t)(M / 256) * ((N + 255) / 256) * batch, wg128 = (int64_t)(M / 256) * (N / 128) * batch;
     const bool w4n_half = w4n_shape && wg256 > 96 && wg256 <= 128 && wg128 >= 192;
-    if (w4n_half && w4n_mode == 1) { pl.kind = GK_W4N; return pl; }
+    if (w4n_half && w4n_mode != 2) { pl.kind = GK_W4N; return pl; }
     // deterministic split-K (see splitk_reduce_kernel): only when the big-tile kernels would leave most CUs idle
     if (tile_pref == 0 && splitk_on && g.batch1 == 1 && (pp_shape || (t256_shape && fb == 1)) && g.c_cs == 1) {
         const int64_t wg = pp_shape ? (int64_t)(M / 256) * (N / 256) * batch : (int64_t)(M / 256) * (N / TBN) * batch;

@@ -266,7 +266,7 @@ def test_generated_gemm_loops_are_in_sync_with_their_generator(tmp_path):
     import re
     import subprocess
     root = os.path.join(os.path.dirname(__file__), "..")
-    env = {k: v for k, v in os.environ.items() if not k.startswith("W4_")}
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("W4_", "W4N_"))}
     subprocess.run([sys.executable, os.path.join(root, "tools", "gen_gemm_w4.py"), str(tmp_path)], check=True, env=env, capture_output=True)
     for name in ("nt", "nn", "tn"):
         fresh = open(os.path.join(tmp_path, f"gemm_w4_loop_{name}.inc")).read()
@@ -279,6 +279,17 @@ def test_generated_gemm_loops_are_in_sync_with_their_generator(tmp_path):
             assert starts == sorted(list(range(0, 256, 4)) * 2)
         # the LDS-DMA requests: 2 prologue k-tiles + 2 loop bodies, 16 each; none in the two peeled k-tiles
         assert committed.count("global_load_lds_dwordx4") == 64
+        assert committed.count("s_barrier") == 1 + 2 * 3 + 1
+        # the 256 x 128-tile form (gemm_w4n_loop_*.inc): 64 MFMAs per k-tile on the accumulator tuples a[4 (8 i + j)], j < 4; 12 requests per k-tile
+        fresh = open(os.path.join(tmp_path, f"gemm_w4n_loop_{name}.inc")).read()
+        committed = open(os.path.join(root, "bdm_db1_amd", "csrc", f"gemm_w4n_loop_{name}.inc")).read()
+        assert fresh == committed, f"gemm_w4n_loop_{name}.inc is stale: run python tools/gen_gemm_w4.py"
+        mf = re.findall(r"v_mfma_f32_16x16x32_bf16 a\[(\d+):(\d+)\]", committed)
+        assert len(mf) == 4 * 64
+        want = sorted([4 * (8 * i + j) for i in range(8) for j in range(4)] * 2)
+        for body in range(4):
+            assert sorted(int(a) for a, _ in mf[body * 64:(body + 1) * 64]) == want
+        assert committed.count("global_load_lds_dwordx4") == 48
         assert committed.count("s_barrier") == 1 + 2 * 3 + 1
 
 
