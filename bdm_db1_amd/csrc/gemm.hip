@@ -286,8 +286,8 @@ static GemmPlan gemm_plan(const GemmShape& g, bool aligned, int64_t ws_bytes) {
     // the 256 x 128 tiling fills a whole one -- micro-batches of 4 sequences: o_net, ff2, the data gradients (knob "w4n": 0 off; 1 before
     // the half-wave split-K; 2 after it; 3 = 1 + the last-wave rule below: the default)
     const int w4n_mode = db1_knob(DB1_KNOB_W4N, 3);
-    const bool w4n_shape = w4n_mode && tile_pref == 0 && (M % 256) == 0 && (N % 128) == 0 && g.c_cs == 1 && g_tri_mode == 0 &&
-                           db1_gemm_w4n_supported(t, fa, fb, g.dtC, (int)batch);
+    const bool w4n_shape = w4n_mode && tile_pref == 0 && (M % 256) == 0 && (N % 128) == 0 && g.c_cs == 1 &&
+                           db1_gemm_w4n_supported(t, fa, fb, g.dtC, (int)batch);   // (incl. its structural-zero rules)
     const int64_t wg256 = (int64_t)(M / 256) * ((N + 255) / 256) * batch, wg128 = (int64_t)(M / 256) * (N / 128) * batch;
     const bool w4n_half = w4n_shape && wg256 > 96 && wg256 <= 128 && wg128 >= 192;
     if (w4n_half && w4n_mode != 2) { pl.kind = GK_W4N; return pl; }
@@ -315,7 +315,9 @@ static GemmPlan gemm_plan(const GemmShape& g, bool aligned, int64_t ws_bytes) {
             if (u.tri_mode == 1 || (u.tri_mode == 2 && (u.K % u.tri_period))) u.tri_mode = 0;
             u.batch1 = S;
             pl.S = S;
-            pl.kind = (pp_shape ? big(u, (int)batch * S, fb == 1) : GK_TILE256) | GK_SPLITK;
+            // (!pp_shape: N is a multiple of 128 only -- the per-head dR contraction: the 256 x 128 form of the 4-wave kernel where it applies)
+            const bool n128 = !pp_shape && w4n_mode && tile_pref == 0 && db1_gemm_w4n_supported(u, fa, fb, DB1_F32, (int)batch * S);
+            pl.kind = (pp_shape ? big(u, (int)batch * S, fb == 1) : (n128 ? GK_W4N : GK_TILE256)) | GK_SPLITK;
             return pl;
         }
     }
@@ -429,7 +431,8 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
         const bool pp_shape = (M % 256) == 0 && (N % 256) == 0;
         int rc = pp_shape ? (fb == 1 ? db1_gemm_pp32_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st)
                                      : db1_gemm_pp_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st))
-                          : db1_gemm_tile256_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st);
+                          : (base == GK_W4N ? db1_gemm_w4n_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st)
+                                            : db1_gemm_tile256_launch(u, fa, fb, DB1_F32, DB1_F32, (int)batch * S, st));
         if (rc) return rc;
         dim3 rg((unsigned)(((int64_t)M * (N / 4) + 255) / 256), (unsigned)batch);
 #define RED(TC, TB) splitk_reduce_kernel<TC, TB><<<rg, 256, 0, st>>>(wsf, (TC*)C, (const TB*)bias, M, N, S, c_rs, c_bs0, beta)

@@ -203,6 +203,29 @@ def test_gemm_structural_zero_hints(ops):
         close(dR.view(L, H, D), ref_dR, 6e-3, name=f"dR tri ({name})")
 
 
+def test_gemm_structural_zero_hint_by_period_at_model_length(ops):
+    """dR = dT^T . (q + v) per head at L = 1024 (the model's length): 8 batches = 8 periods of k, split-K over the periods, on the
+    256 x 128 form of the 4-wave kernel, whose loop walks each period from the tile's first row on and steps over the rest (the k-tiles
+    above the diagonal hold NaNs here: they must never be read); two runs agree bit for bit"""
+    rng = np.random.default_rng(23)
+    H, B, L, D = 2, 8, 1024, 128
+    i = np.arange(L)[:, None]; dd = np.arange(L)[None, :]
+    dT = (bf(rng.standard_normal((H, B, L, L))) * (dd <= i)).astype(np.float32)
+    qv = bf(rng.standard_normal((B, L, H, D))).astype(np.float32)
+    ref = np.einsum("hbik,bihd->khd", dT, qv, optimize=True)
+    poisoned = dT.copy()
+    poisoned[..., (i // 64) * 64 + 63 < (dd // 256) * 256] = np.nan
+    qvd = dev16(qv)
+    outs = []
+    for src in (dev16(dT), dev16(poisoned), dev16(poisoned)):
+        dR = torch.full((L, H * D), float("nan"), device=DEV, dtype=torch.bfloat16)
+        ops.gemm_batched(src.view(H, B * L, L).transpose(1, 2).unsqueeze(1), qvd.view(B * L, H, D).permute(1, 0, 2).unsqueeze(1),
+                         dR.view(L, H, D).permute(1, 0, 2).unsqueeze(1), tri=(2, L))
+        close(dR.view(L, H, D), ref, 6e-3, name="dR by period")
+        outs.append(dR)
+    assert torch.equal(outs[1], outs[2])
+
+
 @pytest.mark.parametrize("case", ["weight_grad", "per_head_batched"])
 def test_gemm_bf16_workspace_split_k(ops, case):
     """small outputs over a long contraction take the deterministic workspace split-K (partials + fixed-order reduce):

@@ -69,8 +69,10 @@ class Gen:
         return (f"s_add_u32 m0, %[ldsw], {imm}", f"global_load_lds_dwordx4 v{VOFF + op * 8 + sub * 4 + it}, {ptr}")
 
     def ptr_step(self):
-        return ["s_sub_u32 s81, s81, 1", "s_cmp_eq_u32 s81, 0",   # (both selects before the adds rewrite scc; 64-bit steps: one pass over k can exceed 2 GiB)
-                "s_cselect_b64 s[76:77], %[backa], %[stepka]", "s_cselect_b64 s[82:83], %[backb], %[stepkb]",
+        # (s81 counts the k-tiles until the next "wrap" step and is reloaded from %[wrapn] there: the per-XCD k rotation wraps once -- wrapn
+        #  is then beyond the loop's length --, the structural-zero mode walks PERIODS of k: wrapn k-tiles, then a longer step over the skipped ones)
+        return ["s_sub_u32 s81, s81, 1", "s_cmp_eq_u32 s81, 0",   # (all selects before the adds rewrite scc; 64-bit steps: one pass over k can exceed 2 GiB)
+                "s_cselect_b64 s[76:77], %[backa], %[stepka]", "s_cselect_b64 s[82:83], %[backb], %[stepkb]", "s_cselect_b32 s81, %[wrapn], s81",
                 "s_add_u32 s72, s72, s76", "s_addc_u32 s73, s73, s77", "s_add_u32 s74, s74, s82", "s_addc_u32 s75, s75, s83"]
 
     def body(self, stage, do_dma, do_next, woff=0):
