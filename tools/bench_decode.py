@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from bdm_db1_amd import TransformerXL, synth  # noqa: E402
+from bdm_db1_amd import TransformerXL, synth, lib  # noqa: E402
+lib.apply_env_knobs()
 from bdm_db1_amd.data import NLPTaskInput  # noqa: E402
 
 q_first = int(sys.argv[1]) if len(sys.argv) > 1 else 22
