@@ -1,7 +1,9 @@
 """Developer check of the 256x256 ping-pong GEMM (DB1_GEMM_TILE=512): all three operand forms, odd/even k-tile counts."""
 import os, sys
 os.environ.setdefault("DB1_GEMM_TILE", "512")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys
+_T = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/
+sys.path.insert(0, _T); sys.path.insert(0, os.path.dirname(_T))   # tools/ (bench_kernels) and the repository root
 import torch
 from bdm_db1_amd import ops
 from bdm_db1_amd import lib; lib.apply_env_knobs()   # DB1_* A/B switches of this script -> the library's thread-local knobs

@@ -1,7 +1,8 @@
 """Experiment: sensitivity of the NT GEMM rate to the base-address offset of W relative to x (memory-channel alignment)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys
+_T = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/
+sys.path.insert(0, _T); sys.path.insert(0, os.path.dirname(_T))   # tools/ (bench_kernels) and the repository root
 import torch
 from bdm_db1_amd import ops
 from bench_kernels import timeit

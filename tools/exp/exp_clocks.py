@@ -1,7 +1,9 @@
 """Experiment: shader clock and socket power while one kernel runs back to back (rocm-smi sampled from a side thread).
-Usage: python tools/exp_clocks.py     (needs a GPU; prints one line per workload)"""
+Usage: python tools/exp/exp_clocks.py     (needs a GPU; prints one line per workload)"""
 import os, subprocess, sys, threading, time, re
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import os, sys
+_T = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/
+sys.path.insert(0, _T); sys.path.insert(0, os.path.dirname(_T))   # tools/ (bench_kernels) and the repository root
 import torch
 from bdm_db1_amd import ops
 

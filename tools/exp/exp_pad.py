@@ -1,9 +1,10 @@
 """Experiment: does a padded leading dimension (row stride not a multiple of 4 KiB) change the NT GEMM rate, and on which operand?"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys
+_T = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/
+sys.path.insert(0, _T); sys.path.insert(0, os.path.dirname(_T))   # tools/ (bench_kernels) and the repository root
 import torch
 from bdm_db1_amd import ops
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from bench_kernels import timeit
 DEV = "cuda"
 T, d = 16384, 2048

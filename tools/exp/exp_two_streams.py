@@ -2,7 +2,7 @@
 """Experiment: do HBM-bound kernels hide behind another sequence's GEMMs?  Two independent DB1-1.3B engines with HALF the micro-batch each,
 driven from two host threads on two HIP streams of one GPU, against one engine with the whole micro-batch.  (If the aggregate rate is
 clearly higher, the step should process its micro-batch as two interleaved halves.)
-    python tools/exp_two_streams.py [batch=64] [steps=6]"""
+    python tools/exp/exp_two_streams.py [batch=64] [steps=6]"""
 import os
 import sys
 import threading
@@ -10,7 +10,9 @@ import time
 from types import SimpleNamespace
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+import os, sys
+_T = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/
+sys.path.insert(0, _T); sys.path.insert(0, os.path.dirname(_T))   # tools/ (bench_kernels) and the repository root
 import torch  # noqa: E402
 
 from bdm_db1_amd import TransformerXL, initialize, synth  # noqa: E402

@@ -1,8 +1,10 @@
 """Experiment: the in-step GEMM shapes of DB1-1.3B at 64 sequences (all three operand layouts) through ops.gemm, for A/B runs of
 the 4-wave hand-scheduled kernels (DB1_W4=0|1|2, or a rebuilt schedule variant: W4_VARIANT=... python tools/gen_gemm_w4.py).
-Usage: python tools/exp_w4.py [reps]"""
+Usage: python tools/exp/exp_w4.py [reps]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(__file__)); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import os, sys
+_T = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/
+sys.path.insert(0, _T); sys.path.insert(0, os.path.dirname(_T))   # tools/ (bench_kernels) and the repository root
 import torch
 from bdm_db1_amd import ops
 from bdm_db1_amd import lib; lib.apply_env_knobs()   # DB1_* A/B switches of this script -> the library's thread-local knobs

@@ -1,5 +1,7 @@
 import torch, sys
-sys.path.insert(0, '.')
+import os, sys
+_T = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/
+sys.path.insert(0, _T); sys.path.insert(0, os.path.dirname(_T))   # tools/ (bench_kernels) and the repository root
 from bdm_db1_amd import ops
 DEV='cuda:0'
 def timeit(f, n=20):

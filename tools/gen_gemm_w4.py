@@ -77,7 +77,7 @@ class Gen:
 
     def body(self, stage, do_dma, do_next, woff=0):
         # slots of barrier A, barrier B, the first read of the next k-tile, and the spacing of the 16 LDS-DMA requests.  Measured on the twelve
-        # in-step GEMM shapes (tools/exp_w4.py, sum of their times): A 31 / spacing 4 / B 39 / reads from 44: 12.21 ms; A 19: 12.09;
+        # in-step GEMM shapes (tools/exp/exp_w4.py, sum of their times): A 31 / spacing 4 / B 39 / reads from 44: 12.21 ms; A 19: 12.09;
         # spacing 5 / 6 / 7: 11.92 / 11.80 / 11.53 (2 or 3: 13.1 -- the requests must not queue up); reads from 40: 11.43; A 17 or 23,
         # B 35: worse; B 43: same; W4_EARLY=7 (seven A fragments of the next ks-1 set read at the end of the previous half, barrier A after
         # slot 13-19): 11.48-11.71, no gain.  (W4_* environment variables: for such experiments only.)
