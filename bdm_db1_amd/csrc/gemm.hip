@@ -289,7 +289,9 @@ static GemmPlan gemm_plan(const GemmShape& g, bool aligned, int64_t ws_bytes) {
     const bool w4n_shape = w4n_mode && tile_pref == 0 && (M % 256) == 0 && (N % 128) == 0 && g.c_cs == 1 &&
                            db1_gemm_w4n_supported(t, fa, fb, g.dtC, (int)batch);   // (incl. its structural-zero rules)
     const int64_t wg256 = (int64_t)(M / 256) * ((N + 255) / 256) * batch, wg128 = (int64_t)(M / 256) * (N / 128) * batch;
-    const bool w4n_half = w4n_shape && wg256 > 96 && wg256 <= 128 && wg128 >= 192;
+    // (a weight gradient over K = 65 536 rows keeps the two-slice split-K of the 256 x 256 kernel: ff2 dW 831 us against 918 us here; at
+    //  K = 16 384 the 256 x 128 kernel wins, 244 against 260 us)
+    const bool w4n_half = w4n_shape && wg256 > 96 && wg256 <= 128 && wg128 >= 192 && !(fa == 1 && (K / TBK) >= 512);
     if (w4n_half && w4n_mode != 2) { pl.kind = GK_W4N; return pl; }
     // deterministic split-K (see splitk_reduce_kernel): only when the big-tile kernels would leave most CUs idle
     if (tile_pref == 0 && splitk_on && g.batch1 == 1 && (pp_shape || (t256_shape && fb == 1)) && g.c_cs == 1) {
