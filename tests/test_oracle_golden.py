@@ -155,3 +155,35 @@ def test_rl_packing_matches_reference():
 def test_param_count_1p3b():
     cfg = O.OracleConfig(n_embed=2048, n_layer=24, n_head=16, n_position=1024, mem_len=1024)
     assert O.count_params(cfg) == 1_210_585_216  # SURVEY.md section 6 (meta-device instantiation of the reference)
+
+
+@pytest.mark.parametrize("name", ["tiny_nlp", "small_window"])
+def test_torch_cpu_restatement_matches_reference(name):
+    """oracle/db1_torch_cpu.py -- the text path in torch eager ops with autograd, the second CPU baseline bench.py times -- against the
+    REFERENCE's golden vectors (fp32 like the reference) and against the NumPy oracle on the same inputs"""
+    torch = pytest.importorskip("torch")
+    from oracle.db1_torch_cpu import TorchCpuModel
+    seed = 100 + list(CASES).index(name)
+    cfg, params, gold, model = build(name, seed)
+    t = make_batch(name, cfg, seed)[0]
+    assert t["kind"] == "nlp"
+    tm = TorchCpuModel(O.OracleConfig(**cfg), params, dtype=torch.float32)
+    logits, loss = tm.forward(t["text_seq"], t["label"], t["loss_mask"])
+    lg = logits.detach().numpy()
+    assert tuple(gold["logits_shape"]) == lg.shape
+    assert abs(float(loss) - gold["loss"]) < 5e-6 * max(1.0, abs(gold["loss"]))
+    np.testing.assert_allclose(lg.reshape(-1)[sample_idx(lg.size, 4096)], gold["logits_sample"], rtol=5e-4, atol=5e-5)
+    grads = tm.backward()
+    ref_logits, ref_loss, _ = model.forward(to_tasks([t]))
+    ref_grads = model.backward()
+    assert np.abs(lg - ref_logits).max() <= 2e-5 * np.abs(ref_logits).max()
+    checked = 0
+    for k, g in ref_grads.items():
+        if k not in grads:
+            continue
+        assert np.abs(grads[k] - g).max() <= 2e-4 * max(np.abs(g).max(), 1e-8) + 1e-9, k
+        if "gnorm/" + k in gold:
+            gn = np.sqrt((grads[k].astype(np.float64) ** 2).sum())
+            assert abs(gn - gold["gnorm/" + k]) <= 2e-4 * max(gold["gnorm/" + k], 1e-6) + 1e-9, k
+            checked += 1
+    assert checked >= 10
