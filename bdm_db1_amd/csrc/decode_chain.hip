@@ -1,0 +1,402 @@
+// One new token through the linear maps of an inference layer as ONE launch (evaluate_rl.py:157-266: batch 1, 1-token calls with a full
+// Transformer-XL memory; transformer_xl.py:227-243 o_net + post-LN, :246-292 PositionwiseFF, :136 the next layer's qkv_net).
+//
+// The 1-token call is a chain of W-streams of 8-34 MB, each a latency chain of its own when it is a launch (rows -> W round trip -> dot
+// products -> store: 6-10 us for 2-7 us of HBM time).  Here the four streams between two attention launches
+//     o_net (input: the merge of the attention's chunk partials)  ->  LayerNorm  ->  ff1 + GEGLU  ->  ff2  ->  LayerNorm  ->  next layer's qkv
+// run inside one kernel of 256 workgroups (one per CU), and ALL of the layer's weights (80 MB = 312 KB per CU) are requested in the first two
+// microseconds of the launch, in the order the stages need them, so HBM streams for the whole launch while the stages hand their vectors over:
+//   * eight WORKER waves per workgroup hold the W rows of o_net, ff1 and ff2 in registers (112 VGPRs); the rows of the next layer's qkv
+//     projection go to LDS (96 KB, global_load_lds: no registers, requested by two waves that do nothing else); a worker only ever waits
+//     for its own requests, in stage order;
+//   * one SERVICE wave per workgroup does everything that depends on other workgroups: it publishes the workgroup's outputs, waits for the
+//     whole vector, applies the residual LayerNorm and leaves the stage's input in LDS for the workers.  It never has W requests outstanding,
+//     so its waits cost nothing (vmcnt retires in order: a worker that polled memory between its prefetches would wait for all of them).
+// Hand-off between workgroups without a counter: every value is stored as a 32-bit word {bf16 value, 16-bit tag of this launch}; the service
+// waves poll the ROW ITSELF (L1 / L2-bypassing loads) until all its words carry the launch's tag.  One memory round trip after the last
+// producer's store instead of store -> wait -> counter add -> counter poll -> load: 2.05 us instead of 4.55 us per hand-off between 256
+// workgroups (tools/exp/sync_bench.hip).  The tag only has to differ from the tag of the PREVIOUS launch on the same scratch (every launch
+// rewrites every word of its three rows): tag = slot + 1, and consecutive launches must use different slots (the layer index, n_layer >= 2).
+// M = 1 row: the products are VALU dot products (fp32 FMA, 8 bf16 of W per 16-byte load), the matrix pipe has nothing to gain at one row.
+// Arithmetic per element as the launches this replaces (db1_linear_decode_attn / db1_linear_decode): the merged attention row, the LayerNorm
+// inputs and outputs, z and act are rounded to bf16 where those store bf16; fp32 accumulation; results agree to fp32 summation order.
+#include "ln_row.h"
+
+#define DC_D 2048
+#define DC_DFF 4096
+#define DC_WG 256
+#define DC_WORKERS 8
+#define DC_DMA_WAVES 2
+#define DC_THREADS ((DC_WORKERS + 1 + DC_DMA_WAVES) * 64)
+#define DC_SPIN_LIMIT (1 << 17)
+
+typedef __attribute__((ext_vector_type(4))) unsigned dc_u32x4;
+// workgroup barrier WITHOUT the vmcnt(0) a __syncthreads() carries (its fence would drain the workers' W prefetches at every stage): LDS
+// traffic of this wave is complete (lgkmcnt), global loads stay in flight
+#define DC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define DC_PIN() __builtin_amdgcn_sched_barrier(0)   /* keep the request batches where they are written (the scheduler would sink them to their uses) */
+
+struct DecodeChainArgs {
+    const float* att_part; int att_nunit, att_H;        // attention partials [H][nunit][64][128 + 2], query row 0
+    const bf16_t* x_res;                                 // the layer's input row [d] (residual of the first LayerNorm)
+    const bf16_t* w_o; const bf16_t* w1; const bf16_t* w2; const bf16_t* w_qkv;   // [d, d], [2 dff, d], [d, dff], [3 d, d] or null (last layer)
+    const bf16_t* b1; const bf16_t* b2;                  // [2 dff], [d]
+    const bf16_t* g1; const bf16_t* be1; const bf16_t* g2; const bf16_t* be2;    // LayerNorm parameters
+    float alpha, eps;
+    unsigned* y_o; unsigned* act; unsigned* f;           // hand-off rows between the stages (global scratch), tagged words: [d], [dff], [d]
+    unsigned tag;                                        // this launch's tag (low 16 bits of every word)
+    bf16_t* h1_out; bf16_t* f_out;                       // last layer only: LN1's output and ff2's output (the pending LayerNorm of the head), [d] each
+    bf16_t* x_next; bf16_t* qkv_next;                    // [d]: LN2 output = the next layer's input; [3 d]: its projection (w_qkv != null)
+    int* err;                                            // set to 1 if a poll ran into its limit (results are then invalid)
+    unsigned long long* ts;                              // test hook (db1_test_decode_chain_timestamps): workgroup 0's stage times, 100 MHz ticks; null in production
+};
+#define DC_TS(k) do { if (p.ts && lane == 0) { if (bid == 0) p.ts[k] = wall_clock64(); if ((k) < 4) p.ts[16 + bid * 4 + (k)] = wall_clock64(); } } while (0)
+
+__device__ __forceinline__ void dc_st_agent(void* p, unsigned lo, unsigned hi) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float dc_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float dc_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ unsigned dc_word(float v, unsigned tag) { return (f2bf_pk(0.f, v) & 0xffff0000u) | tag; }   // {bf16(v), tag}
+
+// NL 16-byte pieces of one W row for this lane: columns (j * 64 + lane) * 8 .. + 7
+template <int NL> struct DcRow { dc_u32x4 w[NL]; };
+template <int NL> __device__ __forceinline__ void dc_load_row(DcRow<NL>& r, const bf16_t* row, int lane) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.w[j] = __builtin_nontemporal_load(reinterpret_cast<const dc_u32x4*>(row + (j * 64 + lane) * 8));
+}
+__device__ __forceinline__ float dc_fma8(const dc_u32x4 w, const dc_u32x4 x, float acc) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        acc = fmaf(dc_lo(w[e]), dc_lo(x[e]), acc);
+        acc = fmaf(dc_hi(w[e]), dc_hi(x[e]), acc);
+    }
+    return acc;
+}
+template <int NL> __device__ __forceinline__ float dc_dot(const DcRow<NL>& r, const bf16_t* xs, int lane) {   // xs: the input vector in LDS
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < NL; j++) acc = dc_fma8(r.w[j], *reinterpret_cast<const dc_u32x4*>(xs + (j * 64 + lane) * 8), acc);
+    return wave_sum(acc);
+}
+
+// service wave: the words (k * 64 + lane) * 8 .. + 7 of a tagged row, k < 2 * NP, read past L1 / L2 (sc1) -- one asm statement per two k with its
+// own wait, so that no request the compiler does not know about is ever outstanding outside it
+__device__ __forceinline__ void dc_read_pair(const unsigned* a, dc_u32x4& w0, dc_u32x4& w1, dc_u32x4& w2, dc_u32x4& w3) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:2064 sc1"
+                 : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(a) : "memory");
+}
+// all words of the row carry the tag?  w[2 k + h] = words (k * 64 + lane) * 8 + 4 h .. + 3.  Returns false if the poll limit ran out.
+template <int NP> __device__ __forceinline__ bool dc_poll_row(const unsigned* row, unsigned tag, int lane, dc_u32x4 (&w)[4 * NP]) {
+    for (int spins = 0; spins < DC_SPIN_LIMIT; spins++) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) dc_read_pair(row + q * 1024 + lane * 8, w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned bad = 0;
+#pragma unroll
+        for (int i = 0; i < 4 * NP; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) bad |= (w[i][e] ^ tag) & 0xffffu;
+        if (__all(bad == 0)) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChainArgs p) {
+    // (separate LDS objects: the compiler then knows that reads of xs / res never touch the rows the LDS-DMA requests are still writing,
+    //  and does not drain vmcnt before them)
+    __shared__ __attribute__((aligned(16))) bf16_t xs[DC_DFF];
+    __shared__ __attribute__((aligned(16))) float res[32];
+    __shared__ __attribute__((aligned(16))) char w3s[24 * DC_D * 2];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bid = blockIdx.x;
+    const bool last_layer = p.w_qkv == nullptr;
+
+    if (wave < DC_WORKERS) {
+        // ------------------------------------------------------------------------------------------------ worker waves
+        DcRow<4> w0;                    // o_net: row bid * 8 + wave
+        dc_load_row(w0, p.w_o + (int64_t)(bid * 8 + wave) * DC_D, lane);
+        DC_PIN();
+        // stage 0 input: the merge of the attention's chunk partials (thread t < 256 owns columns 8 t .. 8 t + 7 = head t / 16), the arithmetic
+        // of relattn_decode_merge2_kernel / db1_linear_decode_attn
+        {
+            const int t = threadIdx.x;
+            if (t < DC_D / 8) {
+                constexpr int NU = 12, DD = 128;
+                const int hh = (t * 8) / DD, d0 = (t * 8) % DD;
+                const float* src = p.att_part + ((int64_t)hh * p.att_nunit * 64) * (DD + 2);
+                float4 olo[NU], ohi[NU];
+                float2 ml[NU];
+#pragma unroll
+                for (int c = 0; c < NU; c++) {
+                    const float* u = src + (int64_t)(c < p.att_nunit ? c : p.att_nunit - 1) * 64 * (DD + 2);
+                    ml[c] = *reinterpret_cast<const float2*>(u + DD);
+                    const float2 a0 = *reinterpret_cast<const float2*>(u + d0), a1 = *reinterpret_cast<const float2*>(u + d0 + 2);
+                    const float2 a2 = *reinterpret_cast<const float2*>(u + d0 + 4), a3 = *reinterpret_cast<const float2*>(u + d0 + 6);
+                    olo[c] = make_float4(a0.x, a0.y, a1.x, a1.y); ohi[c] = make_float4(a2.x, a2.y, a3.x, a3.y);
+                }
+                float mx = -1.0e30f;
+#pragma unroll
+                for (int c = 0; c < NU; c++) mx = fmaxf(mx, c < p.att_nunit ? ml[c].x : -1.0e30f);
+                float l = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NU; c++) {
+                    const float lc = c < p.att_nunit ? ml[c].y : 0.f;
+                    const float wt = lc > 0.f ? __expf(ml[c].x - mx) : 0.f;
+                    l += lc * wt;
+                    o[0] += olo[c].x * wt; o[1] += olo[c].y * wt; o[2] += olo[c].z * wt; o[3] += olo[c].w * wt;
+                    o[4] += ohi[c].x * wt; o[5] += ohi[c].y * wt; o[6] += ohi[c].z * wt; o[7] += ohi[c].w * wt;
+                }
+                Vec16<bf16_t> ov;
+#pragma unroll
+                for (int j = 0; j < 8; j++) ov.v[j] = l > 0.f ? o[j] / l : 0.f;
+                ov.store(&xs[t * 8]);
+            }
+        }
+        // the rest of the layer's weights, requested now in stage order (the merge's registers are free again):
+        //   ff1 rows of this wave: pairs pr = bid * 16 + wave * 2 + {0, 1}: value row pr, gate row dff + pr          (16 pieces)
+        //   (the next layer's qkv rows bid * 24 .. + 23 go to LDS, requested by the DMA waves right after: this wave reads rows wave * 3 + {0, 1, 2})
+        DC_PIN();
+        DcRow<4> w1[4];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int pr = bid * 16 + wave * 2 + j;
+            dc_load_row(w1[2 * j], p.w1 + (int64_t)pr * DC_D, lane);
+            dc_load_row(w1[2 * j + 1], p.w1 + (int64_t)(DC_DFF + pr) * DC_D, lane);
+        }
+        DC_PIN();
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // W0 (and the merge inputs before it) have landed; W1 may be in flight
+        DC_BARRIER();                                   // A0: the merged row is in LDS (worker waves wrote it)
+        {
+            const float s = dc_dot(w0, xs, lane);
+            if (lane == 0) res[wave] = s;
+        }
+        DC_BARRIER();                                   // B0: results ready for the service wave
+        // ---- stage 1: ff1 + GEGLU.  W2 requested now: a CU takes about 160 KB of requests before the requesting wave stalls in the issue
+        // (W0 + W1 = 160 KB; with W2 on top the workers reached A0 at 5-7 us instead of 1.5 us)
+        DcRow<8> w2;
+        dc_load_row(w2, p.w2 + (int64_t)(bid * 8 + wave) * DC_DFF, lane);
+        DC_PIN();
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        DC_BARRIER();                                   // A1: LN1 row in LDS
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float s = dc_dot(w1[j], xs, lane);
+            if (lane == 0) res[wave * 4 + j] = s;          // [wave][pair j >> 1][value / gate]
+        }
+        DC_BARRIER();                                   // B1
+        // ---- stage 2: ff2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DC_BARRIER();                                   // A2: act row (dff) in LDS
+        {
+            const float s = dc_dot(w2, xs, lane);
+            if (lane == 0) res[wave] = s;
+        }
+        DC_BARRIER();                                   // B2
+        if (last_layer) return;
+        // ---- stage 3: the next layer's qkv projection of LN2's row; W from LDS (the DMA waves waited for their requests before this barrier)
+        DC_BARRIER();                                   // A3: LN2 row in LDS, W3 rows in LDS
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                acc = dc_fma8(*reinterpret_cast<const dc_u32x4*>(w3s + ((wave * 3 + j) * 4 + i) * 1024 + lane * 16),
+                              *reinterpret_cast<const dc_u32x4*>(xs + (i * 64 + lane) * 8), acc);
+            const float s = wave_sum(acc);
+            if (lane == 0) res[wave * 3 + j] = s;
+        }
+        DC_BARRIER();                                   // B3
+        return;
+    }
+
+    if (wave > DC_WORKERS) {
+        // ---------------------------------------------------------------------------------------------- LDS-DMA waves
+        // the next layer's qkv rows bid * 24 .. + 23 (96 KB) -> LDS, 12 rows per wave, requested once the workers' requests are queued (after A0):
+        // they arrive last, as they are needed last, and no register holds them.  (In a wave of their own: a compiler that sees LDS-DMA requests
+        // in flight drains vmcnt before every LDS read it cannot tell apart from their destination -- in a worker that is every stage's input.)
+        const int v = wave - DC_WORKERS - 1;
+        DC_BARRIER();                                   // A0
+        DC_BARRIER();                                   // B0
+        DC_BARRIER();                                   // A1: W0 and W1 have landed in every wave of the workgroup, W2 (64 KB) is in flight
+        if (!last_layer) {
+#pragma unroll
+            for (int j = 0; j < 12; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    __builtin_amdgcn_global_load_lds(p.w_qkv + (int64_t)(bid * 24 + v * 12 + j) * DC_D + (i * 64 + lane) * 8,
+                                                     (__attribute__((address_space(3))) void*)(w3s + ((v * 12 + j) * 4 + i) * 1024), 16, 0, 0);
+        }
+        DC_BARRIER();                                   // B1
+        DC_BARRIER();                                   // A2
+        DC_BARRIER();                                   // B2
+        if (last_layer) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows are in LDS
+        DC_BARRIER();                                   // A3
+        DC_BARRIER();                                   // B3
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- service wave
+    // LayerNorm parameters and the residual row of LN1: requested up front (plain loads: written before this launch)
+    const unsigned tag = p.tag;
+    Vec16<bf16_t> xr[4], gg[4], bb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        xr[k].load(p.x_res + (k * 64 + lane) * 8);
+        gg[k].load(p.g1 + (k * 64 + lane) * 8);
+        bb[k].load(p.be1 + (k * 64 + lane) * 8);
+    }
+    DC_TS(0);
+    DC_BARRIER();                                       // A0 (the workers prepared the stage-0 input themselves)
+    DC_TS(1);
+    DC_BARRIER();                                       // B0
+    DC_TS(2);
+    if (lane < 4) dc_st_agent(p.y_o + bid * 8 + lane * 2, dc_word(res[lane * 2], tag), dc_word(res[lane * 2 + 1], tag));   // y_o rows bid * 8 .. + 7 (bf16, as db1_linear_decode_attn stores them)
+    bool live = true;
+    // ---- LN1: h1 = LN(alpha * x_res + y_o) * g1 + be1
+    Vec16<bf16_t> h1[4];
+    {
+        dc_u32x4 w[8];
+        live = dc_poll_row<2>(p.y_o, tag, lane, w) && live;
+        DC_TS(3);
+        Vec16<bf16_t> a[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[k].v[j] = p.alpha * xr[k].v[j] + dc_hi(w[2 * k + (j >> 2)][j & 3]);
+        float mu, rs;
+        ln_row_stats<bf16_t, 4>(a, DC_D, p.eps, mu, rs);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) h1[k].v[j] = bf2f(f2bf((a[k].v[j] - mu) * rs * gg[k].v[j] + bb[k].v[j]));   // h1 is a bf16 row
+            h1[k].store(&xs[(k * 64 + lane) * 8]);
+            if (bid == 0 && p.h1_out) h1[k].store(p.h1_out + (k * 64 + lane) * 8);
+        }
+    }
+    // (the parameters of LN2 and the two biases this workgroup needs: requested before the barrier, used after it)
+#pragma unroll
+    for (int k = 0; k < 4; k++) { gg[k].load(p.g2 + (k * 64 + lane) * 8); bb[k].load(p.be2 + (k * 64 + lane) * 8); }
+    float bias1 = lane < 32 ? bf2f(p.b1[(lane & 1 ? DC_DFF : 0) + bid * 16 + (lane >> 1)]) : 0.f;   // lane = 2 pair + {0: value, 1: gate}
+    float bias2 = lane < 8 ? bf2f(p.b2[bid * 8 + lane]) : 0.f;
+    DC_TS(4);
+    DC_BARRIER();                                       // A1
+    DC_TS(5);
+    DC_BARRIER();                                       // B1
+    DC_TS(6);
+    {   // z = bf16(sum + bias) for both halves, act = bf16(z_v * gelu(z_g)): pairs bid * 16 .. + 15 (res[wave * 4 + 2 j + {0, 1}] = pair wave * 2 + j)
+        const float z = lane < 32 ? bf2f(f2bf(res[lane] + bias1)) : 0.f;
+        const float gate = __shfl_down(z, 1, 64);
+        const float a = z * gelu_fwd_t<bf16_t>(gate);      // valid in even lanes < 32: pair lane >> 1
+        const float a0 = __shfl(a, (lane & 7) * 4, 64), a1 = __shfl(a, (lane & 7) * 4 + 2, 64);   // pairs 2 lane, 2 lane + 1
+        if (lane < 8) dc_st_agent(p.act + bid * 16 + lane * 2, dc_word(a0, tag), dc_word(a1, tag));
+    }
+    {   // act row (dff values) -> LDS as bf16
+        dc_u32x4 w[16];
+        live = dc_poll_row<4>(p.act, tag, lane, w) && live;
+        DC_TS(7);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            dc_u32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = (w[2 * k + (e >> 1)][2 * (e & 1)] >> 16) | (w[2 * k + (e >> 1)][2 * (e & 1) + 1] & 0xffff0000u);
+            *reinterpret_cast<dc_u32x4*>(xs + (k * 64 + lane) * 8) = v;
+        }
+    }
+    DC_TS(8);
+    DC_BARRIER();                                       // A2
+    DC_TS(9);
+    DC_BARRIER();                                       // B2
+    DC_TS(10);
+    {
+        const float c0 = __shfl(bias2, (lane & 3) * 2, 64), c1 = __shfl(bias2, (lane & 3) * 2 + 1, 64);   // (all lanes take part in the exchange)
+        const float v0 = res[(lane & 3) * 2] + c0, v1 = res[(lane & 3) * 2 + 1] + c1;
+        if (lane < 4) {
+            dc_st_agent(p.f + bid * 8 + lane * 2, dc_word(v0, tag), dc_word(v1, tag));
+            if (p.f_out) *reinterpret_cast<unsigned*>(p.f_out + bid * 8 + lane * 2) = f2bf_pk(v0, v1);   // (last layer: the head reads a plain bf16 row)
+        }
+    }
+    if (last_layer) {
+        if (!live && lane == 0) *p.err = 1;
+        return;                                            // (the head's projection normalises LN2's input rows itself: h1_out and f_out)
+    }
+    {   // LN2: x_next = LN(alpha * h1 + f) * g2 + be2
+        dc_u32x4 w[8];
+        live = dc_poll_row<2>(p.f, tag, lane, w) && live;
+        DC_TS(11);
+        Vec16<bf16_t> a[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[k].v[j] = p.alpha * h1[k].v[j] + dc_hi(w[2 * k + (j >> 2)][j & 3]);
+        float mu, rs;
+        ln_row_stats<bf16_t, 4>(a, DC_D, p.eps, mu, rs);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            Vec16<bf16_t> o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o.v[j] = (a[k].v[j] - mu) * rs * gg[k].v[j] + bb[k].v[j];
+            o.store(&xs[(k * 64 + lane) * 8]);
+            if (bid == 0) o.store(p.x_next + (k * 64 + lane) * 8);
+        }
+    }
+    if (!live && lane == 0) *p.err = 1;
+    DC_TS(12);
+    DC_BARRIER();                                       // A3
+    DC_TS(13);
+    DC_BARRIER();                                       // B3
+    DC_TS(14);
+    {   // qkv rows bid * 24 .. + 23 (no bias): 6 stores of 4 values
+        const float v = lane < 24 ? res[lane] : 0.f;
+        const int q4 = (lane < 6 ? lane : 0) * 4;
+        const float v0 = __shfl(v, q4 + 0, 64), v1 = __shfl(v, q4 + 1, 64), v2 = __shfl(v, q4 + 2, 64), v3 = __shfl(v, q4 + 3, 64);
+        if (lane < 6) {
+            uint2 w;
+            w.x = f2bf_pk(v0, v1); w.y = f2bf_pk(v2, v3);
+            *reinterpret_cast<uint2*>(p.qkv_next + bid * 24 + lane * 4) = w;   // read by the NEXT launch: a plain store is enough
+        }
+    }
+}
+
+static unsigned long long* g_dc_ts = nullptr;
+extern "C" void db1_test_decode_chain_timestamps(void* buf16) { g_dc_ts = (unsigned long long*)buf16; }
+
+extern "C" int db1_decode_chain_supported(int d, int dff, int H, int D, int nunit) {
+    return (d == DC_D && dff == DC_DFF && D == 128 && H * D == d && nunit >= 1 && nunit <= 12) ? 1 : 0;
+}
+// scratch: the tagged rows y_o | act | f (32-bit words, shared by all layers: a layer's launch ends before the next one starts), then the error
+// flag.  The caller zeroes it ONCE, when it allocates it (tag 0 is never a launch's tag), and never again.
+#define DC_SLOTS 65535
+extern "C" int64_t db1_decode_chain_error_offset(void) { return (int64_t)(2 * DC_D + DC_DFF) * 4; }
+extern "C" int64_t db1_decode_chain_scratch_bytes(void) { return db1_decode_chain_error_offset() + 64; }
+
+extern "C" int db1_decode_chain(const float* att_part, int nunit, int H, const void* x_res, const void* w_o, const void* w1, const void* b1, const void* w2,
+                                const void* b2, const void* w_qkv_next, const void* g1, const void* be1, const void* g2, const void* be2, float alpha, float eps,
+                                void* h1_out, void* f_out, void* x_next, void* qkv_next, void* scratch, int slot, int d, int dff, void* stream) {
+    if (!db1_decode_chain_supported(d, dff, H, 128, nunit)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "decode_chain: d=%d dff=%d H=%d chunks=%d (built for d 2048, dff 4096, d_head 128, <= 12 chunks)", d, dff, H, nunit);
+    if (slot < 0 || slot >= DC_SLOTS) DB1_FAIL(DB1_ERR_BAD_SHAPE, "decode_chain: slot %d", slot);
+    if (!att_part || !x_res || !w_o || !w1 || !b1 || !w2 || !b2 || !g1 || !be1 || !g2 || !be2 || !scratch || (w_qkv_next && (!x_next || !qkv_next)) || (!w_qkv_next && (!h1_out || !f_out)))
+        DB1_FAIL(DB1_ERR_BAD_SHAPE, "decode_chain: null operand");
+    if (!db1_aligned16(x_res) || !db1_aligned16(w_o) || !db1_aligned16(w1) || !db1_aligned16(w2) || (w_qkv_next && !db1_aligned16(w_qkv_next)) || !db1_aligned16(scratch) ||
+        !db1_aligned16(g1) || !db1_aligned16(be1) || !db1_aligned16(g2) || !db1_aligned16(be2) || (x_next && !db1_aligned16(x_next)) || (h1_out && !db1_aligned16(h1_out)) ||
+        (qkv_next && ((uintptr_t)qkv_next & 7)) || (f_out && ((uintptr_t)f_out & 3)))
+        DB1_FAIL(DB1_ERR_BAD_ALIGN, "decode_chain: operands must be 16-byte aligned");
+    DecodeChainArgs a;
+    a.att_part = att_part; a.att_nunit = nunit; a.att_H = H;
+    a.x_res = (const bf16_t*)x_res; a.w_o = (const bf16_t*)w_o; a.w1 = (const bf16_t*)w1; a.w2 = (const bf16_t*)w2; a.w_qkv = (const bf16_t*)w_qkv_next;
+    a.b1 = (const bf16_t*)b1; a.b2 = (const bf16_t*)b2; a.g1 = (const bf16_t*)g1; a.be1 = (const bf16_t*)be1; a.g2 = (const bf16_t*)g2; a.be2 = (const bf16_t*)be2;
+    a.alpha = alpha; a.eps = eps;
+    unsigned* s = (unsigned*)scratch;
+    a.y_o = s; a.act = s + DC_D; a.f = s + DC_D + DC_DFF;
+    a.err = (int*)(s + 2 * DC_D + DC_DFF);
+    a.tag = (unsigned)slot + 1u;
+    a.ts = g_dc_ts;
+    a.h1_out = (bf16_t*)h1_out; a.f_out = (bf16_t*)f_out; a.x_next = (bf16_t*)x_next; a.qkv_next = (bf16_t*)qkv_next;
+    decode_chain_kernel<<<DC_WG, DC_THREADS, 0, (hipStream_t)stream>>>(a);
+    DB1_CHECK_LAUNCH("decode_chain");
+    return DB1_OK;
+}

@@ -223,6 +223,7 @@ class TransformerXL(nn.Module):
         self.use_decode_fused = True     # ... and, for <= 64 new tokens, linear maps as W streams that finish with GEGLU (post-LN)
         self.use_decode_ln_prologue = True   # ... <= 16 tokens: the residual LayerNorms ride on the way IN to the next linear map
         self.use_decode_attn_partials = True   # ... <= 2 tokens (ring memory): the output projection merges the attention's chunk partials
+        self.use_decode_chain = os.environ.get("DB1_DECODE_CHAIN", "1") != "0"   # ... ONE token (ring memory): the linear maps between two attention launches as one persistent launch (db1_decode_chain)
         self._wversion = 0               # bumped whenever the weights change (invalidates the inference caches)
         self._dec_state = None           # K/V cache of the memory returned by the last forward (see _decode_begin)
         self._dec_R = None               # (version, [R_i = r_net_i(sinusoid(dist)) for dist < mem_len + 64])
@@ -1329,6 +1330,11 @@ class TransformerXL(nn.Module):
             ops.dropout(R_in, R_drop, self._drop_args(self.embd_pdrop, self.SITE_POS, dstep))
             R_in = R_drop
         x = h.view(B * L, d)
+        if (ring is not None and B * L == 1 and self.use_decode_chain and getattr(dec, "partials", False) and self.activation_fn == "geglu" and self.n_layer >= 2 and
+                ops.decode_chain_supported(d, self.d_ff, self.n_head, self.d_head, mlen + L)):
+            x = self._decode_chain_layers(x, mlen, shift, dec)
+            hids, lcs = [], []
+            return self._finish_forward(x, hids, lcs, [], [], [], [], R_in, B, L, shift, dstep, keep, compute_loss, mems, ring, dec, mlen)
         if self.wgrad_defer_ga > 1 and keep and self.training and not self.pre_lnorm and mems is None:
             st = self.wgrad_stash
             if st is None or st.T != B * L or st.ga != self.wgrad_defer_ga:
@@ -1346,6 +1352,36 @@ class TransformerXL(nn.Module):
             layer_fwd = self._layer_fwd_prelnorm if self.pre_lnorm else self._layer_fwd
             x, c = layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep, dec, dstep, **kw)
             lcs.append(c)
+        return self._finish_forward(x, hids, lcs, ecs, shapes, labels, masks, R_in, B, L, shift, dstep, keep, compute_loss, mems, ring, dec, mlen)
+
+    def _decode_chain_layers(self, x, mlen, shift, dec):
+        """ONE new token over the K / V ring: per layer the attention launch (chunk partials) and ONE persistent launch for everything between
+        two attention launches (db1_decode_chain: o_net with the merge, LayerNorm, ff1 + GEGLU, ff2, LayerNorm, the next layer's qkv
+        projection) -- 2 launches per layer instead of 5, and the weights stream without the gaps between launches"""
+        d, H, D, n = self.d_model, self.n_head, self.d_head, self.n_layer
+        a = 1.0 if self.deepnorm_alpha is None else self.deepnorm_alpha
+        W = self.W
+        qkv = self._new(1, 3 * d)
+        ops.gemm(x, W("h.0.dec_attn.qkv_net.weight").t(), qkv)
+        h1_out, f_out = self._new(1, d), self._new(1, d)
+        for i in range(n):
+            p = f"h.{i}."
+            part = self._attention_decode(qkv, i, 1, 1, mlen, shift, dec)
+            last = i == n - 1
+            x_next = None if last else self._new(1, d)
+            qkv_next = None if last else self._new(1, 3 * d)
+            ops.decode_chain(part, mlen + 1, H, x, W(p + "dec_attn.o_net.weight"), W(p + "pos_ff.CoreNet.0.weight"), W(p + "pos_ff.CoreNet.0.bias"),
+                             W(p + "pos_ff.CoreNet.2.weight"), W(p + "pos_ff.CoreNet.2.bias"), None if last else W(f"h.{i + 1}.dec_attn.qkv_net.weight"),
+                             W(p + "dec_attn.layer_norm.weight"), W(p + "dec_attn.layer_norm.bias"), W(p + "pos_ff.layer_norm.weight"),
+                             W(p + "pos_ff.layer_norm.bias"), a, self.layer_norm_epsilon, h1_out if last else None, f_out if last else None, x_next, qkv_next, i)
+            if not last:
+                x, qkv = x_next, qkv_next
+        p = f"h.{n - 1}."
+        return _PendingLN(res=h1_out, y=f_out, alpha=a, gamma=W(p + "pos_ff.layer_norm.weight"),
+                          beta=W(p + "pos_ff.layer_norm.bias"), eps=self.layer_norm_epsilon)
+
+    def _finish_forward(self, x, hids, lcs, ecs, shapes, labels, masks, R_in, B, L, shift, dstep, keep, compute_loss, mems, ring, dec, mlen):
+        d = self.d_model
         head_pend = None
         if isinstance(x, _PendingLN):
             pend, x = x, self._new(B * L, d)

@@ -536,6 +536,42 @@ def linear_decode_attn(part, klen, B, q, H, D, W, y):
     lib.call("db1_linear_decode_attn", P(part), (int(klen) + 127) // 128, B, q, H, D, P(W), P(y), y.stride(0), y.shape[1], stream())
 
 
+_chain_scratch = {}
+
+
+def decode_chain_supported(d, dff, H, D, klen) -> bool:
+    return bool(lib.load().db1_decode_chain_supported(int(d), int(dff), int(H), int(D), (int(klen) + 127) // 128))
+
+
+def decode_chain_scratch(device):
+    """the scratch of db1_decode_chain (tagged hand-off rows + error flag): one buffer per device, zeroed once, here"""
+    device = torch.device(device)
+    if device.index is None:   # "cuda" and "cuda:0" are one buffer
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = _chain_scratch.get(device)
+    if t is None:
+        t = torch.zeros(int(lib.load().db1_decode_chain_scratch_bytes()), dtype=torch.uint8, device=device)
+        _chain_scratch[device] = t
+    return t
+
+
+def decode_chain(part, klen, H, x_res, w_o, w1, b1, w2, b2, w_qkv_next, g1, be1, g2, be2, alpha, eps, h1_out, f_out, x_next, qkv_next, slot):
+    """one new token through o_net (merge of the attention partials) -> LN -> ff1 + GEGLU -> ff2 -> LN -> the next layer's qkv projection, one
+    launch (db1_decode_chain); w_qkv_next None = last layer (h1_out and f_out come back for the head's input LayerNorm).  Consecutive launches
+    need different ``slot`` values (the layer index)."""
+    d, dff = w_o.shape[0], w2.shape[1]
+    for t in (x_res, w_o, w1, b1, w2, b2, g1, be1, g2, be2):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous()
+    lib.call("db1_decode_chain", P(part), (int(klen) + 127) // 128, int(H), P(x_res), P(w_o), P(w1), P(b1), P(w2), P(b2), P(w_qkv_next), P(g1), P(be1), P(g2), P(be2),
+             float(alpha), float(eps), P(h1_out), P(f_out), P(x_next), P(qkv_next), P(decode_chain_scratch(x_res.device)), int(slot), int(d), int(dff), stream())
+
+
+def decode_chain_error(device) -> bool:
+    """did a hand-off poll of a chain launch run into its limit (results invalid)?  Synchronises."""
+    off = int(lib.load().db1_decode_chain_error_offset())
+    return bool(decode_chain_scratch(device)[off:off + 4].view(torch.int32).item())
+
+
 def linear_decode_supported(M, N, K, geglu=False, ln=False, pre=False) -> bool:
     return bool(lib.load().db1_linear_decode_supported(int(M), int(N), int(K), int(geglu), int(bool(ln)) | (2 if pre else 0)))
 

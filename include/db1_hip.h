@@ -164,6 +164,23 @@ int64_t db1_ffn_act_bwd_bias_workspace_bytes(int64_t rows, int n_out, int act);
 int db1_ffn_act_bwd_bias(const void* z, const void* dout, void* dz, float* dbias_acc, int64_t rows, int n_out, int act, int dt,
                          void* ws, int64_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ inference with memory: the linear maps between two attention launches
+ * ONE new token (batch 1) through o_net (fed by the merge of the decode attention's chunk partials, as db1_linear_decode_attn) -> LayerNorm
+ * -> ff1 + GEGLU -> ff2 -> LayerNorm -> the NEXT layer's qkv projection, as one launch of 256 persistent workgroups whose weight stream never
+ * stops (csrc/decode_chain.hip; transformer_xl.py:227-243,246-292,136; evaluate_rl.py:157-266).  w_qkv_next NULL = the last layer: the launch
+ * ends with ff2 and hands back h1_out (LN1's row) and f_out (ff2's row) for the head's own input LayerNorm.  All rows bf16.
+ * The workgroups hand the stage vectors over through scratch rows of tagged 32-bit words ({bf16, tag = slot + 1}; polled until every word
+ * carries the launch's tag): scratch = db1_decode_chain_scratch_bytes() bytes, ZEROED ONCE when allocated and then left alone; consecutive
+ * launches on one scratch must use DIFFERENT slots (0 .. 65534; the layer index, so n_layer >= 2) and run one after the other (one stream).
+ * The int at db1_decode_chain_error_offset() is set to 1 when a poll ran into its limit (all 256 workgroups must be resident at once;
+ * results invalid).  Built for d = 2048, dff = 4096, d_head = 128 (db1_decode_chain_supported). */
+int db1_decode_chain_supported(int d, int dff, int H, int D, int nunit);
+int64_t db1_decode_chain_scratch_bytes(void);
+int64_t db1_decode_chain_error_offset(void);
+int db1_decode_chain(const float* att_part, int nunit, int H, const void* x_res, const void* w_o, const void* w1, const void* b1, const void* w2,
+                     const void* b2, const void* w_qkv_next, const void* g1, const void* be1, const void* g2, const void* be2, float alpha, float eps,
+                     void* h1_out, void* f_out, void* x_next, void* qkv_next, void* scratch, int slot, int d, int dff, void* stream);
+
 /* out_acc[c] += sum_r x[r, c]  (bias / u / v gradients). ldx = row stride in elements. */
 int64_t db1_colsum_acc_workspace_bytes(int64_t rows, int cols);   /* per-chunk partials, added in a fixed order */
 int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int cols, int64_t ldx, int dt, void* ws, int64_t ws_bytes, void* stream);

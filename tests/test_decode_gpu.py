@@ -324,3 +324,47 @@ def test_output_projection_merges_the_attention_partials(B, q, mlen):
     for o, ring in outs[1:]:
         assert torch.equal(o, outs[0][0]) and torch.equal(ring, outs[0][1])
     assert int(ops.decode_tickets(qkv.device).abs().sum().item()) == 0
+
+
+def test_decode_chain_matches_the_separate_launches_at_db1_1p3b_geometry():
+    """db1_decode_chain (one persistent launch per layer for o_net + LN + ff1 / GEGLU + ff2 + LN + the next layer's qkv projection, fed by the
+    attention's chunk partials) against the five launches per layer it replaces, over 1-token calls on a K / V ring at the 1.3B layer
+    geometry (3 layers, mem_len 1024): same logits to fp32 summation order + bf16 rounding, no stage wait ran into its spin limit, and the
+    hipGraph-captured call equals the eager one bit for bit."""
+    from bdm_db1_amd import GraphedRingStep, RingMemory, TransformerXL, synth, ops
+    from bdm_db1_amd.data import NLPTaskInput
+    cfg = synth.db1_config("1.3B", n_layer=3)
+    torch.manual_seed(11)
+    model = TransformerXL(cfg, device=torch.device(DEV), compute_dtype=torch.bfloat16)
+    model.eval()
+    rng = np.random.default_rng(4)
+    calls = [rng.integers(0, 32000, (1, q)) for q in (22, 1, 1, 1, 9, 1, 1)]
+
+    def run(chain):
+        model.use_decode_chain = chain
+        mems = RingMemory(model, 1)
+        outs = []
+        with torch.no_grad():
+            for ids in calls:
+                x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=torch.from_numpy(ids).to(DEV), text_len=None)
+                logits, _, mems = model([x], compute_loss=False, mems=mems)
+                outs.append(logits.float().cpu().numpy())
+        return outs
+    ref, got = run(False), run(True)
+    assert not ops.decode_chain_error(model.dev), "a stage wait of the chain launch ran into its spin limit"
+    for step, (a, b) in enumerate(zip(got, ref)):
+        err = np.abs(a - b).max() / np.abs(b).max()
+        assert err < 1e-2, f"call {step} (q = {calls[step].shape[1]}): rel err {err:.3e}"
+    assert any(c.shape[1] == 1 for c in calls)
+    # graphed = eager, both through the chain launch
+    model.use_decode_chain = True
+    ids = torch.from_numpy(rng.integers(0, 32000, (1, 1))).to(DEV)
+    g = GraphedRingStep(model, 1, 1)
+    mem_e = RingMemory(model, 1)
+    with torch.no_grad():
+        for _ in range(3):
+            lg_g, _ = g(ids)
+            x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
+            lg_e, _, mem_e = model([x], compute_loss=False, mems=mem_e)
+            assert torch.equal(lg_g.float(), lg_e.float())
+    assert not ops.decode_chain_error(model.dev)
