@@ -29,6 +29,9 @@
 #define DC_DMA_WAVES 2
 #define DC_THREADS ((DC_WORKERS + 1 + DC_DMA_WAVES) * 64)
 #define DC_SPIN_LIMIT (1 << 17)
+#ifndef DC_W1_EARLY
+#define DC_W1_EARLY 2   /* ff1 rows (of 4 per wave) requested before the first stage's dot product */
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned dc_u32x4;
 // workgroup barrier WITHOUT the vmcnt(0) a __syncthreads() carries (its fence would drain the workers' W prefetches at every stage): LDS
@@ -41,6 +44,7 @@ struct DecodeChainArgs {
     const bf16_t* x_res;                                 // the layer's input row [d] (residual of the first LayerNorm)
     const bf16_t* w_o; const bf16_t* w1; const bf16_t* w2; const bf16_t* w_qkv;   // [d, d], [2 dff, d], [d, dff], [3 d, d] or null (last layer)
     const bf16_t* b1; const bf16_t* b2;                  // [2 dff], [d]
+    const bf16_t* w_o_next;                              // the NEXT launch's w_o (or null): its rows are touched here so that they wait in L2 / the memory-side cache
     const bf16_t* g1; const bf16_t* be1; const bf16_t* g2; const bf16_t* be2;    // LayerNorm parameters
     float alpha, eps;
     unsigned* y_o; unsigned* act; unsigned* f;           // hand-off rows between the stages (global scratch), tagged words: [d], [dff], [d]
@@ -50,6 +54,7 @@ struct DecodeChainArgs {
     int* err;                                            // set to 1 if a poll ran into its limit (results are then invalid)
     unsigned long long* ts;                              // test hook (db1_test_decode_chain_timestamps): workgroup 0's stage times, 100 MHz ticks; null in production
 };
+#define DC_TSW(k) do { } while (0)   /* (worker-side stamps: their stores enter the wave's vmcnt order and move the waits they are meant to time) */
 #define DC_TS(k) do { if (p.ts && lane == 0) { if (bid == 0) p.ts[k] = wall_clock64(); if ((k) < 4) p.ts[16 + bid * 4 + (k)] = wall_clock64(); } } while (0)
 
 __device__ __forceinline__ void dc_st_agent(void* p, unsigned lo, unsigned hi) {
@@ -58,6 +63,36 @@ __device__ __forceinline__ void dc_st_agent(void* p, unsigned lo, unsigned hi) {
 __device__ __forceinline__ float dc_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float dc_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ unsigned dc_word(float v, unsigned tag) { return (f2bf_pk(0.f, v) & 0xffff0000u) | tag; }   // {bf16(v), tag}
+
+// sum over the 64 lanes, the same value in every lane: DPP adds inside the rows of 16 (4 x ~8 cycles) and one readlane per row, instead of
+// six dependent ds_bpermute round trips (~0.3 us per sum: the LayerNorms and dot products here are latency chains of such sums)
+template <int CTRL> __device__ __forceinline__ float dc_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dc_wave_sum(float x) {
+    x += dc_dpp<0xB1>(x);    // quad_perm [1, 0, 3, 2]
+    x += dc_dpp<0x4E>(x);    // quad_perm [2, 3, 0, 1]
+    x += dc_dpp<0x124>(x);   // row_ror 4
+    x += dc_dpp<0x128>(x);   // row_ror 8: every lane holds its row's sum
+    const int xi = __float_as_int(x);
+    return (__int_as_float(__builtin_amdgcn_readlane(xi, 0)) + __int_as_float(__builtin_amdgcn_readlane(xi, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(xi, 32)) + __int_as_float(__builtin_amdgcn_readlane(xi, 48)));
+}
+// LayerNorm statistics of one row held by one wave (the arithmetic of ln_row_stats: the sum is a bf16 tensor in the reference, two passes)
+__device__ __forceinline__ void dc_ln_stats(Vec16<bf16_t> (&a)[4], float eps, float& mu, float& rs) {
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) { a[k].v[j] = bf2f(f2bf(a[k].v[j])); sum += a[k].v[j]; }
+    mu = dc_wave_sum(sum) * (1.f / DC_D);
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const float c = a[k].v[j] - mu; sq += c * c; }
+    rs = rsqrtf(dc_wave_sum(sq) * (1.f / DC_D) + eps);
+}
 
 // NL 16-byte pieces of one W row for this lane: columns (j * 64 + lane) * 8 .. + 7
 template <int NL> struct DcRow { dc_u32x4 w[NL]; };
@@ -77,7 +112,7 @@ template <int NL> __device__ __forceinline__ float dc_dot(const DcRow<NL>& r, co
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < NL; j++) acc = dc_fma8(r.w[j], *reinterpret_cast<const dc_u32x4*>(xs + (j * 64 + lane) * 8), acc);
-    return wave_sum(acc);
+    return dc_wave_sum(acc);
 }
 
 // service wave: the words (k * 64 + lane) * 8 .. + 7 of a tagged row, k < 2 * NP, read past L1 / L2 (sc1) -- one asm statement per two k with its
@@ -106,6 +141,7 @@ template <int NP> __device__ __forceinline__ bool dc_poll_row(const unsigned* ro
     return false;
 }
 
+template <int NU>   // chunks of the attention partials the merge is unrolled for (>= att_nunit)
 __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChainArgs p) {
     // (separate LDS objects: the compiler then knows that reads of xs / res never touch the rows the LDS-DMA requests are still writing,
     //  and does not drain vmcnt before them)
@@ -120,55 +156,54 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
         DcRow<4> w0;                    // o_net: row bid * 8 + wave
         dc_load_row(w0, p.w_o + (int64_t)(bid * 8 + wave) * DC_D, lane);
         DC_PIN();
-        // stage 0 input: the merge of the attention's chunk partials (thread t < 256 owns columns 8 t .. 8 t + 7 = head t / 16), the arithmetic
-        // of relattn_decode_merge2_kernel / db1_linear_decode_attn
+        DC_TSW(0);
+        // stage 0 input: the merge of the attention's chunk partials (worker thread t owns columns 4 t .. 4 t + 3 = head t / 32), the arithmetic
+        // of relattn_decode_merge2_kernel / db1_linear_decode_attn.  Its inputs are requested, then W1, and only then are they waited for:
+        //   ff1 rows of this wave: pairs pr = bid * 16 + wave * 2 + {0, 1}: value row pr, gate row dff + pr          (16 pieces)
+        //   (ff2's row follows after B0: a CU takes about 160 KB of requests before the requesting wave stalls in the issue -- with W2 up
+        //    here the workers reached A0 at 5-7 us instead of 1.5 us; the next layer's qkv rows go to LDS, requested by the DMA waves after A1)
+        constexpr int DD = 128;
+        const int t = threadIdx.x, hh = (t * 4) / DD, d0 = (t * 4) % DD;
+        float4 ov[NU];
+        float2 ml[NU];
         {
-            const int t = threadIdx.x;
-            if (t < DC_D / 8) {
-                constexpr int NU = 12, DD = 128;
-                const int hh = (t * 8) / DD, d0 = (t * 8) % DD;
-                const float* src = p.att_part + ((int64_t)hh * p.att_nunit * 64) * (DD + 2);
-                float4 olo[NU], ohi[NU];
-                float2 ml[NU];
+            const float* src = p.att_part + ((int64_t)hh * p.att_nunit * 64) * (DD + 2);
 #pragma unroll
-                for (int c = 0; c < NU; c++) {
-                    const float* u = src + (int64_t)(c < p.att_nunit ? c : p.att_nunit - 1) * 64 * (DD + 2);
+            for (int c = 0; c < NU; c++) {     // (row 0 of a unit starts 16-byte aligned: 64 * 130 floats per unit)
+                if (c < p.att_nunit) {
+                    const float* u = src + (int64_t)c * 64 * (DD + 2);
                     ml[c] = *reinterpret_cast<const float2*>(u + DD);
-                    const float2 a0 = *reinterpret_cast<const float2*>(u + d0), a1 = *reinterpret_cast<const float2*>(u + d0 + 2);
-                    const float2 a2 = *reinterpret_cast<const float2*>(u + d0 + 4), a3 = *reinterpret_cast<const float2*>(u + d0 + 6);
-                    olo[c] = make_float4(a0.x, a0.y, a1.x, a1.y); ohi[c] = make_float4(a2.x, a2.y, a3.x, a3.y);
+                    ov[c] = *reinterpret_cast<const float4*>(u + d0);
+                } else {
+                    ml[c] = make_float2(-1.0e30f, 0.f); ov[c] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                float mx = -1.0e30f;
-#pragma unroll
-                for (int c = 0; c < NU; c++) mx = fmaxf(mx, c < p.att_nunit ? ml[c].x : -1.0e30f);
-                float l = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < NU; c++) {
-                    const float lc = c < p.att_nunit ? ml[c].y : 0.f;
-                    const float wt = lc > 0.f ? __expf(ml[c].x - mx) : 0.f;
-                    l += lc * wt;
-                    o[0] += olo[c].x * wt; o[1] += olo[c].y * wt; o[2] += olo[c].z * wt; o[3] += olo[c].w * wt;
-                    o[4] += ohi[c].x * wt; o[5] += ohi[c].y * wt; o[6] += ohi[c].z * wt; o[7] += ohi[c].w * wt;
-                }
-                Vec16<bf16_t> ov;
-#pragma unroll
-                for (int j = 0; j < 8; j++) ov.v[j] = l > 0.f ? o[j] / l : 0.f;
-                ov.store(&xs[t * 8]);
             }
         }
-        // the rest of the layer's weights, requested now in stage order (the merge's registers are free again):
-        //   ff1 rows of this wave: pairs pr = bid * 16 + wave * 2 + {0, 1}: value row pr, gate row dff + pr          (16 pieces)
-        //   (the next layer's qkv rows bid * 24 .. + 23 go to LDS, requested by the DMA waves right after: this wave reads rows wave * 3 + {0, 1, 2})
         DC_PIN();
-        DcRow<4> w1[4];
+        DC_TSW(1);
+        DcRow<4> w1[4];                 // [0] value row pr0, [1] gate row pr0, [2] value row pr1, [3] gate row pr1
+        auto w1_row = [&](int r) { return p.w1 + (int64_t)((r & 1 ? DC_DFF : 0) + bid * 16 + wave * 2 + (r >> 1)) * DC_D; };
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int pr = bid * 16 + wave * 2 + j;
-            dc_load_row(w1[2 * j], p.w1 + (int64_t)pr * DC_D, lane);
-            dc_load_row(w1[2 * j + 1], p.w1 + (int64_t)(DC_DFF + pr) * DC_D, lane);
-        }
+        for (int r = 0; r < DC_W1_EARLY; r++) dc_load_row(w1[r], w1_row(r), lane);
         DC_PIN();
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // W0 (and the merge inputs before it) have landed; W1 may be in flight
+        DC_TSW(2);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * DC_W1_EARLY) : "memory");   // W0 and the merge inputs have landed; the early W1 rows may be in flight
+        {
+            float mx = -1.0e30f;
+#pragma unroll
+            for (int c = 0; c < NU; c++) mx = fmaxf(mx, ml[c].x);
+            float l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NU; c++) {
+                const float wt = ml[c].y > 0.f ? __expf(ml[c].x - mx) : 0.f;
+                l += ml[c].y * wt;
+                o0 += ov[c].x * wt; o1 += ov[c].y * wt; o2 += ov[c].z * wt; o3 += ov[c].w * wt;
+            }
+            uint2 w;
+            w.x = f2bf_pk(l > 0.f ? o0 / l : 0.f, l > 0.f ? o1 / l : 0.f); w.y = f2bf_pk(l > 0.f ? o2 / l : 0.f, l > 0.f ? o3 / l : 0.f);
+            *reinterpret_cast<uint2*>(&xs[t * 4]) = w;
+        }
+        DC_TSW(3);
         DC_BARRIER();                                   // A0: the merged row is in LDS (worker waves wrote it)
         {
             const float s = dc_dot(w0, xs, lane);
@@ -177,6 +212,8 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
         DC_BARRIER();                                   // B0: results ready for the service wave
         // ---- stage 1: ff1 + GEGLU.  W2 requested now: a CU takes about 160 KB of requests before the requesting wave stalls in the issue
         // (W0 + W1 = 160 KB; with W2 on top the workers reached A0 at 5-7 us instead of 1.5 us)
+#pragma unroll
+        for (int r = DC_W1_EARLY; r < 4; r++) dc_load_row(w1[r], w1_row(r), lane);
         DcRow<8> w2;
         dc_load_row(w2, p.w2 + (int64_t)(bid * 8 + wave) * DC_DFF, lane);
         DC_PIN();
@@ -206,7 +243,7 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
             for (int i = 0; i < 4; i++)
                 acc = dc_fma8(*reinterpret_cast<const dc_u32x4*>(w3s + ((wave * 3 + j) * 4 + i) * 1024 + lane * 16),
                               *reinterpret_cast<const dc_u32x4*>(xs + (i * 64 + lane) * 8), acc);
-            const float s = wave_sum(acc);
+            const float s = dc_wave_sum(acc);
             if (lane == 0) res[wave * 3 + j] = s;
         }
         DC_BARRIER();                                   // B3
@@ -230,9 +267,17 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
                     __builtin_amdgcn_global_load_lds(p.w_qkv + (int64_t)(bid * 24 + v * 12 + j) * DC_D + (i * 64 + lane) * 8,
                                                      (__attribute__((address_space(3))) void*)(w3s + ((v * 12 + j) * 4 + i) * 1024), 16, 0, 0);
         }
+        // the next launch opens with a cold read of ITS o_net rows (4.5 us before its first dot product could start): ask for one dword of
+        // each of their 128-byte lines now -- same workgroup index = same XCD = same L2 next time; the values are dropped
+        unsigned touch0 = 0, touch1 = 0;
+        if (p.w_o_next) {
+            const char* nx = reinterpret_cast<const char*>(p.w_o_next + (int64_t)(bid * 8 + v * 4) * DC_D) + lane * 128;   // this wave: 4 rows = 16 KB = 128 lines
+            touch0 = *reinterpret_cast<const unsigned*>(nx); touch1 = *reinterpret_cast<const unsigned*>(nx + 8192);
+        }
         DC_BARRIER();                                   // B1
         DC_BARRIER();                                   // A2
         DC_BARRIER();                                   // B2
+        asm volatile("" :: "v"(touch0), "v"(touch1));      // (the only use of the touched lines)
         if (last_layer) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows are in LDS
         DC_BARRIER();                                   // A3
@@ -269,7 +314,7 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
 #pragma unroll
             for (int j = 0; j < 8; j++) a[k].v[j] = p.alpha * xr[k].v[j] + dc_hi(w[2 * k + (j >> 2)][j & 3]);
         float mu, rs;
-        ln_row_stats<bf16_t, 4>(a, DC_D, p.eps, mu, rs);
+        dc_ln_stats(a, p.eps, mu, rs);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
 #pragma unroll
@@ -334,7 +379,7 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
 #pragma unroll
             for (int j = 0; j < 8; j++) a[k].v[j] = p.alpha * h1[k].v[j] + dc_hi(w[2 * k + (j >> 2)][j & 3]);
         float mu, rs;
-        ln_row_stats<bf16_t, 4>(a, DC_D, p.eps, mu, rs);
+        dc_ln_stats(a, p.eps, mu, rs);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             Vec16<bf16_t> o;
@@ -363,7 +408,8 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
 }
 
 static unsigned long long* g_dc_ts = nullptr;
-extern "C" void db1_test_decode_chain_timestamps(void* buf16) { g_dc_ts = (unsigned long long*)buf16; }
+static int g_dc_ts_slot = -1;
+extern "C" void db1_test_decode_chain_timestamps(void* buf, int slot) { g_dc_ts = (unsigned long long*)buf; g_dc_ts_slot = slot; }
 
 extern "C" int db1_decode_chain_supported(int d, int dff, int H, int D, int nunit) {
     return (d == DC_D && dff == DC_DFF && D == 128 && H * D == d && nunit >= 1 && nunit <= 12) ? 1 : 0;
@@ -375,7 +421,7 @@ extern "C" int64_t db1_decode_chain_error_offset(void) { return (int64_t)(2 * DC
 extern "C" int64_t db1_decode_chain_scratch_bytes(void) { return db1_decode_chain_error_offset() + 64; }
 
 extern "C" int db1_decode_chain(const float* att_part, int nunit, int H, const void* x_res, const void* w_o, const void* w1, const void* b1, const void* w2,
-                                const void* b2, const void* w_qkv_next, const void* g1, const void* be1, const void* g2, const void* be2, float alpha, float eps,
+                                const void* b2, const void* w_qkv_next, const void* w_o_next, const void* g1, const void* be1, const void* g2, const void* be2, float alpha, float eps,
                                 void* h1_out, void* f_out, void* x_next, void* qkv_next, void* scratch, int slot, int d, int dff, void* stream) {
     if (!db1_decode_chain_supported(d, dff, H, 128, nunit)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "decode_chain: d=%d dff=%d H=%d chunks=%d (built for d 2048, dff 4096, d_head 128, <= 12 chunks)", d, dff, H, nunit);
     if (slot < 0 || slot >= DC_SLOTS) DB1_FAIL(DB1_ERR_BAD_SHAPE, "decode_chain: slot %d", slot);
@@ -387,16 +433,17 @@ extern "C" int db1_decode_chain(const float* att_part, int nunit, int H, const v
         DB1_FAIL(DB1_ERR_BAD_ALIGN, "decode_chain: operands must be 16-byte aligned");
     DecodeChainArgs a;
     a.att_part = att_part; a.att_nunit = nunit; a.att_H = H;
-    a.x_res = (const bf16_t*)x_res; a.w_o = (const bf16_t*)w_o; a.w1 = (const bf16_t*)w1; a.w2 = (const bf16_t*)w2; a.w_qkv = (const bf16_t*)w_qkv_next;
+    a.x_res = (const bf16_t*)x_res; a.w_o = (const bf16_t*)w_o; a.w1 = (const bf16_t*)w1; a.w2 = (const bf16_t*)w2; a.w_qkv = (const bf16_t*)w_qkv_next; a.w_o_next = (const bf16_t*)w_o_next;
     a.b1 = (const bf16_t*)b1; a.b2 = (const bf16_t*)b2; a.g1 = (const bf16_t*)g1; a.be1 = (const bf16_t*)be1; a.g2 = (const bf16_t*)g2; a.be2 = (const bf16_t*)be2;
     a.alpha = alpha; a.eps = eps;
     unsigned* s = (unsigned*)scratch;
     a.y_o = s; a.act = s + DC_D; a.f = s + DC_D + DC_DFF;
     a.err = (int*)(s + 2 * DC_D + DC_DFF);
     a.tag = (unsigned)slot + 1u;
-    a.ts = g_dc_ts;
+    a.ts = (g_dc_ts_slot < 0 || g_dc_ts_slot == slot) ? g_dc_ts : nullptr;
     a.h1_out = (bf16_t*)h1_out; a.f_out = (bf16_t*)f_out; a.x_next = (bf16_t*)x_next; a.qkv_next = (bf16_t*)qkv_next;
-    decode_chain_kernel<<<DC_WG, DC_THREADS, 0, (hipStream_t)stream>>>(a);
+    if (nunit <= 9) decode_chain_kernel<9><<<DC_WG, DC_THREADS, 0, (hipStream_t)stream>>>(a);   // (mem_len 1024 + 1 token = 9 chunks)
+    else decode_chain_kernel<12><<<DC_WG, DC_THREADS, 0, (hipStream_t)stream>>>(a);
     DB1_CHECK_LAUNCH("decode_chain");
     return DB1_OK;
 }

@@ -1373,7 +1373,8 @@ class TransformerXL(nn.Module):
             ops.decode_chain(part, mlen + 1, H, x, W(p + "dec_attn.o_net.weight"), W(p + "pos_ff.CoreNet.0.weight"), W(p + "pos_ff.CoreNet.0.bias"),
                              W(p + "pos_ff.CoreNet.2.weight"), W(p + "pos_ff.CoreNet.2.bias"), None if last else W(f"h.{i + 1}.dec_attn.qkv_net.weight"),
                              W(p + "dec_attn.layer_norm.weight"), W(p + "dec_attn.layer_norm.bias"), W(p + "pos_ff.layer_norm.weight"),
-                             W(p + "pos_ff.layer_norm.bias"), a, self.layer_norm_epsilon, h1_out if last else None, f_out if last else None, x_next, qkv_next, i)
+                             W(p + "pos_ff.layer_norm.bias"), a, self.layer_norm_epsilon, h1_out if last else None, f_out if last else None, x_next, qkv_next, i,
+                             w_o_next=W(f"h.{(i + 1) % n}.dec_attn.o_net.weight"))
             if not last:
                 x, qkv = x_next, qkv_next
         p = f"h.{n - 1}."

@@ -555,14 +555,14 @@ def decode_chain_scratch(device):
     return t
 
 
-def decode_chain(part, klen, H, x_res, w_o, w1, b1, w2, b2, w_qkv_next, g1, be1, g2, be2, alpha, eps, h1_out, f_out, x_next, qkv_next, slot):
+def decode_chain(part, klen, H, x_res, w_o, w1, b1, w2, b2, w_qkv_next, g1, be1, g2, be2, alpha, eps, h1_out, f_out, x_next, qkv_next, slot, w_o_next=None):
     """one new token through o_net (merge of the attention partials) -> LN -> ff1 + GEGLU -> ff2 -> LN -> the next layer's qkv projection, one
     launch (db1_decode_chain); w_qkv_next None = last layer (h1_out and f_out come back for the head's input LayerNorm).  Consecutive launches
     need different ``slot`` values (the layer index)."""
     d, dff = w_o.shape[0], w2.shape[1]
     for t in (x_res, w_o, w1, b1, w2, b2, g1, be1, g2, be2):
         assert t.dtype == torch.bfloat16 and t.is_contiguous()
-    lib.call("db1_decode_chain", P(part), (int(klen) + 127) // 128, int(H), P(x_res), P(w_o), P(w1), P(b1), P(w2), P(b2), P(w_qkv_next), P(g1), P(be1), P(g2), P(be2),
+    lib.call("db1_decode_chain", P(part), (int(klen) + 127) // 128, int(H), P(x_res), P(w_o), P(w1), P(b1), P(w2), P(b2), P(w_qkv_next), P(w_o_next), P(g1), P(be1), P(g2), P(be2),
              float(alpha), float(eps), P(h1_out), P(f_out), P(x_next), P(qkv_next), P(decode_chain_scratch(x_res.device)), int(slot), int(d), int(dff), stream())
 
 

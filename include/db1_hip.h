@@ -172,14 +172,15 @@ int db1_ffn_act_bwd_bias(const void* z, const void* dout, void* dz, float* dbias
  * The workgroups hand the stage vectors over through scratch rows of tagged 32-bit words ({bf16, tag = slot + 1}; polled until every word
  * carries the launch's tag): scratch = db1_decode_chain_scratch_bytes() bytes, ZEROED ONCE when allocated and then left alone; consecutive
  * launches on one scratch must use DIFFERENT slots (0 .. 65534; the layer index, so n_layer >= 2) and run one after the other (one stream).
+ * w_o_next (or NULL): the w_o of the launch that follows; its lines are touched so that they wait in L2 / the memory-side cache.
  * The int at db1_decode_chain_error_offset() is set to 1 when a poll ran into its limit (all 256 workgroups must be resident at once;
  * results invalid).  Built for d = 2048, dff = 4096, d_head = 128 (db1_decode_chain_supported). */
 int db1_decode_chain_supported(int d, int dff, int H, int D, int nunit);
 int64_t db1_decode_chain_scratch_bytes(void);
 int64_t db1_decode_chain_error_offset(void);
 int db1_decode_chain(const float* att_part, int nunit, int H, const void* x_res, const void* w_o, const void* w1, const void* b1, const void* w2,
-                     const void* b2, const void* w_qkv_next, const void* g1, const void* be1, const void* g2, const void* be2, float alpha, float eps,
-                     void* h1_out, void* f_out, void* x_next, void* qkv_next, void* scratch, int slot, int d, int dff, void* stream);
+                     const void* b2, const void* w_qkv_next, const void* w_o_next, const void* g1, const void* be1, const void* g2, const void* be2,
+                     float alpha, float eps, void* h1_out, void* f_out, void* x_next, void* qkv_next, void* scratch, int slot, int d, int dff, void* stream);
 
 /* out_acc[c] += sum_r x[r, c]  (bias / u / v gradients). ldx = row stride in elements. */
 int64_t db1_colsum_acc_workspace_bytes(int64_t rows, int cols);   /* per-chunk partials, added in a fixed order */

@@ -36,9 +36,9 @@ int db1_is_experiment_build(void);
 /* an empty kernel named db1_marker_kernel on the stream: lets a kernel trace be cut to the timed region of bench.py (tools/prof_table.py) */
 int db1_test_marker(int tag, void* stream);
 /* db1_decode_chain launches made afterwards write workgroup 0's stage times (wall_clock64 ticks of 10 ns) to buf[0 .. 15] and every
- * workgroup's first four to buf[16 + 4 workgroup ..] (device memory, 16 + 1024 int64;
+ * workgroup's first four to buf[16 + 4 workgroup ..] (device memory, 16 + 2048 int64: [1040 + 4 workgroup ..] worker wave 0's W0 issued / merge inputs requested / W1 issued / merged row written;
  * null switches it off): start, A0, B0, y_o complete, LN1 done, A1, B1, act complete, act in LDS, A2, B2, f complete, LN2 done, A3, B3 */
-void db1_test_decode_chain_timestamps(void* buf16);
+void db1_test_decode_chain_timestamps(void* buf, int slot);   /* slot < 0: every launch; else only launches with that slot */
 
 #ifdef __cplusplus
 }

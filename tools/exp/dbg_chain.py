@@ -52,21 +52,23 @@ torch.cuda.synchronize()
 print("last: h1", e(h1o.float(), h1), "f", e(rows()[2], f_ref), "f_out", e(fo.float(), f_ref), "err", ops.decode_chain_error(dev))
 # stage times of workgroup 0 + whole-launch time
 import ctypes
+import numpy as np
 from bdm_db1_amd import lib
-ts = torch.zeros(16 + 1024, dtype=torch.int64, device=dev)
+ts = torch.zeros(16 + 2048, dtype=torch.int64, device=dev)
 L = lib.load()
 L.db1_test_decode_chain_timestamps.restype = None
-L.db1_test_decode_chain_timestamps(ctypes.c_void_p(ts.data_ptr()))
+L.db1_test_decode_chain_timestamps(ctypes.c_void_p(ts.data_ptr()), -1)
 names = ["start", "A0", "B0", "wait0", "LN1", "A1", "B1", "wait1", "actLDS", "A2", "B2", "wait2", "LN2", "A3", "B3"]
 for rep in range(4):
     ops.decode_chain(part, nunit * 128, H, x, Wo, W1, b1, W2, b2, Wq, g1, be1, g2, be2, alpha, eps, h1o, fo, xn, qn, 2 + rep)
     torch.cuda.synchronize()
     t = ts.cpu().numpy()
     print("rep", rep, " ".join(f"{n}={(t[i] - t[0]) / 100:.2f}" for i, n in enumerate(names)))
-    per = (t[16:].reshape(256, 4) - t[0]) / 100
-    import numpy as np
+    perw = (t[1040:].reshape(256, 4) - t[0]) / 100
+    print("      worker wave 0:  " + "  ".join(f"{n} min {perw[:, i].min():.2f} med {np.median(perw[:, i]):.2f} max {perw[:, i].max():.2f}" for i, n in enumerate(["W0 issued", "merge requested", "W1 issued", "merged row"])))
+    per = (t[16:1040].reshape(256, 4) - t[0]) / 100
     print("      all workgroups: " + "  ".join(f"{n} min {per[:, i].min():.2f} med {np.median(per[:, i]):.2f} max {per[:, i].max():.2f}" for i, n in enumerate(names[:4])))
-L.db1_test_decode_chain_timestamps(ctypes.c_void_p(0))
+L.db1_test_decode_chain_timestamps(ctypes.c_void_p(0), -1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for nrep in (1, 20):
     torch.cuda.synchronize()
