@@ -192,7 +192,9 @@ def decode_leg(model, dev, calls: int = 30):
                "ms_per_call": round(ms_graph, 4), "ms_per_call_list_memory_graph": round(ms_graph_list, 4), "ms_per_call_eager": round(ms_eager, 4), "calls": calls, "tokens_per_s": round(1e3 / ms_graph, 1),
                "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
                             "algorithmic_bytes_per_call": int(bytes_call),
-                            "kernel": "the whole call as one hipGraph replay over a K / V ring (skinny GEMMs over the bf16 weights + relattn_decode_ring)"}}
+                            "kernel": ("the whole call as one hipGraph replay over a K / V ring: per layer relattn_decode_ring (chunk partials) + db1_decode_chain "
+                                       "(o_net with the merge, LN, ff1 + GEGLU, ff2, LN, next qkv as one persistent launch)" if getattr(model, "use_decode_chain", False) and nl >= 2 else
+                                       "the whole call as one hipGraph replay over a K / V ring (skinny GEMMs over the bf16 weights + relattn_decode_ring)")}}
     except Exception as e:   # the decode leg must never take the bench line down
         out = {"ms_per_call": None, "error": repr(e)}
     model.train(was_training)
