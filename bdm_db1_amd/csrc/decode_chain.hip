@@ -4,14 +4,21 @@
 // The 1-token call is a chain of W-streams of 8-34 MB, each a latency chain of its own when it is a launch (rows -> W round trip -> dot
 // products -> store: 6-10 us for 2-7 us of HBM time).  Here the four streams between two attention launches
 //     o_net (input: the merge of the attention's chunk partials)  ->  LayerNorm  ->  ff1 + GEGLU  ->  ff2  ->  LayerNorm  ->  next layer's qkv
-// run inside one kernel of 256 workgroups (one per CU), and ALL of the layer's weights (80 MB = 312 KB per CU) are requested in the first two
-// microseconds of the launch, in the order the stages need them, so HBM streams for the whole launch while the stages hand their vectors over:
-//   * eight WORKER waves per workgroup hold the W rows of o_net, ff1 and ff2 in registers (112 VGPRs); the rows of the next layer's qkv
-//     projection go to LDS (96 KB, global_load_lds: no registers, requested by two waves that do nothing else); a worker only ever waits
-//     for its own requests, in stage order;
-//   * one SERVICE wave per workgroup does everything that depends on other workgroups: it publishes the workgroup's outputs, waits for the
-//     whole vector, applies the residual LayerNorm and leaves the stage's input in LDS for the workers.  It never has W requests outstanding,
-//     so its waits cost nothing (vmcnt retires in order: a worker that polled memory between its prefetches would wait for all of them).
+// run inside one kernel of 256 workgroups (one per CU, 11 waves):
+//   * eight WORKER waves per workgroup hold the W rows of o_net, ff1 and ff2 in registers; each publishes the rows it computed itself;
+//   * one SERVICE wave per workgroup does everything that depends on other workgroups: it waits for the whole stage vector, applies the
+//     residual LayerNorm and leaves the stage's input in LDS for the workers.  It never has W requests outstanding, so its waits cost
+//     nothing (vmcnt retires in order: a worker that polled memory between its prefetches would wait for all of them);
+//   * two DMA waves bring the rows of the next layer's qkv projection into LDS (96 KB, global_load_lds: no registers; in waves of their
+//     own, because a compiler that sees LDS-DMA requests in flight drains vmcnt before every LDS read it cannot tell from their target).
+// Order of the memory requests -- what the CU's memory pipeline allows (tools/exp/stream_first.hip, dbg_chain_inmodel.py):
+//   a CU accepts ~160 KB of outstanding requests, a wave that asks for more stalls IN THE ISSUE until earlier data has returned, and the
+//   CU serves its requests in the order they were made -- a store or poll issued behind a burst of bulk requests waits until the burst
+//   has drained (24 KB / us per CU).  So every stage k runs
+//       dot products -> each worker PUBLISHES its rows -> barrier B_k -> the service wave issues its first poll round -> barrier C_k
+//       -> the workers request the weights of stage k + 1 (just those: they have to land before the next dot product anyway)
+//       -> poll complete -> LayerNorm / activation row into LDS -> barrier A_k+1
+//   and nothing is requested further ahead: W0 + half of W1 before the first stage, the rest of W1 at C0, W2 at C1, W3 (DMA) at A2.
 // Hand-off between workgroups without a counter: every value is stored as a 32-bit word {bf16 value, 16-bit tag of this launch}; the service
 // waves poll the ROW ITSELF (L1 / L2-bypassing loads) until all its words carry the launch's tag.  One memory round trip after the last
 // producer's store instead of store -> wait -> counter add -> counter poll -> load: 2.05 us instead of 4.55 us per hand-off between 256
@@ -94,6 +101,10 @@ __device__ __forceinline__ void dc_ln_stats(Vec16<bf16_t> (&a)[4], float eps, fl
     rs = rsqrtf(dc_wave_sum(sq) * (1.f / DC_D) + eps);
 }
 
+// element j (0 .. 7) of eight bf16 packed in four dwords
+__device__ __forceinline__ float dc_el(const dc_u32x4& v, int j) { return (j & 1) ? dc_hi(v[j >> 1]) : dc_lo(v[j >> 1]); }
+__device__ __forceinline__ dc_u32x4 dc_ld16(const bf16_t* p) { return *reinterpret_cast<const dc_u32x4*>(p); }
+
 // NL 16-byte pieces of one W row for this lane: columns (j * 64 + lane) * 8 .. + 7
 template <int NL> struct DcRow { dc_u32x4 w[NL]; };
 template <int NL> __device__ __forceinline__ void dc_load_row(DcRow<NL>& r, const bf16_t* row, int lane) {
@@ -115,8 +126,7 @@ template <int NL> __device__ __forceinline__ float dc_dot(const DcRow<NL>& r, co
     return dc_wave_sum(acc);
 }
 
-// service wave: the words (k * 64 + lane) * 8 .. + 7 of a tagged row, k < 2 * NP, read past L1 / L2 (sc1) -- one asm statement per two k with its
-// own wait, so that no request the compiler does not know about is ever outstanding outside it
+// service wave: the words (k * 64 + lane) * 8 .. + 7 of a tagged row for two k, read past L1 / L2 (sc1)
 __device__ __forceinline__ void dc_read_pair(const unsigned* a, dc_u32x4& w0, dc_u32x4& w1, dc_u32x4& w2, dc_u32x4& w3) {
     asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
                  "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
@@ -124,19 +134,35 @@ __device__ __forceinline__ void dc_read_pair(const unsigned* a, dc_u32x4& w0, dc
                  "global_load_dwordx4 %3, %4, off offset:2064 sc1"
                  : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(a) : "memory");
 }
-// all words of the row carry the tag?  w[2 k + h] = words (k * 64 + lane) * 8 + 4 h .. + 3.  Returns false if the poll limit ran out.
-template <int NP> __device__ __forceinline__ bool dc_poll_row(const unsigned* row, unsigned tag, int lane, dc_u32x4 (&w)[4 * NP]) {
+// one poll round of a tagged row: w[2 k + h] = words (k * 64 + lane) * 8 + 4 h .. + 3, k < 2 NP.  issue: the requests only; land: wait for them
+// (the registers are operands of the wait, so nothing reads them before it); check: every word carries the tag?
+template <int NP> __device__ __forceinline__ void dc_poll_issue(const unsigned* row, int lane, dc_u32x4 (&w)[4 * NP]) {
+#pragma unroll
+    for (int q = 0; q < NP; q++) dc_read_pair(row + q * 1024 + lane * 8, w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+__device__ __forceinline__ void dc_poll_land(dc_u32x4 (&w)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]) :: "memory");
+}
+__device__ __forceinline__ void dc_poll_land(dc_u32x4 (&w)[16]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]),
+                 "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]) :: "memory");
+}
+template <int N> __device__ __forceinline__ bool dc_poll_check(const dc_u32x4 (&w)[N], unsigned tag) {
+    unsigned bad = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) bad |= (w[i][e] ^ tag) & 0xffffu;
+    return __all(bad == 0);
+}
+// the rounds after the first (which the caller issued ahead of the workers' next bulk requests): false if the poll limit ran out
+template <int NP> __device__ __forceinline__ bool dc_poll_rest(const unsigned* row, unsigned tag, int lane, dc_u32x4 (&w)[4 * NP]) {
+    dc_poll_land(w);
     for (int spins = 0; spins < DC_SPIN_LIMIT; spins++) {
-#pragma unroll
-        for (int q = 0; q < NP; q++) dc_read_pair(row + q * 1024 + lane * 8, w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned bad = 0;
-#pragma unroll
-        for (int i = 0; i < 4 * NP; i++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) bad |= (w[i][e] ^ tag) & 0xffffu;
-        if (__all(bad == 0)) return true;
+        if (dc_poll_check(w, tag)) return true;
         __builtin_amdgcn_s_sleep(2);
+        dc_poll_issue<NP>(row, lane, w);
+        dc_poll_land(w);
     }
     return false;
 }
@@ -146,13 +172,17 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
     // (separate LDS objects: the compiler then knows that reads of xs / res never touch the rows the LDS-DMA requests are still writing,
     //  and does not drain vmcnt before them)
     __shared__ __attribute__((aligned(16))) bf16_t xs[DC_DFF];
-    __shared__ __attribute__((aligned(16))) float res[32];
     __shared__ __attribute__((aligned(16))) char w3s[24 * DC_D * 2];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bid = blockIdx.x;
     const bool last_layer = p.w_qkv == nullptr;
 
     if (wave < DC_WORKERS) {
         // ------------------------------------------------------------------------------------------------ worker waves
+        const unsigned tag = p.tag;
+        float bias1[4], bias2;          // of this wave's ff1 rows ([value, gate] x 2 pairs) and its ff2 row
+#pragma unroll
+        for (int r = 0; r < 4; r++) bias1[r] = bf2f(p.b1[(r & 1 ? DC_DFF : 0) + bid * 16 + wave * 2 + (r >> 1)]);
+        bias2 = bf2f(p.b2[bid * 8 + wave]);
         DcRow<4> w0;                    // o_net: row bid * 8 + wave
         dc_load_row(w0, p.w_o + (int64_t)(bid * 8 + wave) * DC_D, lane);
         DC_PIN();
@@ -205,35 +235,46 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
         }
         DC_TSW(3);
         DC_BARRIER();                                   // A0: the merged row is in LDS (worker waves wrote it)
-        {
+        {   // y_o row bid * 8 + wave, published by this wave itself BEFORE it requests anything else: a CU's memory requests are served in
+            // the order they were made, and bulk requests take microseconds to drain
             const float s = dc_dot(w0, xs, lane);
-            if (lane == 0) res[wave] = s;
+            if (lane == 0) __hip_atomic_store(p.y_o + bid * 8 + wave, dc_word(s, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        DC_BARRIER();                                   // B0: results ready for the service wave
+        DC_BARRIER();                                   // B0: the stage's input row is free again
+        DC_BARRIER();                                   // C0: the service wave's first poll round is queued; now the next stage's weights
         // ---- stage 1: ff1 + GEGLU.  W2 requested now: a CU takes about 160 KB of requests before the requesting wave stalls in the issue
         // (W0 + W1 = 160 KB; with W2 on top the workers reached A0 at 5-7 us instead of 1.5 us)
 #pragma unroll
         for (int r = DC_W1_EARLY; r < 4; r++) dc_load_row(w1[r], w1_row(r), lane);
-        DcRow<8> w2;
-        dc_load_row(w2, p.w2 + (int64_t)(bid * 8 + wave) * DC_DFF, lane);
         DC_PIN();
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DC_BARRIER();                                   // A1: LN1 row in LDS
+        {   // z = bf16(sum + bias) for both halves, act = bf16(z_v * gelu(z_g)): pairs bid * 16 + wave * 2 + {0, 1}
+            float sv[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float s = dc_dot(w1[j], xs, lane);
-            if (lane == 0) res[wave * 4 + j] = s;          // [wave][pair j >> 1][value / gate]
+            for (int j = 0; j < 4; j++) sv[j] = dc_dot(w1[j], xs, lane);
+            const float a0 = bf2f(f2bf(sv[0] + bias1[0])) * gelu_fwd_t<bf16_t>(bf2f(f2bf(sv[1] + bias1[1])));
+            const float a1 = bf2f(f2bf(sv[2] + bias1[2])) * gelu_fwd_t<bf16_t>(bf2f(f2bf(sv[3] + bias1[3])));
+            if (lane == 0) dc_st_agent(p.act + bid * 16 + wave * 2, dc_word(a0, tag), dc_word(a1, tag));
         }
         DC_BARRIER();                                   // B1
+        DC_BARRIER();                                   // C1
+        DcRow<8> w2;                    // ff2 row bid * 8 + wave (K = dff), requested behind the service wave's poll of the act row
+        dc_load_row(w2, p.w2 + (int64_t)(bid * 8 + wave) * DC_DFF, lane);
+        DC_PIN();
         // ---- stage 2: ff2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DC_BARRIER();                                   // A2: act row (dff) in LDS
         {
-            const float s = dc_dot(w2, xs, lane);
-            if (lane == 0) res[wave] = s;
+            const float v = dc_dot(w2, xs, lane) + bias2;
+            if (lane == 0) {
+                __hip_atomic_store(p.f + bid * 8 + wave, dc_word(v, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (p.f_out) p.f_out[bid * 8 + wave] = f2bf(v);   // (last layer: the head reads a plain bf16 row)
+            }
         }
         DC_BARRIER();                                   // B2
         if (last_layer) return;
+        DC_BARRIER();                                   // C2
         // ---- stage 3: the next layer's qkv projection of LN2's row; W from LDS (the DMA waves waited for their requests before this barrier)
         DC_BARRIER();                                   // A3: LN2 row in LDS, W3 rows in LDS
 #pragma unroll
@@ -244,9 +285,8 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
                 acc = dc_fma8(*reinterpret_cast<const dc_u32x4*>(w3s + ((wave * 3 + j) * 4 + i) * 1024 + lane * 16),
                               *reinterpret_cast<const dc_u32x4*>(xs + (i * 64 + lane) * 8), acc);
             const float s = dc_wave_sum(acc);
-            if (lane == 0) res[wave * 3 + j] = s;
+            if (lane == 0) p.qkv_next[bid * 24 + wave * 3 + j] = f2bf(s);   // (no bias; read by the NEXT launch: a plain store is enough)
         }
-        DC_BARRIER();                                   // B3
         return;
     }
 
@@ -258,7 +298,18 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
         const int v = wave - DC_WORKERS - 1;
         DC_BARRIER();                                   // A0
         DC_BARRIER();                                   // B0
-        DC_BARRIER();                                   // A1: W0 and W1 have landed in every wave of the workgroup, W2 (64 KB) is in flight
+        DC_BARRIER();                                   // C0
+        DC_BARRIER();                                   // A1
+        // the next launch opens with a cold read of ITS o_net rows: ask for one dword of each of their 128-byte lines now -- same workgroup
+        // index = same XCD = same L2 next time; the values are dropped
+        unsigned touch0 = 0, touch1 = 0;
+        if (p.w_o_next) {
+            const char* nx = reinterpret_cast<const char*>(p.w_o_next + (int64_t)(bid * 8 + v * 4) * DC_D) + lane * 128;   // this wave: 4 rows = 16 KB = 128 lines
+            touch0 = *reinterpret_cast<const unsigned*>(nx); touch1 = *reinterpret_cast<const unsigned*>(nx + 8192);
+        }
+        DC_BARRIER();                                   // B1
+        DC_BARRIER();                                   // C1
+        DC_BARRIER();                                   // A2: W0, W1 and W2 have landed in every wave of the workgroup -- the CU's request queue is empty
         if (!last_layer) {
 #pragma unroll
             for (int j = 0; j < 12; j++)
@@ -267,82 +318,66 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
                     __builtin_amdgcn_global_load_lds(p.w_qkv + (int64_t)(bid * 24 + v * 12 + j) * DC_D + (i * 64 + lane) * 8,
                                                      (__attribute__((address_space(3))) void*)(w3s + ((v * 12 + j) * 4 + i) * 1024), 16, 0, 0);
         }
-        // the next launch opens with a cold read of ITS o_net rows (4.5 us before its first dot product could start): ask for one dword of
-        // each of their 128-byte lines now -- same workgroup index = same XCD = same L2 next time; the values are dropped
-        unsigned touch0 = 0, touch1 = 0;
-        if (p.w_o_next) {
-            const char* nx = reinterpret_cast<const char*>(p.w_o_next + (int64_t)(bid * 8 + v * 4) * DC_D) + lane * 128;   // this wave: 4 rows = 16 KB = 128 lines
-            touch0 = *reinterpret_cast<const unsigned*>(nx); touch1 = *reinterpret_cast<const unsigned*>(nx + 8192);
-        }
-        DC_BARRIER();                                   // B1
-        DC_BARRIER();                                   // A2
         DC_BARRIER();                                   // B2
         asm volatile("" :: "v"(touch0), "v"(touch1));      // (the only use of the touched lines)
         if (last_layer) return;
+        DC_BARRIER();                                   // C2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows are in LDS
         DC_BARRIER();                                   // A3
-        DC_BARRIER();                                   // B3
         return;
     }
 
     // ---------------------------------------------------------------------------------------------------- service wave
     // LayerNorm parameters and the residual row of LN1: requested up front (plain loads: written before this launch)
     const unsigned tag = p.tag;
-    Vec16<bf16_t> xr[4], gg[4], bb[4];
+    dc_u32x4 xr[4], gg[4], bb[4];          // (eight bf16 per 16 bytes: kept packed, the wave holds a whole polled row next to them)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        xr[k].load(p.x_res + (k * 64 + lane) * 8);
-        gg[k].load(p.g1 + (k * 64 + lane) * 8);
-        bb[k].load(p.be1 + (k * 64 + lane) * 8);
+        xr[k] = dc_ld16(p.x_res + (k * 64 + lane) * 8);
+        gg[k] = dc_ld16(p.g1 + (k * 64 + lane) * 8);
+        bb[k] = dc_ld16(p.be1 + (k * 64 + lane) * 8);
     }
     DC_TS(0);
     DC_BARRIER();                                       // A0 (the workers prepared the stage-0 input themselves)
     DC_TS(1);
-    DC_BARRIER();                                       // B0
+    DC_BARRIER();                                       // B0: every worker of this workgroup has published its y_o row
     DC_TS(2);
-    if (lane < 4) dc_st_agent(p.y_o + bid * 8 + lane * 2, dc_word(res[lane * 2], tag), dc_word(res[lane * 2 + 1], tag));   // y_o rows bid * 8 .. + 7 (bf16, as db1_linear_decode_attn stores them)
     bool live = true;
     // ---- LN1: h1 = LN(alpha * x_res + y_o) * g1 + be1
-    Vec16<bf16_t> h1[4];
+    dc_u32x4 h1[4];
     {
         dc_u32x4 w[8];
-        live = dc_poll_row<2>(p.y_o, tag, lane, w) && live;
+        dc_poll_issue<2>(p.y_o, lane, w);
+        DC_BARRIER();                                   // C0
+        live = dc_poll_rest<2>(p.y_o, tag, lane, w) && live;
         DC_TS(3);
         Vec16<bf16_t> a[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) a[k].v[j] = p.alpha * xr[k].v[j] + dc_hi(w[2 * k + (j >> 2)][j & 3]);
+            for (int j = 0; j < 8; j++) a[k].v[j] = p.alpha * dc_el(xr[k], j) + dc_hi(w[2 * k + (j >> 2)][j & 3]);
         float mu, rs;
         dc_ln_stats(a, p.eps, mu, rs);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) h1[k].v[j] = bf2f(f2bf((a[k].v[j] - mu) * rs * gg[k].v[j] + bb[k].v[j]));   // h1 is a bf16 row
-            h1[k].store(&xs[(k * 64 + lane) * 8]);
-            if (bid == 0 && p.h1_out) h1[k].store(p.h1_out + (k * 64 + lane) * 8);
+            for (int e = 0; e < 4; e++)                     // h1 is a bf16 row
+                h1[k][e] = f2bf_pk((a[k].v[2 * e] - mu) * rs * dc_el(gg[k], 2 * e) + dc_el(bb[k], 2 * e),
+                                   (a[k].v[2 * e + 1] - mu) * rs * dc_el(gg[k], 2 * e + 1) + dc_el(bb[k], 2 * e + 1));
+            *reinterpret_cast<dc_u32x4*>(&xs[(k * 64 + lane) * 8]) = h1[k];
+            if (bid == 0 && p.h1_out) *reinterpret_cast<dc_u32x4*>(p.h1_out + (k * 64 + lane) * 8) = h1[k];
         }
     }
-    // (the parameters of LN2 and the two biases this workgroup needs: requested before the barrier, used after it)
-#pragma unroll
-    for (int k = 0; k < 4; k++) { gg[k].load(p.g2 + (k * 64 + lane) * 8); bb[k].load(p.be2 + (k * 64 + lane) * 8); }
-    float bias1 = lane < 32 ? bf2f(p.b1[(lane & 1 ? DC_DFF : 0) + bid * 16 + (lane >> 1)]) : 0.f;   // lane = 2 pair + {0: value, 1: gate}
-    float bias2 = lane < 8 ? bf2f(p.b2[bid * 8 + lane]) : 0.f;
     DC_TS(4);
     DC_BARRIER();                                       // A1
     DC_TS(5);
     DC_BARRIER();                                       // B1
     DC_TS(6);
-    {   // z = bf16(sum + bias) for both halves, act = bf16(z_v * gelu(z_g)): pairs bid * 16 .. + 15 (res[wave * 4 + 2 j + {0, 1}] = pair wave * 2 + j)
-        const float z = lane < 32 ? bf2f(f2bf(res[lane] + bias1)) : 0.f;
-        const float gate = __shfl_down(z, 1, 64);
-        const float a = z * gelu_fwd_t<bf16_t>(gate);      // valid in even lanes < 32: pair lane >> 1
-        const float a0 = __shfl(a, (lane & 7) * 4, 64), a1 = __shfl(a, (lane & 7) * 4 + 2, 64);   // pairs 2 lane, 2 lane + 1
-        if (lane < 8) dc_st_agent(p.act + bid * 16 + lane * 2, dc_word(a0, tag), dc_word(a1, tag));
-    }
     {   // act row (dff values) -> LDS as bf16
         dc_u32x4 w[16];
-        live = dc_poll_row<4>(p.act, tag, lane, w) && live;
+        dc_poll_issue<4>(p.act, lane, w);
+        DC_BARRIER();                                   // C1
+        live = dc_poll_rest<4>(p.act, tag, lane, w) && live;
         DC_TS(7);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -352,39 +387,36 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
             *reinterpret_cast<dc_u32x4*>(xs + (k * 64 + lane) * 8) = v;
         }
     }
+    // (the parameters of LN2: requested now that the act row's registers are free, used after the next hand-off)
+#pragma unroll
+    for (int k = 0; k < 4; k++) { gg[k] = dc_ld16(p.g2 + (k * 64 + lane) * 8); bb[k] = dc_ld16(p.be2 + (k * 64 + lane) * 8); }
     DC_TS(8);
     DC_BARRIER();                                       // A2
     DC_TS(9);
     DC_BARRIER();                                       // B2
     DC_TS(10);
-    {
-        const float c0 = __shfl(bias2, (lane & 3) * 2, 64), c1 = __shfl(bias2, (lane & 3) * 2 + 1, 64);   // (all lanes take part in the exchange)
-        const float v0 = res[(lane & 3) * 2] + c0, v1 = res[(lane & 3) * 2 + 1] + c1;
-        if (lane < 4) {
-            dc_st_agent(p.f + bid * 8 + lane * 2, dc_word(v0, tag), dc_word(v1, tag));
-            if (p.f_out) *reinterpret_cast<unsigned*>(p.f_out + bid * 8 + lane * 2) = f2bf_pk(v0, v1);   // (last layer: the head reads a plain bf16 row)
-        }
-    }
     if (last_layer) {
         if (!live && lane == 0) *p.err = 1;
         return;                                            // (the head's projection normalises LN2's input rows itself: h1_out and f_out)
     }
     {   // LN2: x_next = LN(alpha * h1 + f) * g2 + be2
         dc_u32x4 w[8];
-        live = dc_poll_row<2>(p.f, tag, lane, w) && live;
+        dc_poll_issue<2>(p.f, lane, w);
+        DC_BARRIER();                                   // C2
+        live = dc_poll_rest<2>(p.f, tag, lane, w) && live;
         DC_TS(11);
         Vec16<bf16_t> a[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) a[k].v[j] = p.alpha * h1[k].v[j] + dc_hi(w[2 * k + (j >> 2)][j & 3]);
+            for (int j = 0; j < 8; j++) a[k].v[j] = p.alpha * dc_el(h1[k], j) + dc_hi(w[2 * k + (j >> 2)][j & 3]);
         float mu, rs;
         dc_ln_stats(a, p.eps, mu, rs);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             Vec16<bf16_t> o;
 #pragma unroll
-            for (int j = 0; j < 8; j++) o.v[j] = (a[k].v[j] - mu) * rs * gg[k].v[j] + bb[k].v[j];
+            for (int j = 0; j < 8; j++) o.v[j] = (a[k].v[j] - mu) * rs * dc_el(gg[k], j) + dc_el(bb[k], j);
             o.store(&xs[(k * 64 + lane) * 8]);
             if (bid == 0) o.store(p.x_next + (k * 64 + lane) * 8);
         }
@@ -393,18 +425,6 @@ __global__ __launch_bounds__(DC_THREADS, 1) void decode_chain_kernel(DecodeChain
     DC_TS(12);
     DC_BARRIER();                                       // A3
     DC_TS(13);
-    DC_BARRIER();                                       // B3
-    DC_TS(14);
-    {   // qkv rows bid * 24 .. + 23 (no bias): 6 stores of 4 values
-        const float v = lane < 24 ? res[lane] : 0.f;
-        const int q4 = (lane < 6 ? lane : 0) * 4;
-        const float v0 = __shfl(v, q4 + 0, 64), v1 = __shfl(v, q4 + 1, 64), v2 = __shfl(v, q4 + 2, 64), v3 = __shfl(v, q4 + 3, 64);
-        if (lane < 6) {
-            uint2 w;
-            w.x = f2bf_pk(v0, v1); w.y = f2bf_pk(v2, v3);
-            *reinterpret_cast<uint2*>(p.qkv_next + bid * 24 + lane * 4) = w;   // read by the NEXT launch: a plain store is enough
-        }
-    }
 }
 
 static unsigned long long* g_dc_ts = nullptr;
