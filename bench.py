@@ -105,25 +105,37 @@ def cpu_baseline(repeats: int = 5):
     torch_port = None
     try:
         from oracle.db1_torch_cpu import TorchCpuModel
-        tthreads = torch.get_num_threads()
-        tmed, truns = {}, {}
-        for k in (1, 2):
-            cfg = O.OracleConfig(n_embed=d, n_layer=k, n_head=H, n_position=L, mem_len=L)
-            tm = TorchCpuModel(cfg, _oracle_params(O, rng, d, H, k, cfg.total_vocab_size))
-            ids = rng.integers(0, 32000, (1, L + 1))
-            ts = []
-            for r in range(repeats + 1):
-                t0 = time.perf_counter()
-                tm.forward(ids[:, :-1], ids[:, 1:], np.ones((1, L), np.float32))
-                tm.backward()
-                if r:
-                    ts.append(time.perf_counter() - t0)
-            truns[k], tmed[k] = ts, float(np.median(ts))
-        tper = max(tmed[2] - tmed[1], 1e-9)
-        tfull = max(tmed[1] - tper, 0.0) + 24 * tper
-        torch_port = {"value": round(L / tfull, 2), "unit": "tokens/s", "cores": int(tthreads),
-                      "sample": f"the same sample through oracle/db1_torch_cpu.py (torch eager ops + autograd, fp32, {tthreads} threads): "
-                                f"{fmt(truns[1])} s; {fmt(truns[2])} s, extrapolated to 24 layers ({tfull:.1f} s/sequence)"}
+        all_threads = torch.get_num_threads()
+        best_t = None
+        # eager torch on many cores loses to itself on few (128 threads: 17 tokens/s on the r04 box, the survey's 8-core run of the reference:
+        # 56): the port is timed at 8 and at 32 threads (median of 3 after one untimed run) and the faster one is reported
+        for tthreads in sorted({min(8, all_threads), min(32, all_threads)}):
+            torch.set_num_threads(tthreads)
+            tmed, truns = {}, {}
+            for k in (1, 2):
+                cfg = O.OracleConfig(n_embed=d, n_layer=k, n_head=H, n_position=L, mem_len=L)
+                tm = TorchCpuModel(cfg, _oracle_params(O, rng, d, H, k, cfg.total_vocab_size))
+                ids = rng.integers(0, 32000, (1, L + 1))
+                ts = []
+                for r in range(3 + 1):
+                    t0 = time.perf_counter()
+                    tm.forward(ids[:, :-1], ids[:, 1:], np.ones((1, L), np.float32))
+                    tm.backward()
+                    if r:
+                        ts.append(time.perf_counter() - t0)
+                truns[k], tmed[k] = ts, float(np.median(ts))
+            tper = max(tmed[2] - tmed[1], 1e-9)
+            tfull = max(tmed[1] - tper, 0.0) + 24 * tper
+            cand = {"value": round(L / tfull, 2), "unit": "tokens/s", "cores": int(tthreads),
+                    "sample": f"the same sample through oracle/db1_torch_cpu.py (torch eager ops + autograd, fp32, {tthreads} threads, median of 3): "
+                              f"{fmt(truns[1])} s; {fmt(truns[2])} s, extrapolated to 24 layers ({tfull:.1f} s/sequence)"}
+            if best_t is None or cand["value"] > best_t["value"]:
+                other = None if best_t is None else {"cores": best_t["cores"], "value": best_t["value"]}
+                best_t = dict(cand, other_thread_count=other) if other else cand
+            else:
+                best_t = dict(best_t, other_thread_count={"cores": cand["cores"], "value": cand["value"]})
+        torch.set_num_threads(all_threads)
+        torch_port = best_t
     except Exception as e:   # (never take the line down)
         torch_port = {"value": None, "error": repr(e)}
     numpy_port = {"value": round(L / full, 2), "unit": "tokens/s", "cores": int(threads)}
@@ -136,7 +148,7 @@ def cpu_baseline(repeats: int = 5):
             "sample": f"DB1-1.3B geometry, 1 sequence x 1024 tokens, fwd+bwd, fp32, two CPU ports of the path timed (value = the faster); NumPy/OpenBLAS oracle: 1 and 2 decoder layers + tied head, "
                       f"median of {repeats} timed runs each after one untimed run ({fmt(runs[1])} s; {fmt(runs[2])} s), extrapolated to 24 layers "
                       f"({full:.1f} s/sequence); {os.cpu_count()} logical CPUs on the box, {threads} BLAS threads (its elementwise passes over [16, 1024, 1024] "
-                      f"fp32 tensors are single-threaded NumPy, which is why it is the slower port); torch-eager port: see torch_eager_port.sample",
+                      f"fp32 tensors are single-threaded NumPy); torch-eager port: see torch_eager_port.sample",
             "tiny_config1": tiny,
             "reference_torch_cpu": {"value": REFERENCE_CPU_TOKENS_PER_S_8_CORES, "unit": "tokens/s", "cores": 8,
                                     "note": "the reference's own torch-CPU forward+backward at the same geometry, timed by the survey in its "
