@@ -431,8 +431,22 @@ static unsigned long long* g_dc_ts = nullptr;
 static int g_dc_ts_slot = -1;
 extern "C" void db1_test_decode_chain_timestamps(void* buf, int slot) { g_dc_ts = (unsigned long long*)buf; g_dc_ts_slot = slot; }
 
+// the 256 workgroups wait for each other: every one of them needs a CU of its own (a partitioned or smaller device would run into the poll
+// bound instead of finishing) -- the current device's CU count, looked up once per device
+static int dc_device_fits() {
+    static int cus[64];
+    static Db1PerDeviceOnce once;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    once.run([dev] {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cus[dev & 63] = n;
+    });
+    return cus[dev & 63] >= DC_WG;
+}
 extern "C" int db1_decode_chain_supported(int d, int dff, int H, int D, int nunit) {
-    return (d == DC_D && dff == DC_DFF && D == 128 && H * D == d && nunit >= 1 && nunit <= 12) ? 1 : 0;
+    return (d == DC_D && dff == DC_DFF && D == 128 && H * D == d && nunit >= 1 && nunit <= 12 && dc_device_fits()) ? 1 : 0;
 }
 // scratch: the tagged rows y_o | act | f (32-bit words, shared by all layers: a layer's launch ends before the next one starts), then the error
 // flag.  The caller zeroes it ONCE, when it allocates it (tag 0 is never a launch's tag), and never again.

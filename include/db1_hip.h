@@ -174,7 +174,7 @@ int db1_ffn_act_bwd_bias(const void* z, const void* dout, void* dz, float* dbias
  * launches on one scratch must use DIFFERENT slots (0 .. 65534; the layer index, so n_layer >= 2) and run one after the other (one stream).
  * w_o_next (or NULL): the w_o of the launch that follows; its lines are touched so that they wait in L2 / the memory-side cache.
  * The int at db1_decode_chain_error_offset() is set to 1 when a poll ran into its limit (all 256 workgroups must be resident at once;
- * results invalid).  Built for d = 2048, dff = 4096, d_head = 128 (db1_decode_chain_supported). */
+ * results invalid).  Built for d = 2048, dff = 4096, d_head = 128 on a device with >= 256 CUs (db1_decode_chain_supported checks both). */
 int db1_decode_chain_supported(int d, int dff, int H, int D, int nunit);
 int64_t db1_decode_chain_scratch_bytes(void);
 int64_t db1_decode_chain_error_offset(void);

@@ -368,3 +368,66 @@ def test_decode_chain_matches_the_separate_launches_at_db1_1p3b_geometry():
             lg_e, _, mem_e = model([x], compute_loss=False, mems=mem_e)
             assert torch.equal(lg_g.float(), lg_e.float())
     assert not ops.decode_chain_error(model.dev)
+
+
+def test_decode_chain_stages_against_fp32_arithmetic():
+    """db1_decode_chain alone, stage by stage: the rows it leaves in its scratch (tagged words: y_o, act, f) and its outputs (h1_out, f_out,
+    x_next, qkv_next) against the same chain in fp32 torch arithmetic with bf16 rounding where the launches it replaces store bf16
+    (transformer_xl.py:227-243,246-292,136), from random chunk partials; both forms of the launch (with the next layer's projection / last
+    layer); every word of the scratch rows carries the launch's tag (slot + 1)."""
+    from bdm_db1_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d, dff, H, D, nunit = 2048, 4096, 16, 128, 9
+    if not ops.decode_chain_supported(d, dff, H, D, nunit * 128):
+        pytest.skip("db1_decode_chain needs 256 CUs")
+    torch.manual_seed(0)
+    bf16 = torch.bfloat16
+    r = lambda *s, sc=1.0: (torch.randn(*s, device=dev) * sc).to(bf16)
+    x = r(1, d)
+    Wo, W1, W2, Wq = r(d, d, sc=0.02), r(2 * dff, d, sc=0.02), r(d, dff, sc=0.02), r(3 * d, d, sc=0.02)
+    b1, b2 = r(2 * dff, sc=0.1), r(d, sc=0.1)
+    g1, be1 = (1 + 0.1 * torch.randn(d, device=dev)).to(bf16), r(d, sc=0.1)
+    g2, be2 = (1 + 0.1 * torch.randn(d, device=dev)).to(bf16), r(d, sc=0.1)
+    part = torch.full((H, nunit, 64, D + 2), float("nan"), device=dev)     # only query row 0 of every unit is read
+    part[:, :, 0, :D] = torch.randn(H, nunit, D, device=dev)
+    part[:, :, 0, D] = torch.randn(H, nunit, device=dev)
+    part[:, :, 0, D + 1] = torch.rand(H, nunit, device=dev) + 0.5
+    part[3, 2, 0, D + 1] = 0.0                                               # a chunk without visible keys contributes nothing
+    alpha, eps = 1.3, 1e-5
+    h1o, fo = torch.zeros(1, d, device=dev, dtype=bf16), torch.zeros(1, d, device=dev, dtype=bf16)
+    xn, qn = torch.zeros(1, d, device=dev, dtype=bf16), torch.zeros(1, 3 * d, device=dev, dtype=bf16)
+    rb = lambda t: t.to(bf16).float()
+    m, l, o = part[:, :, 0, D], part[:, :, 0, D + 1], part[:, :, 0, :D]
+    wt = torch.where(l > 0, torch.exp(m - torch.where(l > 0, m, torch.full_like(m, -1e30)).max(1, keepdim=True).values), torch.zeros_like(m))
+    merged = rb(((o * wt[..., None]).sum(1) / (l * wt).sum(1, keepdim=True)).reshape(1, d))
+
+    def ln(s, g, b):
+        s = rb(s)
+        mu = s.mean(-1, keepdim=True)
+        return rb((s - mu) * torch.rsqrt(((s - mu) ** 2).mean(-1, keepdim=True) + eps) * g.float() + b.float())
+    y_ref = rb(merged @ Wo.float().t())
+    h1 = ln(alpha * x.float() + y_ref, g1, be1)
+    z = rb(h1 @ W1.float().t() + b1.float())
+    act_ref = rb(z[:, :dff] * torch.nn.functional.gelu(z[:, dff:]))
+    f_ref = rb(act_ref @ W2.float().t() + b2.float())
+    xn_ref = ln(alpha * h1 + f_ref, g2, be2)
+    q_ref = rb(xn_ref @ Wq.float().t())
+    err = lambda a, b: ((a.reshape(-1).float() - b.reshape(-1)).abs().max() / b.abs().max()).item()
+
+    def rows():
+        w = ops.decode_chain_scratch(dev)[: (2 * d + dff) * 4].view(torch.int32)
+        val = (w >> 16).to(torch.int16).view(bf16).float()
+        return val[:d], val[d:d + dff], val[d + dff:], (w & 0xffff)
+    for slot, wq in ((4, Wq), (5, None)):     # (consecutive launches use different slots)
+        last = wq is None
+        ops.decode_chain(part, nunit * 128, H, x, Wo, W1, b1, W2, b2, wq, g1, be1, g2, be2, alpha, eps, h1o if last else None, fo if last else None,
+                         None if last else xn, None if last else qn, slot, w_o_next=Wo)
+        torch.cuda.synchronize()
+        assert not ops.decode_chain_error(dev)
+        y_o, act, f, tags = rows()
+        assert tags.unique().tolist() == [slot + 1]
+        assert err(y_o, y_ref) < 4e-3 and err(act, act_ref) < 1e-2 and err(f, f_ref) < 1e-2
+        if last:
+            assert err(h1o, h1) < 5e-3 and err(fo, f_ref) < 1e-2
+        else:
+            assert err(xn, xn_ref) < 1e-2 and err(qn, q_ref) < 1e-2
