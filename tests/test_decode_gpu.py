@@ -326,14 +326,15 @@ def test_output_projection_merges_the_attention_partials(B, q, mlen):
     assert int(ops.decode_tickets(qkv.device).abs().sum().item()) == 0
 
 
-def test_decode_chain_matches_the_separate_launches_at_db1_1p3b_geometry():
+@pytest.mark.parametrize("mem_len", [1024, 1400])
+def test_decode_chain_matches_the_separate_launches_at_db1_1p3b_geometry(mem_len):
     """db1_decode_chain (one persistent launch per layer for o_net + LN + ff1 / GEGLU + ff2 + LN + the next layer's qkv projection, fed by the
     attention's chunk partials) against the five launches per layer it replaces, over 1-token calls on a K / V ring at the 1.3B layer
-    geometry (3 layers, mem_len 1024): same logits to fp32 summation order + bf16 rounding, no stage wait ran into its spin limit, and the
+    geometry (3 layers, mem_len 1024 / 1400): same logits to fp32 summation order + bf16 rounding, no stage wait ran into its spin limit, and the
     hipGraph-captured call equals the eager one bit for bit."""
     from bdm_db1_amd import GraphedRingStep, RingMemory, TransformerXL, synth, ops
     from bdm_db1_amd.data import NLPTaskInput
-    cfg = synth.db1_config("1.3B", n_layer=3)
+    cfg = synth.db1_config("1.3B", n_layer=3, mem_len=mem_len, n_position=max(1024, mem_len))   # (1400 + 1 keys: 12 chunks, the merge's other unrolling)
     torch.manual_seed(11)
     model = TransformerXL(cfg, device=torch.device(DEV), compute_dtype=torch.bfloat16)
     model.eval()
