@@ -36,7 +36,7 @@ class GradSync:
     orders the collective behind the cast (it waits for the launching stream's work) and ``finish`` orders the optimizer behind it."""
 
     def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[str, int, int]], group=None, stage: Optional[torch.Tensor] = None,
-                 cast=None):
+                 cast=None, norm_sq=None):
         self.flat = flat_grad
         self.buckets = {n: (s, e) for n, s, e in buckets}
         self.order = [n for n, _, _ in buckets]
@@ -47,6 +47,16 @@ class GradSync:
         assert stage is None or (stage.numel() == flat_grad.numel() and cast is not None)
         self.handles = []
         self.launched = set()
+        # ``norm_sq(reduced_slice, out1)``: out1[0] = sum of squares of one REDUCED bucket.  Run per bucket as soon as its collective is done
+        # (on a side stream ordered behind it, next to the backward that is still running), so that the global-norm clip needs only the
+        # sum of ``norm_parts`` after the last bucket -- not another pass over all gradients between the last all-reduce and the optimizer.
+        self.norm_sq = norm_sq
+        self.norm_parts = torch.zeros(len(self.order), device=flat_grad.device, dtype=torch.float32) if norm_sq is not None else None
+        # (only a backend whose wait() is a STREAM-level wait -- RCCL -- can be followed from a side stream; gloo's wait() blocks the host, which
+        #  would serialise the backward behind every bucket: there the partial sums are taken in finish())
+        nccl = self.world > 1 and str(dist.get_backend(group)).lower() == "nccl"
+        self._side = torch.cuda.Stream(device=flat_grad.device) if (norm_sq is not None and flat_grad.is_cuda and nccl) else None
+        self._pending_norm = []
         self.time_waits = False    # bench.py --gpus N: HIP-event pairs around the waits of finish() = the exposed communication
         self.wait_events = []
 
@@ -64,7 +74,21 @@ class GradSync:
         if self.stage is not None:
             self.cast(buf, self.stage[s:e])
             buf = self.stage[s:e]
-        self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.handles.append(h)
+        if self.norm_sq is not None:
+            i = self.order.index(name)
+            if self._side is not None:   # the side stream waits for this collective (a stream-level wait: the host and the compute stream go on)
+                self._side.wait_stream(torch.cuda.current_stream(self.flat.device))
+                with torch.cuda.stream(self._side), ops.stream_scope():
+                    h.wait()
+                    self.norm_sq(buf, self.norm_parts[i:i + 1])
+            else:                        # host tensors (gloo tests): a wait would block here; done in finish()
+                self._pending_norm.append((i, buf))
+
+    def reduced_norm_sq(self) -> torch.Tensor:
+        """sum of squares of all reduced gradients (valid after ``finish``): the per-bucket partial sums added in bucket order"""
+        return self.norm_parts.sum(dtype=torch.float32).reshape(1)
 
     def finish(self):
         """launch whatever was not launched by a hook, then wait for everything"""
@@ -76,6 +100,11 @@ class GradSync:
             ev[0].record()
         for h in self.handles:
             h.wait()
+        if self._side is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
+        for i, buf in self._pending_norm:
+            self.norm_sq(buf, self.norm_parts[i:i + 1])
+        self._pending_norm = []
         if ev is not None:
             ev[1].record()
             self.wait_events.append(ev)
@@ -139,7 +168,9 @@ class DB1Engine:
         stage = None
         if self.dp_world > 1 and rdt == "bf16":
             stage = torch.zeros(ar.numel, device=model.device, dtype=torch.bfloat16)
-        self.sync = GradSync(ar.grad, model.grad_buckets(), self.group, stage=stage, cast=ops.cast)
+        # (more than one rank, clipping on: the norm of the reduced gradients is collected bucket by bucket behind each all-reduce)
+        per_bucket_norm = ops.grad_norm_sq if (self.dp_world > 1 and self.clip > 0 and os.environ.get("DB1_PER_BUCKET_NORM", "1") != "0") else None
+        self.sync = GradSync(ar.grad, model.grad_buckets(), self.group, stage=stage, cast=ops.cast, norm_sq=per_bucket_norm)
         self.last_grad_norm_sq = None
 
     # ---- what the reference's drivers call
@@ -192,7 +223,9 @@ class DB1Engine:
         ar = self.module.arena
         grad = self.sync.reduced      # the fp32 arena, or the all-reduced bf16 staging copy
         gscale = 1.0 / self.dp_world  # it holds the SUM over ranks
-        if self.clip > 0:
+        if self.clip > 0 and self.sync.norm_parts is not None and self.dp_world > 1:
+            self._norm_sq.copy_(self.sync.reduced_norm_sq())   # per-bucket sums taken behind each all-reduce: only this scalar sum is left
+        elif self.clip > 0:
             ops.grad_norm_sq(grad, self._norm_sq)   # overwrites; fixed-order partial sums: the clip coefficient is reproducible run to run
         else:
             self._norm_sq.zero_()

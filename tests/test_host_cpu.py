@@ -173,6 +173,18 @@ def _dp_worker(rank, world, port, q):
     all16 = [torch.zeros(n, dtype=torch.bfloat16) for _ in range(world)]
     dist.all_gather(all16, stage)
     ok = ok and all(torch.equal(all16[0], x) for x in all16)                    # every rank holds the same reduced gradients
+    # per-bucket norm of the REDUCED gradients, collected behind each bucket's all-reduce (engine: the global-norm clip then needs only the
+    # sum of the partial sums after the last bucket): equals the norm of the reduced tensor, on every rank, also on a re-used object
+    g.copy_(local)
+    stage.zero_()
+    sq = lambda buf, out: out.copy_((buf.float() ** 2).sum().reshape(1))
+    syncn = GradSync(g, buckets, mpu.get_data_parallel_group(), stage=stage, cast=lambda src, dst: dst.copy_(src), norm_sq=sq)
+    for _ in range(2):
+        syncn.launch("h.2")
+        syncn.finish()
+        ok = ok and syncn.norm_parts.numel() == len(buckets)
+        ok = ok and torch.allclose(syncn.reduced_norm_sq(), (stage.float() ** 2).sum().reshape(1), rtol=1e-6)
+        ok = ok and torch.allclose(syncn.norm_parts[3], (stage[900:1000].float() ** 2).sum(), rtol=1e-6)
     # the data-parallel group is the default communicator itself: no second communicator over the same ranks
     ok = ok and mpu.get_data_parallel_group() is dist.group.WORLD
     # mean-of-ranks via the optimizer's gradient scale (the arena holds the SUM): the update every rank applies is identical
