@@ -206,11 +206,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_implicit_kernel(ConvArgs p)
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int m = wm * 32 + i * 16 + (lane & 15);
-            if (p.part_bias) p.part_bias[(int64_t)blockIdx.z * CI_C + m] = accb[i][0];
-            else atomicAdd(p.gbias + m, accb[i][0]);
+            p.part_bias[(int64_t)blockIdx.z * CI_C + m] = accb[i][0];
         }
     }
-    float* G = p.part ? p.part + (int64_t)blockIdx.z * (CI_C * 9 * CI_C) : (float*)p.y;
+    float* G = p.part + (int64_t)blockIdx.z * (CI_C * 9 * CI_C);   // this pixel range's partial sums (conv_wgrad_reduce_kernel adds the ranges in order)
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -218,11 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_implicit_kernel(ConvArgs p)
             const int m = wm * 32 + i * 16 + (lane & 15);
             const int n = tn * 128 + wn * 64 + j * 16 + (lane >> 4) * 4;
             if (n >= 9 * CI_C) continue;
-            if (p.part) *reinterpret_cast<float4*>(G + (int64_t)m * (9 * CI_C) + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            else {
-#pragma unroll
-                for (int r = 0; r < 4; r++) atomicAdd(G + (int64_t)m * (9 * CI_C) + n + r, acc[i][j][r]);
-            }
+            *reinterpret_cast<float4*>(G + (int64_t)m * (9 * CI_C) + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
 }
 // gp[i] += sum over the pixel ranges of part[z][i], z in increasing order (deterministic)
@@ -349,10 +344,11 @@ extern "C" int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* 
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)dy; a.y = gp_acc; a.bias = nullptr; a.n_patches = n_patches; a.sign = 1;
     const int ks = ci_wgrad_ksplit(n_patches);
     a.ksplit = ks;
-    // with the workspace: per-range partial sums + a fixed-order reduce (bit-reproducible); without: fp32 atomics onto gp_acc
-    a.part = (ws && ws_bytes >= db1_conv3x3_implicit_wgrad_workspace_bytes(n_patches) && db1_aligned16(ws)) ? (float*)ws : nullptr;
+    // per-range partial sums in the caller's workspace + a fixed-order reduce (bit-reproducible): there is no atomic form
+    DB1_NEED_WS(ws, ws_bytes, db1_conv3x3_implicit_wgrad_workspace_bytes(n_patches), "conv3x3_implicit_wgrad");
+    a.part = (float*)ws;
     a.gbias = gbias_acc; a.res = nullptr;
-    a.part_bias = (a.part && gbias_acc) ? a.part + (int64_t)ks * (CI_C * 9 * CI_C) : nullptr;
+    a.part_bias = gbias_acc ? a.part + (int64_t)ks * (CI_C * 9 * CI_C) : nullptr;
     static Db1PerDeviceOnce attr_once;
     attr_once.run([] { hipFuncSetAttribute((const void*)conv_wgrad_implicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); });
     conv_wgrad_implicit_kernel<<<dim3(5, 1, (unsigned)ks), 256, 4 * TILE_BYTES, (hipStream_t)stream>>>(a);

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void ln_bwd_ds_kernel(const T* __restrict__ dy
     }
 }
 
-// dgamma[c] += sum_r dy*xhat ; dbeta[c] += sum_r dy.  thread per column, a chunk of rows per block
+// dgamma[c] += sum_r dy*xhat ; dbeta[c] += sum_r dy.  thread per column; ONE block walks all rows of its columns (generic / fp32 parity
+// path: every accumulator has a single contributor, so the result does not depend on arrival order -- no float atomics)
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const T* __restrict__ dy, const T* __restrict__ s,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -130,8 +131,8 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const T* __restrict__
         ag += g * xh;
         ab += g;
     }
-    atomicAdd(dgamma + c, ag);
-    atomicAdd(dbeta + c, ab);
+    dgamma[c] += ag;
+    dbeta[c] += ab;
 }
 
 // ---- register-resident variants for d == 64 * V * NV (d = 2048 in bf16: NV = 4): the row lives in registers, so the forward
@@ -352,8 +353,8 @@ extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const v
 #undef LN_BWD
     DB1_CHECK_LAUNCH("layernorm bwd ds");
     if (dgamma_acc && dbeta_acc) {
-        const int rpb = 128;
-        dim3 g2((unsigned)((d + 255) / 256), (unsigned)((rows + rpb - 1) / rpb));
+        const int rpb = (int)rows;
+        dim3 g2((unsigned)((d + 255) / 256), 1u);
         if (dt == DB1_F32) ln_bwd_param_kernel<float><<<g2, 256, 0, st>>>((const float*)dy, (const float*)s, mean, rstd, dgamma_acc, dbeta_acc, rows, d, rpb);
         else ln_bwd_param_kernel<bf16_t><<<g2, 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)s, mean, rstd, dgamma_acc, dbeta_acc, rows, d, rpb);
         DB1_CHECK_LAUNCH("layernorm bwd param");
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     int64_t r1 = r0 + rpb < rows ? r0 + rpb : rows;
     float a = 0.f;
     for (int64_t r = r0; r < r1; r++) a += ldf(x + r * ldx + c);
-    atomicAdd(out + c, a);
+    out[c] += a;      // (launched with ONE row block: single contributor)
 }
 
 // vectorised form: a lane owns one 16-byte column group (4 f32 / 8 bf16), a wave reads 1 KiB of one row per load, the 4 waves of a
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * V; i += 256) {
         const int c = blockIdx.x * 64 * V + i;
-        if (c < cols) atomicAdd(out + c, part[0][i] + part[1][i] + part[2][i] + part[3][i]);
+        if (c < cols) out[c] += part[0][i] + part[1][i] + part[2][i] + part[3][i];   // (launched with ONE row block per column group)
     }
 }
 
@@ -687,8 +688,8 @@ extern "C" int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int c
         DB1_CHECK_LAUNCH("colsum_vec");
         return DB1_OK;
     }
-    const int rpb = 128;
-    dim3 g((unsigned)((cols + 255) / 256), (unsigned)((rows + rpb - 1) / rpb));
+    const int rpb = (int)rows;   // unaligned / odd shapes (fp32 parity path): one block per 256 columns walks all rows -- deterministic, not fast
+    dim3 g((unsigned)((cols + 255) / 256), 1u);
     DB1_DISPATCH_DT(dt, T, (colsum_kernel<T><<<g, 256, 0, (hipStream_t)stream>>>((const T*)x, out_acc, rows, cols, ldx, rpb)));
     DB1_CHECK_LAUNCH("colsum");
     return DB1_OK;
@@ -1060,8 +1061,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
         const bool y_ok = y >= 0 && y < V;
         const float mk = y_ok ? mask[t] : 0.f;
         const float nll = y_ok ? l - ldf(row + y) : 0.f;
-        if (tok_loss) tok_loss[t] = mk * nll;  // summed in a fixed order by ce_sum_kernel (65 536 same-address atomics took ~1 ms)
-        else { atomicAdd(sums + 0, mk * nll); atomicAdd(sums + 1, mk); }
+        tok_loss[t] = mk * nll;  // summed in a fixed order by ce_sum_kernel (65 536 same-address atomics took ~1 ms, and made the loss order-dependent)
     }
 }
 // sums[0] += sum_t tok_loss[t], sums[1] += sum_t mask[t]: one block, fixed order (deterministic loss)
@@ -1234,10 +1234,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ x, flo
     }
     if (blockIdx.x == 0) for (int64_t i = nv * V + threadIdx.x; i < n; i += 256) { float f = ldf(x + i); a += f * f; }
     a = block_sum256(a, sm);
-    if (threadIdx.x == 0) atomicAdd(acc, a);
+    if (threadIdx.x == 0) acc[0] += a;     // (launched as ONE workgroup)
 }
-// deterministic variant: per-workgroup partial sums into the caller's workspace, then ONE workgroup adds them in a fixed order (the
-// atomicAdd of sumsq_kernel makes the global norm -- and through the clip coefficient every parameter -- depend on arrival order)
+// the form for large vectors: per-workgroup partial sums into the caller's workspace, then ONE workgroup adds them in a fixed order
+// (per-workgroup atomic adds would make the global norm -- and through the clip coefficient every parameter -- depend on arrival order)
 template <typename T>
 __global__ __launch_bounds__(256) void sumsq_part_kernel(const T* __restrict__ x, float* __restrict__ part, int64_t n) {
     __shared__ float sm[4];
@@ -1281,7 +1281,8 @@ extern "C" int db1_sumsq_acc(const void* x, float* acc, int64_t n, int dt, void*
     if (n <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "sumsq: n");
     if (!db1_aligned16(x)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "sumsq: alignment");
     const int V = dt == DB1_F32 ? 4 : 8;
-    DB1_DISPATCH_DT(dt, T, (sumsq_kernel<T><<<grid_for(n / V + 1), 256, 0, (hipStream_t)stream>>>((const T*)x, acc, n)));
+    // workspace-free form: ONE workgroup (deterministic; fine for a few million elements).  Large vectors: db1_sumsq_det / db1_grad_norm_sq.
+    DB1_DISPATCH_DT(dt, T, (sumsq_kernel<T><<<1, 256, 0, (hipStream_t)stream>>>((const T*)x, acc, n)));
     DB1_CHECK_LAUNCH("sumsq");
     return DB1_OK;
 }

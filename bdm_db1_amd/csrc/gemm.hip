@@ -102,10 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tile_kernel(GemmTileArgs p) 
             TC* c = C + (int64_t)m * p.ldc + n;
             if (sizeof(TC) == 4 && p.ksplit > 1 && p.c_zs != 0) {  // split-K through the workspace: this slice's partial sum, plain store
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(c) + (int64_t)blockIdx.z * p.c_zs) = make_float4(v[0], v[1], v[2], v[3]);
-            } else if (sizeof(TC) == 4 && p.ksplit > 1) {  // split-K: C already holds beta*C (beta == 1); partial sums are added atomically
-#pragma unroll
-                for (int r = 0; r < 4; r++) atomicAdd(reinterpret_cast<float*>(c) + r, v[r]);
-            } else if (sizeof(TC) == 4) {
+            } else if (sizeof(TC) == 4) {   // (a split without a workspace does not exist: the dispatcher returns DB1_ERR_WORKSPACE_TOO_SMALL)
                 if (p.beta != 0.f) {
                     float4 o = *reinterpret_cast<const float4*>(c);
                     v[0] += p.beta * o.x; v[1] += p.beta * o.y; v[2] += p.beta * o.z; v[3] += p.beta * o.w;
@@ -341,11 +338,12 @@ static GemmPlan gemm_plan(const GemmShape& g, bool aligned, int64_t ws_bytes) {
     // to the 128x128 kernel for more workgroups made them 15-20 % slower, so form alone decides)
     const bool want256 = tile_pref == 256 || (tile_pref == 0 && fb == 1);
     if (want256 && t256_shape) { pl.kind = GK_TILE256; return pl; }
-    // atomic split-K for small outputs with a very long contraction (weight gradients of the 64-channel patch convolutions:
-    // 64 x 576 outputs over 1.9 M rows would otherwise occupy 5 of 256 CUs)
+    // split-K for small outputs with a very long contraction (weight gradients of the 64-channel patch convolutions: 64 x 576 outputs
+    // over 1.9 M rows would otherwise occupy 5 of 256 CUs): partial sums in the caller's workspace, added in slice order -- never
+    // float atomics, so only shapes the workspace reduce handles (one batch, unit column stride, N % 4 == 0) are split
     pl.kind = GK_TILE128;
     const int ntiles = t.tiles_m * t.tiles_n * (int)batch;
-    if (g.dtC == DB1_F32 && g.beta == 1.0f && ntiles < 128 && K >= 64 * TBK) {
+    if (g.dtC == DB1_F32 && g.beta == 1.0f && ntiles < 128 && K >= 64 * TBK && batch == 1 && (N % 4) == 0 && g.c_cs == 1) {
         int ks = 512 / ntiles;
         while (ks > 1 && ((K / TBK) % ks || (K / TBK) / ks < 8)) ks--;
         pl.ksplit = ks;
@@ -451,12 +449,12 @@ extern "C" int db1_gemm_strided(const void* A, const void* B, void* C, const voi
     }
     if (base == GK_W4N) return db1_gemm_w4n_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
     if (base == GK_TILE256) return db1_gemm_tile256_launch(t, fa, fb, dtC, dtBias, (int)batch, st);
-    t.ksplit = pl.ksplit;
+    // long-contraction split of a small fp32 output (weight gradients of the patch convolutions): the slices' partial sums are stored in
+    // the caller's workspace and added in a fixed order (bit-reproducible).  Without the workspace the product runs unsplit on the same
+    // kernel (the header's contract for the GEMMs: slower, equally valid) -- never with float atomics.
+    const bool ws_split = pl.ksplit > 1 && ws && db1_aligned16(ws) && ws_bytes >= (int64_t)pl.ksplit * M * N * (int64_t)sizeof(float);
+    t.ksplit = ws_split ? pl.ksplit : 1;
     dim3 grid((unsigned)(t.tiles_m * t.tiles_n), (unsigned)batch, (unsigned)t.ksplit);
-    // long-contraction split of a small fp32 output (weight gradients of the patch convolutions): with a workspace the slices' partial
-    // sums are stored and added in a fixed order (bit-reproducible); without one they are added onto C with fp32 atomics
-    const bool ws_split = pl.ksplit > 1 && batch == 1 && ws && db1_aligned16(ws) && ws_bytes >= (int64_t)pl.ksplit * M * N * (int64_t)sizeof(float) &&
-                          (N % 4) == 0 && g.c_cs == 1;
     void* C_final = C;
     if (ws_split) { t.C = ws; t.ldc = N; t.c_zs = (int64_t)M * N; t.bias = nullptr; t.beta = 0.f; }
     static Db1PerDeviceOnce attr_once;   // 64 KiB of dynamic LDS needs the opt-in attribute: once per device, every instantiation

@@ -1,11 +1,11 @@
 // Deterministic embedding-table gradients (transformer_xl.py:621-672 backward: word, RL local-position and patch-position tables).
 //     dtable[ids[t], :] += dout[t, :]
-// without floating-point atomics: the tokens are ordered by table row with a STABLE device radix sort (rocPRIM) of (row, token index)
-// pairs -- so the tokens of one row appear in token order -- and one wave per run of equal rows adds that run's dout rows in that order
-// and is the only writer of its table row.  Same inputs -> same bits, whatever the scheduling (the atomic version it replaces was the
-// last order-dependent reduction of the step).  The sort's scratch comes from the caller like every other workspace.
-#include <cstring>   // (rocPRIM's headers call memset from host code)
-#include <rocprim/device/device_radix_sort.hpp>
+// without floating-point atomics: the tokens are ordered by table row with a STABLE radix sort of (row, token index) pairs -- so the
+// tokens of one row appear in token order -- and one wave per run of equal rows adds that run's dout rows in that order and is the only
+// writer of its table row.  Same inputs -> same bits, whatever the scheduling (the atomic version it replaces was the last
+// order-dependent reduction of the step).  The sort is the library's own (rs_* below: least-significant-digit passes of 8 bits over as many
+// bits as the table has rows -- two passes for the 33 025-row vocabulary, one for the 128-row position tables); its scratch comes from the
+// caller like every other workspace.  (Rounds 2-4 called rocprim::radix_sort_pairs here: the last vendor primitive on the path.)
 #include "db1_common.h"
 
 #define SC_INVALID 0xFFFFFFFFu
@@ -110,11 +110,79 @@ __global__ __launch_bounds__(256) void scatter_runs_kernel(const T* __restrict__
 }
 
 static inline int64_t sc_al(int64_t x) { return (x + 255) & ~(int64_t)255; }
-static int64_t sc_sort_temp_bytes(int64_t n) {
-    size_t tb = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, tb, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (size_t)n, 0, 32, (hipStream_t)0, false);
-    return (int64_t)tb;
+
+// ---- stable LSD radix sort of (key, value) pairs, 8 bits per pass.  A pass = per-tile digit histograms (one wave per RS_TILE keys) ->
+// exclusive scan over (digit, tile) in digit-major order (one workgroup) -> stable scatter: the wave of a tile walks its keys 64 at a
+// time; lanes holding the same digit find each other with eight ballots (rank = lanes of the group below me), the group's running
+// offset lives in LDS.  Integer arithmetic only: one correct output.  Keys above `cap` (SC_INVALID) sort as cap, i.e. behind every row.
+#define RS_TILE 512
+__device__ __forceinline__ unsigned rs_digit(unsigned k, unsigned cap, int shift) { return ((k > cap ? cap : k) >> shift) & 255u; }
+__global__ __launch_bounds__(64) void rs_hist_kernel(const unsigned* __restrict__ keys, unsigned* __restrict__ hist, int64_t n, unsigned cap, int shift, int nb) {
+    __shared__ unsigned h[256];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) h[i] = 0u;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    for (int s = 0; s < RS_TILE / 64; s++) {
+        const int64_t i = base + s * 64 + lane;
+        if (i < n) atomicAdd(&h[rs_digit(keys[i], cap, shift)], 1u);     // (integer counts in LDS: order-independent)
+    }
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) hist[(int64_t)i * nb + blockIdx.x] = h[i];
 }
+__global__ __launch_bounds__(1024) void rs_scan_kernel(unsigned* __restrict__ hist, int64_t total) {   // exclusive prefix sums in place, one workgroup
+    __shared__ unsigned sm[1024];
+    __shared__ unsigned carry;
+    if (threadIdx.x == 0) carry = 0u;
+    __syncthreads();
+    for (int64_t base = 0; base < total; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const unsigned v = i < total ? hist[i] : 0u;
+        sm[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const unsigned add = threadIdx.x >= off ? sm[threadIdx.x - off] : 0u;
+            __syncthreads();
+            sm[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < total) hist[i] = carry + sm[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sm[1023];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(64) void rs_scatter_kernel(const unsigned* __restrict__ kin, const unsigned* __restrict__ vin, unsigned* __restrict__ kout,
+                                                        unsigned* __restrict__ vout, const unsigned* __restrict__ hist, int64_t n, unsigned cap, int shift, int nb) {
+    __shared__ unsigned off[256];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) off[i] = hist[(int64_t)i * nb + blockIdx.x];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    for (int s = 0; s < RS_TILE / 64; s++) {
+        const int64_t i = base + s * 64 + lane;
+        const bool act = i < n;
+        const unsigned k = act ? kin[i] : 0u, v = act ? vin[i] : 0u;
+        const unsigned dg = rs_digit(k, cap, shift);
+        unsigned long long grp = __ballot(act);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long bal = __ballot(act && ((dg >> b) & 1u));
+            grp &= ((dg >> b) & 1u) ? bal : ~bal;
+        }
+        const unsigned rank = (unsigned)__popcll(grp & ((1ull << lane) - 1ull));
+        const unsigned pos = off[dg] + rank;
+        __syncthreads();                                   // (every lane has read its group's offset)
+        if (act) {
+            kout[pos] = k;
+            vout[pos] = v;
+            if (rank == 0u) off[dg] += (unsigned)__popcll(grp);   // one lane per group: the lowest
+        }
+        __syncthreads();
+    }
+}
+static int64_t rs_temp_bytes(int64_t n) { return sc_al(256 * ((n + RS_TILE - 1) / RS_TILE) * (int64_t)sizeof(unsigned)); }
+static int64_t sc_sort_temp_bytes(int64_t n) { return rs_temp_bytes(n); }
 static int64_t sc_part_bytes(int64_t n) { return sc_al(((n + SC_CHUNK - 1) / SC_CHUNK) * (int64_t)SC_PART_MAX_D * (int64_t)sizeof(float)); }
 extern "C" int64_t db1_embed_scatter_add_workspace_bytes(int64_t n_tokens) {
     if (n_tokens <= 0) return 0;
@@ -139,8 +207,24 @@ int db1_scatter_add_impl(const void* dout, const int64_t* ids, float* dtable_acc
     size_t tb = (size_t)(ws_bytes - 4 * seg - sc_part_bytes(n_tokens));
     scatter_keys_kernel<<<(unsigned)((n_tokens + 255) / 256), 256, 0, st>>>(ids, keys_in, idx_in, n_tokens, n_table_rows);
     DB1_CHECK_LAUNCH(who);
-    if (rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, idx_in, idx_out, (size_t)n_tokens, 0, 32, st, false) != hipSuccess)
-        DB1_FAIL(DB1_ERR_HIP, "%s: radix sort", who);
+    (void)tb;
+    {   // stable sort of (row, token): ceil(bits(n_table_rows) / 8) passes, ping-pong between the two buffer pairs
+        const unsigned cap = (unsigned)n_table_rows;
+        int bits = 0;
+        while (bits < 32 && (cap >> bits)) bits++;
+        const int nb = (int)((n_tokens + RS_TILE - 1) / RS_TILE);
+        unsigned* hist = (unsigned*)temp;
+        for (int shift = 0; shift < bits; shift += 8) {
+            rs_hist_kernel<<<(unsigned)nb, 64, 0, st>>>(keys_in, hist, n_tokens, cap, shift, nb);
+            rs_scan_kernel<<<1, 1024, 0, st>>>(hist, (int64_t)256 * nb);
+            rs_scatter_kernel<<<(unsigned)nb, 64, 0, st>>>(keys_in, idx_in, keys_out, idx_out, hist, n_tokens, cap, shift, nb);
+            DB1_CHECK_LAUNCH(who);
+            unsigned* t0 = keys_in; keys_in = keys_out; keys_out = t0;
+            unsigned* t1 = idx_in; idx_in = idx_out; idx_out = t1;
+        }
+        keys_out = keys_in;    // (after the last swap the sorted pairs are in the "in" pair)
+        idx_out = idx_in;
+    }
     const int64_t nchunk = (n_tokens + SC_CHUNK - 1) / SC_CHUNK;
     if (part && nchunk > 1) {
         DB1_DISPATCH_DT(dt, T, (scatter_chunk_kernel<T><<<(unsigned)(nchunk - 1), 256, 0, st>>>((const T*)dout, ld_dout, keys_out, idx_out, part, n_tokens, d)));

@@ -208,8 +208,7 @@ __global__ __launch_bounds__(256) void gn_gelu_bwd_kernel(const T* __restrict__ 
             sb += dh;
         }
         sg = wave_sum(sg);
-        sb = wave_sum(sb);
-        if (lane == 0) { atomicAdd(dgamma + c, sg); atomicAdd(dbeta + c, sb); }
+        sb = wave_sum(sb);   // (the parameter gradients are formed by gn_param_grad_kernel: one workgroup per channel, fixed order, no atomics)
         c1 += sb * gm;  // sum of (dh * gamma)
         c2 += sg * gm;  // sum of (dh * gamma * xhat)
     }
@@ -223,6 +222,32 @@ __global__ __launch_bounds__(256) void gn_gelu_bwd_kernel(const T* __restrict__ 
         const float dh = ldf(dys + e) * gelu_erf_grad(xh * gm + bt);
         stf(dxs + e, rs * (dh * gm - c1 - xh * c2));
     }
+}
+// dgamma[c] += sum_{n, e} dh * xhat, dbeta[c] += sum_{n, e} dh with dh = dy * gelu'(xhat * gamma + beta): ONE workgroup per channel walks the
+// samples in order (thread t: elements t, t + 256, ... of every sample), block sum in a fixed order: deterministic (generic / fp32 parity path)
+template <typename T, typename TP>
+__global__ __launch_bounds__(256) void gn_param_grad_kernel(const T* __restrict__ dy, const T* __restrict__ x, const TP* __restrict__ gamma,
+                                                            const TP* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* dgamma, float* dbeta, int64_t N, int C, int groups, int hw) {
+    __shared__ float sm[4];
+    const int c = blockIdx.x, cpg = C / groups, g = c / cpg;
+    const float gm = ldf(gamma + c), bt = ldf(beta + c);
+    float sg = 0.f, sb = 0.f;
+    for (int64_t n = 0; n < N; n++) {
+        const float mu = mean[n * groups + g], rs = rstd[n * groups + g];
+        const T* xs = x + (n * C + c) * (int64_t)hw;
+        const T* dys = dy + (n * C + c) * (int64_t)hw;
+        for (int e = threadIdx.x; e < hw; e += 256) {
+            const float xh = (ldf(xs + e) - mu) * rs;
+            const float dh = ldf(dys + e) * gelu_erf_grad(xh * gm + bt);
+            sg += dh * xh;
+            sb += dh;
+        }
+    }
+    sg = block_sum256(sg, sm);
+    __syncthreads();
+    sb = block_sum256(sb, sm);
+    if (threadIdx.x == 0) { dgamma[c] += sg; dbeta[c] += sb; }
 }
 extern "C" int db1_groupnorm_gelu_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean, const float* rstd,
                                       void* dx, float* dgamma_acc, float* dbeta_acc, int64_t N, int C, int hw, int groups, int dt,
@@ -239,6 +264,13 @@ extern "C" int db1_groupnorm_gelu_bwd(const void* dy, const void* x, const void*
     else L_(float, bf16_t);
 #undef L_
     DB1_CHECK_LAUNCH("groupnorm_gelu_bwd");
+#define LP_(T, TP) gn_param_grad_kernel<T, TP><<<(unsigned)C, 256, 0, st>>>((const T*)dy, (const T*)x, (const TP*)gamma, (const TP*)beta, mean, rstd, dgamma_acc, dbeta_acc, N, C, groups, hw)
+    if (dt == DB1_F32 && dtParam == DB1_F32) LP_(float, float);
+    else if (dt == DB1_BF16 && dtParam == DB1_BF16) LP_(bf16_t, bf16_t);
+    else if (dt == DB1_BF16) LP_(bf16_t, float);
+    else LP_(float, bf16_t);
+#undef LP_
+    DB1_CHECK_LAUNCH("groupnorm_gelu_bwd parameters");
     return DB1_OK;
 }
 
@@ -548,12 +580,12 @@ __global__ __launch_bounds__(256) void gn_gelu_nhwc_kernel(const T* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; j++) part[t][j] = sg[j];
         __syncthreads();
-        if (t < GNV_C) { float s = 0.f; for (int r = 0; r < 32; r++) s += part[r * 8 + (t >> 3)][t & 7]; if (pgrad) pgrad[n * (2 * GNV_C) + t] = s; else atomicAdd(dgamma + t, s); stat[1][t] = s * ldf(gamma + t); }
+        if (t < GNV_C) { float s = 0.f; for (int r = 0; r < 32; r++) s += part[r * 8 + (t >> 3)][t & 7]; pgrad[n * (2 * GNV_C) + t] = s; stat[1][t] = s * ldf(gamma + t); }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; j++) part[t][j] = sb[j];
         __syncthreads();
-        if (t < GNV_C) { float s = 0.f; for (int r = 0; r < 32; r++) s += part[r * 8 + (t >> 3)][t & 7]; if (pgrad) pgrad[n * (2 * GNV_C) + GNV_C + t] = s; else atomicAdd(dbeta + t, s); stat[0][t] = s * ldf(gamma + t); }
+        if (t < GNV_C) { float s = 0.f; for (int r = 0; r < 32; r++) s += part[r * 8 + (t >> 3)][t & 7]; pgrad[n * (2 * GNV_C) + GNV_C + t] = s; stat[0][t] = s * ldf(gamma + t); }
         __syncthreads();
         // group sums c1 = sum(dh * gamma), c2 = sum(dh * gamma * xhat) over the cpg channels of the group
         __shared__ float cg[2][GNV_C];
@@ -594,10 +626,11 @@ extern "C" int db1_groupnorm_gelu_nhwc_bwd(const void* dy, const void* x, const 
     if (dt != DB1_BF16 || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "groupnorm_gelu_nhwc_bwd: bf16 activations only");
     if (N <= 0 || C != GNV_C || hw != GNV_HW || groups <= 0 || C % groups) DB1_FAIL(DB1_ERR_UNSUPPORTED, "groupnorm_gelu_nhwc_bwd: needs C=64, hw=256 (got %d, %d)", C, hw);
     hipStream_t st = (hipStream_t)stream;
-    // with the workspace: every sample leaves its (dgamma | dbeta) row and the rows are summed in a fixed order; without: fp32 atomics.
+    // every sample leaves its (dgamma | dbeta) row in the caller's workspace and the rows are summed in a fixed order (no atomic form).
     // (dgamma_acc and dbeta_acc must then be the two halves of ONE [128] accumulator, or are summed by two strided column sums below.)
     const int64_t rows_b = (N * 2 * GNV_C * (int64_t)sizeof(float) + 255) & ~(int64_t)255;
-    float* pgrad = (ws && ws_bytes >= db1_groupnorm_gelu_nhwc_bwd_workspace_bytes(N) && db1_aligned16(ws)) ? (float*)ws : nullptr;
+    DB1_NEED_WS(ws, ws_bytes, db1_groupnorm_gelu_nhwc_bwd_workspace_bytes(N), "groupnorm_gelu_nhwc_bwd");
+    float* pgrad = (float*)ws;
     if (dtParam == DB1_BF16) gn_gelu_nhwc_kernel<bf16_t, bf16_t, true><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)dx, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma_acc, dbeta_acc, C / groups, 0.f, pgrad);
     else gn_gelu_nhwc_kernel<bf16_t, float, true><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, (const float*)gamma, (const float*)beta, (bf16_t*)dx, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma_acc, dbeta_acc, C / groups, 0.f, pgrad);
     if (pgrad) {

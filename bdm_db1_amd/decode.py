@@ -131,6 +131,7 @@ class GraphedRingStep:
             with torch.cuda.graph(g):
                 logits, _, _ = model([self.x], compute_loss=False, mems=self.memory)
         self.graph, self.logits = g, logits
+        self._watch = model._chain_watch   # the captured call's copy of the persistent launches' error flag (None: per-launch path)
         self._version = model._wversion
         if saved_kv is None:
             self.memory.reset()
@@ -147,7 +148,15 @@ class GraphedRingStep:
         (logits [batch, n_new, vocab] (static buffer, overwritten by the next call), the RingMemory)"""
         if self.model._wversion != self._version:
             raise RuntimeError("the weights changed after the graph was captured: build a new GraphedRingStep")
+        self.check()   # the replays the stream has finished (free: a pinned host word)
         if ids is not None and ids.data_ptr() != self.ids.data_ptr():   # (a sampler that writes the next token into ``self.ids`` skips this copy)
             self.ids.copy_(ids)
         self.graph.replay()
         return self.logits, self.memory
+
+    def check(self, synchronize: bool = False):
+        """raise if a replayed persistent launch reported a failed hand-off (TransformerXL.check_decode_chain): call with
+        ``synchronize=True`` before trusting logits that were not read back through a synchronising copy"""
+        if self._watch is not None:
+            self.model._chain_watch = self._watch
+            self.model.check_decode_chain(synchronize)

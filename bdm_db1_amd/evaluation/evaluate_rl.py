@@ -90,8 +90,12 @@ def get_action(args, model, current_seq, vision_seq, cont_tokenizer, len_fixed_p
             model_memory = res[-1]
         logits = masked_logits_for_action(args, res[0], discrete_action, action_space, env_action_mask=action_mask)
         preds = logits[:, -1, :].argmax(-1)
+        picked_host = preds.cpu()            # (synchronises: the call's kernels are done)
+        chk = getattr(model, "check_decode_chain", None)
+        if chk is not None:                  # a persistent one-token launch that could not hand off raises here, before the action is used
+            chk()
         if model_memory is None:
-            current_seq = torch.cat([current_seq, preds.cpu()], dim=0)
+            current_seq = torch.cat([current_seq, picked_host], dim=0)
             if len(current_seq) > args.n_position:
                 if args.use_prompt and prompt_strategy == "fixed_prompt":   # the window behind the fixed prompt slides by one transition
                     current_seq[len_fixed_prompt:] = torch.roll(current_seq[len_fixed_prompt:], -trans).clone()
@@ -105,7 +109,7 @@ def get_action(args, model, current_seq, vision_seq, cont_tokenizer, len_fixed_p
                     current_seq, vision_seq = truncate_sequence_by_stepsize(current_seq, vision_seq, obs_length, action_length, None)
         else:
             assert prompt_strategy != "fixed_prompt"    # the memory slides: a fixed prompt cannot stay in front of it
-            current_seq, vision_seq = preds.cpu().clone(), None
+            current_seq, vision_seq = picked_host.clone(), None
         picked.append(recover_model_predict_token_to_tokenizer_raw(args, preds, discrete_action).cpu())
     if model_memory is not None:                 # the last action token enters the memory too
         model_memory = _model_call(model, current_seq, None, [0], model_memory)[-1]

@@ -65,15 +65,22 @@ class ParamArena:
         self.work_dtype = work_dtype
         self.exp_avg: Optional[torch.Tensor] = None
         self.exp_avg_sq: Optional[torch.Tensor] = None
+        self._views: Dict[int, Tuple[torch.Tensor, dict]] = {}
 
     def view(self, buf: torch.Tensor, name: str, full: bool = False) -> torch.Tensor:
-        # (views are cached per buffer: building one costs ~10 us of host time, and an inference layer asks for a dozen per call.  The
-        # cache belongs to the buffer OBJECT -- an attribute of the tensor itself -- so a reallocated arena buffer (dtype / device move, a
-        # rebuilt engine) takes its views with it when it is freed instead of being kept alive by a stale entry here)
-        cache = buf.__dict__.get("_db1_views")
-        if cache is None:
-            cache = {}
-            buf._db1_views = cache
+        # (views are cached: building one costs ~10 us of host time, and an inference layer asks for a dozen per call.  The cache lives on
+        # the ARENA, keyed by the buffer's identity -- never on the tensor itself: a view holds its base, so tensor -> dict -> view -> base
+        # is a cycle through C++ that Python's collector cannot see, and the buffer would outlive the model.  A buffer that is no longer one
+        # of the arena's (reallocated: dtype / device move, a rebuilt optimizer state) loses its entry the next time a new buffer shows up,
+        # so nothing here keeps a replaced buffer alive, and everything dies with the arena.)
+        ent = self._views.get(id(buf))
+        if ent is None or ent[0] is not buf:
+            live = {id(t) for t in self.__dict__.values() if isinstance(t, torch.Tensor)}
+            for k in [k for k in self._views if k not in live]:
+                del self._views[k]
+            ent = (buf, {})
+            self._views[id(buf)] = ent
+        cache = ent[1]
         key = (name, full)
         v = cache.get(key)
         if v is None:
@@ -105,6 +112,7 @@ class WgradStash:
         self.x = [{k: new(xw[k]) for k in self.KINDS} for _ in range(model.n_layer)]
         self.dy = [{k: new(yw[k]) for k in self.KINDS} for _ in range(model.n_layer)]
         self.slot = 0            # micro-step of the accumulation window the next forward / backward belongs to (set by the engine)
+        self.first = 0           # first micro-step of the window whose operands are in THIS stash (> 0: the token count changed mid-window)
         self.beta = 0.0          # beta of the flush: 0 when the gradient arena was fresh at slot 0
 
     def nbytes(self) -> int:
@@ -224,6 +232,7 @@ class TransformerXL(nn.Module):
         self.use_decode_ln_prologue = True   # ... <= 16 tokens: the residual LayerNorms ride on the way IN to the next linear map
         self.use_decode_attn_partials = True   # ... <= 2 tokens (ring memory): the output projection merges the attention's chunk partials
         self.use_decode_chain = os.environ.get("DB1_DECODE_CHAIN", "1") != "0"   # ... ONE token (ring memory): the linear maps between two attention launches as one persistent launch (db1_decode_chain)
+        self._chain_watch = None         # (pinned copy of the chain's error flag, its scratch) of the last chain call: check_decode_chain()
         self._wversion = 0               # bumped whenever the weights change (invalidates the inference caches)
         self._dec_state = None           # K/V cache of the memory returned by the last forward (see _decode_begin)
         self._dec_R = None               # (version, [R_i = r_net_i(sinusoid(dist)) for dist < mem_len + 64])
@@ -1252,11 +1261,13 @@ class TransformerXL(nn.Module):
 
     def _flush_layer_wgrads(self, i: int, st: WgradStash):
         """the four weight gradients of layer i over every micro-step stashed so far: dW = dy^T x, K = (slot + 1) * T rows"""
+        self._flush_layer_rows(i, st, st.first * st.T, (st.slot + 1) * st.T)
+
+    def _flush_layer_rows(self, i: int, st: WgradStash, lo: int, hi: int):
         p = f"h.{i}."
-        n = (st.slot + 1) * st.T
         for kind, name in (("ff2", "pos_ff.CoreNet.2.weight"), ("ff1", "pos_ff.CoreNet.0.weight"), ("o", "dec_attn.o_net.weight"),
                            ("qkv", "dec_attn.qkv_net.weight")):
-            ops.gemm(st.dy[i][kind][:n].t(), st.x[i][kind][:n], self.G(p + name), beta=st.beta)
+            ops.gemm(st.dy[i][kind][lo:hi].t(), st.x[i][kind][lo:hi], self.G(p + name), beta=st.beta)
 
     def flush_deferred_wgrads(self):
         """(a hipGraph-captured boundary micro-step stashes like the others; the products then run here, outside the graph)"""
@@ -1319,6 +1330,7 @@ class TransformerXL(nn.Module):
             raise ValueError("attention mask hides nothing (transformer_xl.py:177,205-206)")
         dec = self._decode_begin(mems, B, L, mlen) if (mems is not None and mlen > 0) else None
         if ring is not None:
+            self.check_decode_chain()   # (a failed chain launch of an earlier call: raise before more tokens go into the same memory)
             if not (self.use_decode and self.compute_dtype == torch.bfloat16 and ring.B == B and L <= 64 and mlen + L <= ring.cap):
                 raise ValueError("RingMemory needs the bf16 decode path, its own batch size and at most 64 new tokens per call")
             dec = SimpleNamespace(ring=ring, R=self._decode_R(), kv=None, new_kv=[])
@@ -1337,11 +1349,25 @@ class TransformerXL(nn.Module):
             return self._finish_forward(x, hids, lcs, [], [], [], [], R_in, B, L, shift, dstep, keep, compute_loss, mems, ring, dec, mlen)
         if self.wgrad_defer_ga > 1 and keep and self.training and not self.pre_lnorm and mems is None:
             st = self.wgrad_stash
+            if not 0 <= self._wg_slot < self.wgrad_defer_ga:
+                raise RuntimeError(f"weight-gradient stash: micro-step {self._wg_slot} of an accumulation window of {self.wgrad_defer_ga}")
             if st is None or st.T != B * L or st.ga != self.wgrad_defer_ga:
-                self.wgrad_stash = None          # (free the old buffers first)
+                first, beta = 0, 0.0
+                if st is not None and self._wg_slot > 0:
+                    # the token count changed INSIDE an accumulation window (a short last batch, another task mix): the operands of the
+                    # micro-steps done so far live in the old stash.  Form their weight gradients now (rows [first, slot) x T_old), then
+                    # go on in a stash of the new size that starts at this micro-step and accumulates onto what was just written.
+                    if st.first < self._wg_slot:
+                        for i in reversed(range(self.n_layer)):
+                            self._flush_layer_rows(i, st, st.first * st.T, self._wg_slot * st.T)
+                        first, beta = self._wg_slot, 1.0
+                    else:
+                        first, beta = self._wg_slot, st.beta
+                self.wgrad_stash = st = None     # (free the old buffers first)
                 st = self.wgrad_stash = WgradStash(self, B * L, self.wgrad_defer_ga)
-            if not 0 <= self._wg_slot < st.ga:
-                raise RuntimeError(f"weight-gradient stash: micro-step {self._wg_slot} of an accumulation window of {st.ga}")
+                st.first, st.beta = first, beta
+            elif self._wg_slot == 0:
+                st.first = 0
             st.slot = self._wg_slot
         hids, lcs = [], []
         for i in range(self.n_layer):
@@ -1377,9 +1403,32 @@ class TransformerXL(nn.Module):
                              w_o_next=W(f"h.{(i + 1) % n}.dec_attn.o_net.weight"))
             if not last:
                 x, qkv = x_next, qkv_next
+        # the chain's hand-off polls are bounded: if one ran out (a co-tenant kernel, a CU mask: not all 256 workgroups resident) the
+        # launch has set a flag and carried on with garbage.  The flag travels to pinned host memory behind the launches, and
+        # check_decode_chain() -- at the next forward, in get_action after its own synchronisation, in GraphedRingStep -- raises on it.
+        self._chain_watch = ops.decode_chain_flag_fetch(self.dev)
         p = f"h.{n - 1}."
         return _PendingLN(res=h1_out, y=f_out, alpha=a, gamma=W(p + "pos_ff.layer_norm.weight"),
                           beta=W(p + "pos_ff.layer_norm.bias"), eps=self.layer_norm_epsilon)
+
+    def check_decode_chain(self, synchronize: bool = False):
+        """Raise if a persistent one-token launch (db1_decode_chain) reported that a hand-off poll ran into its limit: the logits of that
+        call (and the memory it appended) are invalid.  Without ``synchronize`` this reads the flag copy of the last call the stream has
+        FINISHED -- free, and exact wherever the caller has synchronised anyway (``.cpu()`` / ``.item()`` on the logits); with it, the
+        stream is drained first.  The chain is switched off for this model after a failure (the per-launch path takes over); set
+        ``use_decode_chain = True`` again once the device is exclusive."""
+        w = self._chain_watch
+        if w is None:
+            return
+        if synchronize:
+            torch.cuda.current_stream(self.dev).synchronize()
+        if int(w[0][0]) != 0:
+            self.use_decode_chain = False
+            ops.decode_chain_clear_error(w)
+            self._chain_watch = None
+            raise lib.Db1Error("db1_decode_chain: a hand-off poll ran into its limit (not all 256 workgroups were resident: another kernel, "
+                               "stream or process shares the GPU, or a CU mask is set).  The logits and the appended memory rows of that call are "
+                               "invalid; the persistent path is now off for this model (model.use_decode_chain = False), repeat the episode.")
 
     def _finish_forward(self, x, hids, lcs, ecs, shapes, labels, masks, R_in, B, L, shift, dstep, keep, compute_loss, mems, ring, dec, mlen):
         d = self.d_model
@@ -1466,6 +1515,7 @@ class TransformerXL(nn.Module):
         self._grad_fresh = False
         if self.wgrad_stash is not None and self.wgrad_stash.slot == 0:
             self.wgrad_stash.beta = self._gb          # the flush of this accumulation window writes (fresh arena) or accumulates
+        # (a stash rebuilt mid-window, first > 0, got its beta when it was built: 1 after the partial flush of the old one)
         d, V = self.d_model, self.total_vocab_size
         B, L = ctx.B, ctx.L
         T = B * L

@@ -543,16 +543,48 @@ def decode_chain_supported(d, dff, H, D, klen) -> bool:
     return bool(lib.load().db1_decode_chain_supported(int(d), int(dff), int(H), int(D), (int(klen) + 127) // 128))
 
 
-def decode_chain_scratch(device):
-    """the scratch of db1_decode_chain (tagged hand-off rows + error flag): one buffer per device, zeroed once, here"""
+def _chain_key(device):
     device = torch.device(device)
-    if device.index is None:   # "cuda" and "cuda:0" are one buffer
-        device = torch.device("cuda", torch.cuda.current_device())
-    t = _chain_scratch.get(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()   # "cuda" and "cuda:0" are one device
+    sc = _scope()
+    return idx, (sc[0] if sc is not None else torch.cuda.current_stream(idx).cuda_stream)
+
+
+def decode_chain_scratch(device):
+    """the scratch of db1_decode_chain (tagged hand-off rows + error flag): one buffer per (device, STREAM) like every other scratch
+    buffer here -- the tag of a word is only the layer index, so two models decoding at the same time on two streams must not see each
+    other's rows (or each other's sticky error flag).  Zeroed once, here."""
+    key = _chain_key(device)
+    t = _chain_scratch.get(key)
     if t is None:
-        t = torch.zeros(int(lib.load().db1_decode_chain_scratch_bytes()), dtype=torch.uint8, device=device)
-        _chain_scratch[device] = t
+        t = torch.zeros(int(lib.load().db1_decode_chain_scratch_bytes()), dtype=torch.uint8, device=torch.device("cuda", key[0]))
+        _chain_scratch[key] = t
     return t
+
+
+_chain_flag_host = {}
+
+
+def decode_chain_flag_fetch(device):
+    """enqueue a copy of the chain's error flag into pinned host memory behind the launches issued so far (4 bytes, no synchronisation,
+    legal under hipGraph capture) -> (pinned int32 tensor, the scratch it watches): the pinned word holds the flag once the stream has
+    passed this point"""
+    key = _chain_key(device)
+    h = _chain_flag_host.get(key)
+    if h is None:
+        h = torch.zeros(1, dtype=torch.int32).pin_memory()
+        _chain_flag_host[key] = h
+    sc = decode_chain_scratch(device)
+    off = int(lib.load().db1_decode_chain_error_offset())
+    h.copy_(sc[off:off + 4].view(torch.int32), non_blocking=True)
+    return h, sc
+
+
+def decode_chain_clear_error(watch):
+    h, sc = watch
+    off = int(lib.load().db1_decode_chain_error_offset())
+    sc[off:off + 4].zero_()
+    h.zero_()
 
 
 def decode_chain(part, klen, H, x_res, w_o, w1, b1, w2, b2, w_qkv_next, g1, be1, g2, be2, alpha, eps, h1_out, f_out, x_next, qkv_next, slot, w_o_next=None):

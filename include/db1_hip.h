@@ -28,7 +28,9 @@
  *   - no global mutable state: the library keeps one immutable per-device cache ("this kernel's
  *     dynamic-LDS attribute is set", std::call_once) and reads its A/B environment switches
  *     once; the kernel-steering hooks of the tests are thread-local and live in db1_hip_test.h.
- *     Any number of host threads / devices / streams may call concurrently.
+ *     Any number of host threads / devices / streams may call concurrently;
+ *   - no float atomics anywhere: every reduction across workgroups goes through partial sums (in the workspace) that are added in a fixed
+ *     order, or has a single contributor per output -- the same inputs give the same bits, with or without a workspace.
  */
 #ifndef DB1_HIP_H
 #define DB1_HIP_H
@@ -206,8 +208,9 @@ int db1_cast(const void* x, void* y, int64_t n, int dtIn, int dtOut, void* strea
 int db1_embed_gather_fwd(const void* table, const int64_t* ids, void* out, int64_t n_tokens, int d,
                          int64_t ld_out, int64_t n_table_rows, int dtTable, int dtOut, void* stream);
 /* dtable_acc[ids[t], :] += dout[t, :]; ids outside [0, n_table_rows) are skipped, as they read zeros in the forward.  Deterministic: no
- * float atomics -- the tokens are ordered by table row with a stable device radix sort and every table row is written by the one wave
- * that adds its tokens in token order.  d and ld_dout: multiples of 16 bytes. */
+ * float atomics -- the tokens are ordered by table row with a stable device radix sort (csrc/scatter.hip: the library's own LSD passes,
+ * no vendor primitive) and every table row is written by the one wave that adds its tokens in token order.  d and ld_dout: multiples of
+ * 16 bytes. */
 int64_t db1_embed_scatter_add_workspace_bytes(int64_t n_tokens);   /* sort keys / values + the sort's own scratch + partial rows of long runs (d <= 8192) */
 int db1_embed_scatter_add_bwd(const void* dout, const int64_t* ids, float* dtable_acc, int64_t n_tokens, int d,
                               int64_t ld_dout, int64_t n_table_rows, int dt, void* ws, int64_t ws_bytes, void* stream);
@@ -394,7 +397,7 @@ int db1_conv_wgrad_unpermute(const float* gp, float* g_acc, int Cout, int Cin, i
  *   fwd (sign = +1): y[pix, o] = sum_{tap,c} x[pix + s(tap), c] * w_op[o, tap*64 + c] + bias[o], w_op from db1_conv_weight_permute;
  *   data gradient (sign = -1): x := dy, w_op := db1_conv_weight_permute_t(weight)  ([c, tap*64 + o]), bias = NULL;
  *   wgrad: gp_acc[o, tap*64 + c] += sum_pix dy[pix, o] * x[pix + s(tap), c]   (float32 [64, 576]; the pixel ranges' partial sums are added
- *          in a fixed order through the workspace -- or with fp32 atomics when none is given). */
+ *          in a fixed order through the workspace: db1_conv3x3_implicit_wgrad_workspace_bytes, required). */
 int db1_conv_weight_permute_t(const void* w, void* wp, int Cout, int Cin, int dtIn, int dtOut, void* stream);
 int db1_conv3x3_implicit_fwd(const void* x, const void* w_op, const void* bias, void* y, int64_t n_patches, int sign, int dtBias,
                              void* stream);
@@ -410,7 +413,7 @@ int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, flo
                                int64_t n_patches, void* ws, int64_t ws_bytes, void* stream);
 int db1_groupnorm_gelu_nhwc_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                                 int64_t N, int C, int hw, int groups, float eps, int dt, int dtParam, void* stream);
-int64_t db1_groupnorm_gelu_nhwc_bwd_workspace_bytes(int64_t N);   /* per-sample parameter-gradient rows, summed in a fixed order (without: fp32 atomics) */
+int64_t db1_groupnorm_gelu_nhwc_bwd_workspace_bytes(int64_t N);   /* per-sample parameter-gradient rows, summed in a fixed order (required) */
 int db1_groupnorm_gelu_nhwc_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean,
                                 const float* rstd, void* dx, float* dgamma_acc, float* dbeta_acc,
                                 int64_t N, int C, int hw, int groups, int dt, int dtParam, void* ws, int64_t ws_bytes, void* stream);
@@ -425,9 +428,10 @@ int db1_groupnorm_gelu_bwd(const void* dy, const void* x, const void* gamma, con
                            int64_t N, int C, int hw, int groups, int dt, int dtParam, void* stream);
 
 /* ------------------------------------------------------------------ optimizer
- * acc[0] += sum(x^2)  (global-norm clipping, train_config.py:211-215) */
+ * acc[0] += sum(x^2)  (global-norm clipping, train_config.py:211-215).  Workspace-free form: ONE workgroup, so the sum does not depend on
+ * arrival order -- meant for small vectors; the whole gradient arena goes through db1_sumsq_det / db1_grad_norm_sq. */
 int db1_sumsq_acc(const void* x, float* acc, int64_t n, int dt, void* stream);
-/* the same sum without atomics (per-workgroup partials in the workspace, fixed-order final add); overwrite != 0: acc[0] = sum, else += */
+/* the same sum over the whole chip (per-workgroup partials in the workspace, fixed-order final add); overwrite != 0: acc[0] = sum, else += */
 int64_t db1_sumsq_det_workspace_bytes(int64_t n);
 int db1_sumsq_det(const void* x, float* acc, int64_t n, int dt, int overwrite, void* ws, int64_t ws_bytes, void* stream);
 /* One fused Adam/AdamW step over a flat segment (DeepSpeed FusedAdam stand-in; torch.optim semantics).
@@ -453,7 +457,7 @@ int db1_mulaw_decode(const void* ids, float* out, int64_t n, int ids_are_int64, 
  * path without re-implementing the Python orchestration.  bf16 activations; same conventions (caller-owned device pointers, (ws, ws_bytes)
  * scratch with a size query, asynchronous on `stream`, int status). */
 /* acc[0] = sum(g^2) over a flat gradient segment: the global-norm clip's reduction (train_config.py:211-215).  Deterministic: per-workgroup
- * partial sums through the workspace, added in a fixed order (db1_sumsq_acc adds them with atomics). */
+ * partial sums through the workspace, added in a fixed order. */
 int64_t db1_grad_norm_sq_workspace_bytes(int64_t n);
 int db1_grad_norm_sq(const void* g, float* acc, int64_t n, int dt, void* ws, int64_t ws_bytes, void* stream);
 /* backward of the tied head + masked CE (transformer_xl.py:593-613) from the (lse, sums) a previous db1_lmhead_ce_fwd left: the logits are

@@ -352,7 +352,8 @@ def test_decode_chain_matches_the_separate_launches_at_db1_1p3b_geometry(mem_len
                 outs.append(logits.float().cpu().numpy())
         return outs
     ref, got = run(False), run(True)
-    assert not ops.decode_chain_error(model.dev), "a stage wait of the chain launch ran into its spin limit"
+    assert model._chain_watch is not None, "the one-token calls did not go through db1_decode_chain"
+    model.check_decode_chain(synchronize=True)   # raises if a stage wait of a chain launch ran into its spin limit
     for step, (a, b) in enumerate(zip(got, ref)):
         err = np.abs(a - b).max() / np.abs(b).max()
         assert err < 1e-2, f"call {step} (q = {calls[step].shape[1]}): rel err {err:.3e}"
@@ -368,7 +369,24 @@ def test_decode_chain_matches_the_separate_launches_at_db1_1p3b_geometry(mem_len
             x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
             lg_e, _, mem_e = model([x], compute_loss=False, mems=mem_e)
             assert torch.equal(lg_g.float(), lg_e.float())
-    assert not ops.decode_chain_error(model.dev)
+    g.check(synchronize=True)
+    model.check_decode_chain(synchronize=True)
+    # the product path acts on the flag: a launch that could not hand off (simulated: the sticky flag of the eager stream's
+    # scratch is set by hand) makes the NEXT forward over a ring raise, switches the persistent path off, and the per-launch path then
+    # serves the same call
+    from bdm_db1_amd import lib as db1lib
+    off = int(db1lib.load().db1_decode_chain_error_offset())
+    x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
+    with torch.no_grad():
+        model._chain_watch[1][off:off + 4].view(torch.int32).fill_(1)
+        lg_bad, _, mem_e = model([x], compute_loss=False, mems=mem_e)      # this call's flag copy carries the 1
+        lg_bad.float().cpu()                                               # (a caller reading its logits synchronises)
+        with pytest.raises(db1lib.Db1Error, match="hand-off poll"):
+            model([x], compute_loss=False, mems=mem_e)
+        assert model.use_decode_chain is False and model._chain_watch is None
+        lg_ok, _, mem_e = model([x], compute_loss=False, mems=mem_e)       # per-launch path
+        assert torch.isfinite(lg_ok.float()).all() and model._chain_watch is None
+    model.use_decode_chain = True
 
 
 def test_decode_chain_stages_against_fp32_arithmetic():

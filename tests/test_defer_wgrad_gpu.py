@@ -22,16 +22,17 @@ DEV = "cuda"
 GA = 3
 
 
-def _setup(drop):
+def _setup(drop, ragged=False):
     cfg = dict(case_cfg("small_mixed"))
     cfg.update(dict(n_embed=512, n_head=4, n_layer=3, n_position=256, mem_len=256, text_vocab_size=2000, drop=drop, embd_pdrop=drop))
     params = make_params(cfg, 23)
     rng = np.random.default_rng(8)
     from bdm_db1_amd.data import NLPTaskInput
     batches = []
-    for _ in range(2 * GA):
-        ids = rng.integers(0, 2000, (4, 257))
-        batches.append(NLPTaskInput(position_id=None, attention_mask=None, loss_mask=torch.ones(4, 256, device=DEV), label=torch.from_numpy(ids[:, 1:].copy()).to(DEV),
+    for k in range(2 * GA):
+        nseq = 2 if (ragged and k % GA == 1) else 4      # ragged: the middle micro-step of every window is a short batch
+        ids = rng.integers(0, 2000, (nseq, 257))
+        batches.append(NLPTaskInput(position_id=None, attention_mask=None, loss_mask=torch.ones(nseq, 256, device=DEV), label=torch.from_numpy(ids[:, 1:].copy()).to(DEV),
                                     text_seq=torch.from_numpy(ids[:, :-1].copy()).to(DEV), text_len=None))
     return cfg, params, batches
 
@@ -110,3 +111,23 @@ def test_deferred_weight_gradients_fp32_path():
         a, b = g1[off:off + alloc].double(), g0[off:off + alloc].double()
         if float(b.abs().max()) > 0.0:
             assert float((a - b).abs().max() / b.abs().max()) < 2e-5, name
+
+
+def test_token_count_changes_inside_an_accumulation_window():
+    """ADVICE r4: a micro-step with another token count (a short batch) inside an accumulation window makes the model rebuild its stash;
+    the operands of the micro-steps done so far must not be lost -- they are flushed into the gradient arena before the old stash goes, and
+    the new stash starts at the current micro-step and accumulates on top.  Window = (4, 2, 4) sequences: two rebuilds per window."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    cfg, params, batches = _setup(0.0, ragged=True)
+    l0, g0, p0, offs = _run(cfg, params, batches, defer=False)
+    l1, g1, p1, _ = _run(cfg, params, batches, defer=True)
+    assert l0[:GA] == l1[:GA]
+    assert torch.isfinite(g1).all()
+    for name, (off, shape, alloc) in offs.items():
+        a, b = g1[off:off + alloc].double(), g0[off:off + alloc].double()
+        if float(b.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0, name
+            continue
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-5, name
+    assert all(abs(a - b) < 2e-2 for a, b in zip(l0[GA:], l1[GA:])), (l0, l1)
