@@ -116,3 +116,52 @@ def get_action(args, model, current_seq, vision_seq, cont_tokenizer, len_fixed_p
     if discrete_action:
         return picked[0].item(), (current_seq, vision_seq), model_memory
     return cont_tokenizer.decode(torch.cat(picked), is_action=True).numpy(), (current_seq, vision_seq), model_memory
+
+
+def get_action_batched(args, model, obs_tokens, cont_tokenizer, obs_length, action_length, discrete_action: bool, action_space, model_memory,
+                       action_masks: Optional[np.ndarray] = None):
+    """The memory mode of ``get_action`` for M environments of one kind at once: ONE model call per token for all of them.
+
+    The reference evaluates its environments one by one at batch 1 (evaluate_rl.py:452-482 hands a rank up to ~110 of them), so every new
+    token streams the 2.4 GB of decoder weights once PER ENVIRONMENT; the weights do not care how many rows they multiply, so M
+    environments in one call cost one stream.  Same arithmetic per row as ``get_action`` (evaluate_rl.py:157-266: observation call, one token
+    per call, the memorising call; logits restricted to the action vocabulary, argmax, ids mapped back to tokenizer bins) -- pinned to the
+    reference's golden episode replayed in every row (tests/test_model_gpu.py).
+
+    ``obs_tokens`` [M, q]: the new transition's observation tokens (+ separator) of every environment (token observations: the image-patch
+    form goes through ``get_action``); ``model_memory``: ``model.init_mem(M)`` or a ``RingMemory(model, M)``; ``action_masks`` [M, n] (1 =
+    allowed) or None.  -> (actions [M] or [M, action_length], last tokens [M, 1], model_memory)"""
+    seq = torch.as_tensor(obs_tokens)
+    M = seq.shape[0]
+    picked = []
+    for i_act in range(action_length):
+        if i_act == 0:
+            _, pos_id = _get_action_flag_and_position_id(0, seq.shape[1] - 1, obs_length, action_length, 0)
+        else:
+            pos_id = np.array([0])
+        res = _model_call_batched(model, seq, pos_id, model_memory)
+        model_memory = res[-1]
+        logits = masked_logits_for_action(args, res[0], discrete_action, action_space, env_action_mask=None)
+        if discrete_action and action_masks is not None:
+            penalty = torch.from_numpy(np.abs(np.asarray(action_masks) - 1) * _OUT).to(logits.device)
+            logits[:, -1, :action_space.n] = logits[:, -1, :action_space.n] - penalty
+        preds = logits[:, -1, :].argmax(-1)
+        host = preds.cpu()                       # (synchronises)
+        chk = getattr(model, "check_decode_chain", None)
+        if chk is not None:
+            chk()
+        seq = host[:, None].clone()
+        picked.append(recover_model_predict_token_to_tokenizer_raw(args, preds, discrete_action).cpu())
+    model_memory = _model_call_batched(model, seq, [0], model_memory)[-1]      # the last action token enters the memory too
+    if discrete_action:
+        return picked[0].numpy(), seq, model_memory
+    acts = cont_tokenizer.decode(torch.stack(picked, dim=1).reshape(-1), is_action=True).reshape(M, action_length)
+    return acts.numpy(), seq, model_memory
+
+
+def _model_call_batched(model, tokens, position_id, memory):
+    M = tokens.shape[0]
+    pos = torch.tensor(np.asarray(position_id), dtype=torch.long)[None, :].expand(M, -1).contiguous()
+    x = RLTaskInput(tensor_seq=tokens, vision_seq=None, text_seq=None, attention_mask=None, loss_mask=None, label=None, position_id=pos)
+    x.to(device=model.device)
+    return model([x], compute_loss=False, mems=memory)

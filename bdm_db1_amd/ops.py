@@ -563,6 +563,7 @@ def decode_chain_scratch(device):
 
 
 _chain_flag_host = {}
+_chain_flag_pool = None
 
 
 def decode_chain_flag_fetch(device):
@@ -572,7 +573,18 @@ def decode_chain_flag_fetch(device):
     key = _chain_key(device)
     h = _chain_flag_host.get(key)
     if h is None:
-        h = torch.zeros(1, dtype=torch.int32).pin_memory()
+        # one pinned word per (device, stream), handed out from a small pool that is allocated on the first EAGER call: a stream that is
+        # capturing a graph (its own key) may not allocate pinned memory (hipHostMalloc invalidates the capture)
+        global _chain_flag_pool
+        if _chain_flag_pool is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise lib.Db1Error("db1_decode_chain: the first one-token call must run eagerly (GraphedRingStep warms up before it captures)")
+            _chain_flag_pool = [torch.zeros(64, dtype=torch.int32).pin_memory(), 0]
+        pool, used = _chain_flag_pool
+        if used >= pool.numel():
+            raise lib.Db1Error("db1_decode_chain: more than 64 (device, stream) pairs decode through the persistent launch")
+        h = pool[used:used + 1]
+        _chain_flag_pool[1] = used + 1
         _chain_flag_host[key] = h
     sc = decode_chain_scratch(device)
     off = int(lib.load().db1_decode_chain_error_offset())

@@ -134,6 +134,33 @@ def cpu_baseline(repeats: int = 5):
                 best_t = dict(cand, other_thread_count=other) if other else cand
             else:
                 best_t = dict(best_t, other_thread_count={"cores": cand["cores"], "value": cand["value"]})
+        # ---- and the WHOLE 24-layer model through the faster thread count, measured ("time it once instead of extrapolating"):
+        # one untimed run (first-touch page faults of ~10 GB of saved activations), then one timed forward + backward.  The 24 layers share
+        # the arrays of layer 0 as their initial values (every layer still has its own torch parameter and gradient).
+        try:
+            torch.set_num_threads(best_t["cores"])
+            cfg24 = O.OracleConfig(n_embed=d, n_layer=24, n_head=H, n_position=L, mem_len=L)
+            p1 = _oracle_params(O, rng, d, H, 1, cfg24.total_vocab_size)
+            p24 = dict(p1)
+            for i in range(1, 24):
+                for k_, v_ in p1.items():
+                    if k_.startswith("h.0."):
+                        p24[f"h.{i}." + k_[4:]] = v_
+            tm = TorchCpuModel(cfg24, p24)
+            ids = rng.integers(0, 32000, (1, L + 1))
+            secs = []
+            for r in range(2):
+                t0 = time.perf_counter()
+                tm.forward(ids[:, :-1], ids[:, 1:], np.ones((1, L), np.float32))
+                tm.backward()
+                secs.append(time.perf_counter() - t0)
+            del tm, p24
+            best_t = dict(best_t, extrapolated_value=best_t["value"], value=round(L / secs[1], 2), measured_24_layers=True,
+                          seconds_24_layers=[round(x, 2) for x in secs],
+                          sample=best_t["sample"] + f"; VALUE = all 24 layers + head measured once after one untimed run: {secs[1]:.1f} s per 1024-token sequence "
+                                                    f"(untimed first run {secs[0]:.1f} s)")
+        except Exception as e24:
+            best_t = dict(best_t, measured_24_layers=False, error_24_layers=repr(e24))
         torch.set_num_threads(all_threads)
         torch_port = best_t
     except Exception as e:   # (never take the line down)
@@ -144,9 +171,10 @@ def cpu_baseline(repeats: int = 5):
     else:
         best = {"value": numpy_port["value"], "cores": numpy_port["cores"], "port": "NumPy oracle (oracle/db1_oracle.py)"}
     return {"value": best["value"], "unit": "tokens/s", "cores": best["cores"], "kind": "port", "port": best["port"],
+            "measured_24_layers": bool(torch_port.get("measured_24_layers")) and best["port"].startswith("torch"),
             "numpy_oracle": numpy_port, "torch_eager_port": torch_port,
             "sample": f"DB1-1.3B geometry, 1 sequence x 1024 tokens, fwd+bwd, fp32, two CPU ports of the path timed (value = the faster); NumPy/OpenBLAS oracle: 1 and 2 decoder layers + tied head, "
-                      f"median of {repeats} timed runs each after one untimed run ({fmt(runs[1])} s; {fmt(runs[2])} s), extrapolated to 24 layers "
+                      f"median of {repeats} timed runs each after one untimed run ({fmt(runs[1])} s; {fmt(runs[2])} s), extrapolated to 24 layers (the torch port's value is MEASURED on all 24 layers) "
                       f"({full:.1f} s/sequence); {os.cpu_count()} logical CPUs on the box, {threads} BLAS threads (its elementwise passes over [16, 1024, 1024] "
                       f"fp32 tensors are single-threaded NumPy); torch-eager port: see torch_eager_port.sample",
             "tiny_config1": tiny,
@@ -200,8 +228,34 @@ def decode_leg(model, dev, calls: int = 30):
             torch.cuda.synchronize()
         ms_eager = (time.perf_counter() - t0) / calls * 1e3
         gbps = bytes_call / (ms_graph * 1e-3) / 1e9
+        # M environments per call (evaluate_rl.py:452-482 gives a rank up to ~110 independent environments; get_action_batched): the weights
+        # are streamed once per call whatever M is, every environment brings its own K / V ring (2 x mem x d bf16 per layer)
+        batched = {}
+        for M in (4, 16):
+            try:
+                idsM = torch.randint(0, 32000, (M, 1), device=dev)
+                stepM = GraphedRingStep(model, batch_size=M, n_new=1)
+                stepM.ids.copy_(idsM)
+                for _ in range(5):
+                    stepM(stepM.ids)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(calls):
+                    stepM(stepM.ids)
+                e1.record()
+                torch.cuda.synchronize()
+                msM = e0.elapsed_time(e1) / calls
+                bytesM = nl * (w_layer + M * 2 * mem * d * 2) + V * d * 2
+                batched[str(M)] = {"ms_per_call": round(msM, 4), "tokens_per_s": round(M * 1e3 / msM, 1), "speedup_vs_batch_1": round(M * ms_graph / msM, 2),
+                                   "hbm_frac": round(bytesM / (msM * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_call": int(bytesM)}
+                del stepM
+            except Exception as eM:
+                batched[str(M)] = {"ms_per_call": None, "error": repr(eM)}
         out = {"workload": f"inference with Transformer-XL memory, batch 1, mem_len {mem}, 1 new token per call (evaluate_rl.py:157-266), bf16, K / V of the memory cached",
                "ms_per_call": round(ms_graph, 4), "ms_per_call_list_memory_graph": round(ms_graph_list, 4), "ms_per_call_eager": round(ms_eager, 4), "calls": calls, "tokens_per_s": round(1e3 / ms_graph, 1),
+               "batched_environments": dict(batched, note="M environments per call over one RingMemory(model, M): one weight stream per token for all of them "
+                                                           "(bdm_db1_amd.evaluation.get_action_batched); tokens_per_s = M / ms_per_call"),
                "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
                             "algorithmic_bytes_per_call": int(bytes_call),
                             "kernel": ("the whole call as one hipGraph replay over a K / V ring: per layer relattn_decode_ring (chunk partials) + db1_decode_chain "
@@ -213,43 +267,136 @@ def decode_leg(model, dev, calls: int = 30):
     return out
 
 
-def mixture_leg(engine, model, dev, cfg, B, L, seed, steps: int = 5, warmup: int = 2):
-    """BASELINE config 5 / north_star's target workload on the SAME model and engine, right after the text steps: the mixed-modal
-    pre-training step (50 % RL-trajectory rows with image-patch observations, 25 % text, 25 % caption; synth.mixture_batch) -- forward +
-    backward + clip + Adam, ``steps`` timed steps after ``warmup`` untimed ones, bracketed by device synchronisation like the main leg."""
+def _count_patches(batch):
+    n = 0
+    for t in batch:
+        if getattr(t, "img_seq", None) is not None:
+            n += t.img_seq.shape[0] * (t.img_seq.shape[2] // 16) * (t.img_seq.shape[3] // 16)
+        if getattr(t, "vision_seq", None) is not None:
+            v = t.vision_seq
+            n += v.shape[0] * v.shape[1] * (v.shape[3] // 16) * (v.shape[4] // 16)
+    return int(n)
+
+
+LEG_WORKLOADS = {
+    "rl": "BASELINE config 4: RL-trajectory sequences (Atari-like 3x64x80 observation frames -> 20 image patches + separator + discrete action per "
+          "transition, 47 transitions per sequence; rl_dataset.py:590-752)",
+    "mixture": "BASELINE config 5 stand-in: 50 % RL-trajectory rows with 3x64x80 observation frames, 25 % text rows, 25 % caption rows with one "
+               "3x224x224 image each (blendable_dataset.py:45-72; the 870-task weights are unpublished)",
+    "caption": "BASELINE config 3: caption sequences (8 prompt ids + one 3x224x224 image = 196 patches + 820 text ids; coco_token_dataset.py:104-152)",
+}
+
+
+def workload_leg(engine, model, dev, cfg, B, L, seed, workload: str, world: int = 1, steps: int = 5, warmup: int = 2):
+    """Another of BASELINE.json's workloads on the SAME model, engine and ranks, right after the text steps: forward + backward (+ the
+    bucketed gradient all-reduce with more than one rank) + clip + Adam, ``steps`` timed steps after ``warmup`` untimed ones, bracketed by
+    barrier + device synchronisation and taken as the MAX over ranks like the main leg; tokens/s is the whole job's.  Every rank calls this
+    (the collectives of the step and the all_gather of the timings need all of them); only rank 0's return value is printed."""
     from bdm_db1_amd import synth
     try:
-        batch = synth.mixture_batch(B, L, seed, dev, cfg)
-        n_patches = 0
-        for t in batch:
-            if getattr(t, "img_seq", None) is not None:
-                n_patches += t.img_seq.shape[0] * (t.img_seq.shape[2] // 16) * (t.img_seq.shape[3] // 16)
-            if getattr(t, "vision_seq", None) is not None:
-                v = t.vision_seq
-                n_patches += v.shape[0] * v.shape[1] * (v.shape[3] // 16) * (v.shape[4] // 16)
+        batch = [synth.rl_batch(B, L, seed, dev, cfg)] if workload == "rl" else ([synth.caption_batch(B, L, seed, dev, cfg)] if workload == "caption"
+                                                                                    else synth.mixture_batch(B, L, seed, dev, cfg))
+        n_patches = _count_patches(batch)
+        rows = sum(int(t.label.shape[0]) for t in batch)      # (= B; a tiny debug batch rounds every task of the mixture up to one row)
 
         def step():
             _, loss = engine(batch)
             engine.backward(loss)
             engine.step()
             return loss
+
+        def fence():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
         for _ in range(warmup):
             step()
-        torch.cuda.synchronize()
+        fence()
+        engine.time_comm = world > 1
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
+        fence()
+        dt_local = time.perf_counter() - t0
+        out = {}
+        dt = dt_local
+        if world > 1:
+            ts = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(ts, torch.tensor([dt_local], device=dev, dtype=torch.float64))
+            per_rank = [float(t.item()) for t in ts]
+            dt = max(per_rank)
+            exposed = torch.tensor([engine.exposed_comm_ms()], device=dev, dtype=torch.float64)
+            dist.all_reduce(exposed, op=dist.ReduceOp.MAX)
+            pt = torch.tensor([float(n_patches)], device=dev, dtype=torch.float64)
+            dist.all_reduce(pt)                       # (every rank builds its own rows: the job's patch count is the sum)
+            n_patches_all = int(pt.item())
+            out["data_parallel"] = {"ms_per_step_min": round(min(per_rank) / steps * 1e3, 3), "ms_per_step_max": round(max(per_rank) / steps * 1e3, 3),
+                                    "exposed_comm_ms_per_step_max": round(float(exposed.item()) / steps, 3)}
+        else:
+            n_patches_all = n_patches
+        engine.time_comm = False
+        dt /= steps
+        flops = world * rows * L * FLOP_PER_TOKEN + n_patches_all * FLOP_PER_PATCH
+        out.update({"workload": f"DB1-1.3B {workload} pre-training step -- {LEG_WORKLOADS[workload]} -- seq_len {L}, {rows} sequences/GPU, same model / engine / dropout / "
+                                f"ranks as the text steps",
+                    "n_gpus": world, "sequences_per_gpu": rows, "tokens_per_s": round(world * rows * L / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup,
+                    "image_patches_per_step": n_patches_all,
+                    "pct_mfma_peak_step": round(100.0 * flops / dt / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 2), "final_loss": round(float(loss), 4),
+                    "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)})
+        return out
+    except Exception as e:   # a leg must never take the bench line down (with more than one rank a failure here is fatal for the job anyway)
+        return {"tokens_per_s": None, "error": repr(e)}
+
+
+def ga16_leg(model, dev, cfg, L, seed, micro_batch: int = 4, ga: int = 16, steps: int = 3, warmup: int = 1):
+    """The reference's OWN batch geometry (scripts/evaluate/evaluate_rl_1.2B.sh:28-42; train.py:216-232): micro-batch 4 x gradient
+    accumulation 16 = 64 sequences per optimizer step on this GPU, on the same model: every micro-step's forward + backward is a hipGraph
+    replay (GraphedTrainStep), the weight gradients are formed once per optimizer step from the stashed operands of the 16 micro-steps
+    (WgradStash), then clip + Adam.  One timed step = one OPTIMIZER step (16 micro-steps); ``steps`` of them after ``warmup``."""
+    from types import SimpleNamespace
+    from bdm_db1_amd import GraphedTrainStep, initialize, synth
+    gstep = None
+    try:
+        model._ctx = None
+        model.wgrad_stash = None
+        torch.cuda.empty_cache()
+        eargs = SimpleNamespace(lr=1e-4, weight_decay=0.01, clip_grad=1.0, optimizer="adam", keep_logits=False, fuse_head_loss=True,
+                                gradient_accumulation_steps=ga, defer_wgrad=True)
+        engine, _, _, _ = initialize(eargs, model)
+        engine.train()
+        batch = [synth.text_batch(micro_batch, L, seed, dev)]
+        gstep = GraphedTrainStep(engine, batch)
+
+        def opt_step():
+            for _ in range(ga):
+                loss = gstep(batch)
+                engine.step()
+            return loss
+        for _ in range(warmup):
+            opt_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = opt_step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        flops = B * L * FLOP_PER_TOKEN + n_patches * FLOP_PER_PATCH
-        return {"workload": f"DB1-1.3B mixed-modal pre-training step (BASELINE config 5 stand-in: {batch[0].tensor_seq.shape[0]} RL-trajectory rows with 3x64x80 "
-                            f"observation frames, {batch[1].text_seq.shape[0]} text rows, {batch[2].text_seq.shape[0]} caption rows with one 3x224x224 image each), "
-                            f"seq_len {L}, {B} sequences/GPU, same model / engine / dropout as the text steps",
-                "tokens_per_s": round(B * L / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "image_patches_per_step": int(n_patches),
-                "pct_mfma_peak_step": round(100.0 * flops / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 2), "final_loss": round(float(loss), 4),
-                "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)}
-    except Exception as e:   # the mixture leg must never take the bench line down
-        return {"tokens_per_s": None, "error": repr(e)}
+        toks = micro_batch * ga * L
+        out = {"workload": f"DB1-1.3B text pre-training at the reference's batch geometry: micro-batch {micro_batch} x gradient accumulation {ga} "
+                           f"({micro_batch * ga} sequences of {L} tokens per optimizer step; evaluate_rl_1.2B.sh:28-42), micro-steps as hipGraph replays, weight "
+                           "gradients once per optimizer step from the stashed operands, same model / dropout as the text steps",
+               "tokens_per_s": round(toks / dt, 1), "ms_per_optimizer_step": round(dt * 1e3, 3), "optimizer_steps": steps, "warmup": warmup,
+               "micro_batch": micro_batch, "grad_accumulation": ga,
+               "pct_mfma_peak_step": round(100.0 * toks * FLOP_PER_TOKEN / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 2), "final_loss": round(float(loss), 4),
+               "stash_gib": round(model.wgrad_stash.nbytes() / 2**30, 1) if model.wgrad_stash is not None else None}
+    except Exception as e:   # the leg must never take the bench line down
+        out = {"tokens_per_s": None, "error": repr(e)}
+    if gstep is not None:
+        gstep.close()
+    model.wgrad_stash = None
+    model.wgrad_defer_ga = 0
+    model._ctx = None
+    torch.cuda.empty_cache()
+    return out
 
 
 def rocprof_crosscheck(family_kernels_note: str):
@@ -357,7 +504,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the inference-with-memory leg after the timed steps")
-    ap.add_argument("--no-mixture", action="store_true", help="skip the mixed-modal leg (5 steps of the mixture workload on the same model) after the timed steps")
+    ap.add_argument("--no-mixture", action="store_true", help="skip the RL-trajectory and mixed-modal legs (BASELINE configs 4 / 5: a few steps of each on the same model and ranks) after the timed steps")
+    ap.add_argument("--leg-steps", type=int, default=5, help="timed steps of each extra workload leg")
+    ap.add_argument("--no-ga16", action="store_true", help="skip the leg at the reference's batch geometry (micro-batch 4 x GA 16, graphed micro-steps, 3 optimizer steps; N = 1 only)")
     ap.add_argument("--no-flash", action="store_true")
     ap.add_argument("--flash-probs", choices=["forward", "scratch", "recompute"], default="forward",
                     help="A/B: what the flash backward recomputes (nothing: the forward keeps p~ per layer / the query side only / both sides)")
@@ -408,13 +557,7 @@ def main():
         batch = [synth.rl_batch(B, L, seed, dev, cfg)]
     else:
         batch = synth.mixture_batch(B, L, seed, dev, cfg)
-    n_patches = 0
-    for t in batch:
-        if getattr(t, "img_seq", None) is not None:
-            n_patches += t.img_seq.shape[0] * (t.img_seq.shape[2] // 16) * (t.img_seq.shape[3] // 16)
-        if getattr(t, "vision_seq", None) is not None:
-            v = t.vision_seq
-            n_patches += v.shape[0] * v.shape[1] * (v.shape[3] // 16) * (v.shape[4] // 16)
+    n_patches = _count_patches(batch)
 
     gstep = None
     if args.graph:
@@ -578,8 +721,15 @@ def main():
         out["kernels"] = ks
     if gstep is not None:
         gstep.close()
-    if rank == 0 and world == 1 and not args.no_mixture and args.workload == "text" and args.ga == 1 and gstep is None:
-        out["mixture"] = mixture_leg(engine, model, dev, cfg, B, L, seed + 100)
+    # BASELINE configs 4 and 5 (RL trajectories, the mixture) on the same model / engine / RANKS right after the text steps, so that an N-GPU
+    # run of this command yields their whole-job tokens/s at N too (every rank takes part: the legs contain the step's collectives)
+    if not args.no_mixture and args.workload == "text" and args.ga == 1 and gstep is None:
+        for wl, k in (("rl", 200), ("mixture", 100)):
+            leg = workload_leg(engine, model, dev, cfg, B, L, seed + k, wl, world=world, steps=args.leg_steps, warmup=2)
+            if rank == 0:
+                out[wl] = leg
+    if rank == 0 and world == 1 and not args.no_ga16 and args.workload == "text" and args.ga == 1 and gstep is None and args.layers == 24:
+        out["ga16"] = ga16_leg(model, dev, cfg, L, seed + 300)
     if rank == 0 and world == 1 and not args.no_decode and args.layers == 24:
         out["decode"] = decode_leg(model, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -378,7 +378,7 @@ def test_decode_chain_matches_the_separate_launches_at_db1_1p3b_geometry(mem_len
     off = int(db1lib.load().db1_decode_chain_error_offset())
     x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
     with torch.no_grad():
-        model._chain_watch[1][off:off + 4].view(torch.int32).fill_(1)
+        ops.decode_chain_scratch(model.dev)[off:off + 4].view(torch.int32).fill_(1)    # (the scratch of THIS stream: the graph above has its own)
         lg_bad, _, mem_e = model([x], compute_loss=False, mems=mem_e)      # this call's flag copy carries the 1
         lg_bad.float().cpu()                                               # (a caller reading its logits synchronises)
         with pytest.raises(db1lib.Db1Error, match="hand-off poll"):
@@ -450,3 +450,41 @@ def test_decode_chain_stages_against_fp32_arithmetic():
             assert err(h1o, h1) < 5e-3 and err(fo, f_ref) < 1e-2
         else:
             assert err(xn, xn_ref) < 1e-2 and err(qn, q_ref) < 1e-2
+
+
+@pytest.mark.parametrize("M", [4, 16])
+def test_batched_ring_decode_equals_independent_environments(M):
+    """M environments decoded together over one RingMemory(model, M) -- one weight stream per token for all of them (bench.py's `decode`
+    block: tokens/s at M = 1 / 4 / 16) -- against the same M token streams decoded one environment at a time (batch 1: the persistent
+    one-token launch), at the 1.3B layer geometry with a full memory: the same logits per environment to bf16 rounding of the
+    intermediate rows, and the graphed batched call equals the eager one bit for bit."""
+    from bdm_db1_amd import GraphedRingStep, RingMemory, TransformerXL, synth
+    from bdm_db1_amd.data import NLPTaskInput
+    cfg = synth.db1_config("1.3B", n_layer=2)
+    torch.manual_seed(3)
+    model = TransformerXL(cfg, device=torch.device(DEV), compute_dtype=torch.bfloat16)
+    model.eval()
+    rng = np.random.default_rng(M)
+    calls = [rng.integers(0, 32000, (M, q)) for q in (22, 1, 1, 1)]
+    mk = lambda ids: NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=torch.from_numpy(ids).to(DEV), text_len=None)
+    with torch.no_grad():
+        mems = RingMemory(model, M)
+        together = []
+        for ids in calls:
+            lg, _, mems = model([mk(ids)], compute_loss=False, mems=mems)
+            together.append(lg.float().cpu().numpy())
+        for env in (0, M // 2, M - 1):
+            m1 = RingMemory(model, 1)
+            for step, ids in enumerate(calls):
+                lg, _, m1 = model([mk(ids[env:env + 1])], compute_loss=False, mems=m1)
+                a, b = together[step][env], lg.float().cpu().numpy()[0]
+                err = np.abs(a - b).max() / np.abs(b).max()
+                assert err < 1e-2, (env, step, err)
+        model.check_decode_chain(synchronize=True)
+        g = GraphedRingStep(model, batch_size=M, n_new=1)
+        mem_e = RingMemory(model, M)
+        ids = torch.from_numpy(calls[1]).to(DEV)
+        for _ in range(3):
+            lg_g, _ = g(ids)
+            lg_e, _, mem_e = model([mk(calls[1])], compute_loss=False, mems=mem_e)
+            assert torch.equal(lg_g, lg_e)

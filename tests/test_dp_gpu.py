@@ -158,6 +158,16 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0 and "cpu_baseline" not in out
+    # BASELINE configs 4 / 5 ride along on the same ranks: RL-trajectory and mixture legs with whole-job tokens/s,
+    # per-rank min / max step time and the exposed communication
+    for wl in ("rl", "mixture"):
+        leg = out[wl]
+        assert leg.get("error") is None, leg
+        assert leg["n_gpus"] == 2 and leg["tokens_per_s"] > 0 and leg["image_patches_per_step"] > 0
+        assert abs(leg["tokens_per_s"] - 2 * leg["sequences_per_gpu"] * 1024 / (leg["ms_per_step"] * 1e-3)) < 1e-2 * leg["tokens_per_s"]
+        dp = leg["data_parallel"]
+        assert dp["ms_per_step_min"] <= dp["ms_per_step_max"] and dp["exposed_comm_ms_per_step_max"] >= 0.0
+    assert "ga16" not in out and "decode" not in out      # (single-GPU legs)
 
 
 def test_bench_eight_ranks_on_this_box():
@@ -177,7 +187,7 @@ def test_bench_eight_ranks_on_this_box():
         env["DB1_DIST_BACKEND"] = "gloo"
     env["DB1_LAUNCH_TIMEOUT_S"] = "1200"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--batch", "2", "--no-cpu-baseline",
-                        "--no-kernel-timing"], env=env, capture_output=True, text=True, timeout=1500)
+                        "--no-kernel-timing", "--leg-steps", "1"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -186,6 +196,12 @@ def test_bench_eight_ranks_on_this_box():
     assert out["scaling"] == "weak" and out["value"] > 0 and abs(out["value"] - 8 * 2 * 1024 / (out["ms_per_step"] * 1e-3)) < 1e-2 * out["value"]
     assert "INVALID" not in out and np.isfinite(out["final_loss"]) and 5.0 < out["final_loss"] < 12.0
     assert "forward" in out["config"]["attention_backward"] or "scratch" in out["config"]["attention_backward"] or "recompute" in out["config"]["attention_backward"]
+    # the first 8-GPU run must produce BASELINE configs 4 and 5, not only text: all three workloads in ONE line
+    for wl in ("rl", "mixture"):
+        leg = out[wl]
+        assert leg.get("error") is None, leg
+        assert leg["n_gpus"] == 8 and leg["tokens_per_s"] > 0 and leg["image_patches_per_step"] > 0 and np.isfinite(leg["final_loss"])
+        assert "data_parallel" in leg and leg["data_parallel"]["ms_per_step_min"] <= leg["data_parallel"]["ms_per_step_max"]
 
 
 def test_self_launch_reports_a_failing_rank(tmp_path):

@@ -314,6 +314,37 @@ def test_get_action_replays_the_references_episode_calls(dtype):
                     assert rel_err(memory[-1], gold[f"{case}/{st}/mem_last"]) < (1e-4 if dtype == torch.float32 else 3e-2), (case, st)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_get_action_batched_replays_the_references_episode_in_every_row(dtype):
+    """bdm_db1_amd.evaluation.get_action_batched: M = 3 environments through ONE model call per token (the batch dimension the reference's
+    evaluation leaves at 1, evaluate_rl.py:452-482).  Every row replays the REFERENCE's golden episode (tests/golden/get_action.npz, memory
+    cases): the same actions in every row, and the last layer's memory of every row equals the reference's."""
+    from golden_util import GET_ACTION_CASES, get_action_inputs
+    from bdm_db1_amd.evaluation import get_action_batched
+    from bdm_db1_amd.tokenizer import ContinuousScalarTokenizer
+    gold = dict(np.load(os.path.join(G, "get_action.npz")))
+    cfg, params, _, model, oracle, seed = build("small_mems", compute_dtype=dtype)
+    tok = ContinuousScalarTokenizer(cfg["num_continuous_bin"])
+    M = 3
+    for case, (mem, disc, ol, al, steps, strat, use_prompt, lfp) in GET_ACTION_CASES.items():
+        if not mem:
+            continue
+        args = SimpleNamespace(overlap_with_text=cfg["overlap_with_text"], text_vocab_size=cfg["text_vocab_size"], num_discrete_values=cfg["num_discrete_values"],
+                               n_position=cfg["n_position"], use_prompt=use_prompt)
+        obs, prompt, masks = get_action_inputs(case, cfg)
+        space = SimpleNamespace(n=6) if disc else None
+        memory = model.init_mem(M)
+        with torch.no_grad():
+            for st in range(steps):
+                toks = torch.from_numpy(np.tile(obs[st][None, :], (M, 1)))
+                am = None if masks[st] is None else np.tile(masks[st][None, :], (M, 1))
+                acts, last, memory = get_action_batched(args, model, toks, tok, ol, al, disc, space, memory, action_masks=am)
+                for row in range(M):
+                    assert np.array_equal(np.asarray(acts[row], np.float64).reshape(-1), np.asarray(gold[f"{case}/{st}/act"], np.float64).reshape(-1)), (case, st, row)
+                    assert np.array_equal(last[row].numpy(), gold[f"{case}/{st}/seq"]), (case, st, row)
+                    assert rel_err(memory[-1][row:row + 1], gold[f"{case}/{st}/mem_last"]) < (1e-4 if dtype == torch.float32 else 3e-2), (case, st, row)
+
+
 def test_training_procedure_with_the_references_surface(tmp_path):
     """bdm_db1_amd.train_utils.train (the reference's train / train_step / forward_and_backward_step, src/train_utils/train.py:32-243):
     4 optimizer steps of 2 micro-steps each from an iterator of batches, losses returned per micro-step, TensorBoard-style writer calls,
@@ -481,6 +512,12 @@ def test_bench_line_contract(workload):
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert workload in d["config"]["workload"] and np.isfinite(d["final_loss"])
+    if workload == "text":    # the default line carries BASELINE configs 4 / 5 as legs on the same model (ga16 / decode: 24 layers only)
+        for wl in ("rl", "mixture"):
+            assert d[wl].get("error") is None and d[wl]["tokens_per_s"] > 0 and d[wl]["n_gpus"] == 1, d[wl]
+        assert "ga16" not in d
+    else:
+        assert "rl" not in d and "mixture" not in d
 
 
 @pytest.mark.parametrize("tag", ["plain", "deepnorm"])
