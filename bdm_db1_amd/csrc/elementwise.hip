@@ -1299,6 +1299,52 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     const float step_size = lr / bc1;
     const int64_t nv = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        float4 P = reinterpret_cast<float4*>(p)[i];
+        float gg[4];
+        if (sizeof(GT) == 4) {
+            float4 G = reinterpret_cast<const float4*>(g)[i];
+            gg[0] = G.x; gg[1] = G.y; gg[2] = G.z; gg[3] = G.w;
+        } else {  // bf16 gradients: the all-reduced staging copy of the data-parallel engine (8 B per 4 elements)
+            uint2 G = reinterpret_cast<const uint2*>(g)[i];
+            gg[0] = __uint_as_float(G.x << 16); gg[1] = __uint_as_float(G.x & 0xffff0000u);
+            gg[2] = __uint_as_float(G.y << 16); gg[3] = __uint_as_float(G.y & 0xffff0000u);
+        }
+        float4 M = reinterpret_cast<float4*>(m)[i], Vv = reinterpret_cast<float4*>(v)[i];
+        float pp[4] = {P.x, P.y, P.z, P.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {Vv.x, Vv.y, Vv.z, Vv.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float gr = gg[j] * gs;
+            if (adamw) pp[j] *= (1.f - lr * wd); else gr += wd * pp[j];
+            mm[j] = b1 * mm[j] + omb1 * gr;
+            vv[j] = b2 * vv[j] + omb2 * gr * gr;
+            const float denom = sqrtf(vv[j]) * rsqrt_bc2 + eps;
+            pp[j] -= step_size * mm[j] / denom;
+        }
+        reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (HAS_WORK) {
+            uint2 o;
+            o.x = f2bf_pk(pp[0], pp[1]);
+            o.y = f2bf_pk(pp[2], pp[3]);
+            reinterpret_cast<uint2*>(pw)[i] = o;
+        }
+    }
+}
+// A/B variant (knob "adam_nt" = 1): non-temporal loads / stores of the four arenas, two 16-byte groups per thread in flight
+template <bool HAS_WORK, typename GT>
+__global__ __launch_bounds__(256) void adam_nt_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, bf16_t* __restrict__ pw, int64_t n, float lr, float b1,
+                                                   float b2, float omb1, float omb2, float eps, float wd, int adamw, float bc1, float rsqrt_bc2,
+                                                   float gscale, float clip, const float* norm_sq) {
+    float gs = gscale;
+    if (clip > 0.f && norm_sq) {
+        const float nrm = sqrtf(*norm_sq) * gscale;
+        gs *= fminf(1.f, clip / (nrm + 1e-6f));
+    }
+    const float step_size = lr / bc1;
+    const int64_t nv = n >> 2;
     // every stream is touched exactly once per step (30 B per parameter, 36 GB at DB1-1.3B): non-temporal loads and stores keep the four
     // arenas out of L2 / the memory-side cache, and two 16-byte groups per thread are in flight per iteration (eight loads before the first use)
     typedef __attribute__((ext_vector_type(4))) float f4v;
@@ -1364,6 +1410,12 @@ extern "C" int db1_adam_step(float* p32, const void* g, float* m, float* v, void
     hipStream_t st = (hipStream_t)stream;
     unsigned gr = grid_for(n / 4);
 #define DB1_ADAM_LAUNCH(HW, GT) adam_kernel<HW, GT><<<gr, 256, 0, st>>>(p32, (const GT*)g, m, v, (bf16_t*)p_work, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd, adamw, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, clip, norm_sq)
+    if (db1_knob(DB1_KNOB_ADAM_NT, 0) && p_work && dtGrad == DB1_F32) {
+        adam_nt_kernel<true, float><<<gr, 256, 0, st>>>(p32, (const float*)g, m, v, (bf16_t*)p_work, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
+                                                       (float)eps, (float)wd, adamw, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, clip, norm_sq);
+        DB1_CHECK_LAUNCH("adam (nt)");
+        return DB1_OK;
+    }
     if (p_work) { if (dtGrad == DB1_F32) DB1_ADAM_LAUNCH(true, float); else DB1_ADAM_LAUNCH(true, bf16_t); }
     else { if (dtGrad == DB1_F32) DB1_ADAM_LAUNCH(false, float); else DB1_ADAM_LAUNCH(false, bf16_t); }
 #undef DB1_ADAM_LAUNCH

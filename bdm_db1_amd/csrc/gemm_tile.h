@@ -40,6 +40,7 @@ struct GemmTileArgs {
     void* Cact = nullptr; int64_t ld_act = 0;
     const bf16_t* Zin = nullptr; int64_t ld_z = 0;
     float* colpart = nullptr;
+    int band = 4;       // tile rows per band of the XCD-aware walk of the 4-wave kernels (A/B knob "w4_band")
 };
 
 // ---- staging of one 16 KiB operand (sub-)tile = 16 wave-instructions of 1 KiB, PIECES per wave (wave w takes w*PIECES ..)

@@ -103,9 +103,14 @@ class WgradStash:
     the K = 65 536 ones.  57 KB per token: 90 GB of the 288 at 16 x 4096 tokens -- memory this part has and the reference's GPUs did not."""
     KINDS = ("qkv", "o", "ff1", "ff2")
 
-    def __init__(self, model, T: int, ga: int):
+    def __init__(self, model, T: int, ga: int, nd: int = 0):
         d, di, dff = model.d_model, model.d_inner, model.d_ff
-        self.T, self.ga, self.n_layer = T, ga, model.n_layer
+        self.T, self.ga, self.n_layer, self.nd = T, ga, model.n_layer, nd
+        # the fifth map, r_net (R = r_net(position table), transformer_xl.py:138): its input is the position table of the micro-step (ONE
+        # table for all layers: nd rows -- the embedding dropout redraws it every micro-step), its output gradient dR [nd, d] per layer.
+        # 12 ms of K = 1024 products per optimizer step at 16 x 4096 tokens become 24 products over K = ga * nd rows.
+        self.rin = torch.empty(ga * nd, d, device=model.dev, dtype=model.compute_dtype) if nd else None
+        self.dr = [torch.empty(ga * nd, d, device=model.dev, dtype=model.compute_dtype) for _ in range(model.n_layer)] if nd else None
         xw = {"qkv": d, "o": d, "ff1": d, "ff2": dff}
         yw = {"qkv": 3 * d, "o": d, "ff1": di, "ff2": d}
         new = lambda w: torch.empty(ga * T, w, device=model.dev, dtype=model.compute_dtype)
@@ -113,10 +118,18 @@ class WgradStash:
         self.dy = [{k: new(yw[k]) for k in self.KINDS} for _ in range(model.n_layer)]
         self.slot = 0            # micro-step of the accumulation window the next forward / backward belongs to (set by the engine)
         self.first = 0           # first micro-step of the window whose operands are in THIS stash (> 0: the token count changed mid-window)
+        self.r_used = False      # the forwards of this window put their position tables into rin (False: r_net's gradient is formed per micro-step)
         self.beta = 0.0          # beta of the flush: 0 when the gradient arena was fresh at slot 0
 
     def nbytes(self) -> int:
-        return sum(t.numel() * t.element_size() for L in (self.x, self.dy) for dct in L for t in dct.values())
+        n = sum(t.numel() * t.element_size() for L in (self.x, self.dy) for dct in L for t in dct.values())
+        return n + (sum(t.numel() * t.element_size() for t in [self.rin] + self.dr) if self.nd else 0)
+
+    def rins(self) -> torch.Tensor:
+        return self.rin[self.slot * self.nd:(self.slot + 1) * self.nd]
+
+    def drs(self, i: int) -> torch.Tensor:
+        return self.dr[i][self.slot * self.nd:(self.slot + 1) * self.nd]
 
     def xs(self, i: int, kind: str) -> torch.Tensor:
         return self.x[i][kind][self.slot * self.T:(self.slot + 1) * self.T]
@@ -230,6 +243,7 @@ class TransformerXL(nn.Module):
         self.use_decode = True           # inference with memory: K/V-cached path + fused decode attention when the shape allows
         self.use_decode_fused = True     # ... and, for <= 64 new tokens, linear maps as W streams that finish with GEGLU (post-LN)
         self.use_decode_ln_prologue = True   # ... <= 16 tokens: the residual LayerNorms ride on the way IN to the next linear map
+        self.decode_ln_prologue_max_tokens = 4 # ... (more rows: LayerNorm launches; the prologue is redone by every workgroup of the linear map)
         self.use_decode_attn_partials = True   # ... <= 2 tokens (ring memory): the output projection merges the attention's chunk partials
         self.use_decode_chain = os.environ.get("DB1_DECODE_CHAIN", "1") != "0"   # ... ONE token (ring memory): the linear maps between two attention launches as one persistent launch (db1_decode_chain)
         self._chain_watch = None         # (pinned copy of the chain's error flag, its scratch) of the last chain call: check_decode_chain()
@@ -916,7 +930,10 @@ class TransformerXL(nn.Module):
 
     def _decode_ln_prologue_ok(self, T):
         d, dff = self.d_model, self.d_ff
-        return (self.use_decode_ln_prologue and ops.linear_decode_supported(T, 3 * d, d, False, False, True) and
+        # every workgroup of the linear map normalises ALL T input rows itself, so the prologue's cost grows with T while a LayerNorm launch
+        # costs ~5 us whatever T is: measured at the 1.3B shapes (profiles/r05_decode_batched.txt) the qkv projection with the prologue takes
+        # 8.4 / 11.8 / 34 us at T = 1 / 4 / 16 against 4.5 + 7.5 ... 9 us for launch + plain projection -> on the way in up to 4 rows only
+        return (self.use_decode_ln_prologue and T <= self.decode_ln_prologue_max_tokens and ops.linear_decode_supported(T, 3 * d, d, False, False, True) and
                 ops.linear_decode_supported(T, dff, d, True, False, True))
 
     def _attention_decode(self, qkv, i, B, L, mlen, shift, dec):
@@ -940,7 +957,7 @@ class TransformerXL(nn.Module):
         dec.new_kv.append(kv_all[:, max(0, klen - self.mem_len):])
         return av
 
-    def _attention_bwd(self, dav, c: _Ctx, i, B, L, shift, dstep=None, dqkv_out=None):
+    def _attention_bwd(self, dav, c: _Ctx, i, B, L, shift, dstep=None, dqkv_out=None, dR_out=None):
         """returns dqkv [B*L, 3d] and dR [L, d]; accumulates du / dv_bias"""
         H, D, d = self.n_head, self.d_head, self.d_model
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
@@ -994,7 +1011,7 @@ class TransformerXL(nn.Module):
             dqv = self._new(B, L, H, D)
             ops.gemm_batched(dT, R.view(nd, H, D).permute(1, 0, 2).unsqueeze(1).expand(H, B, nd, D), dqv.permute(2, 0, 1, 3),
                              tri=(1, 0) if tri else (0, 0))                                                               # dq_r
-        dR = self._new(nd, d)
+        dR = self._new(nd, d) if dR_out is None else dR_out
         ops.gemm_batched(dT.view(H, B * L, nd).transpose(1, 2).unsqueeze(1), qv.view(B * L, H, D).permute(1, 0, 2).unsqueeze(1),
                          dR.view(nd, H, D).permute(1, 0, 2).unsqueeze(1), tri=(2, L) if tri else (0, 0))
         if not fused_dq:
@@ -1018,6 +1035,8 @@ class TransformerXL(nn.Module):
             qkv = self._new(T, 3 * d)
             if pend is not None:   # the previous layer left its closing LayerNorm to this projection, which also stores the rows to x
                 ops.linear_decode(pend.y, self.W(p + "dec_attn.qkv_net.weight"), None, qkv, pre=(pend.res, pend.alpha, pend.gamma, pend.beta, pend.eps, x))
+            elif self._decode_fused_ok(T, keep, dstep) and ops.linear_decode_supported(T, 3 * d, d, False, False, False):
+                ops.linear_decode(x, self.W(p + "dec_attn.qkv_net.weight"), None, qkv)    # (<= 64 rows: a stream over W, not a 256-row tile GEMM)
             else:
                 ops.gemm(x, self.W(p + "dec_attn.qkv_net.weight").t(), qkv)
             av = self._attention_decode(qkv, i, B, L, mlen, shift, dec)
@@ -1250,8 +1269,11 @@ class TransformerXL(nn.Module):
             ops.gemm(do.t(), c.av.view(T, d), G(p + "dec_attn.o_net.weight"), beta=self._gb)
         dav = self._new(T, d)
         ops.gemm(do, W(p + "dec_attn.o_net.weight"), dav)
-        dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift, dstep, dqkv_out=None if st is None else st.dys(i, "qkv"))
-        ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=self._gb)
+        defer_r = st is not None and st.nd == R_in.shape[0] and R_in.data_ptr() == st.rins().data_ptr()   # (the forward put this micro-step's table into the stash)
+        dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift, dstep, dqkv_out=None if st is None else st.dys(i, "qkv"),
+                                       dR_out=st.drs(i) if defer_r else None)
+        if not defer_r:
+            ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=self._gb)
         if st is None:
             ops.gemm(dqkv.t(), c.x, G(p + "dec_attn.qkv_net.weight"), beta=self._gb)
         ops.gemm(dqkv, W(p + "dec_attn.qkv_net.weight"), ds1, beta=a)        # dx = a*ds1 + dqkv Wqkv (in place over ds1)
@@ -1268,6 +1290,9 @@ class TransformerXL(nn.Module):
         for kind, name in (("ff2", "pos_ff.CoreNet.2.weight"), ("ff1", "pos_ff.CoreNet.0.weight"), ("o", "dec_attn.o_net.weight"),
                            ("qkv", "dec_attn.qkv_net.weight")):
             ops.gemm(st.dy[i][kind][lo:hi].t(), st.x[i][kind][lo:hi], self.G(p + name), beta=st.beta)
+        if st.nd and st.r_used:      # r_net over the same micro-steps: rows [slot * nd, (slot + 1) * nd) of the position-table stash
+            r0, r1 = (lo // st.T) * st.nd, (hi // st.T) * st.nd
+            ops.gemm(st.dr[i][r0:r1].t(), st.rin[r0:r1], self.G(p + "dec_attn.r_net.weight"), beta=st.beta)
 
     def flush_deferred_wgrads(self):
         """(a hipGraph-captured boundary micro-step stashes like the others; the products then run here, outside the graph)"""
@@ -1351,7 +1376,7 @@ class TransformerXL(nn.Module):
             st = self.wgrad_stash
             if not 0 <= self._wg_slot < self.wgrad_defer_ga:
                 raise RuntimeError(f"weight-gradient stash: micro-step {self._wg_slot} of an accumulation window of {self.wgrad_defer_ga}")
-            if st is None or st.T != B * L or st.ga != self.wgrad_defer_ga:
+            if st is None or st.T != B * L or st.ga != self.wgrad_defer_ga or st.nd != int(R_in.shape[0]):
                 first, beta = 0, 0.0
                 if st is not None and self._wg_slot > 0:
                     # the token count changed INSIDE an accumulation window (a short last batch, another task mix): the operands of the
@@ -1364,11 +1389,15 @@ class TransformerXL(nn.Module):
                     else:
                         first, beta = self._wg_slot, st.beta
                 self.wgrad_stash = st = None     # (free the old buffers first)
-                st = self.wgrad_stash = WgradStash(self, B * L, self.wgrad_defer_ga)
+                st = self.wgrad_stash = WgradStash(self, B * L, self.wgrad_defer_ga, nd=int(R_in.shape[0]))
                 st.first, st.beta = first, beta
             elif self._wg_slot == 0:
                 st.first = 0
             st.slot = self._wg_slot
+            rows = st.rins()                 # this micro-step's position table (after its dropout) lives in the stash: r_net's input
+            rows.copy_(R_in)
+            R_in = rows
+            st.r_used = True
         hids, lcs = [], []
         for i in range(self.n_layer):
             kw = {}
@@ -1471,6 +1500,10 @@ class TransformerXL(nn.Module):
             logits_pad = self._new(T, self.vocab_pad)
             if head_pend is not None:
                 ops.linear_decode(head_pend.y, Wout, None, logits_pad, pre=(head_pend.res, head_pend.alpha, head_pend.gamma, head_pend.beta, head_pend.eps, x))
+            elif (dec is not None and not compute_loss and not keep and x.dtype == torch.bfloat16 and self.use_decode_fused and
+                  ops.linear_decode_supported(T, self.vocab_pad, d, False, False, False)):
+                # a few rows of an inference call with memory: the 136 MB of the tied head as one stream (the 256-row tile GEMM took 290 us for 16 rows)
+                ops.linear_decode(x, Wout, None, logits_pad)
             else:
                 ops.gemm(x, Wout.t(), logits_pad, useful_flops=2.0 * T * V * d)   # (the padded vocabulary columns are not counted as work)
             lm_logits = logits_pad.view(B, L, self.vocab_pad)[:, :, :V]
