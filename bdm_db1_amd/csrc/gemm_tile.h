@@ -37,6 +37,7 @@ struct GemmTileArgs {
     // Cact = z[:, :dff] * gelu(z[:, dff:]) [M, dff] leave the same accumulators.  Backward (NN, db1_gemm_nn_geglu_bwd): the product is
     // dact [M, dff] = dy W2; the epilogue reads Zin = z and writes C = dz [M, 2 dff] plus the column sums of dz per 128-row block to colpart.
     int geglu_dff = 0;
+    int geglu_saved = 0;   // 1: the column halves of C (forward) / Zin (backward) hold the backward's factors gelu(g) | v gelu'(g) instead of z = (v | g)
     void* Cact = nullptr; int64_t ld_act = 0;
     const bf16_t* Zin = nullptr; int64_t ld_z = 0;
     float* colpart = nullptr;

@@ -234,6 +234,10 @@ class TransformerXL(nn.Module):
         self.wgrad_defer_ga = 0          # > 1: training forwards stash the weight-gradient operands of this many micro-steps (set by the engine)
         self._wg_slot = 0                # micro-step index inside the accumulation window (set by the engine before every forward)
         self.use_geglu_epilogue = os.environ.get("DB1_GEGLU_EPI", "1") != "0"   # GEGLU and its backward inside the feed-forward GEMMs' epilogues (large bf16 batches)
+        # ... and the forward leaves the backward's two factors gelu(g) | v gelu'(g) instead of z (db1_gemm_nt_geglu_saved).  OPT-IN: measured on
+        # one box dff2 1080 -> 1013 us, ff1 1712 -> 1735 us per layer (1.1 ms per step, 0.26 %) for one more bf16 rounding of each factor of dz;
+        # the epilogue's cost turned out to be its z / dz traffic, not its arithmetic
+        self.use_geglu_saved = os.environ.get("DB1_GEGLU_SAVED", "0") != "0"
         self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
         self._conv_ops = {}              # (weight name, weight version) -> tap-major GEMM operand
@@ -1096,7 +1100,7 @@ class TransformerXL(nn.Module):
         ops.layernorm_residual_fwd(x, o, a, self.W(p + "dec_attn.layer_norm.weight"), self.W(p + "dec_attn.layer_norm.bias"),
                                    h1, o if keep else None, m1, r1, self.layer_norm_epsilon,
                                    drop=self._drop_args(self.drop_p, 4 * i, dstep))  # s1 = a x + dropout(o) overwrites o
-        z, act = self._ff1_fwd(h1, p, T, act=None if st is None else st.xs(i, "ff2"))
+        z, act = self._ff1_fwd(h1, p, T, act=None if st is None else st.xs(i, "ff2"), keep=keep)
         f = self._new(T, d)
         ops.gemm(act, self.W(p + "pos_ff.CoreNet.2.weight").t(), f, bias=self.W(p + "pos_ff.CoreNet.2.bias"))
         out = self._new(T, d) if (st is None or i + 1 >= self.n_layer) else st.xs(i + 1, "qkv")   # the next layer's input, where its weight gradient will look for it
@@ -1118,25 +1122,38 @@ class TransformerXL(nn.Module):
 
     # ---- PositionwiseFF halves with the activation inside the GEMM where the shape allows (db1_gemm_nt_geglu / db1_gemm_nn_geglu_bwd: the
     # "bias + GEGLU" epilogue of SURVEY 8b; otherwise the same arithmetic as separate launches)
-    def _ff1_fwd(self, x, p, T, act=None):
+    def _ff1_fwd(self, x, p, T, act=None, keep=False):
         """z = x W1^T + b1, act = GEGLU(z)  (transformer_xl.py:264-266, activations.py:19-32)"""
         d, di, dff = self.d_model, self.d_inner, self.d_ff
         z = self._new(T, di)
         act = self._new(T, dff) if act is None else act
         W1, b1 = self.W(p + "pos_ff.CoreNet.0.weight"), self.W(p + "pos_ff.CoreNet.0.bias")
-        if self.use_geglu_epilogue and self.activation_fn == "geglu" and ops.gemm_nt_geglu_fused(T, dff, d, self.compute_dtype):
+        if keep and self._geglu_saved_ok(T):
+            # a forward whose backward will run: the epilogue leaves the two factors the backward multiplies by -- gelu(g) | v gelu'(g) -- where z = (v | g) would go
+            # (db1_gemm_nt_geglu_saved); _ff2_dgrad reads them back through db1_gemm_nn_geglu_bwd_saved.  The tensor is tagged so that the
+            # pairing cannot be mixed up.
+            ops.gemm_nt_geglu_saved(x, W1, b1, z, act)
+            z._db1_geglu_saved = True
+        elif self.use_geglu_epilogue and self.activation_fn == "geglu" and ops.gemm_nt_geglu_fused(T, dff, d, self.compute_dtype):
             ops.gemm_nt_geglu(x, W1, b1, z, act)
         else:
             ops.gemm(x, W1.t(), z, bias=b1)
             ops.ffn_act_fwd(z, act, self.activation_fn)
         return z, act
 
+    def _geglu_saved_ok(self, T: int) -> bool:
+        d, dff = self.d_model, self.d_ff
+        return (self.use_geglu_epilogue and self.use_geglu_saved and self.activation_fn == "geglu" and
+                self.compute_dtype == torch.bfloat16 and ops.gemm_geglu_saved_supported(T, dff, d, d, self.compute_dtype))
+
     def _ff2_dgrad(self, df, z, p, T, dz=None):
         """dz from df = d(loss)/d(CoreNet output): dact = df W2, through the activation; accumulates the first bias's gradient"""
         d, di, dff = self.d_model, self.d_inner, self.d_ff
         dz = self._new(T, di) if dz is None else dz
         W2, gb1 = self.W(p + "pos_ff.CoreNet.2.weight"), self.G(p + "pos_ff.CoreNet.0.bias")
-        if self.use_geglu_epilogue and self.activation_fn == "geglu" and ops.gemm_nn_geglu_bwd_fused(T, dff, d, self.compute_dtype):
+        if getattr(z, "_db1_geglu_saved", False):
+            ops.gemm_nn_geglu_bwd_saved(df, W2, z, dz, gb1)
+        elif self.use_geglu_epilogue and self.activation_fn == "geglu" and ops.gemm_nn_geglu_bwd_fused(T, dff, d, self.compute_dtype):
             ops.gemm_nn_geglu_bwd(df, W2, z, dz, gb1)
         else:
             dact = self._new(T, dff)
@@ -1178,7 +1195,7 @@ class TransformerXL(nn.Module):
         m2, r2 = self._new(T, dtype=torch.float32), self._new(T, dtype=torch.float32)
         ops.layernorm_residual_fwd(h1, None, 1.0, self.W(p + "pos_ff.layer_norm.weight"), self.W(p + "pos_ff.layer_norm.bias"),
                                    fin, None, m2, r2, self.layer_norm_epsilon)
-        z, act = self._ff1_fwd(fin, p, T)
+        z, act = self._ff1_fwd(fin, p, T, keep=keep)
         out = self._new(T, d)
         ops.gemm(act, self.W(p + "pos_ff.CoreNet.2.weight").t(), out, bias=self.W(p + "pos_ff.CoreNet.2.bias"))
         if dstep is not None and self.drop_p > 0:

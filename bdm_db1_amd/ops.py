@@ -361,6 +361,34 @@ def gemm_nn_geglu_bwd(dy, w2, z, dz, dbias_acc):
                             dt_code(dy), ws, wsn, stream()))
 
 
+def gemm_geglu_saved_supported(M: int, dff: int, K_fwd: int, K_bwd: int, dtype) -> bool:
+    """do db1_gemm_nt_geglu_saved / db1_gemm_nn_geglu_bwd_saved exist at this shape (contiguous operands)"""
+    return bool(lib.load().db1_gemm_geglu_saved_supported(M, dff, K_fwd, K_bwd, dt_code(dtype), K_fwd, K_fwd, 2 * dff, dff, K_bwd, dff, 2 * dff))
+
+
+def gemm_nt_geglu_saved(x, w1, bias, s, act):
+    """act = v * gelu(g) for (v | g) = x w1^T + bias, and s [M, 2 dff] = (gelu(g) | v * gelu'(g)): the factors of the backward instead of z"""
+    M, K = x.shape
+    dff = act.shape[1]
+    assert w1.shape == (2 * dff, K) and s.shape == (M, 2 * dff) and x.stride(1) == 1 and w1.stride(1) == 1 and s.stride(1) == 1 and act.stride(1) == 1
+    assert bias is None or bias.dtype == x.dtype
+    _timed("gemm", 2.0 * M * 2 * dff * K,
+           lambda: lib.call("db1_gemm_nt_geglu_saved", P(x), P(w1), P(bias), P(s), P(act), M, dff, K, x.stride(0), w1.stride(0), s.stride(0), act.stride(0),
+                            dt_code(x), stream()))
+
+
+def gemm_nn_geglu_bwd_saved(dy, w2, s, dz, dbias_acc):
+    """dz = ((dy w2) * s[:, :dff] | (dy w2) * s[:, dff:]), dbias_acc += column sums of dz (s from gemm_nt_geglu_saved)"""
+    M, K = dy.shape
+    dff = w2.shape[1]
+    assert w2.shape[0] == K and s.shape == (M, 2 * dff) and dz.shape == (M, 2 * dff) and dbias_acc.dtype == torch.float32 and dbias_acc.numel() == 2 * dff
+    assert dy.stride(1) == 1 and w2.stride(1) == 1 and s.stride(1) == 1 and dz.stride(1) == 1
+    ws, wsn = _ws("db1_gemm_nn_geglu_bwd_saved_workspace_bytes", (M, dff), dy.device)
+    _timed("gemm", 2.0 * M * dff * K,
+           lambda: lib.call("db1_gemm_nn_geglu_bwd_saved", P(dy), P(w2), P(s), P(dz), P(dbias_acc), M, dff, K, dy.stride(0), w2.stride(0), s.stride(0), dz.stride(0),
+                            dt_code(dy), ws, wsn, stream()))
+
+
 def colsum_acc(x2d, out_acc):
     rows, cols = x2d.shape
     assert x2d.stride(1) == 1 and out_acc.dtype == torch.float32

@@ -122,6 +122,19 @@ int db1_gemm_nn_geglu_bwd_fused(int M, int dff, int K, int dt, int64_t lddy, int
 int64_t db1_gemm_nn_geglu_bwd_workspace_bytes(int M, int dff, int K, int dt, int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz);
 int db1_gemm_nn_geglu_bwd(const void* dY, const void* W2, const void* Z, void* dZ, float* dbias_acc, int M, int dff, int K,
                           int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz, int dt, void* ws, int64_t ws_bytes, void* stream);
+/* The same pair with the backward's two factors saved by the forward (round 5): S[M, 2 dff] takes Z's place, S[:, :dff] = gelu(g) and
+ * S[:, dff:] = v * gelu'(g) for (v | g) = the bf16-rounded Z -- what dZ = (dact * gelu(g), dact * v * gelu'(g)) multiplies dact by -- so the
+ * backward epilogue is two products per element (no erf / exp / rcp) and the forward's, which holds Phi(g) and exp(-g^2 / 2) anyway, three
+ * operations more.  ACT as above.  Only for the shapes the fused 4-wave kernels take (db1_gemm_geglu_saved_supported == 1: large bf16
+ * batches; K_fwd / K_bwd = the contraction lengths of the two products); elsewhere DB1_ERR_UNSUPPORTED -- callers keep Z there.  dZ differs
+ * from the Z form's by one more bf16 rounding per factor. */
+int db1_gemm_geglu_saved_supported(int M, int dff, int K_fwd, int K_bwd, int dt, int64_t lda, int64_t ldw1, int64_t lds, int64_t ldact,
+                                   int64_t lddy, int64_t ldw2, int64_t lddz);
+int db1_gemm_nt_geglu_saved(const void* A, const void* W1, const void* bias, void* S, void* ACT, int M, int dff, int K,
+                            int64_t lda, int64_t ldw, int64_t lds, int64_t ldact, int dt, void* stream);
+int64_t db1_gemm_nn_geglu_bwd_saved_workspace_bytes(int M, int dff);
+int db1_gemm_nn_geglu_bwd_saved(const void* dY, const void* W2, const void* S, void* dZ, float* dbias_acc, int M, int dff, int K,
+                                int64_t lddy, int64_t ldw, int64_t lds, int64_t lddz, int dt, void* ws, int64_t ws_bytes, void* stream);
 /* which kernel db1_gemm_strided would pick: 0 = strided fp32-MFMA, 1 = bf16 MFMA tile kernel */
 int db1_gemm_would_use_fast(int M, int N, int K, int dtA, int dtB, int dtC,
                             int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs, int64_t c_cs);
