@@ -695,6 +695,47 @@ extern "C" int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int c
     return DB1_OK;
 }
 
+// y [cols, rows] = x [rows, cols]^T for 2-byte elements: 64 x 64 tiles through LDS, 8-byte accesses on both sides (a lane reads 4
+// consecutive columns of a row and writes 4 consecutive rows' worth of one output row).  Used for the per-weight-version transposed copy of
+// the attention input projection's weight (db1_gemm_nn_headbias).
+__global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int rows, int cols, int64_t ldx, int64_t ldy) {
+    __shared__ unsigned short tile[64][64 + 4];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, t = threadIdx.x;
+    const int lr = t >> 4, lc = (t & 15) * 4;      // 16 rows x 16 four-column groups per pass
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int r = lr + 16 * p;
+        uint2 v = make_uint2(0u, 0u);
+        if (r0 + r < rows && c0 + lc + 3 < cols) v = *reinterpret_cast<const uint2*>(x + (int64_t)(r0 + r) * ldx + c0 + lc);
+        else if (r0 + r < rows) {
+            unsigned short e[4] = {0, 0, 0, 0};
+            for (int j = 0; j < 4; j++) if (c0 + lc + j < cols) e[j] = x[(int64_t)(r0 + r) * ldx + c0 + lc + j];
+            v = make_uint2((unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16));
+        }
+        tile[r][lc] = (unsigned short)(v.x & 0xffffu); tile[r][lc + 1] = (unsigned short)(v.x >> 16);
+        tile[r][lc + 2] = (unsigned short)(v.y & 0xffffu); tile[r][lc + 3] = (unsigned short)(v.y >> 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int oc = lr + 16 * p;                // output row = input column
+        if (c0 + oc >= cols) continue;
+        unsigned short e[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) e[j] = tile[lc + j][oc];
+        unsigned short* dst = y + (int64_t)(c0 + oc) * ldy + r0 + lc;
+        if (r0 + lc + 3 < rows) *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16));
+        else for (int j = 0; j < 4; j++) if (r0 + lc + j < rows) dst[j] = e[j];
+    }
+}
+extern "C" int db1_transpose_bf16(const void* x, void* y, int rows, int cols, int64_t ldx, int64_t ldy, void* stream) {
+    if (rows <= 0 || cols <= 0 || ldx < cols || ldy < rows) DB1_FAIL(DB1_ERR_BAD_SHAPE, "transpose_bf16: rows=%d cols=%d ldx=%lld ldy=%lld", rows, cols, (long long)ldx, (long long)ldy);
+    if ((((uintptr_t)x) & 7) || (((uintptr_t)y) & 7) || (ldx % 4) || (ldy % 4)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "transpose_bf16: 8-byte aligned pointers, leading dimensions multiples of 4");
+    transpose16_kernel<<<dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, (unsigned short*)y, rows, cols, ldx, ldy);
+    DB1_CHECK_LAUNCH("transpose_bf16");
+    return DB1_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) stf(y + i, ldf(a + i) + ldf(b + i));

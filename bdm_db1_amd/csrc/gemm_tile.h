@@ -41,6 +41,7 @@ struct GemmTileArgs {
     void* Cact = nullptr; int64_t ld_act = 0;
     const bf16_t* Zin = nullptr; int64_t ld_z = 0;
     float* colpart = nullptr;
+    int rot = 1;        // NT: per-XCD rotation of the k-tile walk (A/B knob "w4_rot")
     int band = 4;       // tile rows per band of the XCD-aware walk of the 4-wave kernels (A/B knob "w4_band")
 };
 

@@ -233,6 +233,11 @@ class TransformerXL(nn.Module):
         self.wgrad_stash: Optional[WgradStash] = None   # gradient accumulation: weight gradients formed once per optimizer step (engine option defer_wgrad)
         self.wgrad_defer_ga = 0          # > 1: training forwards stash the weight-gradient operands of this many micro-steps (set by the engine)
         self._wg_slot = 0                # micro-step index inside the accumulation window (set by the engine before every forward)
+        # the attention input projection against a transposed weight copy (NN form of the 4-wave kernel).  OPT-IN: alone and back to back the NN
+        # form is 8 % faster at this shape (1190 vs 1300 us), inside the training step the two are equal (same box: 420.6 vs 419.6 ms per
+        # step, profiles/r05_nt_vs_nn.txt) -- a GEMM's isolated speed is not its speed under the step's power / clock state
+        self.use_qkv_nn = os.environ.get("DB1_QKV_NN", "0") != "0"
+        self._wqkv_t, self._wqkv_t_version, self._wqkv_t_wanted = None, -1, False
         self.use_geglu_epilogue = os.environ.get("DB1_GEGLU_EPI", "1") != "0"   # GEGLU and its backward inside the feed-forward GEMMs' epilogues (large bf16 batches)
         # ... and the forward leaves the backward's two factors gelu(g) | v gelu'(g) instead of z (db1_gemm_nt_geglu_saved).  OPT-IN: measured on
         # one box dff2 1080 -> 1013 us, ff1 1712 -> 1735 us per layer (1.1 ms per step, 0.26 %) for one more bf16 rounding of each factor of dz;
@@ -1059,7 +1064,12 @@ class TransformerXL(nn.Module):
                     ops.gemm_nt_headbias_supported(T, 3 * d, d, d)):
                 # q + r_w_bias and q + r_r_bias leave the projection's accumulators directly (the q columns of qkv stay unwritten)
                 quv = (self._new(B, L, self.n_head, self.d_head), self._new(B, L, self.n_head, self.d_head))
-                ops.gemm_nt_headbias(xin, Wqkv, qkv, quv[0], quv[1], self._bias("r_w_bias", i), self._bias("r_r_bias", i), d)
+                if self.use_qkv_nn and ops.gemm_nn_headbias_supported(T, 3 * d, d, d):
+                    # against the weight's transposed copy (one per weight version, refreshed behind the optimizer step): the NN form of the
+                    # 4-wave kernel is 8 % faster at this shape (N = 6144), the only forward projection where the two forms differ
+                    ops.gemm_nn_headbias(xin, self._qkv_weight_t(i), qkv, quv[0], quv[1], self._bias("r_w_bias", i), self._bias("r_r_bias", i), d)
+                else:
+                    ops.gemm_nt_headbias(xin, Wqkv, qkv, quv[0], quv[1], self._bias("r_w_bias", i), self._bias("r_r_bias", i), d)
             else:
                 ops.gemm(xin, Wqkv.t(), qkv)
             R = self._new(R_in.shape[0], d)
@@ -1119,6 +1129,29 @@ class TransformerXL(nn.Module):
         if st is None or not keep or not self.training or self.pre_lnorm or st.T != T or self.wgrad_defer_ga <= 1:
             return None
         return st
+
+    # ---- the attention input projection's weight, transposed: Wqkv^T [d, 3d] per layer, static buffers (a captured micro-step reads them),
+    # valid for ONE weight version.  engine.step() refreshes them right behind Adam (refresh_weight_copies); any other weight change
+    # (load_state_dict, mark_weights_changed) is caught lazily by the next eager forward.
+    def _qkv_weight_t(self, i: int) -> torch.Tensor:
+        self._wqkv_t_wanted = True
+        if self._wqkv_t is None or self._wqkv_t_version != self._wversion:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the transposed projection weights are stale inside a graph capture: call model.refresh_weight_copies() first")
+            self.refresh_weight_copies()
+        return self._wqkv_t[i]
+
+    def refresh_weight_copies(self):
+        """per-weight-version copies that live in static buffers (captured training steps read them): the transposed qkv weights"""
+        if not (self.use_qkv_nn and self.compute_dtype == torch.bfloat16 and self._wqkv_t_wanted):
+            return
+        d = self.d_model
+        with torch.cuda.device(self.dev):
+            if self._wqkv_t is None:
+                self._wqkv_t = [torch.empty(d, 3 * d, device=self.dev, dtype=self.compute_dtype) for _ in range(self.n_layer)]
+            for i in range(self.n_layer):
+                ops.transpose(self.W(f"h.{i}.dec_attn.qkv_net.weight"), self._wqkv_t[i])
+        self._wqkv_t_version = self._wversion
 
     # ---- PositionwiseFF halves with the activation inside the GEMM where the shape allows (db1_gemm_nt_geglu / db1_gemm_nn_geglu_bwd: the
     # "bias + GEGLU" epilogue of SURVEY 8b; otherwise the same arithmetic as separate launches)

@@ -225,6 +225,30 @@ def gemm_nt_headbias(x, w, out, qu, qv, bias_u, bias_v, split_n):
     _timed("gemm", 2.0 * M * N * K, run)
 
 
+def gemm_nn_headbias_supported(M, N, K, split_n) -> bool:
+    return bool(lib.load().db1_gemm_nn_headbias_supported(M, N, K, split_n))
+
+
+def gemm_nn_headbias(x, wt, out, qu, qv, bias_u, bias_v, split_n):
+    """gemm_nt_headbias against the transposed weight copy wt [K, N] (db1_gemm_nn_headbias)"""
+    M, K = x.shape
+    N = wt.shape[1]
+    assert wt.shape[0] == K and x.stride(1) == 1 and wt.stride(1) == 1 and out.stride(1) == 1 and qu.is_contiguous() and qv.is_contiguous()
+    assert x.dtype == wt.dtype == out.dtype == qu.dtype == bias_u.dtype == torch.bfloat16 and bias_u.numel() == split_n == bias_v.numel()
+
+    def run():
+        lib.call("db1_gemm_nn_headbias", P(x), P(wt), P(out), P(qu), P(qv), P(bias_u), P(bias_v), M, N, K, split_n, x.stride(0), wt.stride(0),
+                 out.stride(0), split_n, stream())
+
+    _timed("gemm", 2.0 * M * N * K, run)
+
+
+def transpose(x, y):
+    """y [cols, rows] = x [rows, cols]^T (bf16)"""
+    assert x.dim() == 2 and y.shape == (x.shape[1], x.shape[0]) and x.element_size() == 2 and y.element_size() == 2 and x.stride(1) == 1 and y.stride(1) == 1
+    lib.call("db1_transpose_bf16", P(x), P(y), x.shape[0], x.shape[1], x.stride(0), y.stride(0), stream())
+
+
 def gemm_batched(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, beta: float = 0.0, tri=(0, 0)):
     """4-D views [z0, z1, rows, cols] with arbitrary strides (stride 0 broadcasts).
     ``tri`` = (mode, period): structural-zero hint for ``a`` (db1_gemm_strided_tri), an optimisation only."""

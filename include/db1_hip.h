@@ -104,6 +104,14 @@ int db1_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
 int db1_gemm_nt_headbias_supported(int M, int N, int K, int split_n);
 int db1_gemm_nt_headbias(const void* A, const void* W, void* C, void* Cu, void* Cv, const void* bias_u, const void* bias_v, int M, int N, int K,
                          int split_n, int64_t lda, int64_t ldw, int64_t ldc, int64_t ld_uv, void* stream);
+/* the same projection against the weight's TRANSPOSED copy Wt [K, N] (row stride ldwt): the NN form of the 4-wave kernel, 8 % faster than
+ * the NT form at the DB1-1.3B shape 65 536 x 6144 x 2048 (the other forward projections are equal in both forms).  The copy is the caller's:
+ * db1_transpose_bf16, once per weight version. */
+int db1_gemm_nn_headbias_supported(int M, int N, int K, int split_n);
+int db1_gemm_nn_headbias(const void* A, const void* Wt, void* C, void* Cu, void* Cv, const void* bias_u, const void* bias_v,
+                         int M, int N, int K, int split_n, int64_t lda, int64_t ldwt, int64_t ldc, int64_t ld_uv, void* stream);
+/* y [cols, rows] = x [rows, cols]^T, bf16 (any 2-byte element) */
+int db1_transpose_bf16(const void* x, void* y, int rows, int cols, int64_t ldx, int64_t ldy, void* stream);
 int db1_gemm_nn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
                 int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* ws, int64_t ws_bytes, void* stream);
 int db1_gemm_tn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
