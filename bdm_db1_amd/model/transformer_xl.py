@@ -237,6 +237,8 @@ class TransformerXL(nn.Module):
         # form is 8 % faster at this shape (1190 vs 1300 us), inside the training step the two are equal (same box: 420.6 vs 419.6 ms per
         # step, profiles/r05_nt_vs_nn.txt) -- a GEMM's isolated speed is not its speed under the step's power / clock state
         self.use_qkv_nn = os.environ.get("DB1_QKV_NN", "0") != "0"
+        self.use_rnet_batched = os.environ.get("DB1_RNET_BATCHED", "1") != "0"   # r_net of all layers as one batched launch per forward
+        self._R_all = None
         self._wqkv_t, self._wqkv_t_version, self._wqkv_t_wanted = None, -1, False
         self.use_geglu_epilogue = os.environ.get("DB1_GEGLU_EPI", "1") != "0"   # GEGLU and its backward inside the feed-forward GEMMs' epilogues (large bf16 batches)
         # ... and the forward leaves the backward's two factors gelu(g) | v gelu'(g) instead of z (db1_gemm_nt_geglu_saved).  OPT-IN: measured on
@@ -1072,8 +1074,11 @@ class TransformerXL(nn.Module):
                     ops.gemm_nt_headbias(xin, Wqkv, qkv, quv[0], quv[1], self._bias("r_w_bias", i), self._bias("r_r_bias", i), d)
             else:
                 ops.gemm(xin, Wqkv.t(), qkv)
-            R = self._new(R_in.shape[0], d)
-            ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
+            if self._R_all is not None:      # r_net of all layers as one batched product at the start of the forward (_rnet_all)
+                R = self._R_all[self.n_layer - 1 - i]
+            else:
+                R = self._new(R_in.shape[0], d)
+                ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
             av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c, quv=quv, dstep=dstep, av_out=None if st is None else st.xs(i, "o"))
         if dec is not None and self._decode_fused_ok(T, keep, dstep):
             # few new tokens: every launch is latency, so the linear maps do the layer's small follow-up work themselves (db1_linear_decode):
@@ -1129,6 +1134,24 @@ class TransformerXL(nn.Module):
         if st is None or not keep or not self.training or self.pre_lnorm or st.T != T or self.wgrad_defer_ga <= 1:
             return None
         return st
+
+    # ---- R_i = r_net_i(position table) for ALL layers in one launch (transformer_xl.py:138: the table is the same for every layer and
+    # the product does not depend on the batch).  One layer's product is 1024 x 2048 x 2048 -- 32 tiles, 35 us on a nearly empty chip,
+    # 24 times per forward (and per micro-step: 13 ms per optimizer step at micro-batch 4 x GA 16); batched over the layers it is 768 tiles.
+    # The 24 weights sit at a regular stride in the arena (layers are laid out one after the other, last layer first).
+    def _rnet_all(self, R_in: torch.Tensor):
+        n, d = self.n_layer, self.d_model
+        if not self.use_rnet_batched or n < 2 or self.compute_dtype != torch.bfloat16 or R_in.shape[0] % 256 or d % 256:
+            return None
+        offs = [self.arena.offsets[f"h.{i}.dec_attn.r_net.weight"][0] for i in range(n)]
+        stride = offs[n - 2] - offs[n - 1]               # (layer n-1 comes first)
+        if stride <= 0 or any(offs[i] - offs[i + 1] != stride for i in range(n - 1)):
+            return None
+        W = torch.as_strided(self.arena.work, (n, 1, d, d), (stride, 0, 1, d), offs[n - 1])      # [layer n-1-j][k][n] = W_j[n][k]
+        nd = R_in.shape[0]
+        out = self._new(n, 1, nd, d)
+        ops.gemm_batched(R_in.view(1, 1, nd, d).expand(n, 1, nd, d), W, out)
+        return out.view(n, nd, d)
 
     # ---- the attention input projection's weight, transposed: Wqkv^T [d, 3d] per layer, static buffers (a captured micro-step reads them),
     # valid for ONE weight version.  engine.step() refreshes them right behind Adam (refresh_weight_copies); any other weight change
@@ -1449,6 +1472,7 @@ class TransformerXL(nn.Module):
             R_in = rows
             st.r_used = True
         hids, lcs = [], []
+        self._R_all = self._rnet_all(R_in) if (dec is None and mems is None and not self.pre_lnorm) else None
         for i in range(self.n_layer):
             kw = {}
             if isinstance(x, _PendingLN):   # (inference, <= 16 new tokens) this layer's qkv projection normalises its input rows and stores them to x
@@ -1457,6 +1481,7 @@ class TransformerXL(nn.Module):
             layer_fwd = self._layer_fwd_prelnorm if self.pre_lnorm else self._layer_fwd
             x, c = layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep, dec, dstep, **kw)
             lcs.append(c)
+        self._R_all = None       # (the layers' contexts hold their slices)
         return self._finish_forward(x, hids, lcs, ecs, shapes, labels, masks, R_in, B, L, shift, dstep, keep, compute_loss, mems, ring, dec, mlen)
 
     def _decode_chain_layers(self, x, mlen, shift, dec):

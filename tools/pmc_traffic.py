@@ -20,7 +20,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(out_dir, ctr.lower())
     subprocess.run(["rm", "-rf", d])
     cmd = ["timeout", "600", "rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing", "--no-decode", "--no-mixture"]   # (hipGraph replays under counter collection abort the queue)
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing", "--no-decode", "--no-mixture", "--no-ga16"]   # (hipGraph replays under counter collection abort the queue)
     with open(os.path.join(out_dir, ctr.lower() + ".log"), "w") as lf:
         subprocess.run(cmd, cwd="/tmp", env=env, stdin=subprocess.DEVNULL, stdout=lf, stderr=subprocess.STDOUT)
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)

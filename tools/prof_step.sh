@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/prof_step
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_step -o s -- python $R/bench.py --steps ${PROF_STEPS:-6} --warmup 2 --no-cpu-baseline --no-decode --no-mixture ${BENCH_ARGS} > $R/gpurun_out/prof_step.log 2>&1 </dev/null
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_step -o s -- python $R/bench.py --steps ${PROF_STEPS:-6} --warmup 2 --no-cpu-baseline --no-decode --no-mixture --no-ga16 ${BENCH_ARGS} > $R/gpurun_out/prof_step.log 2>&1 </dev/null
 cd $R
 f=$(ls gpurun_out/prof_step/*kernel_stats.csv | head -1)
 python tools/stats_summary.py "$f" > gpurun_out/step_stats.csv
