@@ -1321,7 +1321,8 @@ class TransformerXL(nn.Module):
             ds2.copy_(df)                # (nothing dropped: df = ds2; the stash keeps it, the in-place dh1 below needs its own copy)
         if st is None:
             ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=self._gb)
-        ops.colsum_acc(df, G(p + "pos_ff.CoreNet.2.bias"))
+        if st is None:      # (with the stash df of every micro-step is kept: the second bias's gradient is ONE column sum per layer at the flush)
+            ops.colsum_acc(df, G(p + "pos_ff.CoreNet.2.bias"))
         dz = self._ff2_dgrad(df, c.z, p, T, dz=None if st is None else st.dys(i, "ff1"))
         if st is None:
             ops.gemm(dz.t(), c.h1, G(p + "pos_ff.CoreNet.0.weight"), beta=self._gb)
@@ -1363,6 +1364,7 @@ class TransformerXL(nn.Module):
         for kind, name in (("ff2", "pos_ff.CoreNet.2.weight"), ("ff1", "pos_ff.CoreNet.0.weight"), ("o", "dec_attn.o_net.weight"),
                            ("qkv", "dec_attn.qkv_net.weight")):
             ops.gemm(st.dy[i][kind][lo:hi].t(), st.x[i][kind][lo:hi], self.G(p + name), beta=st.beta)
+        ops.colsum_acc(st.dy[i]["ff2"][lo:hi], self.G(p + "pos_ff.CoreNet.2.bias"))     # the feed-forward output bias: column sums of the stashed df
         if st.nd and st.r_used:      # r_net over the same micro-steps: rows [slot * nd, (slot + 1) * nd) of the position-table stash
             r0, r1 = (lo // st.T) * st.nd, (hi // st.T) * st.nd
             ops.gemm(st.dr[i][r0:r1].t(), st.rin[r0:r1], self.G(p + "dec_attn.r_net.weight"), beta=st.beta)

@@ -53,8 +53,11 @@ def AK(t, ks):
     return A0 + 136 + 4 * (4 * t + ks)
 
 
-def AR(d, ks):                       # relative-position fragments of distance tile d (0..2; 3: the V^T bank, first iteration only)
-    return A0 + 168 + 4 * (4 * d + ks) if d < 3 else AVT(ks)
+def AR(d, ks, r6=0):                 # relative-position fragments of distance tile d (0..2; 3: the V^T bank, first iteration only)
+    # The three fragment sets ROTATE with the iteration: block r + 1 needs the distance tiles of block r moved down by 32, so its highest
+    # tile (d = 2) IS block r's lowest (d = 0) -- physical set (d + r) mod 3 makes that the same registers, and the steady path reads
+    # only two tiles from the ring (8 ds_read_b128 instead of 12 per iteration: a ninth of the loop's LDS bytes).
+    return A0 + 168 + 4 * (4 * ((d + r6) % 3) + ks) if d < 3 else AVT(ks)
 
 
 def AVT(db):
@@ -180,13 +183,13 @@ def band_scalars(ntiles):
     return o
 
 
-def ring_reads(ntiles):
+def ring_reads(ntiles, r6=0):
     """address adds + fragment reads, k-step major (the MFMAs consume them in that order)"""
     ad, rd = [], []
     for ks in range(4):
         for d in range(ntiles):
             ad.append(valu("v_add_u32", RA + 4 * d + ks, sr(S_RS + d), RING + ks))
-            rd.append(ds_read_b128(AR(d, ks), RA + 4 * d + ks, OFF_R))
+            rd.append(ds_read_b128(AR(d, ks, r6), RA + 4 * d + ks, OFF_R))
     return ad, rd
 
 
@@ -354,11 +357,11 @@ def path_steady(r6):
     per MFMA hide it -- and the wave is issue-bound, so what counts is that it never stalls (measured first version: 35 % of its cycles)."""
     stg_a, par, stg_b = r6 % 3, r6 % 2, (r6 + 2) % 3
     cur, nxt = 1 - par, par                              # block r's scores go to set par; block r-1's are in the other set
-    seq = band_scalars(3)
-    ad, rd = ring_reads(3)
+    seq = band_scalars(2)
+    ad, rd = ring_reads(2, r6)           # distance tiles D0, D1 of block r; D2 = D0 of block r - 1 is still in its registers (AR)
     seq += ad + rd
     chains = [(0, 0, T + 0, 0), (0, 1, T + 4, 16), (1, 1, T + 8, 0), (1, 2, T + 12, 16)]
-    rel = [mfma(acc, AQV(x, ks), AR(d, ks), None if ks == 0 else acc) for ks in range(4) for (x, d, acc, col) in chains]                       # slots 0-15
+    rel = [mfma(acc, AQV(x, ks), AR(d, ks, r6), None if ks == 0 else acc) for ks in range(4) for (x, d, acc, col) in chains]                   # slots 0-15
     smf = [mfma(AS(x, t), AK(t, ks), AQU(x, ks), None if ks == 0 else AS(x, t)) for ks in range(4) for x in range(2) for t in range(2)]      # 16-31
     pv = [mfma(AO(x, db), AVT(db), PB(x), AO(x, db)) for db in range(8) for x in range(2)] + [mfma(AL(x), AONES, PB(x), AL(x)) for x in range(2)]  # 32-49
     items = []
