@@ -311,10 +311,10 @@ extern "C" int64_t db1_layernorm_residual_bwd_workspace_bytes(int64_t rows, int 
     const int rpb = ln_bwd_rpb(rows);
     return ((rows + rpb - 1) / rpb) * 2 * (int64_t)d * (int64_t)sizeof(float);
 }
-extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
-                                          void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc, int64_t rows, int d,
-                                          float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev, int dt,
-                                          int dtParam, void* ws_, int64_t ws_bytes, void* stream) {
+static int ln_bwd_impl(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
+                       void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc, int64_t rows, int d,
+                       float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev, int dt,
+                       int dtParam, void* ws_, int64_t ws_bytes, void* stream, bool parts_only) {
     if (drop_p < 0.f || drop_p >= 1.f) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd: dropout p=%g", (double)drop_p);
     if (dr_out && !db1_aligned16(dr_out)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "layernorm bwd: dr_out alignment");
     const Db1Drop drp = db1_drop_make(drop_p, drop_seed, drop_site, drop_step, drop_step_dev);
@@ -326,7 +326,7 @@ extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const v
     if (dt == DB1_BF16 && ln_reg_nv<bf16_t>(d)) {  // fused one-pass backward (ds + parameter partials)
         const int nv = ln_reg_nv<bf16_t>(d), rpb = ln_bwd_rpb(rows);
         const int nblocks = (int)((rows + rpb - 1) / rpb);
-        const bool params = dgamma_acc && dbeta_acc;
+        const bool params = parts_only || (dgamma_acc && dbeta_acc);
         float* ws = nullptr;
         if (params) {
             DB1_NEED_WS(ws_, ws_bytes, db1_layernorm_residual_bwd_workspace_bytes(rows, d, dt), "layernorm bwd");
@@ -338,12 +338,13 @@ extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const v
 #undef LN_BWD_NV
 #undef LN_BWD_F
         DB1_CHECK_LAUNCH("layernorm bwd (fused)");
-        if (params) {
+        if (params && !parts_only) {
             ln_param_reduce_kernel<<<2 * d / 64, 64 * LNR_WAVES, 0, st>>>(ws, dgamma_acc, dbeta_acc, nblocks, d);
             DB1_CHECK_LAUNCH("layernorm bwd param reduce");
         }
         return DB1_OK;
     }
+    if (parts_only) DB1_FAIL(DB1_ERR_UNSUPPORTED, "layernorm bwd (partials only): the register-resident bf16 kernel only (db1_layernorm_residual_bwd_workspace_bytes > 0)");
     dim3 grid((unsigned)((rows + 3) / 4));
 #define LN_BWD(T, TP) ln_bwd_ds_kernel<T, TP><<<grid, 256, 0, st>>>((const T*)dy, (const T*)s, (const TP*)gamma, mean, rstd, (T*)ds, rows, d, (T*)dr_out, drp)
     if (dt == DB1_F32 && dtParam == DB1_F32) LN_BWD(float, float);
@@ -360,6 +361,24 @@ extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const v
         DB1_CHECK_LAUNCH("layernorm bwd param");
     }
     return DB1_OK;
+}
+
+extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
+                                          void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc, int64_t rows, int d,
+                                          float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev, int dt,
+                                          int dtParam, void* ws_, int64_t ws_bytes, void* stream) {
+    return ln_bwd_impl(dy, s, gamma, mean, rstd, ds, dr_out, dgamma_acc, dbeta_acc, rows, d, drop_p, drop_seed, drop_site, drop_step, drop_step_dev, dt, dtParam,
+                       ws_, ws_bytes, stream, false);
+}
+// the same launch WITHOUT the parameter reduce: the per-block partial sums [blocks][2][d] (float32, db1_layernorm_residual_bwd_workspace_bytes)
+// stay in `parts` for the caller to add up later -- db1_colsum_acc over the [blocks, 2 d] matrix gives (dgamma | dbeta).  Gradient
+// accumulation keeps the partials of every micro-step and reduces once per optimizer step (one launch instead of one per micro-step).
+extern "C" int db1_layernorm_residual_bwd_parts(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
+                                                void* ds, void* dr_out, float* parts, int64_t parts_bytes, int64_t rows, int d,
+                                                float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev, int dt,
+                                                int dtParam, void* stream) {
+    return ln_bwd_impl(dy, s, gamma, mean, rstd, ds, dr_out, nullptr, nullptr, rows, d, drop_p, drop_seed, drop_site, drop_step, drop_step_dev, dt, dtParam,
+                       parts, parts_bytes, stream, true);
 }
 
 // =====================================================================================

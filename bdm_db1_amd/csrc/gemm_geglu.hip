@@ -58,6 +58,23 @@ extern "C" int64_t db1_gemm_nn_geglu_bwd_workspace_bytes(int M, int dff, int K, 
     return up256((int64_t)M * dff * es) + up256(db1_ffn_act_bwd_bias_workspace_bytes(M, dff, DB1_ACT_GEGLU)) +
            db1_gemm_workspace_bytes(M, dff, K, dt, dt, dt, lddy, 1, ldw, 1, dff, 1, 1, 1);
 }
+// the fused backward WITHOUT the bias reduce: the column sums of dz per 128-row block stay in `parts` [M / 128][2 dff] float32 for the caller
+// to add up later (db1_colsum_acc): gradient accumulation reduces once per optimizer step.  Fused shapes only (db1_gemm_nn_geglu_bwd_fused).
+extern "C" int db1_gemm_nn_geglu_bwd_parts(const void* dY, const void* W2, const void* Z, void* dZ, float* parts, int M, int dff, int K, int64_t lddy,
+                                           int64_t ldw, int64_t ldz, int64_t lddz, int dt, void* stream) {
+    if (M <= 0 || dff <= 0 || K <= 0 || !dY || !W2 || !Z || !dZ || !parts) DB1_FAIL(DB1_ERR_BAD_SHAPE, "gemm_nn_geglu_bwd_parts: M=%d dff=%d K=%d / null operand", M, dff, K);
+    if (!geglu_fused_bwd(M, dff, K, dt, lddy, ldw, ldz, lddz, dY, W2, Z, dZ) || !db1_aligned16(parts))
+        DB1_FAIL(DB1_ERR_UNSUPPORTED, "gemm_nn_geglu_bwd_parts: only the shapes of the fused 4-wave kernel (db1_gemm_nn_geglu_bwd_fused)");
+    GemmTileArgs t;
+    t.A = (const bf16_t*)dY; t.B = (const bf16_t*)W2; t.C = dZ; t.bias = nullptr;
+    t.M = M; t.N = dff; t.K = K; t.lda = lddy; t.ldb = ldw; t.ldc = lddz;
+    t.batch1 = 1; t.a_bs0 = t.a_bs1 = t.b_bs0 = t.b_bs1 = t.c_bs0 = t.c_bs1 = 0;
+    t.alpha = 1.f; t.beta = 0.f; t.tiles_m = M / 256; t.tiles_n = dff / 256; t.ksplit = 1;
+    t.tri_mode = 0; t.tri_period = 0;
+    t.split_n = 0; t.Cu = nullptr; t.Cv = nullptr; t.bias_u = nullptr; t.bias_v = nullptr; t.ld_uv = 0;
+    t.geglu_dff = dff; t.Zin = (const bf16_t*)Z; t.ld_z = ldz; t.colpart = parts;
+    return db1_gemm_w4_geglu_bwd_launch(t, (hipStream_t)stream);
+}
 extern "C" int db1_gemm_nn_geglu_bwd(const void* dY, const void* W2, const void* Z, void* dZ, float* dbias_acc, int M, int dff, int K, int64_t lddy,
                                      int64_t ldw, int64_t ldz, int64_t lddz, int dt, void* ws, int64_t ws_bytes, void* stream) {
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "gemm_nn_geglu_bwd: dtype");

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void dqr_part_reduce_kernel(const float* __res
 }
 
 static int dqr_run(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride, float* du_acc,
-                   float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream);
+                   float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream, float* parts_out = nullptr);
 
 extern "C" int db1_relattn_dqr(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride,
                                int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream) {
@@ -222,8 +222,19 @@ extern "C" int db1_relattn_dqr_fused(const void* dT, const void* R, int64_t r_ro
     return dqr_run(dT, R, r_row_stride, dq, dq_row_stride, dq_batch_stride, du_acc, dv_acc, B, L, H, D, ws, ws_bytes, stream);
 }
 
+/* the fused form WITHOUT its two reduces: the per-workgroup column-sum partials stay in `parts` = [2][db1_relattn_dqr_parts_rows(H)][H * 128]
+ * float32 (first the dq_k sums -> du, then the dq_r sums -> dv) for the caller to add up later (db1_colsum_acc over each [rows, H * 128]
+ * half): gradient accumulation reduces once per optimizer step instead of twice per layer and micro-step */
+extern "C" int db1_relattn_dqr_parts_rows(int H) { return dqr_wph(H); }
+extern "C" int db1_relattn_dqr_fused_parts(const void* dT, const void* R, int64_t r_row_stride, void* dq, int64_t dq_row_stride, int64_t dq_batch_stride,
+                                           float* parts, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream) {
+    if (!parts || !db1_aligned16(parts)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_dqr_fused_parts: parts");
+    if ((dq_row_stride % 8) || (dq_batch_stride % 8)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_dqr_fused_parts: dq strides must be multiples of 8 elements");
+    return dqr_run(dT, R, r_row_stride, dq, dq_row_stride, dq_batch_stride, parts, parts, B, L, H, D, ws, ws_bytes, stream, parts);
+}
+
 static int dqr_run(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride, float* du_acc,
-                   float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream) {
+                   float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream, float* parts_out) {
     if (!db1_relattn_dqr_supported(B, L, H, D, DB1_BF16)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_dqr: needs bf16, d_head = 128, L %% 128 == 0, L <= 1024 (got L=%d D=%d)", L, D);
     if (!dT || !R || !out) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_dqr: null buffer");
     if (!db1_aligned16(dT) || !db1_aligned16(out) || (out_row_stride % 4) || (out_batch_stride % 4)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_dqr: alignment");
@@ -236,12 +247,12 @@ static int dqr_run(const void* dT, const void* R, int64_t r_row_stride, void* ou
     a.dT = (const bf16_t*)dT; a.Rt = Rt; a.out = (bf16_t*)out; a.B = B; a.L = L; a.H = H;
     a.wph = dqr_wph(H);
     a.o_rs = out_row_stride; a.o_bs = out_batch_stride;
-    a.part = du_acc ? (float*)((char*)ws + dqr_rt_bytes(L, H)) : nullptr;
+    a.part = parts_out ? parts_out : (du_acc ? (float*)((char*)ws + dqr_rt_bytes(L, H)) : nullptr);
     static Db1PerDeviceOnce attr_once;
     attr_once.run([] { hipFuncSetAttribute((const void*)relattn_dqr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQR_STAGES * DQR_TILE_BYTES); });
     relattn_dqr_kernel<<<dim3((unsigned)(H * a.wph)), 512, DQR_STAGES * DQR_TILE_BYTES, st>>>(a);
     DB1_CHECK_LAUNCH("relattn_dqr");
-    if (du_acc) {
+    if (du_acc && !parts_out) {
         const int cols = H * 128;
         dqr_part_reduce_kernel<<<(cols + 255) / 256, 256, 0, st>>>(a.part, du_acc, a.wph, cols);
         dqr_part_reduce_kernel<<<(cols + 255) / 256, 256, 0, st>>>(a.part + (int64_t)a.wph * cols, dv_acc, a.wph, cols);

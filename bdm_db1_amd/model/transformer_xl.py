@@ -119,11 +119,32 @@ class WgradStash:
         self.slot = 0            # micro-step of the accumulation window the next forward / backward belongs to (set by the engine)
         self.first = 0           # first micro-step of the window whose operands are in THIS stash (> 0: the token count changed mid-window)
         self.r_used = False      # the forwards of this window put their position tables into rin (False: r_net's gradient is formed per micro-step)
+        self.parts, self.ln_parts, self.uv_parts, self.b1_parts = False, [], [], []       # alloc_parts
         self.beta = 0.0          # beta of the flush: 0 when the gradient arena was fresh at slot 0
 
     def nbytes(self) -> int:
         n = sum(t.numel() * t.element_size() for L in (self.x, self.dy) for dct in L for t in dct.values())
-        return n + (sum(t.numel() * t.element_size() for t in [self.rin] + self.dr) if self.nd else 0)
+        n += sum(t.numel() * t.element_size() for t in [self.rin] + self.dr) if self.nd else 0
+        return n + (sum(t.numel() * 4 for L in (self.ln_parts, self.uv_parts, self.b1_parts) for e in L for t in (e if isinstance(e, list) else [e])) if self.parts else 0)
+
+    def alloc_parts(self, model) -> bool:
+        """the small reductions of a micro-step's backward -- LayerNorm parameter gradients (two per layer), the u / v column sums of the dq_r
+        stream, the first feed-forward bias's column sums -- leave their PARTIAL sums here, per micro-step, and are added up once per layer at
+        the flush (db1_colsum_acc over all micro-steps' rows): ~120 launches of 5 us less per micro-step.  Only where every producer has its
+        partials-only form (bf16, register-resident LayerNorm width, fused GEGLU backward, dq_r stream)."""
+        T, ga, d, dff, H, D = self.T, self.ga, model.d_model, model.d_ff, model.n_head, model.d_head
+        dt = model.compute_dtype
+        nln = ops.layernorm_bwd_parts_numel(T, d, dt) if dt == torch.bfloat16 else 0
+        ok = (model.use_partial_stash and nln > 0 and nln % (2 * d) == 0 and model.activation_fn == "geglu" and model.use_geglu_epilogue and not model.untie_r and
+              ops.gemm_nn_geglu_bwd_fused(T, dff, d, dt) and T % 128 == 0 and self.nd and ops.relattn_dqr_supported(T // self.nd, self.nd, H, D, dt))
+        if not ok:
+            return False
+        new = lambda *shape: torch.empty(*shape, device=model.dev, dtype=torch.float32)
+        self.ln_parts = [[new(ga, nln // (2 * d), 2 * d) for _ in range(2)] for _ in range(self.n_layer)]       # [layer][0: pos_ff LN, 1: dec_attn LN]
+        self.uv_parts = [new(ga, 2, ops.relattn_dqr_parts_rows(H), H * D) for _ in range(self.n_layer)]
+        self.b1_parts = [new(ga, T // 128, 2 * dff) for _ in range(self.n_layer)]
+        self.parts = True
+        return True
 
     def rins(self) -> torch.Tensor:
         return self.rin[self.slot * self.nd:(self.slot + 1) * self.nd]
@@ -237,6 +258,7 @@ class TransformerXL(nn.Module):
         # form is 8 % faster at this shape (1190 vs 1300 us), inside the training step the two are equal (same box: 420.6 vs 419.6 ms per
         # step, profiles/r05_nt_vs_nn.txt) -- a GEMM's isolated speed is not its speed under the step's power / clock state
         self.use_qkv_nn = os.environ.get("DB1_QKV_NN", "0") != "0"
+        self.use_partial_stash = os.environ.get("DB1_PARTIAL_STASH", "1") != "0"   # gradient accumulation: the small reductions once per optimizer step (WgradStash.alloc_parts)
         self.use_rnet_batched = os.environ.get("DB1_RNET_BATCHED", "1") != "0"   # r_net of all layers as one batched launch per forward
         self._R_all = None
         self._wqkv_t, self._wqkv_t_version, self._wqkv_t_wanted = None, -1, False
@@ -968,7 +990,7 @@ class TransformerXL(nn.Module):
         dec.new_kv.append(kv_all[:, max(0, klen - self.mem_len):])
         return av
 
-    def _attention_bwd(self, dav, c: _Ctx, i, B, L, shift, dstep=None, dqkv_out=None, dR_out=None):
+    def _attention_bwd(self, dav, c: _Ctx, i, B, L, shift, dstep=None, dqkv_out=None, dR_out=None, uv_parts=None):
         """returns dqkv [B*L, 3d] and dR [L, d]; accumulates du / dv_bias"""
         H, D, d = self.n_head, self.d_head, self.d_model
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
@@ -1017,8 +1039,13 @@ class TransformerXL(nn.Module):
         fused_dq = tri and nd == L and ops.relattn_dqr_supported(B, L, H, D, self.compute_dtype)
         if fused_dq:
             # dq_r streamed out of dT once, added onto dq_k in the same kernel's epilogue together with the u / v gradients' column sums
-            ops.relattn_dqr_fused(dT, R, dqkv5[:, :, 0], self._bias_grad("r_w_bias", i).view(-1), self._bias_grad("r_r_bias", i).view(-1))
+            if uv_parts is not None:      # (gradient accumulation: the two column-sum reduces happen once per optimizer step, WgradStash.alloc_parts)
+                ops.relattn_dqr_fused_parts(dT, R, dqkv5[:, :, 0], uv_parts)
+            else:
+                ops.relattn_dqr_fused(dT, R, dqkv5[:, :, 0], self._bias_grad("r_w_bias", i).view(-1), self._bias_grad("r_r_bias", i).view(-1))
         else:
+            if uv_parts is not None:
+                raise RuntimeError("the partial-sum stash was planned for the dq_r stream kernel, which this backward did not take")
             dqv = self._new(B, L, H, D)
             ops.gemm_batched(dT, R.view(nd, H, D).permute(1, 0, 2).unsqueeze(1).expand(H, B, nd, D), dqv.permute(2, 0, 1, 3),
                              tri=(1, 0) if tri else (0, 0))                                                               # dq_r
@@ -1202,12 +1229,16 @@ class TransformerXL(nn.Module):
         return (self.use_geglu_epilogue and self.use_geglu_saved and self.activation_fn == "geglu" and
                 self.compute_dtype == torch.bfloat16 and ops.gemm_geglu_saved_supported(T, dff, d, d, self.compute_dtype))
 
-    def _ff2_dgrad(self, df, z, p, T, dz=None):
+    def _ff2_dgrad(self, df, z, p, T, dz=None, parts=None):
         """dz from df = d(loss)/d(CoreNet output): dact = df W2, through the activation; accumulates the first bias's gradient"""
         d, di, dff = self.d_model, self.d_inner, self.d_ff
         dz = self._new(T, di) if dz is None else dz
         W2, gb1 = self.W(p + "pos_ff.CoreNet.2.weight"), self.G(p + "pos_ff.CoreNet.0.bias")
-        if getattr(z, "_db1_geglu_saved", False):
+        if parts is not None:
+            if getattr(z, "_db1_geglu_saved", False):
+                raise RuntimeError("the partial-sum stash and the saved-factor GEGLU form are not combined")
+            ops.gemm_nn_geglu_bwd_parts(df, W2, z, dz, parts)
+        elif getattr(z, "_db1_geglu_saved", False):
             ops.gemm_nn_geglu_bwd_saved(df, W2, z, dz, gb1)
         elif self.use_geglu_epilogue and self.activation_fn == "geglu" and ops.gemm_nn_geglu_bwd_fused(T, dff, d, self.compute_dtype):
             ops.gemm_nn_geglu_bwd(df, W2, z, dz, gb1)
@@ -1314,16 +1345,21 @@ class TransformerXL(nn.Module):
             df = st.dys(i, "ff2")
         else:
             df = self._new(T, d) if dropping else ds2
-        ops.layernorm_residual_bwd(dout, c.s2, W(p + "pos_ff.layer_norm.weight"), c.m2, c.r2, ds2 if (dropping or st is None) else df,
-                                   G(p + "pos_ff.layer_norm.weight"), G(p + "pos_ff.layer_norm.bias"),
-                                   dr_out=df if dropping else None, drop=self._drop_args(self.drop_p, 4 * i + 1, dstep))
+        parts = st is not None and st.parts
+        if parts:
+            ops.layernorm_residual_bwd_parts(dout, c.s2, W(p + "pos_ff.layer_norm.weight"), c.m2, c.r2, ds2 if dropping else df, st.ln_parts[i][0][st.slot],
+                                             dr_out=df if dropping else None, drop=self._drop_args(self.drop_p, 4 * i + 1, dstep))
+        else:
+            ops.layernorm_residual_bwd(dout, c.s2, W(p + "pos_ff.layer_norm.weight"), c.m2, c.r2, ds2 if (dropping or st is None) else df,
+                                       G(p + "pos_ff.layer_norm.weight"), G(p + "pos_ff.layer_norm.bias"),
+                                       dr_out=df if dropping else None, drop=self._drop_args(self.drop_p, 4 * i + 1, dstep))
         if st is not None and not dropping:
             ds2.copy_(df)                # (nothing dropped: df = ds2; the stash keeps it, the in-place dh1 below needs its own copy)
         if st is None:
             ops.gemm(df.t(), c.act, G(p + "pos_ff.CoreNet.2.weight"), beta=self._gb)
         if st is None:      # (with the stash df of every micro-step is kept: the second bias's gradient is ONE column sum per layer at the flush)
             ops.colsum_acc(df, G(p + "pos_ff.CoreNet.2.bias"))
-        dz = self._ff2_dgrad(df, c.z, p, T, dz=None if st is None else st.dys(i, "ff1"))
+        dz = self._ff2_dgrad(df, c.z, p, T, dz=None if st is None else st.dys(i, "ff1"), parts=st.b1_parts[i][st.slot] if parts else None)
         if st is None:
             ops.gemm(dz.t(), c.h1, G(p + "pos_ff.CoreNet.0.weight"), beta=self._gb)
         ops.gemm(dz, W(p + "pos_ff.CoreNet.0.weight"), ds2, beta=a)          # dh1 = a*ds2 + dz W1   (in place over ds2)
@@ -1334,9 +1370,13 @@ class TransformerXL(nn.Module):
             do = st.dys(i, "o")
         else:
             do = self._new(T, d) if dropping else ds1
-        ops.layernorm_residual_bwd(dh1, c.s1, W(p + "dec_attn.layer_norm.weight"), c.m1, c.r1, ds1 if (dropping or st is None) else do,
-                                   G(p + "dec_attn.layer_norm.weight"), G(p + "dec_attn.layer_norm.bias"),
-                                   dr_out=do if dropping else None, drop=self._drop_args(self.drop_p, 4 * i, dstep))
+        if parts:
+            ops.layernorm_residual_bwd_parts(dh1, c.s1, W(p + "dec_attn.layer_norm.weight"), c.m1, c.r1, ds1 if dropping else do, st.ln_parts[i][1][st.slot],
+                                             dr_out=do if dropping else None, drop=self._drop_args(self.drop_p, 4 * i, dstep))
+        else:
+            ops.layernorm_residual_bwd(dh1, c.s1, W(p + "dec_attn.layer_norm.weight"), c.m1, c.r1, ds1 if (dropping or st is None) else do,
+                                       G(p + "dec_attn.layer_norm.weight"), G(p + "dec_attn.layer_norm.bias"),
+                                       dr_out=do if dropping else None, drop=self._drop_args(self.drop_p, 4 * i, dstep))
         if st is not None and not dropping:
             ds1.copy_(do)
         if st is None:
@@ -1345,7 +1385,7 @@ class TransformerXL(nn.Module):
         ops.gemm(do, W(p + "dec_attn.o_net.weight"), dav)
         defer_r = st is not None and st.nd == R_in.shape[0] and R_in.data_ptr() == st.rins().data_ptr()   # (the forward put this micro-step's table into the stash)
         dqkv, dR = self._attention_bwd(dav, c, i, B, L, shift, dstep, dqkv_out=None if st is None else st.dys(i, "qkv"),
-                                       dR_out=st.drs(i) if defer_r else None)
+                                       dR_out=st.drs(i) if defer_r else None, uv_parts=st.uv_parts[i][st.slot] if parts else None)
         if not defer_r:
             ops.gemm(dR.t(), R_in, G(p + "dec_attn.r_net.weight"), beta=self._gb)
         if st is None:
@@ -1359,12 +1399,28 @@ class TransformerXL(nn.Module):
         """the four weight gradients of layer i over every micro-step stashed so far: dW = dy^T x, K = (slot + 1) * T rows"""
         self._flush_layer_rows(i, st, st.first * st.T, (st.slot + 1) * st.T)
 
+    def _grad_pair(self, wname: str, bname: str) -> torch.Tensor:
+        """the gradients of a LayerNorm's (weight | bias) as ONE [2 d] accumulator: the two are neighbours in the arena"""
+        ow, sw, _ = self.arena.offsets[wname]
+        ob, sb, _ = self.arena.offsets[bname]
+        n = int(np.prod(sw))
+        assert ob == ow + n and int(np.prod(sb)) == n, (wname, bname)
+        return self.arena.grad[ow:ow + 2 * n]
+
     def _flush_layer_rows(self, i: int, st: WgradStash, lo: int, hi: int):
         p = f"h.{i}."
         for kind, name in (("ff2", "pos_ff.CoreNet.2.weight"), ("ff1", "pos_ff.CoreNet.0.weight"), ("o", "dec_attn.o_net.weight"),
                            ("qkv", "dec_attn.qkv_net.weight")):
             ops.gemm(st.dy[i][kind][lo:hi].t(), st.x[i][kind][lo:hi], self.G(p + name), beta=st.beta)
         ops.colsum_acc(st.dy[i]["ff2"][lo:hi], self.G(p + "pos_ff.CoreNet.2.bias"))     # the feed-forward output bias: column sums of the stashed df
+        if st.parts:       # the small reductions of micro-steps [s0, s1): one column sum each over all their partial rows
+            s0, s1, d = lo // st.T, hi // st.T, self.d_model
+            for site, ln in enumerate(("pos_ff.layer_norm", "dec_attn.layer_norm")):
+                ops.colsum_acc(st.ln_parts[i][site][s0:s1].view(-1, 2 * d), self._grad_pair(p + ln + ".weight", p + ln + ".bias"))
+            uv = st.uv_parts[i][s0:s1]
+            ops.colsum_acc(uv[:, 0].reshape(-1, uv.shape[-1]), self._bias_grad("r_w_bias", i).view(-1))
+            ops.colsum_acc(uv[:, 1].reshape(-1, uv.shape[-1]), self._bias_grad("r_r_bias", i).view(-1))
+            ops.colsum_acc(st.b1_parts[i][s0:s1].view(-1, 2 * self.d_ff), self.G(p + "pos_ff.CoreNet.0.bias"))
         if st.nd and st.r_used:      # r_net over the same micro-steps: rows [slot * nd, (slot + 1) * nd) of the position-table stash
             r0, r1 = (lo // st.T) * st.nd, (hi // st.T) * st.nd
             ops.gemm(st.dr[i][r0:r1].t(), st.rin[r0:r1], self.G(p + "dec_attn.r_net.weight"), beta=st.beta)
@@ -1466,6 +1522,8 @@ class TransformerXL(nn.Module):
                 self.wgrad_stash = st = None     # (free the old buffers first)
                 st = self.wgrad_stash = WgradStash(self, B * L, self.wgrad_defer_ga, nd=int(R_in.shape[0]))
                 st.first, st.beta = first, beta
+                if B * L == B * int(R_in.shape[0]):      # (plain causal training batch: nd = L)
+                    st.alloc_parts(self)
             elif self._wg_slot == 0:
                 st.first = 0
             st.slot = self._wg_slot

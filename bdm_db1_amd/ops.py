@@ -315,6 +315,22 @@ def relattn_dqr_fused(dT, R, dq, du_acc, dv_acc):
                             B, L, H, D, ws, wsn, stream()))
 
 
+def relattn_dqr_parts_rows(H: int) -> int:
+    return int(lib.load().db1_relattn_dqr_parts_rows(int(H)))
+
+
+def relattn_dqr_fused_parts(dT, R, dq, parts):
+    """relattn_dqr_fused without its two reduces: parts [2, rows, H * D] float32 receives the per-workgroup column sums (du half, dv half)"""
+    H, B, L, _ = dT.shape
+    D = dq.shape[-1]
+    assert dT.is_contiguous() and R.stride(1) == 1 and dq.stride(3) == 1 and dq.stride(2) == D and dq.shape == (B, L, H, D)
+    assert parts.dtype == torch.float32 and parts.is_contiguous() and parts.shape == (2, relattn_dqr_parts_rows(H), H * D)
+    ws, wsn = _ws("db1_relattn_dqr_workspace_bytes", (L, H), dT.device)
+    _timed("relattn_dqr", 2.0 * (H * B * L * (L + 1) / 2 + 2 * dq.numel()),
+           lambda: lib.call("db1_relattn_dqr_fused_parts", P(dT), P(R), R.stride(0), P(dq), dq.stride(1), dq.stride(0), P(parts),
+                            B, L, H, D, ws, wsn, stream()))
+
+
 def layernorm_residual_fwd(x, r, alpha, gamma, beta, y, s_out, mean, rstd, eps, drop=NO_DROP):
     rows, d = x.numel() // x.shape[-1], x.shape[-1]
     nstreams = 2 + (r is not None) + (s_out is not None)   # x [, r] in; y [, s] out
@@ -330,6 +346,20 @@ def layernorm_residual_bwd(dy, s, gamma, mean, rstd, ds, dgamma_acc, dbeta_acc, 
     _timed("layernorm_bwd", float(rows * d * dy.element_size() * (3 + (dr_out is not None))),   # dy, s in; ds [, dr] out
            lambda: lib.call("db1_layernorm_residual_bwd", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dr_out), P(dgamma_acc), P(dbeta_acc),
                             rows, d, float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), _drop_dev(drop), dt_code(dy), dt_code(gamma), ws, wsn, stream()))
+
+
+def layernorm_bwd_parts_numel(rows: int, d: int, dtype) -> int:
+    """floats of the partial-sum matrix [blocks, 2 d] of db1_layernorm_residual_bwd_parts (0: this shape has no partials form)"""
+    return int(lib.load().db1_layernorm_residual_bwd_workspace_bytes(int(rows), int(d), dt_code(dtype))) // 4
+
+
+def layernorm_residual_bwd_parts(dy, s, gamma, mean, rstd, ds, parts, dr_out=None, drop=NO_DROP):
+    """layernorm_residual_bwd without the parameter reduce: parts [blocks, 2 d] float32 receives the per-block (dgamma | dbeta) partial sums"""
+    rows, d = dy.numel() // dy.shape[-1], dy.shape[-1]
+    assert parts.dtype == torch.float32 and parts.is_contiguous()
+    _timed("layernorm_bwd", float(rows * d * dy.element_size() * (3 + (dr_out is not None))),
+           lambda: lib.call("db1_layernorm_residual_bwd_parts", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dr_out), P(parts), parts.numel() * 4,
+                            rows, d, float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), _drop_dev(drop), dt_code(dy), dt_code(gamma), stream()))
 
 
 def ffn_act_fwd(z, out, act: str):
@@ -383,6 +413,17 @@ def gemm_nn_geglu_bwd(dy, w2, z, dz, dbias_acc):
     _timed("gemm", 2.0 * M * dff * K,
            lambda: lib.call("db1_gemm_nn_geglu_bwd", P(dy), P(w2), P(z), P(dz), P(dbias_acc), M, dff, K, dy.stride(0), w2.stride(0), z.stride(0), dz.stride(0),
                             dt_code(dy), ws, wsn, stream()))
+
+
+def gemm_nn_geglu_bwd_parts(dy, w2, z, dz, parts):
+    """gemm_nn_geglu_bwd without the bias reduce (fused shapes): parts [M / 128, 2 dff] float32 receives the column sums of dz per 128-row block"""
+    M, K = dy.shape
+    dff = w2.shape[1]
+    assert w2.shape[0] == K and z.shape == (M, 2 * dff) and dz.shape == (M, 2 * dff) and parts.dtype == torch.float32 and parts.shape == (M // 128, 2 * dff)
+    assert dy.stride(1) == 1 and w2.stride(1) == 1 and z.stride(1) == 1 and dz.stride(1) == 1 and parts.is_contiguous()
+    _timed("gemm", 2.0 * M * dff * K,
+           lambda: lib.call("db1_gemm_nn_geglu_bwd_parts", P(dy), P(w2), P(z), P(dz), P(parts), M, dff, K, dy.stride(0), w2.stride(0), z.stride(0), dz.stride(0),
+                            dt_code(dy), stream()))
 
 
 def gemm_geglu_saved_supported(M: int, dff: int, K_fwd: int, K_bwd: int, dtype) -> bool:

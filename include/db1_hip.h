@@ -130,6 +130,9 @@ int db1_gemm_nn_geglu_bwd_fused(int M, int dff, int K, int dt, int64_t lddy, int
 int64_t db1_gemm_nn_geglu_bwd_workspace_bytes(int M, int dff, int K, int dt, int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz);
 int db1_gemm_nn_geglu_bwd(const void* dY, const void* W2, const void* Z, void* dZ, float* dbias_acc, int M, int dff, int K,
                           int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz, int dt, void* ws, int64_t ws_bytes, void* stream);
+/* ... WITHOUT the bias reduce (fused shapes only): parts [M / 128][2 dff] float32 = the column sums of dZ per 128-row block */
+int db1_gemm_nn_geglu_bwd_parts(const void* dY, const void* W2, const void* Z, void* dZ, float* parts, int M, int dff, int K,
+                                int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz, int dt, void* stream);
 /* The same pair with the backward's two factors saved by the forward (round 5): S[M, 2 dff] takes Z's place, S[:, :dff] = gelu(g) and
  * S[:, dff:] = v * gelu'(g) for (v | g) = the bf16-rounded Z -- what dZ = (dact * gelu(g), dact * v * gelu'(g)) multiplies dact by -- so the
  * backward epilogue is two products per element (no erf / exp / rcp) and the forward's, which holds Phi(g) and exp(-g^2 / 2) anyway, three
@@ -169,6 +172,13 @@ int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma,
                                int64_t rows, int d,
                                float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
                                int dt, int dtParam, void* ws, int64_t ws_bytes, void* stream);
+/* the same launch WITHOUT the parameter reduce: the per-block partial sums [blocks][2][d] float32 (parts_bytes >=
+ * db1_layernorm_residual_bwd_workspace_bytes; bf16 rows of the register-resident widths only, else DB1_ERR_UNSUPPORTED) stay in `parts`;
+ * db1_colsum_acc over that [blocks, 2 d] matrix yields (dgamma | dbeta).  For gradient accumulation: one reduce per optimizer step. */
+int db1_layernorm_residual_bwd_parts(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
+                                     void* ds, void* dr_out, float* parts, int64_t parts_bytes, int64_t rows, int d,
+                                     float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
+                                     int dt, int dtParam, void* stream);
 
 /* ------------------------------------------------------------------ dropout
  * y[e] = x[e] * keep(e) * 65536 / (65536 - thr),  thr = round(p * 65536)   (nn.Dropout, transformer_xl.py:409,545,575; y may alias x).
@@ -394,6 +404,11 @@ int db1_relattn_dqr(const void* dT, const void* R, int64_t r_row_stride, void* o
  * float32 accumulators; the per-workgroup partial sums are added in a fixed order (deterministic). */
 int db1_relattn_dqr_fused(const void* dT, const void* R, int64_t r_row_stride, void* dq, int64_t dq_row_stride, int64_t dq_batch_stride,
                           float* du_acc, float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream);
+/* ... WITHOUT its two reduces: parts [2][db1_relattn_dqr_parts_rows(H)][H * 128] float32 receives the per-workgroup column sums (dq_k -> du
+ * half, dq_r -> dv half) for the caller to add up later (db1_colsum_acc per half) */
+int db1_relattn_dqr_parts_rows(int H);
+int db1_relattn_dqr_fused_parts(const void* dT, const void* R, int64_t r_row_stride, void* dq, int64_t dq_row_stride, int64_t dq_batch_stride,
+                                float* parts, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ image-patch embedder pieces
  * (src/tokenizer/vision_embedding.py:65-86).  pixels [N_img, C, Himg, Wimg] -> normalised patches

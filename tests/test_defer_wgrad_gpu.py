@@ -131,3 +131,58 @@ def test_token_count_changes_inside_an_accumulation_window():
             continue
         assert float((a - b).abs().max() / b.abs().max()) < 2e-5, name
     assert all(abs(a - b) < 2e-2 for a, b in zip(l0[GA:], l1[GA:])), (l0, l1)
+
+
+def test_partial_sum_stash_at_the_reference_micro_batch_geometry():
+    """4 sequences of 1024 tokens per micro-step at the DB1-1.3B layer geometry (2 layers), GA 2: here every producer of a small reduction has
+    its partials-only form (db1_layernorm_residual_bwd_parts, db1_relattn_dqr_fused_parts, db1_gemm_nn_geglu_bwd_parts), so the LayerNorm
+    parameter gradients, the u / v column sums and the first feed-forward bias's column sums of BOTH micro-steps are added up once per layer at
+    the flush (WgradStash.alloc_parts), r_net's weight gradient and the second bias come out of the stash too, and r_net runs batched over
+    the layers.  Every gradient equals the per-micro-step engine's up to summation order; the graphed run equals the eager one bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bdm_db1_amd import GraphedTrainStep, TransformerXL, initialize, synth
+    cfg = synth.db1_config("1.3B", n_layer=2, drop=0.1, embd_pdrop=0.1)
+    ga, B, L = 2, 4, 1024
+    batches = [synth.text_batch(B, L, 40 + k, DEV) for k in range(ga)]
+
+    def run(defer, graphed=False):
+        torch.manual_seed(7)
+        model = TransformerXL(cfg)
+        eargs = SimpleNamespace(lr=1e-4, weight_decay=0.01, clip_grad=1.0, optimizer="adamw", keep_logits=False, fuse_head_loss=True,
+                                gradient_accumulation_steps=ga, defer_wgrad=defer)
+        engine, _, _, _ = initialize(eargs, model)
+        engine.train()
+        g = GraphedTrainStep(engine, [batches[0]]) if graphed else None
+        losses = []
+        for k, b in enumerate(batches):
+            if g is not None:
+                loss = g([b])
+            else:
+                _, loss = engine([b])
+                engine.backward(loss)
+            if k == ga - 1:
+                grads = model.arena.grad.detach().clone()
+            engine.step()
+            losses.append(float(loss))
+        if defer:
+            st = model.wgrad_stash
+            assert st is not None and st.parts and st.r_used, "this geometry is meant to take the partial-sum stash"
+        offs = dict(model.arena.offsets)
+        if g is not None:
+            g.close()
+        del engine, model
+        torch.cuda.empty_cache()
+        return losses, grads, offs
+    l0, g0, offs = run(False)
+    l1, g1, _ = run(True)
+    assert l0 == l1
+    for name, (off, shape, alloc) in offs.items():
+        a, b = g1[off:off + alloc].double(), g0[off:off + alloc].double()
+        if float(b.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0, name
+            continue
+        err = float((a - b).abs().max() / b.abs().max())
+        assert err < 5e-5, (name, err)
+    l2, g2, _ = run(True, graphed=True)
+    assert l2 == l1 and torch.equal(g2, g1)
