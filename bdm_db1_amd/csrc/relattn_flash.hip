@@ -1111,7 +1111,11 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
         a.fblk = reinterpret_cast<float*>(ws);
         relattn_flash_bwd_q2_kernel<<<grid, 512, Q2_LDS, s>>>(a);
         DB1_CHECK_LAUNCH("relattn_flash_bwd_q2");
-        const bool kv3_on = db1_knob(DB1_KNOB_FLASH_KV3, 1) != 0;   // A/B knob
+        // 32 keys per wave (256 per workgroup) where that still gives the chip two rounds of workgroups to balance the causal triangle with;
+        // at the reference's micro-batch of 4 sequences it is 256 workgroups -- one per CU, the heaviest key tile alone at the end -- and the
+        // 128-key kernel (512 workgroups) is 0.4 % of the step faster (r05: 132.2-132.5 k vs 131.6-132.0 k tok/s at 4 x GA 16)
+        const int kv3_knob = db1_knob(DB1_KNOB_FLASH_KV3, -1);      // A/B knob: 0 / 1 force
+        const bool kv3_on = kv3_knob >= 0 ? kv3_knob != 0 : (int64_t)B * H * (L / KV3_KEYS) >= 512;
         if (kv3_on && (L % KV3_KEYS) == 0) {   // a wave = 32 keys
             relattn_flash_bwd_kv3_kernel<<<dim3(flash_grid(L / KV3_KEYS, H, B)), 512, KV3_LDS, s>>>(a);
             DB1_CHECK_LAUNCH("relattn_flash_bwd_kv3");

@@ -25,7 +25,7 @@ void db1_test_flash_fwd2(int on);
 /* A/B knobs of the dispatchers for measurements: THREAD-LOCAL (they affect calls made afterwards by the same host thread), unset by
  * default; the library never reads the environment.  Names: "gemm_tile" (128 | 256 | 512 | 1024: pin one tile kernel), "gemm_splitk" (0: no
  * workspace split-K), "pp32_stages" (4 | 5), "linear_decode_splitk" (0 | 1: never split), "w4" (0: the 8-wave GEMM kernels, 2: 4-wave for NT
- * only), "flash_fwd2" (0: the compiled flash-forward loop), "flash_kv3" (0: 16 keys per wave in the key-side backward), "conv_wgrad_ks",
+ * only), "flash_fwd2" (0: the compiled flash-forward loop), "flash_kv3" (0 / 1: force 16 / 32 keys per wave in the key-side backward; -1 or unset: 32 from 512 workgroups on), "conv_wgrad_ks",
  * "geglu_epi" (0: db1_gemm_nt_geglu / db1_gemm_nn_geglu_bwd run as separate GEMM + activation launches at every shape), "gemm_halfwave" (k-tiles
  * per slice from which half-wave outputs are split in two), "w4n" (0: no 256 x 128 tiles of the 4-wave GEMM; 1 / 2 / 3: see gemm.hip), "adam_nt"
  * (1: the Adam kernel with non-temporal streams and two 16-byte groups per thread in flight), "w4_band" (tile rows per band of the 4-wave GEMMs' XCD-aware walk; default 4), "w4_rot" (0: no per-XCD rotation of the NT k-tile walk).
