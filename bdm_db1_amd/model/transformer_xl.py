@@ -1570,7 +1570,8 @@ class TransformerXL(nn.Module):
         # the chain's hand-off polls are bounded: if one ran out (a co-tenant kernel, a CU mask: not all 256 workgroups resident) the
         # launch has set a flag and carried on with garbage.  The flag travels to pinned host memory behind the launches, and
         # check_decode_chain() -- at the next forward, in get_action after its own synchronisation, in GraphedRingStep -- raises on it.
-        self._chain_watch = ops.decode_chain_flag_fetch(self.dev)
+        if os.environ.get("DB1_CHAIN_FLAG_FETCH", "1") != "0":    # (0: measurements only -- a failed hand-off then goes unnoticed)
+            self._chain_watch = ops.decode_chain_flag_fetch(self.dev)
         p = f"h.{n - 1}."
         return _PendingLN(res=h1_out, y=f_out, alpha=a, gamma=W(p + "pos_ff.layer_norm.weight"),
                           beta=W(p + "pos_ff.layer_norm.bias"), eps=self.layer_norm_epsilon)
