@@ -136,6 +136,8 @@ class WgradStash:
         dt = model.compute_dtype
         nln = ops.layernorm_bwd_parts_numel(T, d, dt) if dt == torch.bfloat16 else 0
         ok = (model.use_partial_stash and nln > 0 and nln % (2 * d) == 0 and model.activation_fn == "geglu" and model.use_geglu_epilogue and not model.untie_r and
+              model.use_flash and model.use_flash_bwd and model.dropattn == 0 and not model.use_geglu_saved and self.nd and
+              ops.relattn_flash_supported(T // self.nd, self.nd, H, D, dt) and
               ops.gemm_nn_geglu_bwd_fused(T, dff, d, dt) and T % 128 == 0 and self.nd and ops.relattn_dqr_supported(T // self.nd, self.nd, H, D, dt))
         if not ok:
             return False
