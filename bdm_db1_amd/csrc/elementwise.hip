@@ -303,7 +303,8 @@ extern "C" int db1_layernorm_residual_fwd(const void* x, const void* r, float al
 // reference's micro-batch of 4 sequences (4096 rows gave 128 blocks: half the CUs, 40 us for a 10 us stream) so that >= 512 blocks exist
 static int ln_bwd_rpb(int64_t rows) {
     int rpb = 32;
-    while (rpb > 4 && (rows + rpb - 1) / rpb < 512) rpb >>= 1;
+    const int want = db1_knob(DB1_KNOB_LN_BWD_BLOCKS, 512);     // A/B knob
+    while (rpb > 4 && (rows + rpb - 1) / rpb < want) rpb >>= 1;
     return rpb;
 }
 extern "C" int64_t db1_layernorm_residual_bwd_workspace_bytes(int64_t rows, int d, int dt) {

@@ -28,7 +28,7 @@ void db1_test_flash_fwd2(int on);
  * only), "flash_fwd2" (0: the compiled flash-forward loop), "flash_kv3" (0 / 1: force 16 / 32 keys per wave in the key-side backward; -1 or unset: 32 from 512 workgroups on), "conv_wgrad_ks",
  * "geglu_epi" (0: db1_gemm_nt_geglu / db1_gemm_nn_geglu_bwd run as separate GEMM + activation launches at every shape), "gemm_halfwave" (k-tiles
  * per slice from which half-wave outputs are split in two), "w4n" (0: no 256 x 128 tiles of the 4-wave GEMM; 1 / 2 / 3: see gemm.hip), "adam_nt"
- * (1: the Adam kernel with non-temporal streams and two 16-byte groups per thread in flight), "w4_band" (tile rows per band of the 4-wave GEMMs' XCD-aware walk; default 4), "w4_rot" (0: no per-XCD rotation of the NT k-tile walk).
+ * (1: the Adam kernel with non-temporal streams and two 16-byte groups per thread in flight), "w4_band" (tile rows per band of the 4-wave GEMMs' XCD-aware walk; default 4), "w4_rot" (0: no per-XCD rotation of the NT k-tile walk), "ln_bwd_blocks" (workgroups the fused LayerNorm backward aims for at small row counts; default 512).
  * Returns 0, or DB1_ERR_BAD_SHAPE for an unknown name. */
 int db1_test_set_knob(const char* name, int value);
 void db1_test_clear_knobs(void);
