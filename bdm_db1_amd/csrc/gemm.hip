@@ -516,6 +516,17 @@ extern "C" int db1_gemm_nt_headbias(const void* A, const void* W, void* C, void*
     t.alpha = 1.f; t.beta = 0.f; t.tiles_m = M / 256; t.tiles_n = N / 256; t.ksplit = 1;
     t.tri_mode = 0; t.tri_period = 0;
     t.split_n = split_n; t.Cu = Cu; t.Cv = Cv; t.bias_u = bias_u; t.bias_v = bias_v; t.ld_uv = ld_uv;
+    // the reference's micro-batch of 4 sequences: 384 tiles of 256 x 256 = 1.5 rounds of workgroups; 768 tiles of 256 x 128 fill three (the
+    // dispatcher's rule for plain products, gemm_plan: the 256 x 128 form priced at 0.85 of the 256 x 256 one per FLOP)
+    {
+        const int64_t wg256 = (int64_t)(M / 256) * (N / 256), wg128 = (int64_t)(M / 256) * (N / 128);
+        const double e256 = (double)wg256 / (256.0 * ((wg256 + 255) / 256)), e128 = (double)wg128 / (256.0 * ((wg128 + 255) / 256));
+        const int w4n_mode = db1_knob(DB1_KNOB_W4N, 3);
+        if (w4n_mode >= 3 && w4n_mode != 5 && wg256 < 1024 && 0.85 * e128 > e256 && db1_gemm_w4n_supported(t, 0, 0, DB1_BF16, 1)) {   // (knob value 5: everything but this routing, for the A/B)
+            t.tiles_n = N / 128;
+            return db1_gemm_w4n_launch(t, 0, 0, DB1_BF16, DB1_BF16, 1, (hipStream_t)stream);
+        }
+    }
     return db1_gemm_pp_launch(t, 0, 0, DB1_BF16, DB1_BF16, 1, (hipStream_t)stream);
 }
 // the same projection against the TRANSPOSED weight copy Wt [K, N] (NN form of the 4-wave kernel): at the DB1-1.3B shape (65 536 x 6144 x 2048)

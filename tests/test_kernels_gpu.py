@@ -340,10 +340,11 @@ def test_gemm_4wave_loops_are_bitwise_repeatable(ops, form):
         assert torch.equal(out, first)
 
 
-def test_gemm_nt_head_bias_epilogue(ops):
-    """the attention input projection with q + r_w_bias / q + r_r_bias written from the accumulators (db1_gemm_nt_headbias)"""
+@pytest.mark.parametrize("M,d,K", [(4096 * 4, 1024, 512), (4096, 2048, 512)])
+def test_gemm_nt_head_bias_epilogue(ops, M, d, K):
+    """the attention input projection with q + r_w_bias / q + r_r_bias written from the accumulators (db1_gemm_nt_headbias): 64 x 12 tiles of
+    256 x 256, and the reference's micro-batch (4096 rows x 6144 columns: 1.5 rounds of 256 x 256 tiles -> the 256 x 128 form, round 5)"""
     g = torch.Generator(device="cpu").manual_seed(9)
-    M, d, K = 4096 * 4, 1024, 512   # 64 x 12 tiles of 256x256
     x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
     w = (torch.randn(3 * d, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
     u = torch.randn(d, generator=g).to(torch.bfloat16).to(DEV)
