@@ -147,7 +147,7 @@ class GraphedRingStep:
         """ids [batch, n_new] (or None / ``self.ids`` itself: the tokens are already in the static input buffer) ->
         (logits [batch, n_new, vocab] (static buffer, overwritten by the next call), the RingMemory)"""
         if self.model._wversion != self._version:
-            raise RuntimeError("the weights changed after the graph was captured: build a new GraphedRingStep")
+            raise RuntimeError("the weights changed after the graph was captured (or a persistent launch of this graph failed): build a new GraphedRingStep")
         self.check()   # the replays the stream has finished (free: a pinned host word)
         if ids is not None and ids.data_ptr() != self.ids.data_ptr():   # (a sampler that writes the next token into ``self.ids`` skips this copy)
             self.ids.copy_(ids)
@@ -159,4 +159,11 @@ class GraphedRingStep:
         ``synchronize=True`` before trusting logits that were not read back through a synchronising copy"""
         if self._watch is not None:
             self.model._chain_watch = self._watch
-            self.model.check_decode_chain(synchronize)
+            try:
+                self.model.check_decode_chain(synchronize)
+            except Exception:
+                # the captured graph still contains the persistent launches: this step must not be replayed again (the model has switched the
+                # chain off, so a NEW GraphedRingStep captures the per-launch path)
+                self._version = -1
+                self._watch = None
+                raise
