@@ -6,7 +6,7 @@ Philox masks, AdamW (lr 5e-4, wd 0.01) with the global-norm clip at 1.0, TWENTY 
 over 512 tokens: the loss falls from ln 33 025 = 10.4 to about 6):
 
   * the fp32 HIP engine follows the NumPy oracle (oracle/db1_oracle.py: forward, hand-written backward, clip, AdamW, the same keep
-    decisions) step by step -- by default for the first 3 optimizer steps (the oracle needs ~12 s of host time per step at this size);
+    decisions) step by step -- by default for the first 2 optimizer steps (the oracle needs 12-22 s of host time per step at this size);
     ``DB1_TRAJ_ORACLE_STEPS=20`` runs all twenty (profiles/r05_trajectory.json holds that run's record);
   * the bf16 HIP engine -- eager, as hipGraph replays, and with gradient accumulation 4 + deferred weight gradients (``defer_wgrad``,
     eager and graphed) -- follows the fp32 HIP engine's loss curve and final parameters over all twenty steps within a STATED tolerance:
@@ -37,7 +37,7 @@ from oracle import db1_oracle as O  # noqa: E402
 DEV = "cuda"
 N_LAYER, L, NSEQ, STEPS, GA = 4, 1024, 2, 20, 4
 LR, WD, CLIP = 5e-4, 0.01, 1.0
-ORACLE_STEPS = int(os.environ.get("DB1_TRAJ_ORACLE_STEPS", "3"))
+ORACLE_STEPS = int(os.environ.get("DB1_TRAJ_ORACLE_STEPS", "2"))
 LOSS_TOL, PARAM_TOL, UPDATE_TOL = 2e-2, 2e-2, 0.15         # bf16 vs fp32: the statement of this test (measured: 0.8e-2 / 1.2e-2 / 0.09; GA 4: 1.7e-2 / 0.6e-2 / 0.05)
 
 
