@@ -259,6 +259,7 @@ class TransformerXL(nn.Module):
         # the attention input projection against a transposed weight copy (NN form of the 4-wave kernel).  OPT-IN: alone and back to back the NN
         # form is 8 % faster at this shape (1190 vs 1300 us), inside the training step the two are equal (same box: 420.6 vs 419.6 ms per
         # step, profiles/r05_nt_vs_nn.txt) -- a GEMM's isolated speed is not its speed under the step's power / clock state
+        self.head_chunk_rows = int(os.environ.get("DB1_HEAD_CHUNK", "0"))   # rows of logits alive at a time in the fused head + loss sweep (0: the library's 16 384)
         self.use_qkv_nn = os.environ.get("DB1_QKV_NN", "0") != "0"
         self.use_partial_stash = os.environ.get("DB1_PARTIAL_STASH", "1") != "0"   # gradient accumulation: the small reductions once per optimizer step (WgradStash.alloc_parts)
         self.use_rnet_batched = os.environ.get("DB1_RNET_BATCHED", "1") != "0"   # r_net of all layers as one batched launch per forward
@@ -1628,7 +1629,8 @@ class TransformerXL(nn.Module):
             wname = "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight"
             gW = self.arena.view(self.arena.grad, wname, full=True).view(self.vocab_pad, d)
             dh = self._new(T, d)
-            ops.lmhead_ce(x, Wout, lab, msk, lse, sums, V, dh=dh, dW_acc=gW, beta_dw=0.0 if self._grad_fresh else 1.0, gscale=self.loss_grad_scale)
+            ops.lmhead_ce(x, Wout, lab, msk, lse, sums, V, dh=dh, dW_acc=gW, beta_dw=0.0 if self._grad_fresh else 1.0, gscale=self.loss_grad_scale,
+                          chunk_rows=self.head_chunk_rows)
             loss = sums[0] / sums[1]
             ctx = _Ctx()
             ctx.ecs, ctx.shapes, ctx.lcs, ctx.R_in, ctx.dh_head = ecs, shapes, lcs, R_in, dh
