@@ -26,7 +26,7 @@ void db1_set_error(const char* fmt, ...);
 // A/B knobs for measurements and parity tests (include/db1_hip_test.h: db1_test_set_knob): THREAD-LOCAL, unset by default, never read
 // from the environment -- the library has no process-level mutable state.  db1_knob(id, dflt) = the calling thread's value.
 enum Db1Knob { DB1_KNOB_GEMM_TILE = 0, DB1_KNOB_GEMM_SPLITK, DB1_KNOB_PP32_STAGES, DB1_KNOB_LINEAR_DECODE_SPLITK, DB1_KNOB_W4,
-               DB1_KNOB_FLASH_FWD2, DB1_KNOB_FLASH_KV3, DB1_KNOB_CONV_WGRAD_KS, DB1_KNOB_GEGLU_EPI, DB1_KNOB_GEMM_HALFWAVE, DB1_KNOB_W4N, DB1_KNOB_ADAM_NT, DB1_KNOB_W4_BAND, DB1_KNOB_W4_ROT, DB1_KNOB_LN_BWD_BLOCKS, DB1_KNOB_COUNT };
+               DB1_KNOB_FLASH_FWD2, DB1_KNOB_FLASH_KV3, DB1_KNOB_CONV_WGRAD_KS, DB1_KNOB_GEGLU_EPI, DB1_KNOB_GEMM_HALFWAVE, DB1_KNOB_W4N, DB1_KNOB_COUNT };
 int db1_knob(int id, int dflt);
 
 #define DB1_FAIL(code, ...)           \
@@ -169,6 +169,9 @@ struct Db1Drop {
     float scale;
     unsigned k0, k1, site, step;
     const unsigned* step_dev;   // nullable: the step used is step + *step_dev (a device counter: the value a captured hipGraph reads at REPLAY time)
+    // > 0: the tensor holds SEVERAL micro-steps' rows, rows_per_step each (a whole accumulation window run through one backward): row r belongs to
+    // step + r / rows_per_step and its elements are counted from the first row of that block -- the decisions its own forward drew
+    long long rows_per_step;
 };
 static inline Db1Drop db1_drop_make(float p, uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev = nullptr) {
     Db1Drop d;
@@ -177,7 +180,17 @@ static inline Db1Drop db1_drop_make(float p, uint64_t seed, uint32_t site, uint3
     d.scale = 65536.f / (float)(65536 - (long)d.thr);
     d.k0 = (unsigned)(seed & 0xffffffffu); d.k1 = (unsigned)(seed >> 32); d.site = site; d.step = step;
     d.step_dev = step_dev;
+    d.rows_per_step = 0;
     return d;
+}
+// the element index of (row, column 0) inside the row's micro-step block; advances dr.step to that micro-step (per-row copy of the descriptor)
+__device__ __forceinline__ int64_t db1_drop_row_base(Db1Drop& dr, int64_t row, int d) {
+    if (dr.rows_per_step > 0) {
+        const unsigned m = (unsigned)row / (unsigned)dr.rows_per_step;
+        dr.step += m;
+        row -= (int64_t)m * dr.rows_per_step;
+    }
+    return row * d;
 }
 __device__ __forceinline__ void db1_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned o[4]) {
 #pragma unroll

@@ -96,6 +96,8 @@ __global__ __launch_bounds__(256) void ln_bwd_ds_kernel(const T* __restrict__ dy
     c1 = wave_sum(c1) / (float)d;
     c2 = wave_sum(c2) / (float)d;
     T* dsr = ds + row * d;
+    Db1Drop drow = drp;
+    const int64_t ebase = db1_drop_row_base(drow, row, d);
     for (int i = lane * V; i < d; i += 64 * V) {
         Vec16<T> a, b, o;
         a.load(dyr + i);
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void ln_bwd_ds_kernel(const T* __restrict__ dy
         }
         o.store(dsr + i);
         if (dr_out) {   // gradient of the dropped sub-layer output: the same keep decisions as the forward
-            if (drp.thr) db1_drop_apply<V>(drp, row * d + i, o.v);
+            if (drp.thr) db1_drop_apply<V>(drow, ebase + i, o.v);
             o.store(dr_out + row * d + i);
         }
     }
@@ -210,6 +212,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const T* __restrict__
             }
         c1 = wave_sum(c1) / (float)d;
         c2 = wave_sum(c2) / (float)d;
+        Db1Drop drow = drp;
+        const int64_t ebase = db1_drop_row_base(drow, row, d);
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             Vec16<T> o;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const T* __restrict__
             for (int j = 0; j < V; j++) o.v[j] = rs * (a[k].v[j] * gam[k][j] - c1 - b[k].v[j] * c2);
             o.store(ds + row * d + (k * 64 + lane) * V);
             if (dr_out) {   // gradient of the dropped sub-layer output: ds under the forward's keep decisions (regenerated, not stored)
-                if (drp.thr) db1_drop_apply<V>(drp, row * d + (k * 64 + lane) * V, o.v);
+                if (drp.thr) db1_drop_apply<V>(drow, ebase + (k * 64 + lane) * V, o.v);
                 o.store(dr_out + row * d + (k * 64 + lane) * V);
             }
         }
@@ -303,7 +307,7 @@ extern "C" int db1_layernorm_residual_fwd(const void* x, const void* r, float al
 // reference's micro-batch of 4 sequences (4096 rows gave 128 blocks: half the CUs, 40 us for a 10 us stream) so that >= 512 blocks exist
 static int ln_bwd_rpb(int64_t rows) {
     int rpb = 32;
-    const int want = db1_knob(DB1_KNOB_LN_BWD_BLOCKS, 512);     // A/B knob
+    const int want = 512;     // (256 / 512 / 1024 measured at 4096 rows, profiles/r05e_*: 512)
     while (rpb > 4 && (rows + rpb - 1) / rpb < want) rpb >>= 1;
     return rpb;
 }
@@ -314,11 +318,13 @@ extern "C" int64_t db1_layernorm_residual_bwd_workspace_bytes(int64_t rows, int 
 }
 static int ln_bwd_impl(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                        void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc, int64_t rows, int d,
-                       float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev, int dt,
-                       int dtParam, void* ws_, int64_t ws_bytes, void* stream, bool parts_only) {
+                       float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev, int64_t drop_rows_per_step,
+                       int dt, int dtParam, void* ws_, int64_t ws_bytes, void* stream, bool parts_only) {
     if (drop_p < 0.f || drop_p >= 1.f) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd: dropout p=%g", (double)drop_p);
     if (dr_out && !db1_aligned16(dr_out)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "layernorm bwd: dr_out alignment");
-    const Db1Drop drp = db1_drop_make(drop_p, drop_seed, drop_site, drop_step, drop_step_dev);
+    if (drop_rows_per_step < 0 || drop_rows_per_step > 0x7fffffff || rows > 0x7fffffff) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd: rows / drop_rows_per_step");
+    Db1Drop drp = db1_drop_make(drop_p, drop_seed, drop_site, drop_step, drop_step_dev);
+    drp.rows_per_step = drop_rows_per_step;
     if (!db1_dt_ok(dt) || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "layernorm bwd: dtype");
     const int V = dt == DB1_F32 ? 4 : 8;
     if (rows <= 0 || d <= 0 || d % V) DB1_FAIL(DB1_ERR_BAD_SHAPE, "layernorm bwd: d=%d must be a multiple of %d", d, V);
@@ -366,20 +372,20 @@ static int ln_bwd_impl(const void* dy, const void* s, const void* gamma, const f
 
 extern "C" int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                                           void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc, int64_t rows, int d,
-                                          float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev, int dt,
-                                          int dtParam, void* ws_, int64_t ws_bytes, void* stream) {
-    return ln_bwd_impl(dy, s, gamma, mean, rstd, ds, dr_out, dgamma_acc, dbeta_acc, rows, d, drop_p, drop_seed, drop_site, drop_step, drop_step_dev, dt, dtParam,
-                       ws_, ws_bytes, stream, false);
+                                          float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
+                                          int64_t drop_rows_per_step, int dt, int dtParam, void* ws_, int64_t ws_bytes, void* stream) {
+    return ln_bwd_impl(dy, s, gamma, mean, rstd, ds, dr_out, dgamma_acc, dbeta_acc, rows, d, drop_p, drop_seed, drop_site, drop_step, drop_step_dev, drop_rows_per_step,
+                       dt, dtParam, ws_, ws_bytes, stream, false);
 }
 // the same launch WITHOUT the parameter reduce: the per-block partial sums [blocks][2][d] (float32, db1_layernorm_residual_bwd_workspace_bytes)
 // stay in `parts` for the caller to add up later -- db1_colsum_acc over the [blocks, 2 d] matrix gives (dgamma | dbeta).  Gradient
 // accumulation keeps the partials of every micro-step and reduces once per optimizer step (one launch instead of one per micro-step).
 extern "C" int db1_layernorm_residual_bwd_parts(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                                                 void* ds, void* dr_out, float* parts, int64_t parts_bytes, int64_t rows, int d,
-                                                float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev, int dt,
-                                                int dtParam, void* stream) {
-    return ln_bwd_impl(dy, s, gamma, mean, rstd, ds, dr_out, nullptr, nullptr, rows, d, drop_p, drop_seed, drop_site, drop_step, drop_step_dev, dt, dtParam,
-                       parts, parts_bytes, stream, true);
+                                                float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
+                                                int64_t drop_rows_per_step, int dt, int dtParam, void* stream) {
+    return ln_bwd_impl(dy, s, gamma, mean, rstd, ds, dr_out, nullptr, nullptr, rows, d, drop_p, drop_seed, drop_site, drop_step, drop_step_dev, drop_rows_per_step,
+                       dt, dtParam, parts, parts_bytes, stream, true);
 }
 
 // =====================================================================================
@@ -715,46 +721,6 @@ extern "C" int db1_colsum_acc(const void* x, float* out_acc, int64_t rows, int c
     return DB1_OK;
 }
 
-// y [cols, rows] = x [rows, cols]^T for 2-byte elements: 64 x 64 tiles through LDS, 8-byte accesses on both sides (a lane reads 4
-// consecutive columns of a row and writes 4 consecutive rows' worth of one output row).  Used for the per-weight-version transposed copy of
-// the attention input projection's weight (db1_gemm_nn_headbias).
-__global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int rows, int cols, int64_t ldx, int64_t ldy) {
-    __shared__ unsigned short tile[64][64 + 4];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, t = threadIdx.x;
-    const int lr = t >> 4, lc = (t & 15) * 4;      // 16 rows x 16 four-column groups per pass
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const int r = lr + 16 * p;
-        uint2 v = make_uint2(0u, 0u);
-        if (r0 + r < rows && c0 + lc + 3 < cols) v = *reinterpret_cast<const uint2*>(x + (int64_t)(r0 + r) * ldx + c0 + lc);
-        else if (r0 + r < rows) {
-            unsigned short e[4] = {0, 0, 0, 0};
-            for (int j = 0; j < 4; j++) if (c0 + lc + j < cols) e[j] = x[(int64_t)(r0 + r) * ldx + c0 + lc + j];
-            v = make_uint2((unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16));
-        }
-        tile[r][lc] = (unsigned short)(v.x & 0xffffu); tile[r][lc + 1] = (unsigned short)(v.x >> 16);
-        tile[r][lc + 2] = (unsigned short)(v.y & 0xffffu); tile[r][lc + 3] = (unsigned short)(v.y >> 16);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const int oc = lr + 16 * p;                // output row = input column
-        if (c0 + oc >= cols) continue;
-        unsigned short e[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) e[j] = tile[lc + j][oc];
-        unsigned short* dst = y + (int64_t)(c0 + oc) * ldy + r0 + lc;
-        if (r0 + lc + 3 < rows) *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16));
-        else for (int j = 0; j < 4; j++) if (r0 + lc + j < rows) dst[j] = e[j];
-    }
-}
-extern "C" int db1_transpose_bf16(const void* x, void* y, int rows, int cols, int64_t ldx, int64_t ldy, void* stream) {
-    if (rows <= 0 || cols <= 0 || ldx < cols || ldy < rows) DB1_FAIL(DB1_ERR_BAD_SHAPE, "transpose_bf16: rows=%d cols=%d ldx=%lld ldy=%lld", rows, cols, (long long)ldx, (long long)ldy);
-    if ((((uintptr_t)x) & 7) || (((uintptr_t)y) & 7) || (ldx % 4) || (ldy % 4)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "transpose_bf16: 8-byte aligned pointers, leading dimensions multiples of 4");
-    transpose16_kernel<<<dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, (unsigned short*)y, rows, cols, ldx, ldy);
-    DB1_CHECK_LAUNCH("transpose_bf16");
-    return DB1_OK;
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n) {
@@ -1393,71 +1359,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         }
     }
 }
-// A/B variant (knob "adam_nt" = 1): non-temporal loads / stores of the four arenas, two 16-byte groups per thread in flight
-template <bool HAS_WORK, typename GT>
-__global__ __launch_bounds__(256) void adam_nt_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, bf16_t* __restrict__ pw, int64_t n, float lr, float b1,
-                                                   float b2, float omb1, float omb2, float eps, float wd, int adamw, float bc1, float rsqrt_bc2,
-                                                   float gscale, float clip, const float* norm_sq) {
-    float gs = gscale;
-    if (clip > 0.f && norm_sq) {
-        const float nrm = sqrtf(*norm_sq) * gscale;
-        gs *= fminf(1.f, clip / (nrm + 1e-6f));
-    }
-    const float step_size = lr / bc1;
-    const int64_t nv = n >> 2;
-    // every stream is touched exactly once per step (30 B per parameter, 36 GB at DB1-1.3B): non-temporal loads and stores keep the four
-    // arenas out of L2 / the memory-side cache, and two 16-byte groups per thread are in flight per iteration (eight loads before the first use)
-    typedef __attribute__((ext_vector_type(4))) float f4v;
-    typedef __attribute__((ext_vector_type(2))) unsigned u2v;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < nv; i0 += 2 * stride) {
-        f4v P[2], M[2], Vv[2], G4[2];
-        u2v G2[2];
-        bool on[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int64_t i = i0 + u * stride;
-            on[u] = i < nv;
-            const int64_t ic = on[u] ? i : i0;      // (clamped address: the loads stay unconditional)
-            P[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p) + ic);
-            if (sizeof(GT) == 4) G4[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(g) + ic);
-            else G2[u] = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(g) + ic);   // bf16 gradients: the all-reduced staging copy (8 B per 4 elements)
-            M[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(m) + ic);
-            Vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(v) + ic);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            if (!on[u]) continue;
-            const int64_t i = i0 + u * stride;
-            float gg[4];
-            if (sizeof(GT) == 4) { gg[0] = G4[u][0]; gg[1] = G4[u][1]; gg[2] = G4[u][2]; gg[3] = G4[u][3]; }
-            else {
-                gg[0] = __uint_as_float(G2[u][0] << 16); gg[1] = __uint_as_float(G2[u][0] & 0xffff0000u);
-                gg[2] = __uint_as_float(G2[u][1] << 16); gg[3] = __uint_as_float(G2[u][1] & 0xffff0000u);
-            }
-            f4v pp = P[u], mm = M[u], vv = Vv[u];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float gr = gg[j] * gs;
-                if (adamw) pp[j] *= (1.f - lr * wd); else gr += wd * pp[j];
-                mm[j] = b1 * mm[j] + omb1 * gr;
-                vv[j] = b2 * vv[j] + omb2 * gr * gr;
-                const float denom = sqrtf(vv[j]) * rsqrt_bc2 + eps;
-                pp[j] -= step_size * mm[j] / denom;
-            }
-            __builtin_nontemporal_store(pp, reinterpret_cast<f4v*>(p) + i);
-            __builtin_nontemporal_store(mm, reinterpret_cast<f4v*>(m) + i);
-            __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(v) + i);
-            if (HAS_WORK) {   // (the working copy is what the next forward reads first: a plain store)
-                uint2 o;
-                o.x = f2bf_pk(pp[0], pp[1]);
-                o.y = f2bf_pk(pp[2], pp[3]);
-                reinterpret_cast<uint2*>(pw)[i] = o;
-            }
-        }
-    }
-}
 extern "C" int db1_adam_step(float* p32, const void* g, float* m, float* v, void* p_work, int64_t n, double lr, double beta1,
                              double beta2, double eps, double wd, int adamw, int step, float gscale, float clip,
                              const float* norm_sq, int dtGrad, int dtWork, void* stream) {
@@ -1471,12 +1372,6 @@ extern "C" int db1_adam_step(float* p32, const void* g, float* m, float* v, void
     hipStream_t st = (hipStream_t)stream;
     unsigned gr = grid_for(n / 4);
 #define DB1_ADAM_LAUNCH(HW, GT) adam_kernel<HW, GT><<<gr, 256, 0, st>>>(p32, (const GT*)g, m, v, (bf16_t*)p_work, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd, adamw, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, clip, norm_sq)
-    if (db1_knob(DB1_KNOB_ADAM_NT, 0) && p_work && dtGrad == DB1_F32) {
-        adam_nt_kernel<true, float><<<gr, 256, 0, st>>>(p32, (const float*)g, m, v, (bf16_t*)p_work, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
-                                                       (float)eps, (float)wd, adamw, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, clip, norm_sq);
-        DB1_CHECK_LAUNCH("adam (nt)");
-        return DB1_OK;
-    }
     if (p_work) { if (dtGrad == DB1_F32) DB1_ADAM_LAUNCH(true, float); else DB1_ADAM_LAUNCH(true, bf16_t); }
     else { if (dtGrad == DB1_F32) DB1_ADAM_LAUNCH(false, float); else DB1_ADAM_LAUNCH(false, bf16_t); }
 #undef DB1_ADAM_LAUNCH

@@ -529,33 +529,6 @@ extern "C" int db1_gemm_nt_headbias(const void* A, const void* W, void* C, void*
     }
     return db1_gemm_pp_launch(t, 0, 0, DB1_BF16, DB1_BF16, 1, (hipStream_t)stream);
 }
-// the same projection against the TRANSPOSED weight copy Wt [K, N] (NN form of the 4-wave kernel): at the DB1-1.3B shape (65 536 x 6144 x 2048)
-// the NN kernel takes 1190 us where the NT one takes 1300 (profiles/r05_nt_vs_nn.txt; the other forward shapes are equal in both forms)
-extern "C" int db1_gemm_nn_headbias_supported(int M, int N, int K, int split_n) {
-    GemmTileArgs t;
-    t.A = nullptr; t.B = nullptr; t.C = nullptr; t.bias = nullptr;
-    t.M = M; t.N = N; t.K = K; t.lda = K; t.ldb = N; t.ldc = N; t.batch1 = 1;
-    t.a_bs0 = t.a_bs1 = t.b_bs0 = t.b_bs1 = t.c_bs0 = t.c_bs1 = 0; t.alpha = 1.f; t.beta = 0.f; t.tiles_m = M / 256; t.tiles_n = N / 256; t.ksplit = 1;
-    t.tri_mode = 0; t.tri_period = 0; t.split_n = split_n; t.Cu = t.Cv = nullptr; t.bias_u = t.bias_v = nullptr; t.ld_uv = split_n;
-    return (db1_gemm_nt_headbias_supported(M, N, K, split_n) && db1_gemm_w4_supported(t, 0, 1, DB1_BF16, 1)) ? 1 : 0;
-}
-extern "C" int db1_gemm_nn_headbias(const void* A, const void* Wt, void* C, void* Cu, void* Cv, const void* bias_u, const void* bias_v, int M, int N, int K,
-                                    int split_n, int64_t lda, int64_t ldwt, int64_t ldc, int64_t ld_uv, void* stream) {
-    if (!A || !Wt || !C || !Cu || !Cv || !bias_u || !bias_v) DB1_FAIL(DB1_ERR_BAD_SHAPE, "gemm_nn_headbias: null operand");
-    if (!db1_aligned16(A) || !db1_aligned16(Wt) || !db1_aligned16(C) || !db1_aligned16(Cu) || !db1_aligned16(Cv) || (lda % 8) || (ldwt % 8) || (ldc % 4) ||
-        (ld_uv % 4) || lda < K || ldwt < N || ldc < N || ld_uv < split_n)
-        DB1_FAIL(DB1_ERR_BAD_ALIGN, "gemm_nn_headbias: alignment / leading dimensions");
-    GemmTileArgs t;
-    t.A = (const bf16_t*)A; t.B = (const bf16_t*)Wt; t.C = C; t.bias = nullptr;
-    t.M = M; t.N = N; t.K = K; t.lda = lda; t.ldb = ldwt; t.ldc = ldc;
-    t.batch1 = 1; t.a_bs0 = t.a_bs1 = t.b_bs0 = t.b_bs1 = t.c_bs0 = t.c_bs1 = 0;
-    t.alpha = 1.f; t.beta = 0.f; t.tiles_m = M / 256; t.tiles_n = N / 256; t.ksplit = 1;
-    t.tri_mode = 0; t.tri_period = 0;
-    t.split_n = split_n; t.Cu = Cu; t.Cv = Cv; t.bias_u = bias_u; t.bias_v = bias_v; t.ld_uv = ld_uv;
-    if (!db1_gemm_nt_headbias_supported(M, N, K, split_n) || !db1_gemm_w4_supported(t, 0, 1, DB1_BF16, 1))
-        DB1_FAIL(DB1_ERR_UNSUPPORTED, "gemm_nn_headbias: M=%d N=%d K=%d split=%d (db1_gemm_nn_headbias_supported)", M, N, K, split_n);
-    return db1_gemm_w4_launch(t, 0, 1, DB1_BF16, DB1_BF16, 1, (hipStream_t)stream);
-}
 extern "C" int db1_gemm_nn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                            int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* ws, int64_t ws_bytes, void* stream) {
     return db1_gemm_strided(A, B, C, bias, M, N, K, dtAB, dtAB, dtC, dtAB, lda, 1, ldb, 1, ldc, 1, 1, 1, 0, 0, 0, 0, 0, 0, alpha, beta, ws, ws_bytes, stream);

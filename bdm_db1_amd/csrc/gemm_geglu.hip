@@ -107,52 +107,3 @@ extern "C" int db1_gemm_nn_geglu_bwd(const void* dY, const void* W2, const void*
     if (rc) return rc;
     return db1_ffn_act_bwd_bias(Z, dact, dZ, dbias_acc, M, dff, DB1_ACT_GEGLU, dt, ws_act, n_act, stream);
 }
-
-// ---- the same pair with the backward's two factors saved by the forward (round 5).  S [M, 2 dff] takes z's place: S[:, :dff] = gelu(g),
-// S[:, dff:] = v * gelu'(g) with (v, g) = the bf16-rounded halves of z = x W1^T + b1 -- the two numbers per element the backward multiplies
-// dact by.  The backward's epilogue is then two products per element (no erf / exp / rcp), and the forward's, which has Phi(g) and
-// exp(-g^2 / 2) in registers anyway, three more operations.  Both exist for the shapes the fused 4-wave kernels take (large bf16 batches:
-// db1_gemm_geglu_saved_supported); every other shape keeps z (db1_gemm_nt_geglu / db1_gemm_nn_geglu_bwd).  dz differs from the z form's by
-// one more bf16 rounding of each factor (2^-9 relative).
-extern "C" int db1_gemm_geglu_saved_supported(int M, int dff, int K_fwd, int K_bwd, int dt, int64_t lda, int64_t ldw1, int64_t lds, int64_t ldact,
-                                              int64_t lddy, int64_t ldw2, int64_t lddz) {
-    return (geglu_fused_fwd(M, dff, K_fwd, dt, lda, ldw1, lds, ldact, nullptr, nullptr, nullptr, nullptr) &&
-            geglu_fused_bwd(M, dff, K_bwd, dt, lddy, ldw2, lds, lddz, nullptr, nullptr, nullptr, nullptr)) ? 1 : 0;
-}
-extern "C" int db1_gemm_nt_geglu_saved(const void* A, const void* W1, const void* bias, void* S, void* ACT, int M, int dff, int K, int64_t lda,
-                                       int64_t ldw, int64_t lds, int64_t ldact, int dt, void* stream) {
-    if (M <= 0 || dff <= 0 || K <= 0 || !A || !W1 || !S || !ACT) DB1_FAIL(DB1_ERR_BAD_SHAPE, "gemm_nt_geglu_saved: M=%d dff=%d K=%d / null operand", M, dff, K);
-    if (!geglu_fused_fwd(M, dff, K, dt, lda, ldw, lds, ldact, A, W1, S, ACT))
-        DB1_FAIL(DB1_ERR_UNSUPPORTED, "gemm_nt_geglu_saved: only the shapes of the fused 4-wave kernel (db1_gemm_geglu_saved_supported); use db1_gemm_nt_geglu");
-    GemmTileArgs t;
-    t.A = (const bf16_t*)A; t.B = (const bf16_t*)W1; t.C = S; t.bias = bias;
-    t.M = M; t.N = 2 * dff; t.K = K; t.lda = lda; t.ldb = ldw; t.ldc = lds;
-    t.batch1 = 1; t.a_bs0 = t.a_bs1 = t.b_bs0 = t.b_bs1 = t.c_bs0 = t.c_bs1 = 0;
-    t.alpha = 1.f; t.beta = 0.f; t.tiles_m = M / 256; t.tiles_n = 2 * dff / 256; t.ksplit = 1;
-    t.tri_mode = 0; t.tri_period = 0;
-    t.split_n = 0; t.Cu = nullptr; t.Cv = nullptr; t.bias_u = nullptr; t.bias_v = nullptr; t.ld_uv = 0;
-    t.geglu_dff = dff; t.Cact = ACT; t.ld_act = ldact; t.geglu_saved = 1;
-    return db1_gemm_w4_geglu_fwd_launch(t, dt, (hipStream_t)stream);
-}
-extern "C" int64_t db1_gemm_nn_geglu_bwd_saved_workspace_bytes(int M, int dff) {
-    return M > 0 && dff > 0 ? (int64_t)(M / 128) * 2 * dff * (int64_t)sizeof(float) : 0;   // the per-row-block column sums of dz
-}
-extern "C" int db1_gemm_nn_geglu_bwd_saved(const void* dY, const void* W2, const void* S, void* dZ, float* dbias_acc, int M, int dff, int K,
-                                           int64_t lddy, int64_t ldw, int64_t lds, int64_t lddz, int dt, void* ws, int64_t ws_bytes, void* stream) {
-    if (M <= 0 || dff <= 0 || K <= 0 || !dY || !W2 || !S || !dZ || !dbias_acc) DB1_FAIL(DB1_ERR_BAD_SHAPE, "gemm_nn_geglu_bwd_saved: M=%d dff=%d K=%d / null operand", M, dff, K);
-    if (!geglu_fused_bwd(M, dff, K, dt, lddy, ldw, lds, lddz, dY, W2, S, dZ))
-        DB1_FAIL(DB1_ERR_UNSUPPORTED, "gemm_nn_geglu_bwd_saved: only the shapes of the fused 4-wave kernel (db1_gemm_geglu_saved_supported); use db1_gemm_nn_geglu_bwd");
-    DB1_NEED_WS(ws, ws_bytes, db1_gemm_nn_geglu_bwd_saved_workspace_bytes(M, dff), "gemm_nn_geglu_bwd_saved");
-    hipStream_t st = (hipStream_t)stream;
-    GemmTileArgs t;
-    t.A = (const bf16_t*)dY; t.B = (const bf16_t*)W2; t.C = dZ; t.bias = nullptr;
-    t.M = M; t.N = dff; t.K = K; t.lda = lddy; t.ldb = ldw; t.ldc = lddz;
-    t.batch1 = 1; t.a_bs0 = t.a_bs1 = t.b_bs0 = t.b_bs1 = t.c_bs0 = t.c_bs1 = 0;
-    t.alpha = 1.f; t.beta = 0.f; t.tiles_m = M / 256; t.tiles_n = dff / 256; t.ksplit = 1;
-    t.tri_mode = 0; t.tri_period = 0;
-    t.split_n = 0; t.Cu = nullptr; t.Cv = nullptr; t.bias_u = nullptr; t.bias_v = nullptr; t.ld_uv = 0;
-    t.geglu_dff = dff; t.Zin = (const bf16_t*)S; t.ld_z = lds; t.colpart = (float*)ws; t.geglu_saved = 1;
-    int rc = db1_gemm_w4_geglu_bwd_launch(t, st);
-    if (rc) return rc;
-    return db1_colsum_part_reduce_launch((const float*)ws, dbias_acc, M / 128, 2 * dff, st);
-}

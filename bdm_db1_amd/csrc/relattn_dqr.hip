@@ -33,6 +33,11 @@ struct DqrArgs {
     // dT tiles -- one more tile per item -- so the counted vmcnt waits of the stream stay valid (plain global loads in the epilogue sit in
     // the same queue and broke them: measured and reverted before this version).
     float* part;
+    // groups (ngroups > 1): the batch is ngroups blocks of B / ngroups sequences and every block has its OWN R (a gradient-accumulation window
+    // run through one backward: each micro-step drew its own position-table dropout).  wph is a multiple of ngroups: workgroup j of a head
+    // works for block j % ngroups only, so its stationary R^T never changes; Rt of block g at + g * rt_gs elements.
+    int ngroups;
+    int64_t rt_gs;
 };
 
 __device__ __forceinline__ int dqr_swz(int row) { return ((((row & 7) ^ ((row & 8) >> 1))) << 1) | ((row >> 3) & 1); }  // natural-order row fragments
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(512, 1) void relattn_dqr_kernel(DqrArgs p) {
     // stationary operand: R_h^T rows d = 16 wave + a, k = 32 ks + 8 g .. +7
     dqr_bf16x8 rfr[DQR_MAX_L / 32];
     {
-        const bf16_t* rt = p.Rt + ((int64_t)h * 128 + 16 * wave + a) * L + 8 * g;
+        const bf16_t* rt = p.Rt + (int64_t)(j % p.ngroups) * p.rt_gs + ((int64_t)h * 128 + 16 * wave + a) * L + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < DQR_MAX_L / 32; ks++)
             rfr[ks] = ks * 32 < L ? *reinterpret_cast<const dqr_bf16x8*>(rt + ks * 32) : (dqr_bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -70,14 +75,15 @@ __global__ __launch_bounds__(512, 1) void relattn_dqr_kernel(DqrArgs p) {
 
     // the stream of tiles: items t = j, j + wph, ... (t -> batch b = t / NT, row tile (t + b) % NT: every workgroup sees every row tile
     // equally often), and inside an item the k-tiles 0 .. (i0 + 63) / 128
-    const int n_items = p.B * NT;
+    const int grp = j % p.ngroups, jj = j / p.ngroups, wpg = p.wph / p.ngroups, bper = p.B / p.ngroups;   // (one group: grp = 0, jj = j, wpg = wph)
+    const int n_items = bper * NT;
     const int fused = p.part != nullptr ? 1 : 0;
     struct Cur { int t, kt, nk, b, i0; };   // nk = tiles of the item in the stream: its dT k-tiles (+ the dq_k tile in fused mode, last)
     auto item_of = [&](int t, Cur& c) __attribute__((always_inline)) {
-        c.t = t; c.kt = 0; c.b = t / NT; c.i0 = ((t + c.b) % NT) * DQR_ROWS; c.nk = (c.i0 + DQR_ROWS - 1) / DQR_KT + 1 + fused;
+        c.t = t; c.kt = 0; c.b = grp * bper + t / NT; c.i0 = ((t + c.b) % NT) * DQR_ROWS; c.nk = (c.i0 + DQR_ROWS - 1) / DQR_KT + 1 + fused;
     };
     auto advance = [&](Cur& c) __attribute__((always_inline)) {  // next tile of the stream (c.t >= n_items: past the end)
-        if (++c.kt >= c.nk) { const int t = c.t + p.wph; if (t < n_items) item_of(t, c); else { c.t = t; c.kt = 0; c.nk = 1; } }
+        if (++c.kt >= c.nk) { const int t = c.t + wpg; if (t < n_items) item_of(t, c); else { c.t = t; c.kt = 0; c.nk = 1; } }
     };
     auto stage = [&](const Cur& c, int st) __attribute__((always_inline)) {
         const unsigned dst = lds0 + st * DQR_TILE_BYTES + wave * 2048;
@@ -92,14 +98,14 @@ __global__ __launch_bounds__(512, 1) void relattn_dqr_kernel(DqrArgs p) {
         }
     };
     Cur cs, cc;                      // staging cursor (DQR_STAGES - 1 tiles ahead), compute cursor
-    if (j >= n_items) {              // (more workgroups than items: never at the model's sizes) -- its partial rows must still be defined
+    if (jj >= n_items) {             // (more workgroups than items: never at the model's sizes) -- its partial rows must still be defined
         if (p.part && tid < 128) {
             p.part[(int64_t)j * p.H * 128 + h * 128 + tid] = 0.f;
             p.part[((int64_t)p.wph + j) * p.H * 128 + h * 128 + tid] = 0.f;
         }
         return;
     }
-    item_of(j, cs);
+    item_of(jj, cs);
     cc = cs;
     int issued = 0;
 #pragma unroll
@@ -178,8 +184,11 @@ __global__ __launch_bounds__(512, 1) void relattn_dqr_kernel(DqrArgs p) {
 }
 
 // R [nd][H * 128] -> Rt [H * 128][nd]
-__global__ __launch_bounds__(256) void relattn_dqr_transpose_kernel(const bf16_t* __restrict__ R, bf16_t* __restrict__ Rt, int nd, int HD, int64_t r_rs) {
+__global__ __launch_bounds__(256) void relattn_dqr_transpose_kernel(const bf16_t* __restrict__ R, bf16_t* __restrict__ Rt, int nd, int HD, int64_t r_rs,
+                                                                    int64_t r_gs, int64_t rt_gs) {
     __shared__ bf16_t tile[32][33];
+    R += (int64_t)blockIdx.z * r_gs;
+    Rt += (int64_t)blockIdx.z * rt_gs;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8) tile[r][tx] = (r0 + r < nd && c0 + tx < HD) ? R[(int64_t)(r0 + r) * r_rs + c0 + tx] : (bf16_t)0;
     __syncthreads();
@@ -207,7 +216,8 @@ __global__ __launch_bounds__(256) void dqr_part_reduce_kernel(const float* __res
 }
 
 static int dqr_run(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride, float* du_acc,
-                   float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream, float* parts_out = nullptr);
+                   float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream, float* parts_out = nullptr, int ngroups = 1,
+                   int64_t r_group_stride = 0);
 
 extern "C" int db1_relattn_dqr(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride,
                                int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream) {
@@ -233,21 +243,42 @@ extern "C" int db1_relattn_dqr_fused_parts(const void* dT, const void* R, int64_
     return dqr_run(dT, R, r_row_stride, dq, dq_row_stride, dq_batch_stride, parts, parts, B, L, H, D, ws, ws_bytes, stream, parts);
 }
 
+/* the fused form over a batch of `ngroups` blocks of B / ngroups sequences, block g with its own R at R + g * r_group_stride elements (every
+ * micro-step of a gradient-accumulation window has its own position-table dropout, hence its own R; transformer_xl.py:138,575): ONE launch
+ * for the whole window.  ngroups must divide B and the head's workgroup count (256 / H); ws >= db1_relattn_dqr_groups_workspace_bytes. */
+extern "C" int64_t db1_relattn_dqr_groups_workspace_bytes(int L, int H, int ngroups) {
+    return (int64_t)(ngroups > 0 ? ngroups : 1) * dqr_rt_bytes(L, H) + 2 * (int64_t)dqr_wph(H) * H * 128 * (int64_t)sizeof(float);
+}
+extern "C" int db1_relattn_dqr_groups_supported(int B, int L, int H, int D, int dt, int ngroups) {
+    return (db1_relattn_dqr_supported(B, L, H, D, dt) && ngroups >= 1 && B % ngroups == 0 && dqr_wph(H) % ngroups == 0) ? 1 : 0;
+}
+extern "C" int db1_relattn_dqr_fused_groups(const void* dT, const void* R, int64_t r_row_stride, int64_t r_group_stride, int ngroups, void* dq,
+                                            int64_t dq_row_stride, int64_t dq_batch_stride, float* du_acc, float* dv_acc, int B, int L, int H, int D,
+                                            void* ws, int64_t ws_bytes, void* stream) {
+    if (!du_acc || !dv_acc) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_dqr_fused_groups: null accumulator");
+    if ((dq_row_stride % 8) || (dq_batch_stride % 8)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_dqr_fused_groups: dq strides must be multiples of 8 elements");
+    if (!db1_relattn_dqr_groups_supported(B, L, H, D, DB1_BF16, ngroups)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_dqr_fused_groups: ngroups=%d must divide B=%d and %d", ngroups, B, dqr_wph(H));
+    return dqr_run(dT, R, r_row_stride, dq, dq_row_stride, dq_batch_stride, du_acc, dv_acc, B, L, H, D, ws, ws_bytes, stream, nullptr, ngroups, r_group_stride);
+}
+
 static int dqr_run(const void* dT, const void* R, int64_t r_row_stride, void* out, int64_t out_row_stride, int64_t out_batch_stride, float* du_acc,
-                   float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream, float* parts_out) {
+                   float* dv_acc, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream, float* parts_out, int ngroups, int64_t r_group_stride) {
     if (!db1_relattn_dqr_supported(B, L, H, D, DB1_BF16)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "relattn_dqr: needs bf16, d_head = 128, L %% 128 == 0, L <= 1024 (got L=%d D=%d)", L, D);
     if (!dT || !R || !out) DB1_FAIL(DB1_ERR_BAD_SHAPE, "relattn_dqr: null buffer");
     if (!db1_aligned16(dT) || !db1_aligned16(out) || (out_row_stride % 4) || (out_batch_stride % 4)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "relattn_dqr: alignment");
     hipStream_t st = (hipStream_t)stream;
-    DB1_NEED_WS(ws, ws_bytes, db1_relattn_dqr_workspace_bytes(L, H), "relattn_dqr");
+    DB1_NEED_WS(ws, ws_bytes, db1_relattn_dqr_groups_workspace_bytes(L, H, ngroups), "relattn_dqr");
     bf16_t* Rt = (bf16_t*)ws;
-    relattn_dqr_transpose_kernel<<<dim3((unsigned)((H * 128 + 31) / 32), (unsigned)((L + 31) / 32)), 256, 0, st>>>((const bf16_t*)R, Rt, L, H * 128, r_row_stride);
+    const int64_t rt_gs = dqr_rt_bytes(L, H) / (int64_t)sizeof(bf16_t);
+    relattn_dqr_transpose_kernel<<<dim3((unsigned)((H * 128 + 31) / 32), (unsigned)((L + 31) / 32), (unsigned)ngroups), 256, 0, st>>>((const bf16_t*)R, Rt, L, H * 128,
+                                                                                                                                   r_row_stride, r_group_stride, rt_gs);
     DB1_CHECK_LAUNCH("relattn_dqr transpose");
     DqrArgs a;
     a.dT = (const bf16_t*)dT; a.Rt = Rt; a.out = (bf16_t*)out; a.B = B; a.L = L; a.H = H;
     a.wph = dqr_wph(H);
     a.o_rs = out_row_stride; a.o_bs = out_batch_stride;
-    a.part = parts_out ? parts_out : (du_acc ? (float*)((char*)ws + dqr_rt_bytes(L, H)) : nullptr);
+    a.ngroups = ngroups; a.rt_gs = rt_gs;
+    a.part = parts_out ? parts_out : (du_acc ? (float*)((char*)ws + (int64_t)ngroups * dqr_rt_bytes(L, H)) : nullptr);
     static Db1PerDeviceOnce attr_once;
     attr_once.run([] { hipFuncSetAttribute((const void*)relattn_dqr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQR_STAGES * DQR_TILE_BYTES); });
     relattn_dqr_kernel<<<dim3((unsigned)(H * a.wph)), 512, DQR_STAGES * DQR_TILE_BYTES, st>>>(a);

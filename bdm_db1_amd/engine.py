@@ -138,7 +138,15 @@ class DB1Engine:
         model.loss_grad_scale = 1.0 / self._ga
         # gradient accumulation with the weight gradients formed ONCE per optimizer step (model.WgradStash: the operands of all micro-steps are
         # kept -- 57 KB per token -- and dW = dy^T x runs over K = ga * T rows on the boundary micro-step): opt-in, `defer_wgrad=True`
-        self.defer_wgrad = bool(g("defer_wgrad", False)) and self._ga > 1
+        # gradient accumulation with ONE backward per optimizer step (model.BackwardWindow): the micro-steps run forward (+ the fused head / loss
+        # sweep, which yields each micro-step's loss and dh) into window-sized activation buffers, `backward(loss)` of the non-boundary micro-steps
+        # only records, and the boundary runs the backward of the whole window as one pass over ga x B sequences -- the reference's loop
+        # (train.py:216-232) needs a loss per micro-step, gradients only at step().  Opt-in, `defer_backward=True`; takes the place of defer_wgrad
+        # (the window's weight gradients are K = ga * T products anyway).  Micro-steps the window cannot hold (fp32, pre-LN, a sliding
+        # window, kept logits) fall back to their own backward.
+        self.defer_backward = bool(g("defer_backward", False)) and self._ga > 1
+        model.bwd_window_ga = self._ga if self.defer_backward else 0
+        self.defer_wgrad = bool(g("defer_wgrad", False)) and self._ga > 1 and not self.defer_backward
         model.wgrad_defer_ga = self._ga if self.defer_wgrad else 0
         self.micro_steps = 0
         self.global_steps = 0
@@ -207,7 +215,7 @@ class DB1Engine:
         per-layer buckets are all-reduced while the backward of the earlier layers is still running."""
         boundary = self.is_gradient_accumulation_boundary()
         hook = self.sync.launch if (boundary and self.overlap_comm and self.dp_world > 1) else None
-        self.module.backward(grad_scale=1.0 / self._ga, layer_done_hook=hook, flush_wgrads=boundary)
+        self.module.backward(grad_scale=1.0 / self._ga, layer_done_hook=hook, flush_wgrads=boundary, window_boundary=boundary)
         return loss
 
     def step(self):

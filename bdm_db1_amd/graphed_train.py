@@ -70,10 +70,20 @@ class GraphedTrainStep:
         self.loss = {}
         # eager warm-up on the static inputs (allocates every workspace / cached table, decides the attention-backward mode), then the
         # accumulators it touched are cleared again
+        self.window = bool(getattr(engine, "defer_backward", False)) and model.bwd_window_ga > 1
+        ga = engine.gradient_accumulation_steps()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(2):
+            if self.window:      # one whole window: allocates the window's buffers (outside any graph pool) and every workspace of the big backward
+                for k in range(ga):
+                    self.step_dev.add_(1)
+                    model._wg_slot = k
+                    _, loss = model(self.static)
+                    model.backward(grad_scale=model.loss_grad_scale, layer_done_hook=None, window_boundary=(k == ga - 1))
+                if model._win is None or model._win.sig is None:
+                    self.window = False      # (this configuration does not take the window: every micro-step keeps its own backward)
+            for _ in range(0 if self.window else 2):
                 self.step_dev.add_(1)
                 model._wg_slot = 0
                 _, loss = model(self.static)
@@ -87,7 +97,25 @@ class GraphedTrainStep:
         # run at the same time), so their intermediate buffers cost what one micro-step costs.
         self.defer = bool(getattr(engine, "defer_wgrad", False)) and model.wgrad_defer_ga > 1
         self.pool = torch.cuda.graph_pool_handle()
-        slots = range(engine.gradient_accumulation_steps()) if self.defer else (0,)
+        self.win_ctx = {}
+        if self.window:
+            # deferred backward: one graph per micro-step of the window, FORWARD only (each writes its own row block of the window's buffers);
+            # the backward of the whole window runs eagerly on the boundary (so the bucket all-reduces of more than one rank start from inside
+            # it as usual).  Every graph has its OWN pool: what a forward leaves for the boundary outside the window's buffers (the embedding
+            # contexts: ids, the image-patch embedder's activations) must survive the replays of the other micro-steps.
+            for slot in range(ga):
+                model._grad_fresh = slot == 0
+                model._wg_slot = slot
+                model._win.n = slot
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.step_dev.add_(1)
+                    _, loss = model(self.static)
+                self.graphs[(slot == 0, slot)], self.loss[(slot == 0, slot)] = g, loss
+                self.win_ctx[slot] = model._win.ctxs[slot]
+                model._ctx = None
+            model._win.ctxs, model._win.n = [None] * ga, 0
+        slots = () if self.window else (range(ga) if self.defer else (0,))
         for slot in slots:
             for fresh in ((True,) if (self.defer and slot == 0) else ((False,) if self.defer else (True, False))):
                 model._grad_fresh = fresh
@@ -131,7 +159,7 @@ class GraphedTrainStep:
                 st.vision_row_ids.copy_(r, non_blocking=True)
                 st.vision_col_ids.copy_(c, non_blocking=True)
         boundary = eng.is_gradient_accumulation_boundary()
-        if eng.dp_world > 1 and boundary:
+        if eng.dp_world > 1 and boundary and not self.window:
             # the bucket all-reduces are launched from inside this backward: eager, on the same device counter
             self.step_dev.add_(1)
             model._wg_slot = eng.micro_steps % eng.gradient_accumulation_steps()
@@ -140,6 +168,23 @@ class GraphedTrainStep:
             model._drop_step += 1      # host mirror of the device counter (what engine.save_checkpoint stores)
             return loss
         fresh = bool(model._grad_fresh)
+        if self.window:
+            slot = eng.micro_steps % eng.gradient_accumulation_steps()
+            key = (slot == 0, slot)
+            win = model._win
+            if key not in self.graphs or win.n != slot or (slot == 0 and not fresh):
+                raise RuntimeError(f"GraphedTrainStep (deferred backward): micro-step {slot} of the window with {win.n} forwards recorded and fresh={fresh}: "
+                                   "the first micro-step of a window must follow an optimizer step (or zero_grad), the others must follow it in order")
+            self.graphs[key].replay()
+            win.ctxs[slot], win.n = self.win_ctx[slot], slot + 1
+            model._drop_step += 1
+            if boundary:
+                hook = eng.sync.launch if (eng.overlap_comm and eng.dp_world > 1) else None
+                with torch.cuda.device(model.dev):
+                    from . import ops
+                    with ops.stream_scope():
+                        model._backward_window(model.loss_grad_scale, hook)
+            return self.loss[key]
         slot = eng.micro_steps % eng.gradient_accumulation_steps() if self.defer else 0
         key = (fresh, slot)
         if key not in self.graphs:

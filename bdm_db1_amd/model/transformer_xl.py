@@ -161,6 +161,45 @@ class WgradStash:
         return self.dy[i][kind][self.slot * self.T:(self.slot + 1) * self.T]
 
 
+class BackwardWindow:
+    """Activations of ALL micro-steps of a gradient-accumulation window, for ONE backward at the window's boundary (engine option
+    ``defer_backward``).  The reference's loop (src/train_utils/train.py:216-232: ``loss = engine(x); engine.backward(loss); engine.step()`` per
+    micro-step) needs a LOSS per micro-step, not a backward per micro-step: gradients are only observable at ``step()``.  So the forwards of a
+    window write what the backward needs into row block [m n0, (m + 1) n0) of window-sized buffers (every kept tensor has its batch / token
+    dimension first), and the boundary runs the backward once over ga x B sequences -- at the reference's 4 x 16 geometry the same launches as
+    the 64-sequence step instead of 16 x (one 256 x 128 tile per CU, per-workgroup fixed costs over 4 sequences).  Memory: what a 64-sequence
+    step keeps (this part's 288 GB hold it; the reference's GPUs did not)."""
+
+    def __init__(self, ga: int):
+        self.ga = int(ga)
+        self.bufs: Dict[tuple, torch.Tensor] = {}
+        self.ctxs: List[Optional["_Ctx"]] = [None] * self.ga
+        self.n = 0               # forwards of the current window recorded so far
+        self.slot = 0            # row block the running forward writes
+        self.sig = None          # (B, L, nd) of the micro-steps in the buffers
+
+    def take(self, model, key: tuple, shape: Tuple[int, ...], dtype) -> torch.Tensor:
+        buf = self.bufs.get(key)
+        n0 = int(shape[0])
+        if buf is None:
+            buf = torch.empty((self.ga * n0,) + tuple(int(x) for x in shape[1:]), device=model.dev, dtype=dtype)
+            self.bufs[key] = buf
+        if buf.shape[0] != self.ga * n0 or tuple(buf.shape[1:]) != tuple(shape[1:]) or buf.dtype != dtype:
+            raise RuntimeError(f"backward window: buffer {key} was built for another shape ({tuple(buf.shape)} vs {self.ga} x {tuple(shape)})")
+        return buf[self.slot * n0:(self.slot + 1) * n0]
+
+    def full(self, key: tuple, n: int) -> torch.Tensor:
+        """rows of the first n micro-steps"""
+        buf = self.bufs[key]
+        return buf[:n * (buf.shape[0] // self.ga)]
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+    def reset(self):
+        self.bufs, self.ctxs, self.n, self.slot, self.sig = {}, [None] * self.ga, 0, 0, None
+
+
 class _PendingLN(SimpleNamespace):
     """a layer output whose closing residual LayerNorm has not been applied yet: LN(alpha * res + y) * gamma + beta (inference path)"""
 
@@ -256,6 +295,12 @@ class TransformerXL(nn.Module):
         self.wgrad_stash: Optional[WgradStash] = None   # gradient accumulation: weight gradients formed once per optimizer step (engine option defer_wgrad)
         self.wgrad_defer_ga = 0          # > 1: training forwards stash the weight-gradient operands of this many micro-steps (set by the engine)
         self._wg_slot = 0                # micro-step index inside the accumulation window (set by the engine before every forward)
+        # > 1: training forwards keep their activations in window-sized buffers and the backward of the whole window runs ONCE, on the boundary
+        # micro-step (BackwardWindow; set by the engine, option defer_backward)
+        self.bwd_window_ga = 0
+        self._win: Optional[BackwardWindow] = None
+        self._win_on = False             # the running forward writes into the window
+        self._drop_rps = 0               # window backward: rows per micro-step of the tensors the LayerNorm backward regenerates dropout for
         # the attention input projection against a transposed weight copy (NN form of the 4-wave kernel).  OPT-IN: alone and back to back the NN
         # form is 8 % faster at this shape (1190 vs 1300 us), inside the training step the two are equal (same box: 420.6 vs 419.6 ms per
         # step, profiles/r05_nt_vs_nn.txt) -- a GEMM's isolated speed is not its speed under the step's power / clock state
@@ -416,10 +461,18 @@ class TransformerXL(nn.Module):
         """(p, seed, site, step[, device step counter]) of one dropout site, or ops.NO_DROP outside training / at p = 0"""
         if step is None or p <= 0.0:
             return ops.NO_DROP
+        if self._drop_rps:     # (the backward of a whole accumulation window: row r of the tensor belongs to step + r // rows_per_step)
+            return (p, self.dropout_seed, site, step, self._drop_step_dev, self._drop_rps)
         return (p, self.dropout_seed, site, step, self._drop_step_dev) if self._drop_step_dev is not None else (p, self.dropout_seed, site, step)
 
     def _new(self, *shape, dtype=None):
         return torch.empty(*shape, device=self.dev, dtype=self.compute_dtype if dtype is None else dtype)
+
+    def _keep(self, key: tuple, *shape, dtype=None):
+        """a tensor the backward will read: this micro-step's row block of the accumulation window's buffer (BackwardWindow), or a fresh tensor"""
+        if self._win_on:
+            return self._win.take(self, key, shape, self.compute_dtype if dtype is None else dtype)
+        return self._new(*shape, dtype=dtype)
 
     def _probs_mode(self, B: int, L: int) -> str:
         """flash_probs_mode, demoted from "forward" to "scratch" when keeping B*H*L*L bf16 (+ L/32 floats per row) for every layer would
@@ -466,7 +519,10 @@ class TransformerXL(nn.Module):
     def _dev_ids(self, t) -> torch.Tensor:
         if not torch.is_tensor(t):
             t = torch.as_tensor(np.asarray(t))
-        return t.to(device=self.dev, dtype=torch.int64).contiguous()
+        r = t.to(device=self.dev, dtype=torch.int64).contiguous()
+        if self.bwd_window_ga > 1 and self.training and r.data_ptr() == t.data_ptr():
+            r = r.clone()    # (deferred backward: the ids are read at the window's boundary -- the caller may have refilled its tensor by then)
+        return r
 
     # ------------------------------------------------------------------ vision encoder (vision_embedding.py:65-180)
     def _vision_position_ids(self, h0: int, w0: int, n_img: int):
@@ -887,13 +943,13 @@ class TransformerXL(nn.Module):
             if quv is not None:  # written by the projection's epilogue (db1_gemm_nt_headbias)
                 qu, qv = quv
             else:
-                qu, qv = self._new(B, Lq, H, D), self._new(B, Lq, H, D)
+                qu, qv = self._keep(("qu", i), B, Lq, H, D), self._keep(("qv", i), B, Lq, H, D)
                 ops.relattn_add_head_bias(qkv, u, vb, qu, qv, B, Lq, Lk, H, D)
-            lse = self._new(B, H, Lq, dtype=torch.float32)
+            lse = self._keep(("lse", i), B, H, Lq, dtype=torch.float32)
             probs = mblk = None
-            if c is not None and self.use_flash_bwd and self._probs_mode(B, Lq) == "forward":
-                probs = self._new(B * H, Lq // 32, Lq // 16, 512)
-                mblk = self._new(B * H, Lq // 32, Lq, dtype=torch.float32)
+            if c is not None and self.use_flash_bwd and self._probs_mode(B * (self.bwd_window_ga if self._win_on else 1), Lq) == "forward":
+                probs = self._keep(("probs", i), B * H, Lq // 32, Lq // 16, 512)
+                mblk = self._keep(("mblk", i), B * H, Lq // 32, Lq, dtype=torch.float32)
             ops.relattn_flash_fwd(qu, qv, qkv.view(B, Lk, 3, H, D), R, av, lse, B, Lq, H, D, shift, 1.0 / math.sqrt(D), probs=probs, mblk=mblk)
             if c is not None:
                 c.lse, c.qu, c.qv, c.probs, c.mblk = lse, qu, qv, probs, mblk
@@ -999,6 +1055,9 @@ class TransformerXL(nn.Module):
         u, vb = self._bias("r_w_bias", i), self._bias("r_r_bias", i)
         qkv, R = c.qkv, c.R
         nd = R.shape[0]
+        # deferred backward over an accumulation window: the batch is ng blocks of B / ng sequences (micro-steps), each with its own R
+        Rg = getattr(c, "Rg", None)
+        ng = 1 if Rg is None else int(Rg.shape[0])
         scale = 1.0 / math.sqrt(D)
         dqkv = self._new(B * L, 3 * d) if dqkv_out is None else dqkv_out
         dqkv5 = dqkv.view(B, L, 3, H, D)
@@ -1043,18 +1102,28 @@ class TransformerXL(nn.Module):
         if fused_dq:
             # dq_r streamed out of dT once, added onto dq_k in the same kernel's epilogue together with the u / v gradients' column sums
             if uv_parts is not None:      # (gradient accumulation: the two column-sum reduces happen once per optimizer step, WgradStash.alloc_parts)
+                assert ng == 1
                 ops.relattn_dqr_fused_parts(dT, R, dqkv5[:, :, 0], uv_parts)
+            elif ng > 1:
+                ops.relattn_dqr_fused_groups(dT, Rg, dqkv5[:, :, 0], self._bias_grad("r_w_bias", i).view(-1), self._bias_grad("r_r_bias", i).view(-1))
             else:
                 ops.relattn_dqr_fused(dT, R, dqkv5[:, :, 0], self._bias_grad("r_w_bias", i).view(-1), self._bias_grad("r_r_bias", i).view(-1))
         else:
-            if uv_parts is not None:
-                raise RuntimeError("the partial-sum stash was planned for the dq_r stream kernel, which this backward did not take")
+            if uv_parts is not None or ng > 1:
+                raise RuntimeError("the partial-sum stash / the deferred backward were planned for the dq_r stream kernel, which this backward did not take")
             dqv = self._new(B, L, H, D)
             ops.gemm_batched(dT, R.view(nd, H, D).permute(1, 0, 2).unsqueeze(1).expand(H, B, nd, D), dqv.permute(2, 0, 1, 3),
                              tri=(1, 0) if tri else (0, 0))                                                               # dq_r
-        dR = self._new(nd, d) if dR_out is None else dR_out
-        ops.gemm_batched(dT.view(H, B * L, nd).transpose(1, 2).unsqueeze(1), qv.view(B * L, H, D).permute(1, 0, 2).unsqueeze(1),
-                         dR.view(nd, H, D).permute(1, 0, 2).unsqueeze(1), tri=(2, L) if tri else (0, 0))
+        if ng > 1:       # dR of every micro-step: the same batched product with (head, micro-step) as the two batch dimensions
+            assert dR_out is None and nd == L
+            Bm = B // ng
+            dR = self._new(ng * nd, d)
+            ops.gemm_batched(dT.view(H, ng, Bm * L, nd).transpose(2, 3), qv.view(ng, Bm * L, H, D).permute(2, 0, 1, 3),
+                             dR.view(ng, nd, H, D).permute(2, 0, 1, 3), tri=(2, L) if tri else (0, 0))
+        else:
+            dR = self._new(nd, d) if dR_out is None else dR_out
+            ops.gemm_batched(dT.view(H, B * L, nd).transpose(1, 2).unsqueeze(1), qv.view(B * L, H, D).permute(1, 0, 2).unsqueeze(1),
+                             dR.view(nd, H, D).permute(1, 0, 2).unsqueeze(1), tri=(2, L) if tri else (0, 0))
         if not fused_dq:
             # dq = dq_k + dq_r, du = colsum(dq_k), dv_bias = colsum(dq_r): one pass over the two matrices
             ops.add2d_colsums(dqv.view(B * L, d), dq2d, dq2d, self._bias_grad("r_r_bias", i).view(-1), self._bias_grad("r_w_bias", i).view(-1))
@@ -1072,6 +1141,12 @@ class TransformerXL(nn.Module):
             sx = st.xs(i, "qkv")
             sx.copy_(x)
             x = sx
+        win = self._win_on and dec is None and mem is None       # deferred backward: everything the backward reads goes to the window's buffers (_keep)
+        if win:
+            wx = self._keep(("x", i), T, d)
+            if x.data_ptr() != wx.data_ptr():                    # (layer 0: the embedding output; later layers were written there directly)
+                wx.copy_(x)
+                x = wx
         if dec is not None:  # K/V-cached inference: only the new tokens are projected (identical maths: qkv_net has no bias)
             qkv = self._new(T, 3 * d)
             if pend is not None:   # the previous layer left its closing LayerNorm to this projection, which also stores the rows to x
@@ -1088,14 +1163,14 @@ class TransformerXL(nn.Module):
                 xin = cat.view(B * Lk, d)
             else:
                 Lk, xin = L, x
-            qkv = self._new(B * Lk, 3 * d)
+            qkv = self._keep(("qkv", i), B * Lk, 3 * d) if win else self._new(B * Lk, 3 * d)
             quv = None
             Wqkv = self.W(p + "dec_attn.qkv_net.weight")
             if (mem is None and shift >= 1 and self.use_flash and self.use_flash_bwd and self.compute_dtype == torch.bfloat16 and
                     not (self.dropattn > 0 and dstep is not None) and self.use_headbias_epilogue and ops.relattn_flash_supported(B, L, self.n_head, self.d_head, self.compute_dtype) and
                     ops.gemm_nt_headbias_supported(T, 3 * d, d, d)):
                 # q + r_w_bias and q + r_r_bias leave the projection's accumulators directly (the q columns of qkv stay unwritten)
-                quv = (self._new(B, L, self.n_head, self.d_head), self._new(B, L, self.n_head, self.d_head))
+                quv = (self._keep(("qu", i), B, L, self.n_head, self.d_head), self._keep(("qv", i), B, L, self.n_head, self.d_head))
                 if self.use_qkv_nn and ops.gemm_nn_headbias_supported(T, 3 * d, d, d):
                     # against the weight's transposed copy (one per weight version, refreshed behind the optimizer step): the NN form of the
                     # 4-wave kernel is 8 % faster at this shape (N = 6144), the only forward projection where the two forms differ
@@ -1107,9 +1182,10 @@ class TransformerXL(nn.Module):
             if self._R_all is not None:      # r_net of all layers as one batched product at the start of the forward (_rnet_all)
                 R = self._R_all[self.n_layer - 1 - i]
             else:
-                R = self._new(R_in.shape[0], d)
+                R = self._keep(("R", i), R_in.shape[0], d) if win else self._new(R_in.shape[0], d)
                 ops.gemm(R_in, self.W(p + "dec_attn.r_net.weight").t(), R)
-            av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c, quv=quv, dstep=dstep, av_out=None if st is None else st.xs(i, "o"))
+            av = self._attention_fwd(qkv, R, i, B, L, Lk, mlen, shift, c, quv=quv, dstep=dstep,
+                                     av_out=st.xs(i, "o") if st is not None else (self._keep(("av", i), T, d) if win else None))
         if dec is not None and self._decode_fused_ok(T, keep, dstep):
             # few new tokens: every launch is latency, so the linear maps do the layer's small follow-up work themselves (db1_linear_decode):
             # GEGLU in the epilogue, and the residual LayerNorms either on the way IN to the next linear map (<= 16 tokens: no launch, no
@@ -1138,18 +1214,22 @@ class TransformerXL(nn.Module):
             ops.linear_decode(act, self.W(p + "pos_ff.CoreNet.2.weight"), self.W(p + "pos_ff.CoreNet.2.bias"), f)
             ops.layernorm_residual_fwd(h1, f, a, g2, b2, out, None, stat(), stat(), eps)
             return out, None
-        o = self._new(T, d)
+        o = self._keep(("s1", i), T, d)
         ops.gemm(av.view(T, d), self.W(p + "dec_attn.o_net.weight").t(), o)
-        h1 = self._new(T, d) if st is None else st.xs(i, "ff1")
-        m1, r1 = self._new(T, dtype=torch.float32), self._new(T, dtype=torch.float32)
+        h1 = self._keep(("h1", i), T, d) if st is None else st.xs(i, "ff1")
+        m1, r1 = self._keep(("m1", i), T, dtype=torch.float32), self._keep(("r1", i), T, dtype=torch.float32)
         ops.layernorm_residual_fwd(x, o, a, self.W(p + "dec_attn.layer_norm.weight"), self.W(p + "dec_attn.layer_norm.bias"),
                                    h1, o if keep else None, m1, r1, self.layer_norm_epsilon,
                                    drop=self._drop_args(self.drop_p, 4 * i, dstep))  # s1 = a x + dropout(o) overwrites o
-        z, act = self._ff1_fwd(h1, p, T, act=None if st is None else st.xs(i, "ff2"), keep=keep)
-        f = self._new(T, d)
+        z, act = self._ff1_fwd(h1, p, T, act=st.xs(i, "ff2") if st is not None else (self._keep(("act", i), T, dff) if win else None), keep=keep,
+                               z=self._keep(("z", i), T, di) if win else None)
+        f = self._keep(("s2", i), T, d)
         ops.gemm(act, self.W(p + "pos_ff.CoreNet.2.weight").t(), f, bias=self.W(p + "pos_ff.CoreNet.2.bias"))
-        out = self._new(T, d) if (st is None or i + 1 >= self.n_layer) else st.xs(i + 1, "qkv")   # the next layer's input, where its weight gradient will look for it
-        m2, r2 = self._new(T, dtype=torch.float32), self._new(T, dtype=torch.float32)
+        if st is not None and i + 1 < self.n_layer:
+            out = st.xs(i + 1, "qkv")                 # the next layer's input, where its weight gradient will look for it
+        else:
+            out = self._keep(("x", i + 1), T, d) if (win and i + 1 < self.n_layer) else self._new(T, d)
+        m2, r2 = self._keep(("m2", i), T, dtype=torch.float32), self._keep(("r2", i), T, dtype=torch.float32)
         ops.layernorm_residual_fwd(h1, f, a, self.W(p + "pos_ff.layer_norm.weight"), self.W(p + "pos_ff.layer_norm.bias"),
                                    out, f if keep else None, m2, r2, self.layer_norm_epsilon,
                                    drop=self._drop_args(self.drop_p, 4 * i + 1, dstep))
@@ -1179,7 +1259,7 @@ class TransformerXL(nn.Module):
             return None
         W = torch.as_strided(self.arena.work, (n, 1, d, d), (stride, 0, 1, d), offs[n - 1])      # [layer n-1-j][k][n] = W_j[n][k]
         nd = R_in.shape[0]
-        out = self._new(n, 1, nd, d)
+        out = self._keep(("Rall",), n, 1, nd, d)
         ops.gemm_batched(R_in.view(1, 1, nd, d).expand(n, 1, nd, d), W, out)
         return out.view(n, nd, d)
 
@@ -1208,10 +1288,10 @@ class TransformerXL(nn.Module):
 
     # ---- PositionwiseFF halves with the activation inside the GEMM where the shape allows (db1_gemm_nt_geglu / db1_gemm_nn_geglu_bwd: the
     # "bias + GEGLU" epilogue of SURVEY 8b; otherwise the same arithmetic as separate launches)
-    def _ff1_fwd(self, x, p, T, act=None, keep=False):
+    def _ff1_fwd(self, x, p, T, act=None, keep=False, z=None):
         """z = x W1^T + b1, act = GEGLU(z)  (transformer_xl.py:264-266, activations.py:19-32)"""
         d, di, dff = self.d_model, self.d_inner, self.d_ff
-        z = self._new(T, di)
+        z = self._new(T, di) if z is None else z
         act = self._new(T, dff) if act is None else act
         W1, b1 = self.W(p + "pos_ff.CoreNet.0.weight"), self.W(p + "pos_ff.CoreNet.0.bias")
         if keep and self._geglu_saved_ok(T):
@@ -1501,12 +1581,15 @@ class TransformerXL(nn.Module):
             ops.dropout(R_in, R_drop, self._drop_args(self.embd_pdrop, self.SITE_POS, dstep))
             R_in = R_drop
         x = h.view(B * L, d)
+        self._win_on = False
+        if self.bwd_window_ga > 1 and keep and self.training and mems is None and ring is None:
+            R_in = self._window_begin(B, L, shift, R_in, dstep)      # (deferred backward: this micro-step's position table joins the window's)
         if (ring is not None and B * L == 1 and self.use_decode_chain and getattr(dec, "partials", False) and self.activation_fn == "geglu" and self.n_layer >= 2 and
                 ops.decode_chain_supported(d, self.d_ff, self.n_head, self.d_head, mlen + L)):
             x = self._decode_chain_layers(x, mlen, shift, dec)
             hids, lcs = [], []
             return self._finish_forward(x, hids, lcs, [], [], [], [], R_in, B, L, shift, dstep, keep, compute_loss, mems, ring, dec, mlen)
-        if self.wgrad_defer_ga > 1 and keep and self.training and not self.pre_lnorm and mems is None:
+        if self.wgrad_defer_ga > 1 and keep and self.training and not self.pre_lnorm and mems is None and not self._win_on:
             st = self.wgrad_stash
             if not 0 <= self._wg_slot < self.wgrad_defer_ga:
                 raise RuntimeError(f"weight-gradient stash: micro-step {self._wg_slot} of an accumulation window of {self.wgrad_defer_ga}")
@@ -1545,7 +1628,46 @@ class TransformerXL(nn.Module):
             x, c = layer_fwd(i, x, R_in, B, L, mlen, shift, None if mems is None else mems[i], keep, dec, dstep, **kw)
             lcs.append(c)
         self._R_all = None       # (the layers' contexts hold their slices)
-        return self._finish_forward(x, hids, lcs, ecs, shapes, labels, masks, R_in, B, L, shift, dstep, keep, compute_loss, mems, ring, dec, mlen)
+        try:
+            return self._finish_forward(x, hids, lcs, ecs, shapes, labels, masks, R_in, B, L, shift, dstep, keep, compute_loss, mems, ring, dec, mlen)
+        finally:
+            self._win_on = False
+
+    # ---- deferred backward (BackwardWindow): the forwards of an accumulation window write into window-sized buffers, ONE backward at its boundary
+    def _window_ok(self, B: int, L: int, shift: int, nd: int) -> bool:
+        ga, H, D, dt = self.bwd_window_ga, self.n_head, self.d_head, self.compute_dtype
+        return (not self.pre_lnorm and dt == torch.bfloat16 and self.use_flash and self.use_flash_bwd and self.dropattn == 0 and self.fuse_head_loss and
+                not self.keep_logits and self.activation_fn == "geglu" and shift >= L and nd == L and
+                ops.relattn_flash_supported(B, L, H, D, dt) and ops.relattn_dqr_groups_supported(ga * B, L, H, D, dt, ga) and
+                self._probs_mode(ga * B, L) == "forward")
+
+    def _window_begin(self, B: int, L: int, shift: int, R_in: torch.Tensor, dstep):
+        """called by a training forward when the engine defers the backward: joins the window (and returns the position table's copy inside it)
+        or, when this micro-step cannot (another shape, an unsupported configuration), first runs the backward of what the window holds"""
+        win = self._win
+        if win is None or win.ga != self.bwd_window_ga:
+            win = self._win = BackwardWindow(self.bwd_window_ga)
+        nd = int(R_in.shape[0])
+        sig = (B, L, nd)
+        ok = self._window_ok(B, L, shift, nd)
+        if win.n > 0 and (not ok or win.sig != sig or win.n >= win.ga):
+            # a micro-step that does not fit the window in flight (a short last batch, another task mix): the window's gradients are formed
+            # now, over the micro-steps it holds, and this one starts over
+            self._backward_window(self.loss_grad_scale, None)
+        if not ok:
+            return R_in
+        if win.sig != sig:
+            win.reset()
+            win.sig = sig
+        if win.n > 0:
+            c0 = win.ctxs[0]
+            if (c0.dstep is None) != (dstep is None) or (dstep is not None and self._drop_step_dev is None and dstep != c0.dstep + win.n):
+                raise RuntimeError("deferred backward: the dropout steps of an accumulation window must be consecutive")
+        win.slot = win.n
+        self._win_on = True
+        rows = self._keep(("rin",), nd, self.d_model)
+        rows.copy_(R_in)
+        return rows
 
     def _decode_chain_layers(self, x, mlen, shift, dec):
         """ONE new token over the K / V ring: per layer the attention launch (chunk partials) and ONE persistent launch for everything between
@@ -1628,13 +1750,20 @@ class TransformerXL(nn.Module):
             # loss, dh and the head's weight gradient in one sweep: the logits only ever exist 16 384 rows at a time (in the workspace)
             wname = "word_embedding.weight" if self.share_input_output_embedding else "lm_head.weight"
             gW = self.arena.view(self.arena.grad, wname, full=True).view(self.vocab_pad, d)
-            dh = self._new(T, d)
-            ops.lmhead_ce(x, Wout, lab, msk, lse, sums, V, dh=dh, dW_acc=gW, beta_dw=0.0 if self._grad_fresh else 1.0, gscale=self.loss_grad_scale,
+            dh = self._keep(("dh",), T, d)
+            # (deferred backward: the head's weight gradient of the window's first micro-step writes, the later ones accumulate -- no backward in between)
+            first_writer = self._grad_fresh and not (self._win_on and self._win.slot > 0)
+            ops.lmhead_ce(x, Wout, lab, msk, lse, sums, V, dh=dh, dW_acc=gW, beta_dw=0.0 if first_writer else 1.0, gscale=self.loss_grad_scale,
                           chunk_rows=self.head_chunk_rows)
             loss = sums[0] / sums[1]
             ctx = _Ctx()
             ctx.ecs, ctx.shapes, ctx.lcs, ctx.R_in, ctx.dh_head = ecs, shapes, lcs, R_in, dh
             ctx.B, ctx.L, ctx.shift, ctx.dstep, ctx.fused_scale = B, L, shift, dstep, self.loss_grad_scale
+            ctx.win = self._win_on
+            if self._win_on:       # the layers' tensors live in the window's buffers: the per-micro-step contexts are not needed
+                ctx.lcs = None
+                self._win.ctxs[self._win.slot] = ctx
+                self._win.n = self._win.slot + 1
             self._ctx = ctx
         else:
             logits_pad = self._new(T, self.vocab_pad)
@@ -1670,14 +1799,82 @@ class TransformerXL(nn.Module):
             res = res + (new_mems,)
         return res
 
-    def backward(self, grad_scale: float = 1.0, layer_done_hook=None, flush_wgrads: bool = True):
+    def backward(self, grad_scale: float = 1.0, layer_done_hook=None, flush_wgrads: bool = True, window_boundary: bool = True):
         """Accumulate d(loss * grad_scale)/d(params) of the last forward into the gradient arena.
         ``layer_done_hook(name)`` fires as soon as a layer's gradients are final (used by the data-parallel
         engine to start that layer's bucket all-reduce while earlier layers are still in backward).
         ``flush_wgrads`` (only with a ``wgrad_stash``): form the stashed weight gradients in this backward (the last micro-step of an
-        accumulation window); False on the other micro-steps."""
+        accumulation window); False on the other micro-steps.
+        ``window_boundary`` (only after forwards that joined a BackwardWindow, engine option defer_backward): False = nothing to do yet, the
+        activations stay in the window; True = the backward of every micro-step the window holds, as one pass."""
         with torch.cuda.device(self.dev), ops.stream_scope():
+            ctx = self._ctx
+            if ctx is not None and getattr(ctx, "win", False):
+                self._ctx = None
+                if abs(grad_scale - ctx.fused_scale) > 1e-12 * max(1.0, abs(grad_scale)):
+                    raise RuntimeError(f"backward(grad_scale={grad_scale}) after a fused head sweep taken at loss_grad_scale={ctx.fused_scale}")
+                if window_boundary:
+                    self._backward_window(grad_scale, layer_done_hook)
+                return None
             return self._backward(grad_scale, layer_done_hook, flush_wgrads)
+
+    def _window_layer_ctx(self, i: int, n: int, B: int, L: int) -> _Ctx:
+        win, H, D = self._win, self.n_head, self.d_head
+        f = lambda k: win.full((k, i), n)
+        c = _Ctx()
+        c.x, c.qkv, c.av, c.s1, c.m1, c.r1 = f("x"), f("qkv"), f("av").view(B, L, H, D), f("s1"), f("m1"), f("r1")
+        c.h1, c.z, c.act, c.s2, c.m2, c.r2 = f("h1"), f("z"), f("act"), f("s2"), f("m2"), f("r2")
+        c.lse, c.qu, c.qv, c.probs, c.mblk, c.flash = f("lse"), f("qu"), f("qv"), f("probs"), f("mblk"), True
+        if ("Rall",) in win.bufs:      # r_net of all layers in one launch per micro-step: [n micro-steps, layer (last first), nd, d]
+            nl = self.n_layer
+            ra = win.full(("Rall",), n)
+            c.Rg = ra.view(n, nl, ra.shape[-2], ra.shape[-1])[:, nl - 1 - i]
+        else:
+            r = f("R")
+            c.Rg = r.view(n, r.shape[0] // n, r.shape[1])
+        c.R = c.Rg[0]
+        return c
+
+    def _backward_window(self, grad_scale, layer_done_hook):
+        """the backward of the n micro-steps a BackwardWindow holds, as ONE pass over n x B sequences (same kernels as a single micro-step of
+        that size; per-micro-step: the dropout steps -- by row block inside the LayerNorm backward --, the relative-position tables R of the
+        dq_r stream and dR, and the embedding backward)"""
+        win = self._win
+        n = 0 if win is None else win.n
+        if n == 0:
+            return
+        ctxs = win.ctxs[:n]
+        c0 = ctxs[0]
+        if any(abs(c.fused_scale - grad_scale) > 1e-12 * max(1.0, abs(grad_scale)) for c in ctxs):
+            raise RuntimeError("deferred backward: the micro-steps of the window were taken at different loss scales")
+        self._ctx = None
+        self._gb = 0.0 if self._grad_fresh else 1.0
+        self._grad_fresh = False
+        d = self.d_model
+        Bm, L = c0.B, c0.L
+        T, B = Bm * L, n * Bm
+        # dropout step of the window's first micro-step: the host counter's value then, or -- under a captured forward, whose step is the device
+        # counter's value at replay -- the distance back from the counter's current value (the window's last forward bumped it last)
+        step0 = None if c0.dstep is None else (-(n - 1) if self._drop_step_dev is not None else c0.dstep)
+        dh = win.full(("dh",), n)
+        R_in = win.full(("rin",), n)
+        try:
+            self._drop_rps = T
+            for i in reversed(range(self.n_layer)):
+                dh = self._layer_bwd(i, dh, self._window_layer_ctx(i, n, B, L), R_in, B, L, c0.shift, step0, flush=False)
+                if layer_done_hook is not None:
+                    layer_done_hook(f"h.{i}")
+        finally:
+            self._drop_rps = 0
+        for m, c in enumerate(ctxs):
+            dhm = dh[m * T:(m + 1) * T]
+            if step0 is not None and self.embd_pdrop > 0:   # gradient through the embedding dropout: that micro-step's keep decisions
+                ops.dropout(dhm, dhm, self._drop_args(self.embd_pdrop, self.SITE_EMBED, step0 + m))
+            self._embed_bwd(dhm.view(Bm, L, d), c.ecs, c.shapes)
+        if layer_done_hook is not None:
+            layer_done_hook("embeddings")
+        win.ctxs = [None] * win.ga
+        win.n = 0
 
     def _backward(self, grad_scale, layer_done_hook, flush_wgrads=True):
         ctx = self._ctx
@@ -1724,6 +1921,8 @@ class TransformerXL(nn.Module):
         self.arena.grad.zero_()
         self._grad_fresh = True
         self._ctx = None
+        if self._win is not None:       # (forwards recorded for a deferred backward are dropped with the gradients)
+            self._win.ctxs, self._win.n = [None] * self._win.ga, 0
 
     def gemm_first_grads(self) -> List[str]:
         """parameters whose gradient's FIRST writer in a backward is a GEMM (which can write with beta = 0): the five weight matrices of

@@ -288,17 +288,26 @@ def relattn_dqr(dT, R, dqv):
            lambda: lib.call("db1_relattn_dqr", P(dT), P(R), R.stride(0), P(dqv), dqv.stride(1), dqv.stride(0), B, L, H, D, ws, wsn, stream()))
 
 
-NO_DROP = (0.0, 0, 0, 0)   # (p, seed, site, step[, device step counter: the step used is step + *counter, read when the kernel runs])
+NO_DROP = (0.0, 0, 0, 0)   # (p, seed, site, step[, device step counter: the step used is step + *counter, read when the kernel runs[, rows per step]])
 
 
 def _drop_dev(drop):
     return P(drop[4]) if len(drop) > 4 and drop[4] is not None else _vp(0)
 
 
+def _drop_step(drop) -> int:
+    return int(drop[3]) & 0xFFFFFFFF     # (a window backward passes first-step offsets below zero on top of a device counter: modulo 2^32 like the kernel's add)
+
+
+def _drop_rps(drop) -> int:
+    """rows per micro-step when the rows are a whole accumulation window's (db1_layernorm_residual_bwd: drop_rows_per_step), else 0"""
+    return int(drop[5]) if len(drop) > 5 and drop[5] else 0
+
+
 def dropout(x, y, drop):
     """y = dropout(x) with the counter-based keep decisions of ``drop = (p, seed, site, step)`` (y may alias x; also its own backward)"""
     p, seed, site, step = drop[:4]
-    lib.call("db1_dropout", P(x), P(y), x.numel(), float(p), int(seed), int(site), int(step), _drop_dev(drop), dt_code(x), stream())
+    lib.call("db1_dropout", P(x), P(y), x.numel(), float(p), int(seed), int(site), _drop_step(drop), _drop_dev(drop), dt_code(x), stream())
 
 
 def relattn_dqr_fused(dT, R, dq, du_acc, dv_acc):
@@ -312,6 +321,24 @@ def relattn_dqr_fused(dT, R, dq, du_acc, dv_acc):
     # algorithmic bytes: the causal half of dT read once, dq read and written
     _timed("relattn_dqr", 2.0 * (H * B * L * (L + 1) / 2 + 2 * dq.numel()),
            lambda: lib.call("db1_relattn_dqr_fused", P(dT), P(R), R.stride(0), P(dq), dq.stride(1), dq.stride(0), P(du_acc), P(dv_acc),
+                            B, L, H, D, ws, wsn, stream()))
+
+
+def relattn_dqr_groups_supported(B, L, H, D, dtype, ngroups) -> bool:
+    return bool(lib.load().db1_relattn_dqr_groups_supported(B, L, H, D, dt_code(dtype), int(ngroups)))
+
+
+def relattn_dqr_fused_groups(dT, Rg, dq, du_acc, dv_acc):
+    """relattn_dqr_fused over a batch of ng = Rg.shape[0] blocks of B / ng sequences, block g with its own R = Rg[g] ([ng, L, H*D] view: a
+    whole accumulation window's attention backward in one launch)"""
+    H, B, L, _ = dT.shape
+    D = dq.shape[-1]
+    ng = Rg.shape[0]
+    assert dT.is_contiguous() and Rg.dim() == 3 and Rg.stride(2) == 1 and dq.stride(3) == 1 and dq.stride(2) == D and dq.shape == (B, L, H, D)
+    assert du_acc.dtype == torch.float32 and dv_acc.dtype == torch.float32 and du_acc.numel() == H * D == dv_acc.numel()
+    ws, wsn = _ws("db1_relattn_dqr_groups_workspace_bytes", (L, H, ng), dT.device)
+    _timed("relattn_dqr", 2.0 * (H * B * L * (L + 1) / 2 + 2 * dq.numel()),
+           lambda: lib.call("db1_relattn_dqr_fused_groups", P(dT), P(Rg), Rg.stride(1), Rg.stride(0), ng, P(dq), dq.stride(1), dq.stride(0), P(du_acc), P(dv_acc),
                             B, L, H, D, ws, wsn, stream()))
 
 
@@ -345,7 +372,8 @@ def layernorm_residual_bwd(dy, s, gamma, mean, rstd, ds, dgamma_acc, dbeta_acc, 
     ws, wsn = _ws("db1_layernorm_residual_bwd_workspace_bytes", (rows, d, dt_code(dy)), dy.device)
     _timed("layernorm_bwd", float(rows * d * dy.element_size() * (3 + (dr_out is not None))),   # dy, s in; ds [, dr] out
            lambda: lib.call("db1_layernorm_residual_bwd", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dr_out), P(dgamma_acc), P(dbeta_acc),
-                            rows, d, float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), _drop_dev(drop), dt_code(dy), dt_code(gamma), ws, wsn, stream()))
+                            rows, d, float(drop[0]), int(drop[1]), int(drop[2]), _drop_step(drop), _drop_dev(drop), _drop_rps(drop), dt_code(dy), dt_code(gamma),
+                            ws, wsn, stream()))
 
 
 def layernorm_bwd_parts_numel(rows: int, d: int, dtype) -> int:
@@ -359,7 +387,8 @@ def layernorm_residual_bwd_parts(dy, s, gamma, mean, rstd, ds, parts, dr_out=Non
     assert parts.dtype == torch.float32 and parts.is_contiguous()
     _timed("layernorm_bwd", float(rows * d * dy.element_size() * (3 + (dr_out is not None))),
            lambda: lib.call("db1_layernorm_residual_bwd_parts", P(dy), P(s), P(gamma), P(mean), P(rstd), P(ds), P(dr_out), P(parts), parts.numel() * 4,
-                            rows, d, float(drop[0]), int(drop[1]), int(drop[2]), int(drop[3]), _drop_dev(drop), dt_code(dy), dt_code(gamma), stream()))
+                            rows, d, float(drop[0]), int(drop[1]), int(drop[2]), _drop_step(drop), _drop_dev(drop), _drop_rps(drop), dt_code(dy), dt_code(gamma),
+                            stream()))
 
 
 def ffn_act_fwd(z, out, act: str):

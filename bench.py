@@ -348,11 +348,14 @@ def workload_leg(engine, model, dev, cfg, B, L, seed, workload: str, world: int 
         return {"tokens_per_s": None, "error": repr(e)}
 
 
-def ga16_leg(model, dev, cfg, L, seed, micro_batch: int = 4, ga: int = 16, steps: int = 3, warmup: int = 1):
+def ga16_leg(model, dev, cfg, L, seed, micro_batch: int = 4, ga: int = 16, steps: int = 3, warmup: int = 1, mode: str = "backward"):
     """The reference's OWN batch geometry (scripts/evaluate/evaluate_rl_1.2B.sh:28-42; train.py:216-232): micro-batch 4 x gradient
-    accumulation 16 = 64 sequences per optimizer step on this GPU, on the same model: every micro-step's forward + backward is a hipGraph
-    replay (GraphedTrainStep), the weight gradients are formed once per optimizer step from the stashed operands of the 16 micro-steps
-    (WgradStash), then clip + Adam.  One timed step = one OPTIMIZER step (16 micro-steps); ``steps`` of them after ``warmup``."""
+    accumulation 16 = 64 sequences per optimizer step on this GPU, on the same model.  ``mode`` "backward" (default): every micro-step's
+    FORWARD (+ the fused head / loss sweep: its loss and dh) is a hipGraph replay into the accumulation window's activation buffers and the
+    backward of all 16 micro-steps runs ONCE, on the boundary, as one pass over 64 sequences (engine option defer_backward,
+    model.BackwardWindow); "wgrad" (round 4 / 5): forward + backward per micro-step as a replay, only the weight gradients once per
+    optimizer step from the stashed operands (WgradStash).  Then clip + Adam.  One timed step = one OPTIMIZER step (16 micro-steps);
+    ``steps`` of them after ``warmup``."""
     from types import SimpleNamespace
     from bdm_db1_amd import GraphedTrainStep, initialize, synth
     gstep = None
@@ -361,11 +364,13 @@ def ga16_leg(model, dev, cfg, L, seed, micro_batch: int = 4, ga: int = 16, steps
         model.wgrad_stash = None
         torch.cuda.empty_cache()
         eargs = SimpleNamespace(lr=1e-4, weight_decay=0.01, clip_grad=1.0, optimizer="adam", keep_logits=False, fuse_head_loss=True,
-                                gradient_accumulation_steps=ga, defer_wgrad=True)
+                                gradient_accumulation_steps=ga, defer_wgrad=mode == "wgrad", defer_backward=mode == "backward")
         engine, _, _, _ = initialize(eargs, model)
         engine.train()
         batch = [synth.text_batch(micro_batch, L, seed, dev)]
         gstep = GraphedTrainStep(engine, batch)
+        if mode == "backward" and not gstep.window:
+            raise RuntimeError("the deferred backward did not take this configuration")
 
         def opt_step():
             for _ in range(ga):
@@ -382,18 +387,24 @@ def ga16_leg(model, dev, cfg, L, seed, micro_batch: int = 4, ga: int = 16, steps
         dt = (time.perf_counter() - t0) / steps
         toks = micro_batch * ga * L
         out = {"workload": f"DB1-1.3B text pre-training at the reference's batch geometry: micro-batch {micro_batch} x gradient accumulation {ga} "
-                           f"({micro_batch * ga} sequences of {L} tokens per optimizer step; evaluate_rl_1.2B.sh:28-42), micro-steps as hipGraph replays, weight "
-                           "gradients once per optimizer step from the stashed operands, same model / dropout as the text steps",
+                           f"({micro_batch * ga} sequences of {L} tokens per optimizer step; evaluate_rl_1.2B.sh:28-42), " +
+                           ("micro-step forwards as hipGraph replays into the accumulation window, ONE backward per optimizer step over the whole window"
+                            if mode == "backward" else "micro-steps as hipGraph replays, weight gradients once per optimizer step from the stashed operands") +
+                           ", same model / dropout as the text steps", "mode": mode,
                "tokens_per_s": round(toks / dt, 1), "ms_per_optimizer_step": round(dt * 1e3, 3), "optimizer_steps": steps, "warmup": warmup,
                "micro_batch": micro_batch, "grad_accumulation": ga,
                "pct_mfma_peak_step": round(100.0 * toks * FLOP_PER_TOKEN / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 2), "final_loss": round(float(loss), 4),
-               "stash_gib": round(model.wgrad_stash.nbytes() / 2**30, 1) if model.wgrad_stash is not None else None}
+               "stash_gib": round(model.wgrad_stash.nbytes() / 2**30, 1) if model.wgrad_stash is not None else None,
+               "window_gib": round(model._win.nbytes() / 2**30, 1) if (mode == "backward" and model._win is not None) else None,
+               "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)}
     except Exception as e:   # the leg must never take the bench line down
         out = {"tokens_per_s": None, "error": repr(e)}
     if gstep is not None:
         gstep.close()
     model.wgrad_stash = None
     model.wgrad_defer_ga = 0
+    model._win = None
+    model.bwd_window_ga = 0
     model._ctx = None
     torch.cuda.empty_cache()
     return out
@@ -496,6 +507,9 @@ def main():
                                                       "scripts/evaluate/evaluate_rl_1.2B.sh:28-42): one timed step = GA x (fwd + bwd) + clip + Adam")
     ap.add_argument("--graph", action="store_true", help="forward + backward of a micro-step as one hipGraph replay (bdm_db1_amd.GraphedTrainStep): what small "
                                                          "micro-batches need (at 4 sequences the eager step is host-bound); no per-kernel timing in this mode")
+    ap.add_argument("--defer-backward", action="store_true", help="with --ga > 1: ONE backward per optimizer step over the whole accumulation window (engine option "
+                    "defer_backward, model.BackwardWindow); the forwards of the micro-steps write into window-sized activation buffers")
+    ap.add_argument("--ga16-mode", default=os.environ.get("DB1_GA16_MODE", "backward"), choices=["backward", "wgrad"], help="the ga16 leg: one backward per window / per-micro-step backward with deferred weight gradients")
     ap.add_argument("--no-defer-wgrad", action="store_true", help="with --ga > 1: form the weight gradients per micro-step (K = micro-batch tokens, fp32 accumulate) instead of "
                                                                   "once per optimizer step from the stashed operands of all micro-steps (bdm_db1_amd WgradStash)")
     ap.add_argument("--layers", type=int, default=24, help="debug only: anything but 24 is not the benchmark config")
@@ -544,7 +558,8 @@ def main():
     model.use_flash = not args.no_flash
     model.flash_probs_mode = args.flash_probs
     eargs = SimpleNamespace(lr=1e-4, weight_decay=0.01, clip_grad=1.0, optimizer="adam", keep_logits=False, fuse_head_loss=not args.materialise_logits,
-                            gradient_accumulation_steps=args.ga, defer_wgrad=args.ga > 1 and not args.no_defer_wgrad)
+                            gradient_accumulation_steps=args.ga, defer_wgrad=args.ga > 1 and not args.no_defer_wgrad,
+                            defer_backward=args.ga > 1 and args.defer_backward)
     engine, _, _, _ = initialize(eargs, model, mpu=mpu if world > 1 else None)
     engine.train()
     B, L = args.batch, cfg.n_position
@@ -632,7 +647,7 @@ def main():
         "config": {"workload": f"DB1-1.3B {args.workload} causal LM pre-training step (fwd+bwd+clip+Adam, training mode: dropout "
                                f"{args.dropout:g} on embeddings / attention / feed-forward outputs as the reference's defaults), seq_len 1024, "
                                f"{B} sequences/GPU/micro-step x {args.ga} micro-step(s) per optimizer step, random-init weights", "dropout": args.dropout, "n_layer": args.layers, "n_embed": 2048, "n_head": 16,
-                   "seq_len": L, "batch_per_gpu": B, "grad_accumulation": args.ga, "micro_step_as_hipgraph": bool(args.graph), "weight_gradients": ("once per optimizer step from the stashed operands of all micro-steps" if getattr(engine, "defer_wgrad", False) else "per micro-step"), "global_batch": B * world * args.ga, "parallelism": f"dp{world}",
+                   "seq_len": L, "batch_per_gpu": B, "grad_accumulation": args.ga, "micro_step_as_hipgraph": bool(args.graph), "weight_gradients": ("once per optimizer step from the stashed operands of all micro-steps" if getattr(engine, "defer_wgrad", False) else ("one backward per optimizer step over the whole accumulation window" if getattr(engine, "defer_backward", False) else "per micro-step")), "global_batch": B * world * args.ga, "parallelism": f"dp{world}",
                    "attention_backward": {"forward": "nothing recomputed (the forward keeps its probabilities)", "scratch": "query side recomputes, P / dS through scratch",
                                           "recompute": "both sides recompute"}[model._probs_mode(B, L)],
                    "params": int(sum(int(np.prod(s)) for _, s, _ in model.arena.offsets.values()))},
@@ -729,7 +744,7 @@ def main():
             if rank == 0:
                 out[wl] = leg
     if rank == 0 and world == 1 and not args.no_ga16 and args.workload == "text" and args.ga == 1 and gstep is None and args.layers == 24:
-        out["ga16"] = ga16_leg(model, dev, cfg, L, seed + 300)
+        out["ga16"] = ga16_leg(model, dev, cfg, L, seed + 300, mode=args.ga16_mode)
     if rank == 0 and world == 1 and not args.no_decode and args.layers == 24:
         out["decode"] = decode_leg(model, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

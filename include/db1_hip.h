@@ -104,14 +104,6 @@ int db1_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
 int db1_gemm_nt_headbias_supported(int M, int N, int K, int split_n);
 int db1_gemm_nt_headbias(const void* A, const void* W, void* C, void* Cu, void* Cv, const void* bias_u, const void* bias_v, int M, int N, int K,
                          int split_n, int64_t lda, int64_t ldw, int64_t ldc, int64_t ld_uv, void* stream);
-/* the same projection against the weight's TRANSPOSED copy Wt [K, N] (row stride ldwt): the NN form of the 4-wave kernel, 8 % faster than
- * the NT form at the DB1-1.3B shape 65 536 x 6144 x 2048 (the other forward projections are equal in both forms).  The copy is the caller's:
- * db1_transpose_bf16, once per weight version. */
-int db1_gemm_nn_headbias_supported(int M, int N, int K, int split_n);
-int db1_gemm_nn_headbias(const void* A, const void* Wt, void* C, void* Cu, void* Cv, const void* bias_u, const void* bias_v,
-                         int M, int N, int K, int split_n, int64_t lda, int64_t ldwt, int64_t ldc, int64_t ld_uv, void* stream);
-/* y [cols, rows] = x [rows, cols]^T, bf16 (any 2-byte element) */
-int db1_transpose_bf16(const void* x, void* y, int rows, int cols, int64_t ldx, int64_t ldy, void* stream);
 int db1_gemm_nn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
                 int64_t lda, int64_t ldb, int64_t ldc, int dtAB, int dtC, float alpha, float beta, void* ws, int64_t ws_bytes, void* stream);
 int db1_gemm_tn(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
@@ -133,19 +125,6 @@ int db1_gemm_nn_geglu_bwd(const void* dY, const void* W2, const void* Z, void* d
 /* ... WITHOUT the bias reduce (fused shapes only): parts [M / 128][2 dff] float32 = the column sums of dZ per 128-row block */
 int db1_gemm_nn_geglu_bwd_parts(const void* dY, const void* W2, const void* Z, void* dZ, float* parts, int M, int dff, int K,
                                 int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz, int dt, void* stream);
-/* The same pair with the backward's two factors saved by the forward (round 5): S[M, 2 dff] takes Z's place, S[:, :dff] = gelu(g) and
- * S[:, dff:] = v * gelu'(g) for (v | g) = the bf16-rounded Z -- what dZ = (dact * gelu(g), dact * v * gelu'(g)) multiplies dact by -- so the
- * backward epilogue is two products per element (no erf / exp / rcp) and the forward's, which holds Phi(g) and exp(-g^2 / 2) anyway, three
- * operations more.  ACT as above.  Only for the shapes the fused 4-wave kernels take (db1_gemm_geglu_saved_supported == 1: large bf16
- * batches; K_fwd / K_bwd = the contraction lengths of the two products); elsewhere DB1_ERR_UNSUPPORTED -- callers keep Z there.  dZ differs
- * from the Z form's by one more bf16 rounding per factor. */
-int db1_gemm_geglu_saved_supported(int M, int dff, int K_fwd, int K_bwd, int dt, int64_t lda, int64_t ldw1, int64_t lds, int64_t ldact,
-                                   int64_t lddy, int64_t ldw2, int64_t lddz);
-int db1_gemm_nt_geglu_saved(const void* A, const void* W1, const void* bias, void* S, void* ACT, int M, int dff, int K,
-                            int64_t lda, int64_t ldw, int64_t lds, int64_t ldact, int dt, void* stream);
-int64_t db1_gemm_nn_geglu_bwd_saved_workspace_bytes(int M, int dff);
-int db1_gemm_nn_geglu_bwd_saved(const void* dY, const void* W2, const void* S, void* dZ, float* dbias_acc, int M, int dff, int K,
-                                int64_t lddy, int64_t ldw, int64_t lds, int64_t lddz, int dt, void* ws, int64_t ws_bytes, void* stream);
 /* which kernel db1_gemm_strided would pick: 0 = strided fp32-MFMA, 1 = bf16 MFMA tile kernel */
 int db1_gemm_would_use_fast(int M, int N, int K, int dtA, int dtB, int dtC,
                             int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int64_t c_rs, int64_t c_cs);
@@ -165,20 +144,23 @@ int db1_layernorm_residual_fwd(const void* x, const void* r, float alpha, const 
                                float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
                                int dt, int dtParam, void* stream);
 /* ds = dL/ds (dtype dt); dr_out (nullable) = dL/dr = ds under the forward's keep decisions (== ds when drop_p = 0);
- * dgamma_acc / dbeta_acc: float32 [d], accumulated. */
+ * dgamma_acc / dbeta_acc: float32 [d], accumulated.
+ * drop_rows_per_step (0: off): the rows are SEVERAL micro-steps' rows, drop_rows_per_step each, run through one backward (a whole gradient-
+ * accumulation window, TransformerXL's deferred backward): row r takes the keep decisions of step drop_step + r / drop_rows_per_step, its
+ * elements counted from the first row of its block -- what that micro-step's own forward drew. */
 int64_t db1_layernorm_residual_bwd_workspace_bytes(int64_t rows, int d, int dt);   /* per-block parameter-gradient partials */
 int db1_layernorm_residual_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                                void* ds, void* dr_out, float* dgamma_acc, float* dbeta_acc,
                                int64_t rows, int d,
                                float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
-                               int dt, int dtParam, void* ws, int64_t ws_bytes, void* stream);
+                               int64_t drop_rows_per_step, int dt, int dtParam, void* ws, int64_t ws_bytes, void* stream);
 /* the same launch WITHOUT the parameter reduce: the per-block partial sums [blocks][2][d] float32 (parts_bytes >=
  * db1_layernorm_residual_bwd_workspace_bytes; bf16 rows of the register-resident widths only, else DB1_ERR_UNSUPPORTED) stay in `parts`;
  * db1_colsum_acc over that [blocks, 2 d] matrix yields (dgamma | dbeta).  For gradient accumulation: one reduce per optimizer step. */
 int db1_layernorm_residual_bwd_parts(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                                      void* ds, void* dr_out, float* parts, int64_t parts_bytes, int64_t rows, int d,
                                      float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_step, const uint32_t* drop_step_dev,
-                                     int dt, int dtParam, void* stream);
+                                     int64_t drop_rows_per_step, int dt, int dtParam, void* stream);
 
 /* ------------------------------------------------------------------ dropout
  * y[e] = x[e] * keep(e) * 65536 / (65536 - thr),  thr = round(p * 65536)   (nn.Dropout, transformer_xl.py:409,545,575; y may alias x).
@@ -409,6 +391,14 @@ int db1_relattn_dqr_fused(const void* dT, const void* R, int64_t r_row_stride, v
 int db1_relattn_dqr_parts_rows(int H);
 int db1_relattn_dqr_fused_parts(const void* dT, const void* R, int64_t r_row_stride, void* dq, int64_t dq_row_stride, int64_t dq_batch_stride,
                                 float* parts, int B, int L, int H, int D, void* ws, int64_t ws_bytes, void* stream);
+/* ... over a batch made of `ngroups` blocks of B / ngroups sequences, block g with its OWN R at R + g * r_group_stride elements: a whole
+ * gradient-accumulation window run through ONE backward (TransformerXL's deferred backward; every micro-step drew its own position-table
+ * dropout, transformer_xl.py:575, hence its own R = r_net(table), :138).  ngroups must divide B and the 256 / H workgroups of a head. */
+int db1_relattn_dqr_groups_supported(int B, int L, int H, int D, int dt, int ngroups);
+int64_t db1_relattn_dqr_groups_workspace_bytes(int L, int H, int ngroups);
+int db1_relattn_dqr_fused_groups(const void* dT, const void* R, int64_t r_row_stride, int64_t r_group_stride, int ngroups, void* dq,
+                                 int64_t dq_row_stride, int64_t dq_batch_stride, float* du_acc, float* dv_acc, int B, int L, int H, int D,
+                                 void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ image-patch embedder pieces
  * (src/tokenizer/vision_embedding.py:65-86).  pixels [N_img, C, Himg, Wimg] -> normalised patches
