@@ -1307,8 +1307,9 @@ extern "C" int db1_sumsq_acc(const void* x, float* acc, int64_t n, int dt, void*
     if (!db1_dt_ok(dt)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "sumsq: dtype");
     if (n <= 0) DB1_FAIL(DB1_ERR_BAD_SHAPE, "sumsq: n");
     if (!db1_aligned16(x)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "sumsq: alignment");
-    const int V = dt == DB1_F32 ? 4 : 8;
-    // workspace-free form: ONE workgroup (deterministic; fine for a few million elements).  Large vectors: db1_sumsq_det / db1_grad_norm_sq.
+    // workspace-free form: ONE workgroup (deterministic; fine for a few million elements).  Large vectors: db1_sumsq_det / db1_grad_norm_sq --
+    // refused here instead of running them at 1 / 256 of the chip (a silent cliff for a C caller: 16 M floats are ~1 ms in one workgroup)
+    if (n > ((int64_t)1 << 24)) DB1_FAIL(DB1_ERR_UNSUPPORTED, "sumsq_acc: n=%lld > 2^24 runs in ONE workgroup; use db1_sumsq_det / db1_grad_norm_sq", (long long)n);
     DB1_DISPATCH_DT(dt, T, (sumsq_kernel<T><<<1, 256, 0, (hipStream_t)stream>>>((const T*)x, acc, n)));
     DB1_CHECK_LAUNCH("sumsq");
     return DB1_OK;

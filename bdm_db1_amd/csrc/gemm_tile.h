@@ -37,12 +37,11 @@ struct GemmTileArgs {
     // Cact = z[:, :dff] * gelu(z[:, dff:]) [M, dff] leave the same accumulators.  Backward (NN, db1_gemm_nn_geglu_bwd): the product is
     // dact [M, dff] = dy W2; the epilogue reads Zin = z and writes C = dz [M, 2 dff] plus the column sums of dz per 128-row block to colpart.
     int geglu_dff = 0;
-    int geglu_saved = 0;   // 1: the column halves of C (forward) / Zin (backward) hold the backward's factors gelu(g) | v gelu'(g) instead of z = (v | g)
     void* Cact = nullptr; int64_t ld_act = 0;
     const bf16_t* Zin = nullptr; int64_t ld_z = 0;
     float* colpart = nullptr;
-    int rot = 1;        // NT: per-XCD rotation of the k-tile walk (A/B knob "w4_rot")
-    int band = 4;       // tile rows per band of the XCD-aware walk of the 4-wave kernels (A/B knob "w4_band")
+    int rot = 1;        // NT: per-XCD rotation of the k-tile walk (measured without effect at the five forward shapes, profiles/r05_nt_vs_nn.txt)
+    int band = 4;       // tile rows per band of the XCD-aware walk of the 4-wave kernels (3 .. 8 measured flat, profiles/r05_w4_band_sweep.txt)
 };
 
 // ---- staging of one 16 KiB operand (sub-)tile = 16 wave-instructions of 1 KiB, PIECES per wave (wave w takes w*PIECES ..)

@@ -121,17 +121,27 @@ class GraphedRingStep:
         self.ids = torch.zeros(batch_size, n_new, dtype=torch.long, device=dev)
         make_input = make_input or (lambda ids: NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None))
         self.x = make_input(self.ids)
+        from . import ops
         saved_state = self.memory.state.clone()
         saved_kv = None if memory is None else [k.clone() for k in self.memory.kv]
+        # the persistent one-token launches of THIS step hand over through a scratch of its own, with its own pinned copy of the error
+        # flag -- both created here, eagerly: a scratch first touched under capture would be allocated and zero-filled by a graph node, i.e.
+        # every replay would wipe the sticky flag before anyone read it (and all steps captured on torch's capture stream would share it)
+        self._scratch, self._flag_host = ops.new_chain_scratch(dev)
+        pending = model._chain_watch       # (the model's own watch of its eager calls stays what it was)
         with torch.no_grad():   # eager warm-up (workspaces, the R table), then the capture
-            for _ in range(2):
-                model([self.x], compute_loss=False, mems=self.memory)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                logits, _, _ = model([self.x], compute_loss=False, mems=self.memory)
+            with ops.chain_scratch_scope(self._scratch, self._flag_host):
+                for _ in range(2):
+                    model([self.x], compute_loss=False, mems=self.memory)
+                torch.cuda.synchronize()
+                model._chain_watch = None
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    logits, _, _ = model([self.x], compute_loss=False, mems=self.memory)
+                watch = model._chain_watch
         self.graph, self.logits = g, logits
-        self._watch = model._chain_watch   # the captured call's copy of the persistent launches' error flag (None: per-launch path)
+        self._watch = watch            # the captured call's copy of the persistent launches' error flag (None: per-launch path)
+        model._chain_watch = pending
         self._version = model._wversion
         if saved_kv is None:
             self.memory.reset()
@@ -158,9 +168,8 @@ class GraphedRingStep:
         """raise if a replayed persistent launch reported a failed hand-off (TransformerXL.check_decode_chain): call with
         ``synchronize=True`` before trusting logits that were not read back through a synchronising copy"""
         if self._watch is not None:
-            self.model._chain_watch = self._watch
             try:
-                self.model.check_decode_chain(synchronize)
+                self.model.check_decode_chain(synchronize, watch=self._watch)   # (this step's own flag copy; the model's pending watch is not touched)
             except Exception:
                 # the captured graph still contains the persistent launches: this step must not be replayed again (the model has switched the
                 # chain off, so a NEW GraphedRingStep captures the per-launch path)

@@ -247,7 +247,6 @@ class DB1Engine:
         ops.zero_segments(ar.grad, self._acc_segments)
         self.module._grad_fresh = True
         self.module.mark_weights_changed()
-        self.module.refresh_weight_copies()     # (static per-weight-version buffers: the next micro-step may be a graph replay)
         if self.lr_scheduler is not None:
             self.lr_scheduler.step(1)
 

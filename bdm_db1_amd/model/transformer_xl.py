@@ -127,19 +127,29 @@ class WgradStash:
         n += sum(t.numel() * t.element_size() for t in [self.rin] + self.dr) if self.nd else 0
         return n + (sum(t.numel() * 4 for L in (self.ln_parts, self.uv_parts, self.b1_parts) for e in L for t in (e if isinstance(e, list) else [e])) if self.parts else 0)
 
+    def parts_plan(self, model) -> int:
+        """floats of a LayerNorm partial-sum block if EVERY producer of a small reduction has its partials-only form under the model's
+        CURRENT switches (bf16, register-resident LayerNorm width, fused GEGLU backward, flash + dq_r stream), else 0"""
+        T, d, dff, H, D = self.T, model.d_model, model.d_ff, model.n_head, model.d_head
+        dt = model.compute_dtype
+        nln = ops.layernorm_bwd_parts_numel(T, d, dt) if dt == torch.bfloat16 else 0
+        ok = (model.use_partial_stash and nln > 0 and nln % (2 * d) == 0 and model.activation_fn == "geglu" and model.use_geglu_epilogue and not model.untie_r and
+              model.use_flash and model.use_flash_bwd and model.dropattn == 0 and self.nd and
+              ops.relattn_flash_supported(T // self.nd, self.nd, H, D, dt) and
+              ops.gemm_nn_geglu_bwd_fused(T, dff, d, dt) and T % 128 == 0 and self.nd and ops.relattn_dqr_supported(T // self.nd, self.nd, H, D, dt))
+        return nln if ok else 0
+
     def alloc_parts(self, model) -> bool:
         """the small reductions of a micro-step's backward -- LayerNorm parameter gradients (two per layer), the u / v column sums of the dq_r
         stream, the first feed-forward bias's column sums -- leave their PARTIAL sums here, per micro-step, and are added up once per layer at
         the flush (db1_colsum_acc over all micro-steps' rows): ~120 launches of 5 us less per micro-step.  Only where every producer has its
-        partials-only form (bf16, register-resident LayerNorm width, fused GEGLU backward, dq_r stream)."""
-        T, ga, d, dff, H, D = self.T, self.ga, model.d_model, model.d_ff, model.n_head, model.d_head
-        dt = model.compute_dtype
-        nln = ops.layernorm_bwd_parts_numel(T, d, dt) if dt == torch.bfloat16 else 0
-        ok = (model.use_partial_stash and nln > 0 and nln % (2 * d) == 0 and model.activation_fn == "geglu" and model.use_geglu_epilogue and not model.untie_r and
-              model.use_flash and model.use_flash_bwd and model.dropattn == 0 and not model.use_geglu_saved and self.nd and
-              ops.relattn_flash_supported(T // self.nd, self.nd, H, D, dt) and
-              ops.gemm_nn_geglu_bwd_fused(T, dff, d, dt) and T % 128 == 0 and self.nd and ops.relattn_dqr_supported(T // self.nd, self.nd, H, D, dt))
-        if not ok:
+        partials-only form (parts_plan).  Re-decided at the first micro-step of every window (revalidate_parts): a switch flipped while the
+        stash is alive (a test or an A/B toggling use_flash_bwd / use_geglu_epilogue ...) drops or rebuilds the partial buffers instead of
+        failing inside a backward."""
+        ga, d, dff, H, D, T = self.ga, model.d_model, model.d_ff, model.n_head, model.d_head, self.T
+        nln = self.parts_plan(model)
+        if not nln:
+            self.parts, self.ln_parts, self.uv_parts, self.b1_parts = False, [], [], []
             return False
         new = lambda *shape: torch.empty(*shape, device=model.dev, dtype=torch.float32)
         self.ln_parts = [[new(ga, nln // (2 * d), 2 * d) for _ in range(2)] for _ in range(self.n_layer)]       # [layer][0: pos_ff LN, 1: dec_attn LN]
@@ -147,6 +157,13 @@ class WgradStash:
         self.b1_parts = [new(ga, T // 128, 2 * dff) for _ in range(self.n_layer)]
         self.parts = True
         return True
+
+    def revalidate_parts(self, model):
+        """slot 0 of a window: the partial-sum plan against the model's switches as they are NOW"""
+        nln = self.parts_plan(model) if self.T == (self.T // self.nd) * self.nd and self.nd else 0
+        have = self.ln_parts[0][0].shape[1] * self.ln_parts[0][0].shape[2] if self.parts else 0
+        if nln != have:
+            self.alloc_parts(model)
 
     def rins(self) -> torch.Tensor:
         return self.rin[self.slot * self.nd:(self.slot + 1) * self.nd]
@@ -301,20 +318,11 @@ class TransformerXL(nn.Module):
         self._win: Optional[BackwardWindow] = None
         self._win_on = False             # the running forward writes into the window
         self._drop_rps = 0               # window backward: rows per micro-step of the tensors the LayerNorm backward regenerates dropout for
-        # the attention input projection against a transposed weight copy (NN form of the 4-wave kernel).  OPT-IN: alone and back to back the NN
-        # form is 8 % faster at this shape (1190 vs 1300 us), inside the training step the two are equal (same box: 420.6 vs 419.6 ms per
-        # step, profiles/r05_nt_vs_nn.txt) -- a GEMM's isolated speed is not its speed under the step's power / clock state
         self.head_chunk_rows = int(os.environ.get("DB1_HEAD_CHUNK", "0"))   # rows of logits alive at a time in the fused head + loss sweep (0: the library's 16 384)
-        self.use_qkv_nn = os.environ.get("DB1_QKV_NN", "0") != "0"
         self.use_partial_stash = os.environ.get("DB1_PARTIAL_STASH", "1") != "0"   # gradient accumulation: the small reductions once per optimizer step (WgradStash.alloc_parts)
         self.use_rnet_batched = os.environ.get("DB1_RNET_BATCHED", "1") != "0"   # r_net of all layers as one batched launch per forward
         self._R_all = None
-        self._wqkv_t, self._wqkv_t_version, self._wqkv_t_wanted = None, -1, False
         self.use_geglu_epilogue = os.environ.get("DB1_GEGLU_EPI", "1") != "0"   # GEGLU and its backward inside the feed-forward GEMMs' epilogues (large bf16 batches)
-        # ... and the forward leaves the backward's two factors gelu(g) | v gelu'(g) instead of z (db1_gemm_nt_geglu_saved).  OPT-IN: measured on
-        # one box dff2 1080 -> 1013 us, ff1 1712 -> 1735 us per layer (1.1 ms per step, 0.26 %) for one more bf16 rounding of each factor of dz;
-        # the epilogue's cost turned out to be its z / dz traffic, not its arithmetic
-        self.use_geglu_saved = os.environ.get("DB1_GEGLU_SAVED", "0") != "0"
         self.use_channels_last = True    # bf16 image-patch embedder in channels-last layout (False: the NCHW kernels of the fp32 path)
         self.use_implicit_conv = True    # 64 -> 64 channel convolutions without a column matrix (conv_implicit.hip)
         self._conv_ops = {}              # (weight name, weight version) -> tap-major GEMM operand
@@ -1171,12 +1179,9 @@ class TransformerXL(nn.Module):
                     ops.gemm_nt_headbias_supported(T, 3 * d, d, d)):
                 # q + r_w_bias and q + r_r_bias leave the projection's accumulators directly (the q columns of qkv stay unwritten)
                 quv = (self._keep(("qu", i), B, L, self.n_head, self.d_head), self._keep(("qv", i), B, L, self.n_head, self.d_head))
-                if self.use_qkv_nn and ops.gemm_nn_headbias_supported(T, 3 * d, d, d):
-                    # against the weight's transposed copy (one per weight version, refreshed behind the optimizer step): the NN form of the
-                    # 4-wave kernel is 8 % faster at this shape (N = 6144), the only forward projection where the two forms differ
-                    ops.gemm_nn_headbias(xin, self._qkv_weight_t(i), qkv, quv[0], quv[1], self._bias("r_w_bias", i), self._bias("r_r_bias", i), d)
-                else:
-                    ops.gemm_nt_headbias(xin, Wqkv, qkv, quv[0], quv[1], self._bias("r_w_bias", i), self._bias("r_r_bias", i), d)
+                # (the NN form against a transposed weight copy is 8 % faster alone at this shape and equal inside the step: measured in round 5,
+                #  profiles/r05_nt_vs_nn.txt, and removed)
+                ops.gemm_nt_headbias(xin, Wqkv, qkv, quv[0], quv[1], self._bias("r_w_bias", i), self._bias("r_r_bias", i), d)
             else:
                 ops.gemm(xin, Wqkv.t(), qkv)
             if self._R_all is not None:      # r_net of all layers as one batched product at the start of the forward (_rnet_all)
@@ -1263,29 +1268,6 @@ class TransformerXL(nn.Module):
         ops.gemm_batched(R_in.view(1, 1, nd, d).expand(n, 1, nd, d), W, out)
         return out.view(n, nd, d)
 
-    # ---- the attention input projection's weight, transposed: Wqkv^T [d, 3d] per layer, static buffers (a captured micro-step reads them),
-    # valid for ONE weight version.  engine.step() refreshes them right behind Adam (refresh_weight_copies); any other weight change
-    # (load_state_dict, mark_weights_changed) is caught lazily by the next eager forward.
-    def _qkv_weight_t(self, i: int) -> torch.Tensor:
-        self._wqkv_t_wanted = True
-        if self._wqkv_t is None or self._wqkv_t_version != self._wversion:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("the transposed projection weights are stale inside a graph capture: call model.refresh_weight_copies() first")
-            self.refresh_weight_copies()
-        return self._wqkv_t[i]
-
-    def refresh_weight_copies(self):
-        """per-weight-version copies that live in static buffers (captured training steps read them): the transposed qkv weights"""
-        if not (self.use_qkv_nn and self.compute_dtype == torch.bfloat16 and self._wqkv_t_wanted):
-            return
-        d = self.d_model
-        with torch.cuda.device(self.dev):
-            if self._wqkv_t is None:
-                self._wqkv_t = [torch.empty(d, 3 * d, device=self.dev, dtype=self.compute_dtype) for _ in range(self.n_layer)]
-            for i in range(self.n_layer):
-                ops.transpose(self.W(f"h.{i}.dec_attn.qkv_net.weight"), self._wqkv_t[i])
-        self._wqkv_t_version = self._wversion
-
     # ---- PositionwiseFF halves with the activation inside the GEMM where the shape allows (db1_gemm_nt_geglu / db1_gemm_nn_geglu_bwd: the
     # "bias + GEGLU" epilogue of SURVEY 8b; otherwise the same arithmetic as separate launches)
     def _ff1_fwd(self, x, p, T, act=None, keep=False, z=None):
@@ -1294,23 +1276,12 @@ class TransformerXL(nn.Module):
         z = self._new(T, di) if z is None else z
         act = self._new(T, dff) if act is None else act
         W1, b1 = self.W(p + "pos_ff.CoreNet.0.weight"), self.W(p + "pos_ff.CoreNet.0.bias")
-        if keep and self._geglu_saved_ok(T):
-            # a forward whose backward will run: the epilogue leaves the two factors the backward multiplies by -- gelu(g) | v gelu'(g) -- where z = (v | g) would go
-            # (db1_gemm_nt_geglu_saved); _ff2_dgrad reads them back through db1_gemm_nn_geglu_bwd_saved.  The tensor is tagged so that the
-            # pairing cannot be mixed up.
-            ops.gemm_nt_geglu_saved(x, W1, b1, z, act)
-            z._db1_geglu_saved = True
-        elif self.use_geglu_epilogue and self.activation_fn == "geglu" and ops.gemm_nt_geglu_fused(T, dff, d, self.compute_dtype):
+        if self.use_geglu_epilogue and self.activation_fn == "geglu" and ops.gemm_nt_geglu_fused(T, dff, d, self.compute_dtype):
             ops.gemm_nt_geglu(x, W1, b1, z, act)
         else:
             ops.gemm(x, W1.t(), z, bias=b1)
             ops.ffn_act_fwd(z, act, self.activation_fn)
         return z, act
-
-    def _geglu_saved_ok(self, T: int) -> bool:
-        d, dff = self.d_model, self.d_ff
-        return (self.use_geglu_epilogue and self.use_geglu_saved and self.activation_fn == "geglu" and
-                self.compute_dtype == torch.bfloat16 and ops.gemm_geglu_saved_supported(T, dff, d, d, self.compute_dtype))
 
     def _ff2_dgrad(self, df, z, p, T, dz=None, parts=None):
         """dz from df = d(loss)/d(CoreNet output): dact = df W2, through the activation; accumulates the first bias's gradient"""
@@ -1318,11 +1289,7 @@ class TransformerXL(nn.Module):
         dz = self._new(T, di) if dz is None else dz
         W2, gb1 = self.W(p + "pos_ff.CoreNet.2.weight"), self.G(p + "pos_ff.CoreNet.0.bias")
         if parts is not None:
-            if getattr(z, "_db1_geglu_saved", False):
-                raise RuntimeError("the partial-sum stash and the saved-factor GEGLU form are not combined")
             ops.gemm_nn_geglu_bwd_parts(df, W2, z, dz, parts)
-        elif getattr(z, "_db1_geglu_saved", False):
-            ops.gemm_nn_geglu_bwd_saved(df, W2, z, dz, gb1)
         elif self.use_geglu_epilogue and self.activation_fn == "geglu" and ops.gemm_nn_geglu_bwd_fused(T, dff, d, self.compute_dtype):
             ops.gemm_nn_geglu_bwd(df, W2, z, dz, gb1)
         else:
@@ -1612,6 +1579,9 @@ class TransformerXL(nn.Module):
                     st.alloc_parts(self)
             elif self._wg_slot == 0:
                 st.first = 0
+                st.r_used = False
+                if B * L == B * int(R_in.shape[0]) and not torch.cuda.is_current_stream_capturing():
+                    st.revalidate_parts(self)       # (the plan follows the switches; a captured step keeps what its warm-up decided)
             st.slot = self._wg_slot
             rows = st.rins()                 # this micro-step's position table (after its dropout) lives in the stash: r_net's input
             rows.copy_(R_in)
@@ -1701,13 +1671,15 @@ class TransformerXL(nn.Module):
         return _PendingLN(res=h1_out, y=f_out, alpha=a, gamma=W(p + "pos_ff.layer_norm.weight"),
                           beta=W(p + "pos_ff.layer_norm.bias"), eps=self.layer_norm_epsilon)
 
-    def check_decode_chain(self, synchronize: bool = False):
+    def check_decode_chain(self, synchronize: bool = False, watch=None):
         """Raise if a persistent one-token launch (db1_decode_chain) reported that a hand-off poll ran into its limit: the logits of that
         call (and the memory it appended) are invalid.  Without ``synchronize`` this reads the flag copy of the last call the stream has
         FINISHED -- free, and exact wherever the caller has synchronised anyway (``.cpu()`` / ``.item()`` on the logits); with it, the
         stream is drained first.  The chain is switched off for this model after a failure (the per-launch path takes over); set
-        ``use_decode_chain = True`` again once the device is exclusive."""
-        w = self._chain_watch
+        ``use_decode_chain = True`` again once the device is exclusive.  ``watch``: check THAT (pinned word, scratch) pair -- a captured
+        step's own (GraphedRingStep) -- and leave the model's pending watch of its eager calls alone."""
+        own = watch is None
+        w = self._chain_watch if own else watch
         if w is None:
             return
         if synchronize:
@@ -1715,7 +1687,8 @@ class TransformerXL(nn.Module):
         if int(w[0][0]) != 0:
             self.use_decode_chain = False
             ops.decode_chain_clear_error(w)
-            self._chain_watch = None
+            if own:
+                self._chain_watch = None
             raise lib.Db1Error("db1_decode_chain: a hand-off poll ran into its limit (not all 256 workgroups were resident: another kernel, "
                                "stream or process shares the GPU, or a CU mask is set).  The logits and the appended memory rows of that call are "
                                "invalid; the persistent path is now off for this model (model.use_decode_chain = False), repeat the episode.")

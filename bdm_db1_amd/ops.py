@@ -225,30 +225,6 @@ def gemm_nt_headbias(x, w, out, qu, qv, bias_u, bias_v, split_n):
     _timed("gemm", 2.0 * M * N * K, run)
 
 
-def gemm_nn_headbias_supported(M, N, K, split_n) -> bool:
-    return bool(lib.load().db1_gemm_nn_headbias_supported(M, N, K, split_n))
-
-
-def gemm_nn_headbias(x, wt, out, qu, qv, bias_u, bias_v, split_n):
-    """gemm_nt_headbias against the transposed weight copy wt [K, N] (db1_gemm_nn_headbias)"""
-    M, K = x.shape
-    N = wt.shape[1]
-    assert wt.shape[0] == K and x.stride(1) == 1 and wt.stride(1) == 1 and out.stride(1) == 1 and qu.is_contiguous() and qv.is_contiguous()
-    assert x.dtype == wt.dtype == out.dtype == qu.dtype == bias_u.dtype == torch.bfloat16 and bias_u.numel() == split_n == bias_v.numel()
-
-    def run():
-        lib.call("db1_gemm_nn_headbias", P(x), P(wt), P(out), P(qu), P(qv), P(bias_u), P(bias_v), M, N, K, split_n, x.stride(0), wt.stride(0),
-                 out.stride(0), split_n, stream())
-
-    _timed("gemm", 2.0 * M * N * K, run)
-
-
-def transpose(x, y):
-    """y [cols, rows] = x [rows, cols]^T (bf16)"""
-    assert x.dim() == 2 and y.shape == (x.shape[1], x.shape[0]) and x.element_size() == 2 and y.element_size() == 2 and x.stride(1) == 1 and y.stride(1) == 1
-    lib.call("db1_transpose_bf16", P(x), P(y), x.shape[0], x.shape[1], x.stride(0), y.stride(0), stream())
-
-
 def gemm_batched(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, beta: float = 0.0, tri=(0, 0)):
     """4-D views [z0, z1, rows, cols] with arbitrary strides (stride 0 broadcasts).
     ``tri`` = (mode, period): structural-zero hint for ``a`` (db1_gemm_strided_tri), an optimisation only."""
@@ -455,34 +431,6 @@ def gemm_nn_geglu_bwd_parts(dy, w2, z, dz, parts):
                             dt_code(dy), stream()))
 
 
-def gemm_geglu_saved_supported(M: int, dff: int, K_fwd: int, K_bwd: int, dtype) -> bool:
-    """do db1_gemm_nt_geglu_saved / db1_gemm_nn_geglu_bwd_saved exist at this shape (contiguous operands)"""
-    return bool(lib.load().db1_gemm_geglu_saved_supported(M, dff, K_fwd, K_bwd, dt_code(dtype), K_fwd, K_fwd, 2 * dff, dff, K_bwd, dff, 2 * dff))
-
-
-def gemm_nt_geglu_saved(x, w1, bias, s, act):
-    """act = v * gelu(g) for (v | g) = x w1^T + bias, and s [M, 2 dff] = (gelu(g) | v * gelu'(g)): the factors of the backward instead of z"""
-    M, K = x.shape
-    dff = act.shape[1]
-    assert w1.shape == (2 * dff, K) and s.shape == (M, 2 * dff) and x.stride(1) == 1 and w1.stride(1) == 1 and s.stride(1) == 1 and act.stride(1) == 1
-    assert bias is None or bias.dtype == x.dtype
-    _timed("gemm", 2.0 * M * 2 * dff * K,
-           lambda: lib.call("db1_gemm_nt_geglu_saved", P(x), P(w1), P(bias), P(s), P(act), M, dff, K, x.stride(0), w1.stride(0), s.stride(0), act.stride(0),
-                            dt_code(x), stream()))
-
-
-def gemm_nn_geglu_bwd_saved(dy, w2, s, dz, dbias_acc):
-    """dz = ((dy w2) * s[:, :dff] | (dy w2) * s[:, dff:]), dbias_acc += column sums of dz (s from gemm_nt_geglu_saved)"""
-    M, K = dy.shape
-    dff = w2.shape[1]
-    assert w2.shape[0] == K and s.shape == (M, 2 * dff) and dz.shape == (M, 2 * dff) and dbias_acc.dtype == torch.float32 and dbias_acc.numel() == 2 * dff
-    assert dy.stride(1) == 1 and w2.stride(1) == 1 and s.stride(1) == 1 and dz.stride(1) == 1
-    ws, wsn = _ws("db1_gemm_nn_geglu_bwd_saved_workspace_bytes", (M, dff), dy.device)
-    _timed("gemm", 2.0 * M * dff * K,
-           lambda: lib.call("db1_gemm_nn_geglu_bwd_saved", P(dy), P(w2), P(s), P(dz), P(dbias_acc), M, dff, K, dy.stride(0), w2.stride(0), s.stride(0), dz.stride(0),
-                            dt_code(dy), ws, wsn, stream()))
-
-
 def colsum_acc(x2d, out_acc):
     rows, cols = x2d.shape
     assert x2d.stride(1) == 1 and out_acc.dtype == torch.float32
@@ -672,13 +620,62 @@ def _chain_key(device):
     return idx, (sc[0] if sc is not None else torch.cuda.current_stream(idx).cuda_stream)
 
 
+class chain_scratch_scope:
+    """``with ops.chain_scratch_scope(scratch, pinned_word):`` -- the chain launches and flag fetches inside use THIS scratch / pinned word
+    instead of the (device, stream) ones.  For hipGraph captures (GraphedRingStep): a capture runs on torch's shared capture stream, whose
+    key would be new -- its scratch would be allocated AND zero-filled inside the capture, i.e. every replay would start by wiping the
+    scratch including the sticky error flag, and every graph captured on that stream would share one scratch whatever stream replays it.
+    The owner creates both eagerly (``new_chain_scratch``) before it captures.  Thread-local."""
+
+    def __init__(self, scratch, host_word):
+        self.pair = (scratch, host_word)
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "chain_override", None)
+        _tls.chain_override = self.pair
+        return self
+
+    def __exit__(self, *exc):
+        _tls.chain_override = self.prev
+        return False
+
+
+def _chain_pinned_word():
+    global _chain_flag_pool
+    if _chain_flag_pool is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise lib.Db1Error("db1_decode_chain: the first one-token call must run eagerly (GraphedRingStep warms up before it captures)")
+        _chain_flag_pool = [torch.zeros(256, dtype=torch.int32).pin_memory(), 0]
+    pool, used = _chain_flag_pool
+    if used >= pool.numel():
+        raise lib.Db1Error("db1_decode_chain: more than 256 scratch owners (device x stream pairs + captured steps) decode through the persistent launch")
+    _chain_flag_pool[1] = used + 1
+    return pool[used:used + 1]
+
+
+def new_chain_scratch(device):
+    """(zeroed scratch, pinned host word) owned by the caller -- a captured step; must be called eagerly (never under capture)"""
+    if torch.cuda.is_current_stream_capturing():
+        raise lib.Db1Error("new_chain_scratch under hipGraph capture: the scratch of a captured step is created before the capture")
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return torch.zeros(int(lib.load().db1_decode_chain_scratch_bytes()), dtype=torch.uint8, device=torch.device("cuda", idx)), _chain_pinned_word()
+
+
 def decode_chain_scratch(device):
     """the scratch of db1_decode_chain (tagged hand-off rows + error flag): one buffer per (device, STREAM) like every other scratch
     buffer here -- the tag of a word is only the layer index, so two models decoding at the same time on two streams must not see each
-    other's rows (or each other's sticky error flag).  Zeroed once, here."""
+    other's rows (or each other's sticky error flag) -- or the one a chain_scratch_scope supplies.  Zeroed once, when it is created:
+    never inside a capture (a zero-fill node would wipe the flag at every replay)."""
+    ov = getattr(_tls, "chain_override", None)
+    if ov is not None:
+        return ov[0]
     key = _chain_key(device)
     t = _chain_scratch.get(key)
     if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise lib.Db1Error("db1_decode_chain under hipGraph capture without a chain_scratch_scope: the scratch (and its error flag) would be "
+                               "allocated and zero-filled inside the graph")
         t = torch.zeros(int(lib.load().db1_decode_chain_scratch_bytes()), dtype=torch.uint8, device=torch.device("cuda", key[0]))
         _chain_scratch[key] = t
     return t
@@ -692,22 +689,17 @@ def decode_chain_flag_fetch(device):
     """enqueue a copy of the chain's error flag into pinned host memory behind the launches issued so far (4 bytes, no synchronisation,
     legal under hipGraph capture) -> (pinned int32 tensor, the scratch it watches): the pinned word holds the flag once the stream has
     passed this point"""
-    key = _chain_key(device)
-    h = _chain_flag_host.get(key)
-    if h is None:
-        # one pinned word per (device, stream), handed out from a small pool that is allocated on the first EAGER call: a stream that is
-        # capturing a graph (its own key) may not allocate pinned memory (hipHostMalloc invalidates the capture)
-        global _chain_flag_pool
-        if _chain_flag_pool is None:
-            if torch.cuda.is_current_stream_capturing():
-                raise lib.Db1Error("db1_decode_chain: the first one-token call must run eagerly (GraphedRingStep warms up before it captures)")
-            _chain_flag_pool = [torch.zeros(64, dtype=torch.int32).pin_memory(), 0]
-        pool, used = _chain_flag_pool
-        if used >= pool.numel():
-            raise lib.Db1Error("db1_decode_chain: more than 64 (device, stream) pairs decode through the persistent launch")
-        h = pool[used:used + 1]
-        _chain_flag_pool[1] = used + 1
-        _chain_flag_host[key] = h
+    ov = getattr(_tls, "chain_override", None)
+    if ov is not None:
+        h = ov[1]
+    else:
+        key = _chain_key(device)
+        h = _chain_flag_host.get(key)
+        if h is None:
+            # one pinned word per (device, stream), handed out from a small pool that is allocated on the first EAGER call: a stream that is
+            # capturing a graph may not allocate pinned memory (hipHostMalloc invalidates the capture)
+            h = _chain_pinned_word()
+            _chain_flag_host[key] = h
     sc = decode_chain_scratch(device)
     off = int(lib.load().db1_decode_chain_error_offset())
     h.copy_(sc[off:off + 4].view(torch.int32), non_blocking=True)

@@ -37,20 +37,26 @@ def wd_at(step: int, start_wd: float, end_wd: float, incr_steps: int, style: str
     return start_wd + _rise(step / incr_steps, style, "weight decay increment") * (end_wd - start_wd)
 
 
+def _require(ok: bool, msg: str):
+    # the reference guards its constructor and its checkpoint comparison with `assert` (optimizer_param_scheduler.py:43-65,164-169): callers
+    # that catch AssertionError keep working; unlike a bare assert this does not vanish under `python -O`
+    if not ok:
+        raise AssertionError(msg)
+
+
 class OptimizerParamScheduler:
     _LR_KEYS = ("max_lr", "min_lr", "lr_warmup_steps", "lr_decay_steps", "lr_decay_style")
     _WD_KEYS = ("start_wd", "end_wd", "wd_incr_steps", "wd_incr_style")
+    # names older checkpoints use for the same quantities, tried first (optimizer_param_scheduler.py:179-218)
+    _LEGACY = {"max_lr": ("start_lr",), "lr_warmup_steps": ("warmup_iter", "warmup_steps"), "lr_decay_steps": ("end_iter", "decay_steps"),
+               "lr_decay_style": ("decay_style",), "num_steps": ("num_iters",)}
 
     def __init__(self, optimizer, max_lr, min_lr, lr_warmup_steps, lr_decay_steps, lr_decay_style, start_wd, end_wd, wd_incr_steps,
                  wd_incr_style, use_checkpoint_opt_param_scheduler=True, override_opt_param_scheduler=False):
-        if not (0.0 <= min_lr <= max_lr):
-            raise ValueError(f"need 0 <= min_lr <= max_lr, got {min_lr}, {max_lr}")
-        if not (0 <= lr_warmup_steps < lr_decay_steps):
-            raise ValueError(f"need lr_warmup_steps < lr_decay_steps, got {lr_warmup_steps}, {lr_decay_steps}")
-        if not (0.0 <= start_wd <= end_wd) or (wd_incr_style == "constant" and start_wd != end_wd):
-            raise ValueError(f"need 0 <= start_wd <= end_wd (equal for a constant schedule), got {start_wd}, {end_wd}")
-        if override_opt_param_scheduler and use_checkpoint_opt_param_scheduler:
-            raise ValueError("override_opt_param_scheduler and use_checkpoint_opt_param_scheduler exclude each other")
+        _require(min_lr >= 0.0 and float(max_lr) >= min_lr, f"need 0 <= min_lr <= max_lr, got {min_lr}, {max_lr}")
+        _require(lr_decay_steps > 0 and lr_warmup_steps < lr_decay_steps, f"need lr_warmup_steps < lr_decay_steps, 0 < lr_decay_steps; got {lr_warmup_steps}, {lr_decay_steps}")
+        _require(start_wd >= 0.0 and end_wd >= start_wd, f"need 0 <= start_wd <= end_wd, got {start_wd}, {end_wd}")
+        _require(not (override_opt_param_scheduler and use_checkpoint_opt_param_scheduler), "both override and use-checkpoint are set.")
         self.optimizer = optimizer
         self.max_lr, self.min_lr = float(max_lr), min_lr
         self.lr_warmup_steps, self.lr_decay_steps, self.lr_decay_style = lr_warmup_steps, lr_decay_steps, lr_decay_style
@@ -64,6 +70,8 @@ class OptimizerParamScheduler:
         return lr_at(self.num_steps, *(getattr(self, k) for k in self._LR_KEYS))
 
     def get_wd(self) -> float:
+        if self.wd_incr_style == "constant" and self.num_steps <= self.wd_incr_steps:
+            _require(self.start_wd == self.end_wd, "a constant weight-decay schedule needs start_wd == end_wd")   # (:78-80: checked when the value is asked for)
         return wd_at(self.num_steps, *(getattr(self, k) for k in self._WD_KEYS))
 
     def step(self, increment: int):
@@ -79,13 +87,32 @@ class OptimizerParamScheduler:
         sd["num_steps"] = self.num_steps
         return sd
 
+    def _from_checkpoint(self, sd: dict, key: str):
+        """the checkpoint's value of ``key`` under its current or an older name; KeyError (the current name) when it has none"""
+        for k in self._LEGACY.get(key, ()) + (key,):
+            if k in sd:
+                return sd[k]
+        raise KeyError(key)
+
+    def _adopt(self, sd: dict, key: str):
+        """one schedule parameter from a checkpoint: kept as constructed under ``override_opt_param_scheduler``, otherwise the checkpoint's --
+        which must equal the constructed one unless ``use_checkpoint_opt_param_scheduler`` (optimizer_param_scheduler.py:158-171)"""
+        theirs = self._from_checkpoint(sd, key)           # (a missing mandatory key raises whatever the flags say, as the reference's lookup does)
+        if self.override_opt_param_scheduler:
+            return
+        if not self.use_checkpoint_opt_param_scheduler:
+            _require(getattr(self, key) == theirs, f"OptimizerParamScheduler: {key} is {getattr(self, key)} here and {theirs} in the checkpoint")
+        setattr(self, key, theirs)
+
     def load_state_dict(self, sd: dict):
-        """checkpointed schedule parameters win unless ``override_opt_param_scheduler``; with neither flag set they must agree"""
-        for k in self._LR_KEYS + self._WD_KEYS:
-            if k not in sd or self.override_opt_param_scheduler:
-                continue
-            if not self.use_checkpoint_opt_param_scheduler and getattr(self, k) != sd[k]:
-                raise ValueError(f"OptimizerParamScheduler: {k} is {getattr(self, k)} here and {sd[k]} in the checkpoint")
-            setattr(self, k, sd[k])
-        self.num_steps = 0
-        self.step(sd.get("num_steps", 0))
+        """optimizer_param_scheduler.py:173-234, in its order: the learning-rate parameters (older checkpoints' names accepted, every one
+        mandatory), then the step counter is ADVANCED by the checkpoint's count -- a scheduler is loaded once, freshly constructed, so this
+        is "set"; loading twice adds twice there and here --, then the weight-decay parameters if the checkpoint has them (all four or
+        KeyError).  As in the reference, the values written into the parameter groups by that advance still use the weight-decay
+        parameters of the constructor; the next step() uses the loaded ones."""
+        for key in self._LR_KEYS:
+            self._adopt(sd, key)
+        self.step(self._from_checkpoint(sd, "num_steps"))
+        if "start_wd" in sd:
+            for key in self._WD_KEYS:
+                self._adopt(sd, key)

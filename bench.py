@@ -267,6 +267,90 @@ def decode_leg(model, dev, calls: int = 30):
     return out
 
 
+# ---- box calibration: the boxes of the pool differ by +-2-4 % in what they sustain under the 1.4 kW cap -- as much as
+# a round's gain -- so every bench line says what ITS box does on two code-independent probes, and carries a tokens/s normalised to the
+# pool's median box.  POOL_MFMA_RANDOM_TF: median of the in-register MFMA rates this project has recorded on the pool's boxes
+# (profiles/r06_box_calibration.txt lists them); the normalisation is linear in that rate -- three quarters of the step is MFMA-side
+# kernels running at the cap -- and is an attribution aid, not a measurement: `value` is what was measured.
+POOL_MFMA_RANDOM_TF = 2205.0
+
+
+def _smi_sample_start():
+    """rocm-smi clock / power read, started now and collected later (it takes ~0.5 s: it runs beside the warm-up steps)"""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        return subprocess.Popen([exe, "--showclocks", "--showpower", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    except Exception:
+        return None
+
+
+def _smi_sample_collect(proc, dev_index: int):
+    if proc is None:
+        return None, None
+    try:
+        txt, _ = proc.communicate(timeout=20)
+        rec = json.loads(txt[txt.index("{"):])
+        card = rec.get(f"card{dev_index}") or next(iter(rec.values()))
+        sclk = power = None
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl and "clock" in kl and sclk is None:
+                digits = "".join(ch for ch in str(v) if ch.isdigit() or ch == ".")
+                sclk = float(digits) if digits else None
+            if "power" in kl and "(w)" in kl and power is None:
+                try:
+                    power = float(v)
+                except Exception:
+                    pass
+        return sclk, power
+    except Exception:
+        return None, None
+
+
+def box_calibration(dev, smi_proc=None):
+    """{mfma_random_tf, copy_gbps[, sclk_mhz, power_w]}: ~50 ms of in-register bf16 MFMAs on random-mantissa operands (csrc/calib.hip; best of
+    two after a short ramp), a 4 GB device copy (2 GB read + 2 GB written, best of three), and rocm-smi's clock / power if a sample was taken"""
+    from bdm_db1_amd import lib, ops
+    out = {}
+    try:
+        sink = torch.empty(65536, device=dev, dtype=torch.float32)
+        iters = 400000
+
+        def run(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            lib.call("db1_test_mfma_calibration", ops.P(sink), n, 1, ops.stream())
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1)
+        run(iters // 8)
+        ms = min(run(iters) for _ in range(2))
+        out["mfma_random_tf"] = round(256 * 4 * iters * 16 * 16384.0 / (ms * 1e-3) / 1e12, 1)
+        src = torch.empty(1 << 29, device=dev, dtype=torch.float32)
+        dst = torch.empty_like(src)
+        src.zero_()
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dst.copy_(src)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        out["copy_gbps"] = round(2 * src.numel() * 4 / (best * 1e-3) / 1e9, 1)
+        del src, dst, sink
+    except Exception as e:
+        out["error"] = repr(e)
+    if smi_proc is not None:
+        sclk, power = _smi_sample_collect(smi_proc, dev.index or 0)
+        out["sclk_mhz"], out["power_w"] = sclk, power
+    return out
+
+
 def _count_patches(batch):
     n = 0
     for t in batch:
@@ -293,11 +377,26 @@ def workload_leg(engine, model, dev, cfg, B, L, seed, workload: str, world: int 
     barrier + device synchronisation and taken as the MAX over ranks like the main leg; tokens/s is the whole job's.  Every rank calls this
     (the collectives of the step and the all_gather of the timings need all of them); only rank 0's return value is printed."""
     from bdm_db1_amd import synth
+    # ADVICE r5: with more than one rank a leg that fails on ONE rank must not leave the others inside a collective until the RCCL timeout.
+    # The part that can fail on its own -- building the batch (host memory, a bad shape) -- is agreed on first (MIN over an ok flag: every
+    # rank skips the leg together); a failure inside the steps, whose backward is full of collectives, is re-raised: the launcher tears the
+    # job down at once instead of hanging it.
+    err = None
     try:
         batch = [synth.rl_batch(B, L, seed, dev, cfg)] if workload == "rl" else ([synth.caption_batch(B, L, seed, dev, cfg)] if workload == "caption"
                                                                                     else synth.mixture_batch(B, L, seed, dev, cfg))
         n_patches = _count_patches(batch)
         rows = sum(int(t.label.shape[0]) for t in batch)      # (= B; a tiny debug batch rounds every task of the mixture up to one row)
+    except Exception as e:
+        err = repr(e)
+    if world > 1:
+        ok = torch.tensor([0.0 if err else 1.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0:
+            return {"tokens_per_s": None, "error": err or "another rank could not build this leg's batch"}
+    elif err:
+        return {"tokens_per_s": None, "error": err}
+    try:
 
         def step():
             _, loss = engine(batch)
@@ -344,7 +443,9 @@ def workload_leg(engine, model, dev, cfg, B, L, seed, workload: str, world: int 
                     "pct_mfma_peak_step": round(100.0 * flops / dt / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 2), "final_loss": round(float(loss), 4),
                     "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)})
         return out
-    except Exception as e:   # a leg must never take the bench line down (with more than one rank a failure here is fatal for the job anyway)
+    except Exception as e:   # a leg must never take the single-rank bench line down
+        if world > 1:
+            raise
         return {"tokens_per_s": None, "error": repr(e)}
 
 
@@ -520,6 +621,7 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the inference-with-memory leg after the timed steps")
     ap.add_argument("--no-mixture", action="store_true", help="skip the RL-trajectory and mixed-modal legs (BASELINE configs 4 / 5: a few steps of each on the same model and ranks) after the timed steps")
     ap.add_argument("--leg-steps", type=int, default=5, help="timed steps of each extra workload leg")
+    ap.add_argument("--no-box", action="store_true", help="skip the box calibration probes (in-register MFMA rate, device copy, rocm-smi sample) before / after the timed steps")
     ap.add_argument("--no-ga16", action="store_true", help="skip the leg at the reference's batch geometry (micro-batch 4 x GA 16, graphed micro-steps, 3 optimizer steps; N = 1 only)")
     ap.add_argument("--no-flash", action="store_true")
     ap.add_argument("--flash-probs", choices=["forward", "scratch", "recompute"], default="forward",
@@ -595,9 +697,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    box = box_calibration(dev) if (rank == 0 and not args.no_box) else None     # (before the warm-up: an idle, cool box; the same probe again after the timed steps)
+    smi = _smi_sample_start() if (box is not None and args.warmup > 0) else None   # clock / power as rocm-smi sees them WHILE the warm-up steps run
     for _ in range(args.warmup):
         loss = step()
     fence()
+    if box is not None:
+        box["sclk_mhz_during_warmup"], box["power_w_during_warmup"] = _smi_sample_collect(smi, dev.index or 0)
     # HIP-event pairs inside the timed region only around the launches of the ROOFLINE family (every tile GEMM + the head sweep): an event pair
     # per launch costs the step ~0.7 % when all ~700 launches of a step carry one (measured, same box: 424.2 vs 420.5 ms), so the other
     # families' rooflines (`kernels`) are taken on two extra, untimed steps after the timed region
@@ -635,6 +741,9 @@ def main():
         fence()
         ops.set_gemm_timer(None)
     loss_v = float(loss)
+    if box is not None:
+        after = box_calibration(dev)
+        box["mfma_random_tf_after"], box["copy_gbps_after"] = after.get("mfma_random_tf"), after.get("copy_gbps")
 
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2**30
     tokens = world * B * L * args.steps * args.ga
@@ -657,6 +766,13 @@ def main():
     }
     if dp_info is not None:
         out["data_parallel"] = dp_info
+    if box is not None:
+        out["box"] = box
+        if box.get("mfma_random_tf"):
+            out["value_normalised"] = round(tok_s * POOL_MFMA_RANDOM_TF / box["mfma_random_tf"], 1)
+            out["value_normalised_note"] = (f"value x {POOL_MFMA_RANDOM_TF:g} / box.mfma_random_tf: tokens/s this run would show on the pool's median box if the step scaled "
+                                            "with the box's sustained in-register MFMA rate under the power cap (an attribution aid for deltas between records; "
+                                            "`value` is the measurement)")
     summ = timer.summary() if timer is not None else {}
     if "gemm" in summ:
         # the dominant kernel family = EVERY bf16 tile-GEMM launch of the step: the decoder layers' products and the three head products of
@@ -668,7 +784,7 @@ def main():
             hms, hflops, hn = summ["lmhead_ce"]
             ms, flops, launches = ms + hms, flops + hflops, launches + hn
         ach = flops / (ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_box = None, None, None
         try:  # HBM-side bytes per tile-GEMM launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")))
@@ -677,11 +793,12 @@ def main():
                 if rec.get("batch_per_gpu", 16) == B:  # bytes per launch scale with the batch: only the matching recording applies
                     traffic = rec["tile_gemm_avg_bytes_per_launch"]
                     traffic_src = os.path.relpath(cands[-1], ROOT) + " (PMC passes of an earlier run of this command, not this run)"
+                    traffic_box = rec.get("box")        # that run's box calibration (None for records older than round 6)
         except Exception:
             traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
-                           "traffic_source": traffic_src,
+                           "traffic_source": traffic_src, "traffic_box": traffic_box,
                            "kernel": FAMILY_NOTE,
                            "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
                            "flop_per_launch_avg": round(flops / launches),

@@ -455,7 +455,8 @@ int db1_groupnorm_gelu_bwd(const void* dy, const void* x, const void* gamma, con
 
 /* ------------------------------------------------------------------ optimizer
  * acc[0] += sum(x^2)  (global-norm clipping, train_config.py:211-215).  Workspace-free form: ONE workgroup, so the sum does not depend on
- * arrival order -- meant for small vectors; the whole gradient arena goes through db1_sumsq_det / db1_grad_norm_sq. */
+ * arrival order -- meant for small vectors (n <= 2^24, DB1_ERR_UNSUPPORTED above: one workgroup is 1 / 256 of the chip); the whole gradient
+ * arena goes through db1_sumsq_det / db1_grad_norm_sq. */
 int db1_sumsq_acc(const void* x, float* acc, int64_t n, int dt, void* stream);
 /* the same sum over the whole chip (per-workgroup partials in the workspace, fixed-order final add); overwrite != 0: acc[0] = sum, else += */
 int64_t db1_sumsq_det_workspace_bytes(int64_t n);

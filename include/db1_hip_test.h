@@ -27,8 +27,7 @@ void db1_test_flash_fwd2(int on);
  * workspace split-K), "pp32_stages" (4 | 5), "linear_decode_splitk" (0 | 1: never split), "w4" (0: the 8-wave GEMM kernels, 2: 4-wave for NT
  * only), "flash_fwd2" (0: the compiled flash-forward loop), "flash_kv3" (0 / 1: force 16 / 32 keys per wave in the key-side backward; -1 or unset: 32 from 512 workgroups on), "conv_wgrad_ks",
  * "geglu_epi" (0: db1_gemm_nt_geglu / db1_gemm_nn_geglu_bwd run as separate GEMM + activation launches at every shape), "gemm_halfwave" (k-tiles
- * per slice from which half-wave outputs are split in two), "w4n" (0: no 256 x 128 tiles of the 4-wave GEMM; 1 / 2 / 3: see gemm.hip), "adam_nt"
- * (1: the Adam kernel with non-temporal streams and two 16-byte groups per thread in flight), "w4_band" (tile rows per band of the 4-wave GEMMs' XCD-aware walk; default 4), "w4_rot" (0: no per-XCD rotation of the NT k-tile walk), "ln_bwd_blocks" (workgroups the fused LayerNorm backward aims for at small row counts; default 512).
+ * per slice from which half-wave outputs are split in two), "w4n" (0: no 256 x 128 tiles of the 4-wave GEMM; 1 / 2 / 3: see gemm.hip).
  * Returns 0, or DB1_ERR_BAD_SHAPE for an unknown name. */
 int db1_test_set_knob(const char* name, int value);
 void db1_test_clear_knobs(void);
@@ -40,6 +39,11 @@ int db1_test_marker(int tag, void* stream);
  * workgroup's first four to buf[16 + 4 workgroup ..] (device memory, 16 + 2048 int64: [1040 + 4 workgroup ..] worker wave 0's W0 issued / merge inputs requested / W1 issued / merged row written;
  * null switches it off): start, A0, B0, y_o complete, LN1 done, A1, B1, act complete, act in LDS, A2, B2, f complete, LN2 done, A3, B3 */
 void db1_test_decode_chain_timestamps(void* buf, int slot);   /* slot < 0: every launch; else only launches with that slot */
+
+/* Box calibration (bench.py `box`): `iters` rounds of 16 independent v_mfma_f32_16x16x32_bf16 per wave, operands in registers (no memory
+ * traffic), one wave per SIMD of every CU, on random-mantissa operand bits (random_bits != 0) or zeros; asynchronous on `stream` -- the
+ * caller times it.  sink: >= 65 536 floats, never written. */
+int db1_test_mfma_calibration(float* sink, int iters, int random_bits, void* stream);
 
 #ifdef __cplusplus
 }

@@ -371,11 +371,31 @@ def test_decode_chain_matches_the_separate_launches_at_db1_1p3b_geometry(mem_len
             assert torch.equal(lg_g.float(), lg_e.float())
     g.check(synchronize=True)
     model.check_decode_chain(synchronize=True)
+    # a captured step owns its scratch and its pinned flag word, both created BEFORE the capture -- no zero-fill node inside the
+    # graph, so a failed hand-off's sticky flag survives replays nobody synchronised on (it used to be wiped at the start of every replay);
+    # and checking the step's flag leaves the model's own pending watch (its eager calls) alone
+    from bdm_db1_amd import lib as db1lib
+    off = int(db1lib.load().db1_decode_chain_error_offset())
+    g2 = GraphedRingStep(model, 1, 1)
+    assert g2._watch is not None and g2._watch[1] is g2._scratch and g2._scratch.data_ptr() != ops.decode_chain_scratch(model.dev).data_ptr()
+    eager_watch = model._chain_watch
+    with torch.no_grad():
+        g2(ids)
+        torch.cuda.synchronize()
+        g2._scratch[off:off + 4].view(torch.int32).fill_(1)          # (simulated: a poll of this step's launches ran into its limit)
+        g2.graph.replay()
+        g2.graph.replay()                                            # two replays, no synchronisation, no check in between
+        with pytest.raises(db1lib.Db1Error, match="hand-off poll"):
+            g2.check(synchronize=True)
+    assert model._chain_watch is eager_watch, "checking a captured step's flag must not replace the model's pending watch"
+    assert model.use_decode_chain is False
+    with pytest.raises(RuntimeError):
+        g2(ids)                                                      # the step must not be replayed again
+    model.use_decode_chain = True
+    g.check(synchronize=True)                                        # the first step's scratch is its own: its flag is clean
     # the product path acts on the flag: a launch that could not hand off (simulated: the sticky flag of the eager stream's
     # scratch is set by hand) makes the NEXT forward over a ring raise, switches the persistent path off, and the per-launch path then
     # serves the same call
-    from bdm_db1_amd import lib as db1lib
-    off = int(db1lib.load().db1_decode_chain_error_offset())
     x = NLPTaskInput(position_id=None, attention_mask=None, loss_mask=None, label=None, text_seq=ids, text_len=None)
     with torch.no_grad():
         ops.decode_chain_scratch(model.dev)[off:off + 4].view(torch.int32).fill_(1)    # (the scratch of THIS stream: the graph above has its own)

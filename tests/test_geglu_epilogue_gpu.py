@@ -107,54 +107,6 @@ def test_geglu_entry_points_fall_back_to_separate_launches(ops, dtype, M, K, dff
         assert np.abs(a1.double().cpu().numpy() - ar).max() <= 1e-5 * np.abs(ar).max()
 
 
-@pytest.mark.parametrize("M,K,dff", [(2560, 2048, 4096), (10240, 512, 1024)])
-def test_geglu_saved_factor_pair(ops, M, K, dff):
-    """db1_gemm_nt_geglu_saved / db1_gemm_nn_geglu_bwd_saved (round 5): the forward leaves S = (gelu(g) | v gelu'(g)) where z = (v | g) would
-    go, the backward multiplies dact by the two halves.  act is bit-identical to the z form's; S equals the two factors computed from the z
-    form's stored z to a bf16 last place (and the NT kernel's k order); dz equals the z form's to one more bf16 rounding per factor, and the
-    oracle's GEGLU backward on the stored z within the bf16 tolerance; the bias gradient is the column sum of the stored dz, run-to-run
-    identical."""
-    dt = torch.bfloat16
-    x, W1, b1, dy, W2 = _mk(M, K, dff, dt, 21)
-    assert ops.gemm_geglu_saved_supported(M, dff, K, K, dt), "this shape is meant to take the saved-factor pair"
-    z0, a0 = torch.empty(M, 2 * dff, device=DEV, dtype=dt), torch.empty(M, dff, device=DEV, dtype=dt)
-    ops.gemm_nt_geglu(x, W1, b1, z0, a0)
-    s1, a1 = torch.full_like(z0, float("nan")), torch.full_like(a0, float("nan"))
-    ops.gemm_nt_geglu_saved(x, W1, b1, s1, a1)
-    assert torch.equal(a1.view(torch.int16), a0.view(torch.int16)), "act of the saved-factor forward differs from the z form's"
-    zf = z0.double().cpu().numpy()
-    v, g = zf[:, :dff], zf[:, dff:]
-    sf = s1.double().cpu().numpy()
-    assert np.isfinite(sf).all()
-    assert np.abs(sf[:, :dff] - O.gelu(g)).max() <= 5e-3 * np.abs(O.gelu(g)).max()
-    want_d = v * O.gelu_grad(g)
-    assert np.abs(sf[:, dff:] - want_d).max() <= 5e-3 * np.abs(want_d).max()
-    # ---- backward
-    dz0, dz1 = torch.empty_like(z0), torch.full_like(z0, float("nan"))
-    gb0, gb1 = torch.full((2 * dff,), 0.25, device=DEV), torch.full((2 * dff,), 0.25, device=DEV)
-    ops.gemm_nn_geglu_bwd(dy, W2, z0, dz0, gb0)
-    ops.gemm_nn_geglu_bwd_saved(dy, W2, s1, dz1, gb1)
-    a, b = dz1.double().cpu().numpy(), dz0.double().cpu().numpy()
-    assert np.isfinite(a).all()
-    assert np.abs(a - b).max() <= 1.2e-2 * np.abs(b).max() and np.linalg.norm(a - b) <= 4e-3 * np.linalg.norm(b)     # two more bf16 roundings per element
-    da = torch.empty(M, dff, device=DEV, dtype=dt)
-    ops.gemm(dy, W2, da)
-    daf = da.double().cpu().numpy()
-    dref = np.concatenate([daf * O.gelu(g), daf * v * O.gelu_grad(g)], -1)
-    assert np.abs(a - dref).max() <= 1.2e-2 * np.abs(dref).max() and np.linalg.norm(a - dref) <= 5e-3 * np.linalg.norm(dref)
-    want = dz1.double().sum(0).cpu().numpy() + 0.25
-    assert np.abs(gb1.double().cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max(), "bias gradient != column sums of the stored dz"
-    gb2 = torch.full((2 * dff,), 0.25, device=DEV)
-    ops.gemm_nn_geglu_bwd_saved(dy, W2, s1, torch.empty_like(z0), gb2)
-    assert torch.equal(gb1, gb2)
-    # small shapes do not have the pair: the entry points say so instead of running something else
-    from bdm_db1_amd import lib as db1lib
-    assert not ops.gemm_geglu_saved_supported(768, 384, 256, 256, dt)
-    xs, W1s, b1s, dys, W2s = _mk(768, 256, 384, dt, 3)
-    with pytest.raises(db1lib.Db1Error):
-        ops.gemm_nt_geglu_saved(xs, W1s, b1s, torch.empty(768, 768, device=DEV, dtype=dt), torch.empty(768, 384, device=DEV, dtype=dt))
-
-
 def test_model_step_with_and_without_the_geglu_epilogue_agree():
     """two DB1-1.3B-geometry layers, bf16, one training step each way: the fused epilogues change which launches run and the k order of the
     first feed-forward product (last-bit flips of z), nothing else: loss and every gradient agree far inside the bf16 tolerance"""
@@ -164,30 +116,26 @@ def test_model_step_with_and_without_the_geglu_epilogue_agree():
     cfg = synth.db1_config("1.3B", n_layer=2, drop=0.1, embd_pdrop=0.1)
     B, L = 12, 1024
     outs = []
-    for fused, saved in ((True, True), (True, False), (False, False)):
+    for fused in (True, False):
         torch.manual_seed(5)
         model = TransformerXL(cfg)
-        model.use_geglu_epilogue, model.use_geglu_saved = fused, saved
+        model.use_geglu_epilogue = fused
         model.train()
         batch = [synth.text_batch(B, L, 77, model.dev)]
         _, loss = model(batch)
-        assert model._geglu_saved_ok(B * L) == (fused and saved)
         model.backward()
         outs.append((float(loss), model.arena.grad.clone(), dict(model.arena.offsets)))
         del model
         torch.cuda.empty_cache()
-    (l2_, g2, offs), (l1, g1, _), (l0, g0, _) = outs
-    assert abs(l1 - l0) <= 1e-4 * abs(l0) and l2_ == l1      # (the saved-factor forward's act is the z form's bit for bit)
-    # the saved-factor form rounds the two factors of dz to bf16 once more (2^-9 each): a little above the z form's agreement, far inside
-    # the bf16 path's own distance from fp32 (1-2 % per weight gradient, tests/test_full_depth_gpu.py)
-    for gx, tol in ((g1, 5e-3), (g2, 1e-2)):
-        worst = 0.0
-        for name, (off, shape, alloc) in offs.items():
-            a, b = gx[off:off + alloc].double(), g0[off:off + alloc].double()
-            if float(b.abs().max()) == 0.0:
-                assert float(a.abs().max()) == 0.0, name
-                continue
-            l2 = float((a - b).norm() / b.norm())
-            worst = max(worst, l2)
-            assert l2 <= tol, (name, l2)
-        print(f"worst relative L2 of a gradient against the unfused step: {worst:.2e} (limit {tol:.0e})")
+    (l1, g1, offs), (l0, g0, _) = outs
+    assert abs(l1 - l0) <= 1e-4 * abs(l0)
+    worst = 0.0
+    for name, (off, shape, alloc) in offs.items():
+        a, b = g1[off:off + alloc].double(), g0[off:off + alloc].double()
+        if float(b.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0, name
+            continue
+        l2 = float((a - b).norm() / b.norm())
+        worst = max(worst, l2)
+        assert l2 <= 5e-3, (name, l2)
+    print(f"worst relative L2 of a gradient against the unfused step: {worst:.2e} (limit 5e-03)")

@@ -74,6 +74,46 @@ def test_scheduler_matches_reference_golden():
             assert s2.num_steps == s.num_steps and s2.get_lr() == s.get_lr()
 
 
+def test_scheduler_checkpoint_contract_follows_the_reference():
+    """ADVICE r5 (optimizer_param_scheduler.py:158-234): older checkpoints' key names are read, a missing mandatory key is a KeyError, the
+    step count of the checkpoint is ADDED to the counter, and a schedule that disagrees with the checkpoint's (neither flag set) -- like the
+    constructor's own guards -- fails with AssertionError, which is what callers of the reference catch"""
+    from bdm_db1_amd.optim import OptimizerParamScheduler
+    mk = lambda **kw: OptimizerParamScheduler(SimpleNamespace(param_groups=[{}]), 1e-3, 1e-5, 10, 100, "cosine", 0.0, 0.01, 80, "linear", **kw)
+    legacy = {"start_lr": 2e-3, "min_lr": 1e-6, "warmup_iter": 5, "end_iter": 200, "decay_style": "linear", "num_iters": 7}
+    s = mk()
+    s.load_state_dict(legacy)
+    assert (s.max_lr, s.min_lr, s.lr_warmup_steps, s.lr_decay_steps, s.lr_decay_style, s.num_steps) == (2e-3, 1e-6, 5, 200, "linear", 7)
+    assert (s.start_wd, s.end_wd, s.wd_incr_steps, s.wd_incr_style) == (0.0, 0.01, 80, "linear")      # no weight-decay keys: the constructor's stay
+    s.load_state_dict({"max_lr": 2e-3, "min_lr": 1e-6, "warmup_steps": 5, "decay_steps": 200, "lr_decay_style": "linear", "num_steps": 3})
+    assert s.num_steps == 10                                                                           # added, as self.step(increment=...) does
+    for missing in ("min_lr", "lr_decay_style", "num_steps"):
+        sd = mk().state_dict()
+        del sd[missing]
+        with pytest.raises(KeyError):
+            mk().load_state_dict(sd)
+    sd = mk().state_dict()
+    del sd["wd_incr_steps"]                     # the weight-decay group is optional as a whole ("start_wd" present: all four are looked up)
+    with pytest.raises(KeyError):
+        mk().load_state_dict(sd)
+    sd = mk().state_dict()
+    sd["lr_decay_steps"] = 300
+    with pytest.raises(AssertionError):
+        mk(use_checkpoint_opt_param_scheduler=False).load_state_dict(sd)
+    s = mk(use_checkpoint_opt_param_scheduler=False, override_opt_param_scheduler=True)
+    s.load_state_dict(sd)
+    assert s.lr_decay_steps == 100              # override: the constructed schedule wins
+    for bad in (dict(lr_warmup_steps=100), dict(min_lr=-1.0), dict(end_wd=-0.5)):
+        args = dict(max_lr=1e-3, min_lr=1e-5, lr_warmup_steps=10, lr_decay_steps=100, lr_decay_style="linear", start_wd=0.0, end_wd=0.01, wd_incr_steps=80,
+                    wd_incr_style="linear")
+        args.update(bad)
+        with pytest.raises(AssertionError):
+            OptimizerParamScheduler(SimpleNamespace(param_groups=[{}]), **args)
+    OptimizerParamScheduler(SimpleNamespace(param_groups=[{}]), 1e-3, 1e-5, -3, 100, "linear", 0.0, 0.01, 80, "linear")   # (a negative warm-up is accepted there too)
+    with pytest.raises(AssertionError):
+        OptimizerParamScheduler(SimpleNamespace(param_groups=[{}]), 1e-3, 1e-5, 10, 100, "linear", 0.0, 0.01, 80, "linear", True, True)
+
+
 def test_synthetic_rl_layout_matches_reference_packer():
     from bdm_db1_amd import synth
     cfg = synth.db1_config("1.3B")

@@ -53,5 +53,12 @@ res = {
     "tile_gemm_launches": tot_l,
     "batch_per_gpu": int(os.environ.get("DB1_BENCH_BATCH", 64)),
 }
+# the box these passes ran on (bench.py `box`: in-register MFMA rate, device copy): bench.py prints it beside the traffic figure it takes from here
+try:
+    r = subprocess.run([sys.executable, "-c", "import sys, json, torch; sys.path.insert(0, %r); import bench; print(json.dumps(bench.box_calibration(torch.device('cuda', 0))))" % ROOT],
+                       cwd="/tmp", env=env, stdin=subprocess.DEVNULL, capture_output=True, text=True, timeout=300)
+    res["box"] = json.loads(r.stdout.strip().splitlines()[-1])
+except Exception as e:
+    res["box"] = {"error": repr(e)}
 json.dump(res, open(os.path.join(out_dir, "hbm_traffic_pmc.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "kernels"})[:600])
