@@ -362,6 +362,8 @@ def test_gemm_nt_head_bias_epilogue(ops, M, d, K):
     assert bool((out[:, :d] == 5.0).all()), "the query columns of the packed output are not written"
 
 
+@pytest.mark.parametrize("M,N,K,with_bias", [(4352, 4096, 512, True), (8192, 8448, 128, False), (2560 * 4, 2048 * 4, 256, True),
+                                                (2048, 2304, 384, False), (1024, 1024, 2048, True), (768, 512, 640, False)])
 def test_gemm_bf16_nt_more_tiles_than_cus(ops, M, N, K, with_bias):
     """NT, bf16 output, more than 256 tiles of 256x256 (several rounds of workgroups per CU, the LDS-staged epilogue with and without
     bias) and the k-tile counts of the hand-scheduled 4-wave loop (K a multiple of 128 from 256: 2 peeled k-tiles + pairs; the
