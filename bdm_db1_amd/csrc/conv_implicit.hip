@@ -126,6 +126,148 @@ __global__ __launch_bounds__(256, 2) void conv_implicit_kernel(ConvArgs p) {
             store_frag<bf16_t, TBIAS>(acc[i][j], Y, CI_C, wave * 64 + i * 16 + (lane & 15), j * 16 + (lane >> 4) * 4, 1.f, 0.f, p.bias);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------- fwd / dgrad, patch-resident
+// Round 6.  The kernel above walks the nine taps as nine k-steps of a tile GEMM: per patch it stages 9 x (32 KB of tap-shifted pixels + 8 KB
+// of weights) from L2 and pays nine request -> vmcnt(0) -> barrier round trips -- 19 us per patch for 2.2 us of MFMAs (RL step, 60 160
+// patches: 2.26 ms per convolution, 1.7 TB/s of its 3.9 GB, 0.2 of the MFMA peak; profiles/r06c_rl_step_table.txt).  A patch is its own
+// zero-padded image (vision_embedding.py:44-63: the padding is at the PATCH border), so nothing outside its 32 KB is ever needed:
+//   * ONE workgroup per CU, persistent over patches; the whole weight operand [64][576] (72 KB) is staged once per workgroup;
+//   * a patch's [256 pixels][64 channels] image is staged ONCE (32 KB, two buffers: patch k + 1 lands while patch k is computed) and the nine
+//     taps are nine different ROW addresses into it: the A fragment of (pixel tile i, tap) is the same ds_read_b128 at pixel + shift, and a
+//     lane whose shifted pixel is outside the patch reads a row of zeros that sits in front of each buffer (one lane-constant address
+//     per (i, tap), the second k-step is address ^ 64);
+//   * one barrier per patch; the LDS-DMA is issued from inline asm (hipcc drains vmcnt(0) before the first LDS read it cannot disambiguate
+//     from a pending builtin DMA, which is what serialised the kernel above).
+// Bytes per patch: 32 KB read + 32 KB written (the kernel is HBM-bound at ~0.8 ms per convolution at 60 160 patches), 288 MFMAs and 144
+// fragment reads per wave.  Same arithmetic and output as conv_implicit_kernel (fp32 accumulation over the same 576 products per output;
+// the order of the k-steps is the same: tap-major).
+#define CP_W_BYTES (9 * 8192)                 // nine tap slabs [64 outputs][64 k] (K-major rows of 128 B, chunk swizzle c ^ (row & 7))
+#define CP_X_BYTES (CI_HW * 128)              // one patch [256 pixels][128 B]
+#define CP_X_STRIDE (CP_X_BYTES + 256)        // a 256-byte row of zeros in front of each patch buffer
+#define CP_LDS (CP_W_BYTES + 2 * CP_X_STRIDE)
+__device__ __forceinline__ void cp_glds16(const void* src, unsigned dst_lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst_lds) : "memory");
+}
+template <typename TBIAS>
+__global__ __launch_bounds__(256, 1) void conv_patch_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xm = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+    const unsigned xbase0 = lds0 + CP_W_BYTES + 256;          // buffer b at xbase0 + b * CP_X_STRIDE, its zero row 256 bytes below
+    if (tid < 128) {                                          // the two zero rows
+        *reinterpret_cast<unsigned*>(smem + CP_W_BYTES + (tid >> 6) * CP_X_STRIDE + (tid & 63) * 4) = 0u;
+    }
+    // weights, once: 72 pieces of 8 rows; wave w takes pieces 18 w .. 18 w + 17
+#pragma unroll
+    for (int it = 0; it < 18; it++) {
+        const int q = wave * 18 + it, tap = q >> 3;
+        const int r = (q & 7) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (r & 7);
+        cp_glds16(p.w + (int64_t)r * (9 * CI_C) + tap * CI_C + c * 8, lds0 + q * 1024);
+    }
+    auto stage = [&](int64_t patch, int buf) {                // 32 pieces of 8 pixels; wave w takes pieces 8 w .. 8 w + 7
+        const bf16_t* xp = p.x + patch * (CI_HW * CI_C);
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int q = wave * 8 + it;
+            const int r = q * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            cp_glds16(xp + r * CI_C + c * 8, xbase0 + buf * CP_X_STRIDE + q * 1024);
+        }
+    };
+    // lane-constant fragment addresses, relative to a patch buffer: (pixel tile i, tap) -> the shifted pixel's row, or the zero row below the buffer
+    int aoff[4][9];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int y = wave * 4 + i + p.sign * (tap / 3 - 1), x = xm + p.sign * (tap % 3 - 1);
+            const bool ok = y >= 0 && y < CI_P && x >= 0 && x < CI_P;
+            const int ps = y * CI_P + x;
+            aoff[i][tap] = ok ? ps * 128 + ((g ^ (ps & 7)) << 4) : -256 + (g << 4);
+        }
+    unsigned boff[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int row = j * 16 + xm;
+        boff[j] = lds0 + row * 128 + ((g ^ (row & 7)) << 4);
+    }
+    typedef __attribute__((address_space(3))) const bf16x8_t* lds_frag_ptr;
+    // this lane's 16 bias values (output n = 16 j + 4 g + r), once
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) bv[j][r] = p.bias ? ldf((const TBIAS*)p.bias + j * 16 + g * 4 + r) : 0.f;
+    const int64_t first = blockIdx.x, stride = gridDim.x;
+    if (first < p.n_patches) stage(first, 0);
+    int buf = 0;
+    bool first_iter = true;
+    for (int64_t patch = first; patch < p.n_patches; patch += stride) {
+        // this patch's image has landed (the first time: and the weights).  The 16 output stores of the previous patch were issued AFTER its
+        // requests and may stay in flight (vmcnt retires in issue order): waiting for their acknowledgements here cost ~2 us per patch.
+        if (first_iter) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        first_iter = false;
+        const int64_t pix0 = patch * CI_HW;
+        // the residual rows of this patch (vision_embedding.py:84), requested BEFORE the next patch's image so that they are the older requests
+        uint2 rv[4][4];
+        if (p.res) {
+            const bf16_t* Rr = p.res + pix0 * CI_C;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) rv[i][j] = *reinterpret_cast<const uint2*>(Rr + (int64_t)(wave * 64 + i * 16 + xm) * CI_C + j * 16 + g * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (patch + stride < p.n_patches) stage(patch + stride, buf ^ 1);      // (that buffer was last read before the barrier)
+        else {   // keep the count of the wait above: eight requests per wave and iteration (the last patch re-reads itself into the idle buffer)
+            stage(patch, buf ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned xb = xbase0 + buf * CP_X_STRIDE;
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8_t af[4], bfr[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) af[i] = *(lds_frag_ptr)(size_t)((xb + (unsigned)aoff[i][tap]) ^ (ks << 6));
+#pragma unroll
+                for (int j = 0; j < 4; j++) bfr[j] = *(lds_frag_ptr)(size_t)((boff[j] + tap * 8192) ^ (ks << 6));
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // swapped: D[n][m]
+            }
+        }
+        bf16_t* Y = (bf16_t*)p.y + pix0 * CI_C;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float v[4] = {acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1], acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3]};
+                if (p.res) {
+                    v[0] += __uint_as_float(rv[i][j].x << 16); v[1] += __uint_as_float(rv[i][j].x & 0xffff0000u);
+                    v[2] += __uint_as_float(rv[i][j].y << 16); v[3] += __uint_as_float(rv[i][j].y & 0xffff0000u);
+                }
+                uint2 o;
+                o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]);
+                *reinterpret_cast<uint2*>(Y + (int64_t)(wave * 64 + i * 16 + xm) * CI_C + j * 16 + g * 4) = o;
+            }
+        buf ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------------------------------------------- wgrad
 // gp[o, n] += sum_pix dY[pix, o] * G[pix, n],  G[pix, tap*64 + c] = X[pix + s(tap), c].  Tile: M = 64 outputs (one M-major sub-tile,
 // half used), N = 128 columns = taps 2 tn, 2 tn + 1 (the fifth tile holds tap 8 only), k-tiles of 64 pixels (a quarter patch).
@@ -318,6 +460,18 @@ extern "C" int db1_conv3x3_implicit_fwd_res(const void* x, const void* w_op, con
         hipFuncSetAttribute((const void*)conv_implicit_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CI_STAGE_BYTES);
     });
     hipStream_t st = (hipStream_t)stream;
+    if (db1_knob(DB1_KNOB_CONV_PATCH, 1)) {     // (A/B knob "conv_patch": 0 = the nine-k-step tile form above)
+        static Db1PerDeviceOnce attr_patch;
+        attr_patch.run([] {
+            hipFuncSetAttribute((const void*)conv_patch_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
+            hipFuncSetAttribute((const void*)conv_patch_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
+        });
+        const unsigned grid = (unsigned)(n_patches < 256 ? n_patches : 256);     // one persistent workgroup per CU
+        if (bias && dtBias == DB1_BF16) conv_patch_kernel<bf16_t><<<grid, 256, CP_LDS, st>>>(a);
+        else conv_patch_kernel<float><<<grid, 256, CP_LDS, st>>>(a);
+        DB1_CHECK_LAUNCH("conv3x3_implicit_fwd (patch-resident)");
+        return DB1_OK;
+    }
     if (bias && dtBias == DB1_BF16) conv_implicit_kernel<bf16_t><<<(unsigned)n_patches, 256, 2 * CI_STAGE_BYTES, st>>>(a);
     else conv_implicit_kernel<float><<<(unsigned)n_patches, 256, 2 * CI_STAGE_BYTES, st>>>(a);
     DB1_CHECK_LAUNCH("conv3x3_implicit_fwd");

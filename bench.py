@@ -648,7 +648,8 @@ def main():
         from bdm_db1_amd.engine import init_distributed
         init_distributed(dist_backend=backend)   # "nccl" is RCCL on ROCm: one process per GPU over xGMI, high-priority comm stream
 
-    from bdm_db1_amd import TransformerXL, initialize, mpu, ops, synth
+    from bdm_db1_amd import TransformerXL, initialize, lib, mpu, ops, synth
+    lib.apply_env_knobs()      # (A/B runs only: DB1_* dispatcher knobs of include/db1_hip_test.h; nothing is set in a default run)
     from types import SimpleNamespace
     if world > 1:
         mpu.initialize_model_parallel()

@@ -27,7 +27,7 @@ void db1_test_flash_fwd2(int on);
  * workspace split-K), "pp32_stages" (4 | 5), "linear_decode_splitk" (0 | 1: never split), "w4" (0: the 8-wave GEMM kernels, 2: 4-wave for NT
  * only), "flash_fwd2" (0: the compiled flash-forward loop), "flash_kv3" (0 / 1: force 16 / 32 keys per wave in the key-side backward; -1 or unset: 32 from 512 workgroups on), "conv_wgrad_ks",
  * "geglu_epi" (0: db1_gemm_nt_geglu / db1_gemm_nn_geglu_bwd run as separate GEMM + activation launches at every shape), "gemm_halfwave" (k-tiles
- * per slice from which half-wave outputs are split in two), "w4n" (0: no 256 x 128 tiles of the 4-wave GEMM; 1 / 2 / 3: see gemm.hip).
+ * per slice from which half-wave outputs are split in two), "w4n" (0: no 256 x 128 tiles of the 4-wave GEMM; 1 / 2 / 3: see gemm.hip), "conv_patch" (0: the 3x3 convolutions' forward / data gradient as nine k-steps of a tile GEMM instead of the patch-resident kernel).
  * Returns 0, or DB1_ERR_BAD_SHAPE for an unknown name. */
 int db1_test_set_knob(const char* name, int value);
 void db1_test_clear_knobs(void);

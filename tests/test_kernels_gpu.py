@@ -934,6 +934,38 @@ def test_implicit_3x3_convolutions(ops):
     assert torch.equal(gp2, gp) and torch.equal(gb2, gb)       # fixed-order partial sums: bit-reproducible
 
 
+@pytest.mark.parametrize("N", [3, 256, 700])
+def test_patch_resident_convolution_equals_the_tile_form(ops, N):
+    """round 6: db1_conv3x3_implicit_fwd's default kernel keeps a patch (and the whole weight operand) in LDS and reads the nine taps as nine
+    row addresses into it; one persistent workgroup per CU walks the patches through two image buffers.  Same products in the same order
+    as the nine-k-step tile form (knob conv_patch = 0): bit-identical outputs -- forward with bias, with bias + residual, data gradient --
+    for fewer patches than CUs, exactly one each, and several per workgroup (incl. the idle re-stage behind a workgroup's last patch)."""
+    from bdm_db1_amd import lib as db1lib
+    rng = np.random.default_rng(77 + N)
+    x = dev16(rng.standard_normal((N * 256, 64)))
+    w = dev16(rng.standard_normal((64, 64, 3, 3)) * 0.1)
+    bias = dev16(rng.standard_normal(64))
+    res = dev16(rng.standard_normal((N * 256, 64)))
+    w_op, w_t = (torch.empty(64, 576, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    ops.conv_weight_permute(w, w_op, 64, 64)
+    ops.conv_weight_permute_t(w, w_t, 64, 64)
+    outs = {}
+    for knob in (0, 1):
+        db1lib.set_knob("conv_patch", knob)
+        try:
+            y0, y1, y2 = (torch.full((N * 256, 64), float("nan"), device=DEV, dtype=torch.bfloat16) for _ in range(3))
+            ops.conv3x3_implicit_fwd(x, w_op, bias, y0, N, sign=1)
+            ops.conv3x3_implicit_fwd(x, w_op, bias, y1, N, sign=1, res=res)
+            ops.conv3x3_implicit_fwd(x, w_t, None, y2, N, sign=-1)
+            ops.conv3x3_implicit_fwd(x, w_op, bias.float(), y0.clone(), N, sign=1)     # (fp32 bias instantiation runs)
+            outs[knob] = (y0, y1, y2)
+        finally:
+            db1lib.load().db1_test_clear_knobs()
+    for a, b_, name in zip(outs[1], outs[0], ("fwd + bias", "fwd + bias + residual", "data gradient")):
+        assert torch.isfinite(a.float()).all(), name
+        assert torch.equal(a.view(torch.int16), b_.view(torch.int16)), f"patch-resident {name} differs from the tile form (N = {N})"
+
+
 def test_conv1_fused_kernel_equals_im2col_plus_gemm(ops):
     """db1_conv1_fused_fwd (3 -> 64 channels on 16 x 16 patches, channels-last): its column matrix is bit-equal to db1_im2col3x3_nhwc's and its
     output equals the K = 32 GEMM over that matrix up to the bf16 rounding of the result"""
