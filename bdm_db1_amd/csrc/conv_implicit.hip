@@ -150,6 +150,10 @@ __device__ __forceinline__ void cp_glds16(const void* src, unsigned dst_lds) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst_lds) : "memory");
 }
+// (Measured and dropped, same box, 60 160 patches: the weight fragments in REGISTERS for the workgroup's whole walk instead of in LDS -- half the
+// fragment reads per MFMA -- 1322 -> 1580 us: hipcc parks the 288 registers in AGPRs and copies each one back before its MFMA, 235 moves per
+// patch; profiles/r06e_conv_patch_ab.txt.  What bounds the kernel is the one patch in flight per CU: 32 KB at a CU's share of HBM is ~1.7 us
+// plus the request latency, against 2.3 us of MFMAs -- 3.0 TB/s of the 5 a copy reaches; a third image buffer does not fit beside the weights.)
 template <typename TBIAS>
 __global__ __launch_bounds__(256, 1) void conv_patch_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
@@ -362,6 +366,108 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_implicit_kernel(ConvArgs p)
             *reinterpret_cast<float4*>(G + (int64_t)m * (9 * CI_C) + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
 }
+// ---------------------------------------------------------------------------------------------------------------------- wgrad, patch-resident
+// Round 6, the weight gradient in the same form: gp[o, tap*64 + c] += sum_pix dY[pix, o] * X[pix + s(tap), c] with k = the PIXEL index, so both
+// operands are read "against the grain" (ds_read_b64_tr_b16).  One persistent workgroup per CU keeps ALL of gp -- 64 x 576 fp32 = 144
+// accumulators per lane -- in registers over every patch it walks (wave w owns input channels 16 w .. 16 w + 15 of all nine taps and all 64
+// outputs: 36 MFMA tiles), and writes one partial slab at the end (added in workgroup order by conv_wgrad_reduce_kernel: deterministic).
+//   * X is staged into an 18 x 18 image whose border is zero (written once; the LDS-DMA only ever writes the 16 x 16 interior), so a tap is a
+//     constant address offset and no lane ever tests a bound; dY [256 pixels][64 outputs] as it is.  Two buffers each: patch k + 1 lands while
+//     patch k is contracted.  32-byte column blocks are XOR-swizzled with bit 1 of the pixel slot (source side, in the DMA's lane -> chunk
+//     map), which makes the four pixel rows of a 16-lane transpose read hit eight distinct bank groups, shifted or not.
+//   * per 32-pixel k-step a wave reads 4 dY fragments and 9 X fragments (26 transpose reads) for 36 + 1 MFMAs (the + 1: its share of the
+//     bias gradient, a ones operand against its dY fragment).
+// Bytes per patch: 64 KB read, nothing written.  The tile form above re-reads X nine times through L2 and pays a vmcnt(0) + barrier per
+// 64 pixels (2.7 ms per convolution at 60 160 patches).
+__device__ __forceinline__ bf16x8_t ot_select(const bf16x8_t (&yf)[4], int w) {   // (w is wave-uniform: scalar branches, no register indexing)
+    return w == 0 ? yf[0] : (w == 1 ? yf[1] : (w == 2 ? yf[2] : yf[3]));
+}
+#define WP_XB (18 * 18 * 128)                 // padded patch image: 41 472 B
+#define WP_DB (CI_HW * 128)
+#define WP_LDS (2 * WP_XB + 2 * WP_DB)
+__global__ __launch_bounds__(256, 1) void conv_wgrad_patch_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+    const unsigned xb0 = lds0, db0 = lds0 + 2 * WP_XB;
+    for (int o = tid * 16; o < 2 * WP_XB; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0u, 0u, 0u, 0u);   // the zero borders (and interiors, once)
+    const bf16_t* dY = p.w;
+    auto stage = [&](int64_t patch, int buf) {
+        const bf16_t* xp = p.x + patch * (CI_HW * CI_C);
+        const bf16_t* yp = dY + patch * (CI_HW * CI_C);
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int q = wave * 8 + it;                         // piece: 8 pixels of patch row q >> 1
+            const int y = q >> 1, x = (q & 1) * 8 + (lane >> 3);
+            const int slot = (y + 1) * 18 + 1 + x;               // pixel slot in the padded image
+            const int cx = (lane & 7) ^ (((slot >> 1) & 1) << 1);
+            cp_glds16(xp + (y * CI_P + x) * CI_C + cx * 8, xb0 + buf * WP_XB + ((y + 1) * 18 + 1 + (q & 1) * 8) * 128);
+            const int r = q * 8 + (lane >> 3);
+            const int cy = (lane & 7) ^ (((r >> 1) & 1) << 1);
+            cp_glds16(yp + r * CI_C + cy * 8, db0 + buf * WP_DB + q * 1024);
+        }
+    };
+    // lane-constant transpose-read addresses (k-step 0, buffer 0): a 16-lane group passes (pixel row kb + i16 / 4, 4 elements at column block + (i16 % 4) * 4)
+    const int prow = g * 8 + (i16 >> 2);                          // + 4 h: the lane's pixel inside a 32-pixel k-step
+    unsigned xoff[2][9], yoff[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int pm = prow + 4 * h, py = pm >> 4, px = pm & 15;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int slot = (py + tap / 3) * 18 + px + tap % 3;  // (y + 1 + dy) * 18 + (x + 1 + dx), dy = tap / 3 - 1, dx = tap % 3 - 1
+            xoff[h][tap] = xb0 + slot * 128 + ((wave ^ ((slot >> 1) & 1)) << 5) + (i16 & 3) * 8;
+        }
+#pragma unroll
+        for (int ot = 0; ot < 4; ot++) yoff[ot][h] = db0 + pm * 128 + ((ot ^ ((pm >> 1) & 1)) << 5) + (i16 & 3) * 8;
+    }
+    f32x4 acc[9][4], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int ot = 0; ot < 4; ot++) acc[t][ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    auto trfrag = [&](unsigned a0, unsigned a1) __attribute__((always_inline)) {
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(size_t)a0);
+        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(size_t)a1);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    const int64_t first = blockIdx.x, stride = gridDim.x;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the zeros are in place before the first image lands on top of them
+    if (first < p.n_patches) stage(first, 0);
+    int buf = 0;
+    for (int64_t patch = first; patch < p.n_patches; patch += stride) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this patch's two images have landed; everybody is done with the other pair
+        if (patch + stride < p.n_patches) stage(patch + stride, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned xo = buf * WP_XB, yo = buf * WP_DB;
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            bf16x8_t yf[4];
+#pragma unroll
+            for (int ot = 0; ot < 4; ot++) yf[ot] = trfrag(yoff[ot][0] + yo + ks * 4096, yoff[ot][1] + yo + ks * 4096);
+            accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, ot_select(yf, wave), accb, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const bf16x8_t xf = trfrag(xoff[0][t] + xo + ks * (36 * 128), xoff[1][t] + xo + ks * (36 * 128));
+#pragma unroll
+                for (int ot = 0; ot < 4; ot++) acc[t][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf[ot], acc[t][ot], 0, 0, 0);   // D[c][o]
+            }
+        }
+        buf ^= 1;
+    }
+    // this workgroup's partial slab: lane (i16 = output inside its tile, g) holds input channels 16 wave + 4 g .. + 3 of tap t
+    float* G = p.part + (int64_t)blockIdx.x * (CI_C * 9 * CI_C);
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int ot = 0; ot < 4; ot++)
+            *reinterpret_cast<float4*>(G + (int64_t)(ot * 16 + i16) * (9 * CI_C) + t * CI_C + wave * 16 + g * 4) =
+                make_float4(acc[t][ot][0], acc[t][ot][1], acc[t][ot][2], acc[t][ot][3]);
+    if (p.part_bias && g == 0) p.part_bias[(int64_t)blockIdx.x * CI_C + wave * 16 + i16] = accb[0];   // (every row of the ones product holds the same sums)
+}
+
 // gp[i] += sum over the pixel ranges of part[z][i], z in increasing order (deterministic)
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gp, int nz,
                                                                 const float* __restrict__ part_bias, float* __restrict__ gbias) {
@@ -478,6 +584,7 @@ extern "C" int db1_conv3x3_implicit_fwd_res(const void* x, const void* w_op, con
     return DB1_OK;
 }
 
+static int ci_wgrad_patch_grid(int64_t n_patches) { return (int)(n_patches < 256 ? n_patches : 256); }   // one persistent workgroup per CU
 static int ci_wgrad_ksplit(int64_t n_patches) {
     const int64_t nk = n_patches * (CI_HW / TBK);
     // 5 column tiles x ks pixel ranges workgroups, two per CU (64 KB of LDS each): 102 ranges = 510 workgroups are ONE round of the 512
@@ -488,7 +595,9 @@ static int ci_wgrad_ksplit(int64_t n_patches) {
     return ks;
 }
 extern "C" int64_t db1_conv3x3_implicit_wgrad_workspace_bytes(int64_t n_patches) {
-    return n_patches > 0 ? (int64_t)ci_wgrad_ksplit(n_patches) * (CI_C * 9 * CI_C + CI_C) * (int64_t)sizeof(float) : 0;
+    if (n_patches <= 0) return 0;
+    const int ks = ci_wgrad_ksplit(n_patches), wg = ci_wgrad_patch_grid(n_patches);      // partial slabs of either form (the A/B knob picks at call time)
+    return (int64_t)(ks > wg ? ks : wg) * (CI_C * 9 * CI_C + CI_C) * (int64_t)sizeof(float);
 }
 extern "C" int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, float* gbias_acc, int64_t n_patches, void* ws, int64_t ws_bytes,
                                           void* stream) {
@@ -496,7 +605,8 @@ extern "C" int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* 
     if (!dy || !x || !gp_acc || !db1_aligned16(dy) || !db1_aligned16(x)) DB1_FAIL(DB1_ERR_BAD_ALIGN, "conv3x3_implicit_wgrad: operands must be 16-byte aligned");
     ConvArgs a;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)dy; a.y = gp_acc; a.bias = nullptr; a.n_patches = n_patches; a.sign = 1;
-    const int ks = ci_wgrad_ksplit(n_patches);
+    const bool patch_form = db1_knob(DB1_KNOB_CONV_PATCH, 1) != 0;
+    const int ks = patch_form ? ci_wgrad_patch_grid(n_patches) : ci_wgrad_ksplit(n_patches);
     a.ksplit = ks;
     // per-range partial sums in the caller's workspace + a fixed-order reduce (bit-reproducible): there is no atomic form
     DB1_NEED_WS(ws, ws_bytes, db1_conv3x3_implicit_wgrad_workspace_bytes(n_patches), "conv3x3_implicit_wgrad");
@@ -504,8 +614,12 @@ extern "C" int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* 
     a.gbias = gbias_acc; a.res = nullptr;
     a.part_bias = gbias_acc ? a.part + (int64_t)ks * (CI_C * 9 * CI_C) : nullptr;
     static Db1PerDeviceOnce attr_once;
-    attr_once.run([] { hipFuncSetAttribute((const void*)conv_wgrad_implicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); });
-    conv_wgrad_implicit_kernel<<<dim3(5, 1, (unsigned)ks), 256, 4 * TILE_BYTES, (hipStream_t)stream>>>(a);
+    attr_once.run([] {
+        hipFuncSetAttribute((const void*)conv_wgrad_implicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+        hipFuncSetAttribute((const void*)conv_wgrad_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
+    });
+    if (patch_form) conv_wgrad_patch_kernel<<<dim3((unsigned)ks), 256, WP_LDS, (hipStream_t)stream>>>(a);
+    else conv_wgrad_implicit_kernel<<<dim3(5, 1, (unsigned)ks), 256, 4 * TILE_BYTES, (hipStream_t)stream>>>(a);
     DB1_CHECK_LAUNCH("conv3x3_implicit_wgrad");
     if (a.part) {
         conv_wgrad_reduce_kernel<<<(CI_C * 9 * CI_C + CI_C + 255) / 256, 256, 0, (hipStream_t)stream>>>(a.part, gp_acc, ks, a.part_bias, gbias_acc);

@@ -769,11 +769,9 @@ class TransformerXL(nn.Module):
             row_ids, col_ids = self._vision_position_ids(h0, w0, n_img)
         c.row_ids, c.col_ids = self._dev_ids(row_ids).reshape(-1), self._dev_ids(col_ids).reshape(-1)
         assert c.row_ids.numel() == N
-        tmp = self._new(N, d)
-        ops.embed_gather(self.W("vision_encoder.row_position_embeddings.weight"), c.row_ids, tmp)
-        ops.add(emb, tmp, emb)
-        ops.embed_gather(self.W("vision_encoder.col_position_embeddings.weight"), c.col_ids, tmp)
-        ops.add(emb, tmp, emb)
+        # emb += row_position_embeddings[row_ids] + col_position_embeddings[col_ids] (vision_embedding.py:170-178) in one pass over emb
+        ops.vision_pos_add(emb.view(N, d), self.W("vision_encoder.row_position_embeddings.weight"), self.W("vision_encoder.col_position_embeddings.weight"),
+                           c.row_ids, c.col_ids)
         c.N, c.C, c.n_img = N, C, n_img
         return emb.view(n_img, h0 * w0, d), c
 

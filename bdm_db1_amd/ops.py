@@ -477,6 +477,14 @@ def embed_gather(table, ids, out2d):
     lib.call("db1_embed_gather_fwd", P(table), P(ids), P(out2d), n, d, out2d.stride(0), table.shape[0], dt_code(table), dt_code(out2d), stream())
 
 
+def vision_pos_add(out2d, row_table, col_table, row_ids, col_ids):
+    """out[t] += row_table[row_ids[t]] + col_table[col_ids[t]] (db1_vision_pos_add)"""
+    n, d = out2d.shape
+    assert out2d.is_contiguous() and row_table.shape == col_table.shape and row_table.shape[1] == d and row_table.dtype == col_table.dtype
+    assert row_ids.dtype == torch.int64 and col_ids.dtype == torch.int64 and row_ids.numel() == n == col_ids.numel()
+    lib.call("db1_vision_pos_add", P(out2d), P(row_table), P(col_table), P(row_ids), P(col_ids), n, d, row_table.shape[0], dt_code(row_table), dt_code(out2d), stream())
+
+
 def embed_scatter_add(dout2d, ids, dtable_acc):
     n, d = dout2d.shape
     assert ids.dtype == torch.int64 and dtable_acc.dtype == torch.float32 and dout2d.stride(1) == 1

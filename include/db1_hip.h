@@ -220,6 +220,10 @@ int db1_cast(const void* x, void* y, int64_t n, int dtIn, int dtOut, void* strea
  * out[t, :] = table[ids[t], :] (zeros where ids[t] < 0)   (transformer_xl.py:627-629, 665, 677, 686) */
 int db1_embed_gather_fwd(const void* table, const int64_t* ids, void* out, int64_t n_tokens, int d,
                          int64_t ld_out, int64_t n_table_rows, int dtTable, int dtOut, void* stream);
+/* out[t, :] += row_table[row_ids[t], :] + col_table[col_ids[t], :]  (VisionEmbedding's position term, vision_embedding.py:117-180, added
+ * onto the patch embeddings in one pass; (out + row) + col in fp32, one rounding; ids outside the tables add nothing) */
+int db1_vision_pos_add(void* out, const void* row_table, const void* col_table, const int64_t* row_ids, const int64_t* col_ids, int64_t n,
+                       int d, int64_t n_table_rows, int dtTable, int dt, void* stream);
 /* dtable_acc[ids[t], :] += dout[t, :]; ids outside [0, n_table_rows) are skipped, as they read zeros in the forward.  Deterministic: no
  * float atomics -- the tokens are ordered by table row with a stable device radix sort (csrc/scatter.hip: the library's own LSD passes,
  * no vendor primitive) and every table row is written by the one wave that adds its tokens in token order.  d and ld_dout: multiples of

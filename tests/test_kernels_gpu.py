@@ -958,12 +958,56 @@ def test_patch_resident_convolution_equals_the_tile_form(ops, N):
             ops.conv3x3_implicit_fwd(x, w_op, bias, y1, N, sign=1, res=res)
             ops.conv3x3_implicit_fwd(x, w_t, None, y2, N, sign=-1)
             ops.conv3x3_implicit_fwd(x, w_op, bias.float(), y0.clone(), N, sign=1)     # (fp32 bias instantiation runs)
-            outs[knob] = (y0, y1, y2)
+            gp, gb = torch.full((64, 576), 0.5, device=DEV), torch.full((64,), -0.25, device=DEV)
+            ops.conv3x3_implicit_wgrad(res, x, gp, N, gbias_acc=gb)                    # (res plays dY)
+            gp2, gb2 = torch.full((64, 576), 0.5, device=DEV), torch.full((64,), -0.25, device=DEV)
+            ops.conv3x3_implicit_wgrad(res, x, gp2, N, gbias_acc=gb2)
+            assert torch.equal(gp, gp2) and torch.equal(gb, gb2), "the weight gradient is not run-to-run identical"
+            outs[knob] = (y0, y1, y2, gp, gb)
         finally:
             db1lib.load().db1_test_clear_knobs()
-    for a, b_, name in zip(outs[1], outs[0], ("fwd + bias", "fwd + bias + residual", "data gradient")):
+    for a, b_, name in zip(outs[1][:3], outs[0][:3], ("fwd + bias", "fwd + bias + residual", "data gradient")):
         assert torch.isfinite(a.float()).all(), name
         assert torch.equal(a.view(torch.int16), b_.view(torch.int16)), f"patch-resident {name} differs from the tile form (N = {N})"
+    # the weight / bias gradients: the same bf16 products, summed in another order in fp32 (per-workgroup partial slabs vs per-pixel-range ones)
+    for a, b_, name in zip(outs[1][3:], outs[0][3:], ("weight gradient", "bias gradient")):
+        ref = b_.double()
+        assert torch.isfinite(a).all() and float((a.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), f"patch-resident {name} (N = {N})"
+    # ... and against fp64 arithmetic on the bf16 operands, for the smallest case
+    if N == 3:
+        xs = x.double().view(N, 16, 16, 64)
+        xp = torch.zeros(N, 18, 18, 64, dtype=torch.float64, device=DEV)
+        xp[:, 1:17, 1:17] = xs
+        dyf = res.double().view(N * 256, 64)
+        want = torch.stack([dyf.t() @ xp[:, t // 3:t // 3 + 16, t % 3:t % 3 + 16].reshape(N * 256, 64) for t in range(9)], 1).reshape(64, 576) + 0.5
+        assert float((outs[1][3].double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_vision_position_add_and_vector_add(ops, dtype):
+    """db1_vision_pos_add (round 6): out += row_table[row_ids] + col_table[col_ids] in one pass (vision_embedding.py:170-178; it was two
+    gathers + two adds), fp32 sum (out + row) + col with one rounding; ids outside the table add nothing.  And db1_add's 16-byte form
+    (aligned, n a multiple of the vector) against its scalar form (odd n)."""
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(3)
+    N, d, V = 333, 512, 128
+    emb = torch.randn(N, d, generator=g).to(td).to(DEV)
+    rt, ct = torch.randn(V, d, generator=g).to(td).to(DEV), torch.randn(V, d, generator=g).to(td).to(DEV)
+    rid, cid = torch.randint(0, V, (N,), generator=g).to(DEV), torch.randint(0, V, (N,), generator=g).to(DEV)
+    rid[5], cid[7] = -1, V + 3
+    okr, okc = ((rid >= 0) & (rid < V)).unsqueeze(1), ((cid >= 0) & (cid < V)).unsqueeze(1)
+    want = ((emb.float() + torch.where(okr, rt.float()[rid.clamp(0, V - 1)], torch.zeros(1, device=DEV))) +
+            torch.where(okc, ct.float()[cid.clamp(0, V - 1)], torch.zeros(1, device=DEV))).to(td)
+    out = emb.clone()
+    ops.vision_pos_add(out, rt, ct, rid, cid)
+    assert torch.equal(out, want)
+    for n in (8 * 1000, 8 * 1000 + 3):
+        a, b = torch.randn(n, generator=g).to(td).to(DEV), torch.randn(n, generator=g).to(td).to(DEV)
+        y = torch.empty_like(a)
+        ops.add(a, b, y)
+        assert torch.equal(y, (a.float() + b.float()).to(td))
+        ops.add(a, b, a)      # in place
+        assert torch.equal(a, y)
 
 
 def test_conv1_fused_kernel_equals_im2col_plus_gemm(ops):

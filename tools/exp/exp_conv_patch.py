@@ -26,5 +26,8 @@ for rnd in range(2):
         t0 = timeit(lambda: ops.conv3x3_implicit_fwd(x, w_op, bias, y, N, sign=1))
         t1 = timeit(lambda: ops.conv3x3_implicit_fwd(x, w_op, bias, y, N, sign=1, res=res))
         t2 = timeit(lambda: ops.conv3x3_implicit_fwd(x, w_op, None, y, N, sign=-1))
+        gp = torch.zeros(64, 576, device=dev)
+        gbias = torch.zeros(64, device=dev)
+        t3 = timeit(lambda: ops.conv3x3_implicit_wgrad(res, x, gp, N, gbias_acc=gbias))
         gb = 2 * N * 256 * 64 * 2 / 1e9
-        print(f"round {rnd} conv_patch={knob}: fwd {t0:.0f} us ({gb / t0 * 1e6 / 1e3:.2f} TB/s)  fwd+res {t1:.0f} us  dgrad {t2:.0f} us   ({N} patches)")
+        print(f"round {rnd} conv_patch={knob}: fwd {t0:.0f} us ({gb / t0 * 1e6 / 1e3:.2f} TB/s)  fwd+res {t1:.0f} us  dgrad {t2:.0f} us  wgrad {t3:.0f} us   ({N} patches)")
