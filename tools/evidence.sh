@@ -24,6 +24,10 @@ cp gpurun_out/step_table.json $E/${TAG}_step_table.json; cp gpurun_out/step_tabl
 timeout 600 python bench.py --batch 4 --ga 16 --steps 4 --warmup 2 --no-cpu-baseline --no-decode > $E/${TAG}_bench_b4_ga16.json 2> $E/bench_b4.err </dev/null
 timeout 600 python bench.py --batch 4 --ga 16 --graph --steps 4 --warmup 2 --no-cpu-baseline --no-decode > $E/${TAG}_bench_b4_ga16_graph.json 2> $E/bench_b4g.err </dev/null
 timeout 600 python bench.py --batch 8 --ga 8 --graph --steps 4 --warmup 2 --no-cpu-baseline --no-decode > $E/${TAG}_bench_b8_ga8_graph.json 2> $E/bench_b8g.err </dev/null
+# round 6: ONE backward per optimizer step over the whole accumulation window (engine option defer_backward), forwards as hipGraph replays / eager
+timeout 600 python bench.py --batch 4 --ga 16 --graph --defer-backward --steps 4 --warmup 2 --no-cpu-baseline --no-decode --no-mixture --no-ga16 > $E/${TAG}_bench_b4_ga16_graph_window.json 2> $E/bench_b4gw.err </dev/null
+timeout 600 python bench.py --batch 4 --ga 16 --defer-backward --steps 4 --warmup 2 --no-cpu-baseline --no-decode --no-mixture --no-ga16 > $E/${TAG}_bench_b4_ga16_window.json 2> $E/bench_b4w.err </dev/null
+timeout 600 python bench.py --batch 8 --ga 8 --graph --defer-backward --steps 4 --warmup 2 --no-cpu-baseline --no-decode --no-mixture --no-ga16 > $E/${TAG}_bench_b8_ga8_graph_window.json 2> $E/bench_b8gw.err </dev/null
 if [ "$1" = "pmc" ]; then
   # PMC of the attention kernels (separate passes, no trace domains): matrix pipe, LDS conflicts, L2 hit rate, wave states
   bash tools/pmc_run.sh relattn_flash "flash 64" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" > /dev/null 2>&1
