@@ -313,6 +313,8 @@ class DB1Engine:
             ops.zero_segments(self.module.arena.grad, self._acc_segments)
         self.module._grad_fresh = True
         self.module._ctx = None
+        if getattr(self.module, "_win", None) is not None:      # (forwards recorded for a deferred backward belong to the interrupted window)
+            self.module._win.ctxs, self.module._win.n = [None] * self.module._win.ga, 0
         self.sync.handles, self.sync.launched = [], set()
         if state.get("dropout"):
             rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
