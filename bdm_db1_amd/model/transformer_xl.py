@@ -1789,6 +1789,13 @@ class TransformerXL(nn.Module):
                 return None
             return self._backward(grad_scale, layer_done_hook, flush_wgrads)
 
+    def free_backward_window(self):
+        """release the accumulation window's activation buffers (as large as a ga x micro-batch step keeps: 149 GiB at 16 x 4 x 1024 tokens of
+        DB1-1.3B) -- e.g. before a memory-hungry evaluation between training phases; the next training forward under defer_backward rebuilds
+        them.  Forwards recorded for a backward that has not run yet are dropped with them."""
+        self._win = None
+        self._ctx = None
+
     def _window_layer_ctx(self, i: int, n: int, B: int, L: int) -> _Ctx:
         win, H, D = self._win, self.n_head, self.d_head
         f = lambda k: win.full((k, i), n)
