@@ -230,9 +230,24 @@ def rescale_sub(x):
     return o + [nop(1), I(f"s_setpc_b64 {sr(S_RET, 2)}", "branch")]
 
 
+PACK = os.environ.get("FW3_PACK", "0") != "0"   # packed fp32 VALU (v_pk_fma_f32 / v_pk_add_f32: two elements per instruction, the same roundings).  Measured round 6, same box, B = 64: 311 instead of 327 instructions per iteration, bit-identical results, and 832-836 us against 816-822 us: SLOWER (a packed fp32 op takes two passes; the unpacked stream interleaves finer) -- off, profiles/r06h_flash_fwd3_pack.txt
+
+
 def exp_pairs(x, cur):
     return [[I(f"v_fma_f32 {R(cur + i)}, {R(cur + i)}, {sr(S_C2)}, {R(MC + x)}", "valu", {cur + i, MC + x}, {cur + i}),
              valu("v_exp_f32", cur + i, cur + i, kind="trans")] for i in range(8)]
+
+
+def exp_pk(x, cur):
+    """(s c2 + mc) of elements 2 j, 2 j + 1 as ONE v_pk_fma_f32: c2 is read twice from the low half of its (even-aligned) SGPR pair, mc of tile
+    x from half x of the (MC, MC + 1) register pair (op_sel picks the half for the low result, op_sel_hi for the high one)"""
+    sel = f"op_sel:[0,0,{x}] op_sel_hi:[1,0,{x}]"
+    return [I(f"v_pk_fma_f32 {R(cur + 2 * j, 2)}, {R(cur + 2 * j, 2)}, {sr(S_C2, 2)}, {R(MC, 2)} {sel}", "valu",
+              {cur + 2 * j, cur + 2 * j + 1, MC, MC + 1}, {cur + 2 * j, cur + 2 * j + 1}) for j in range(4)]
+
+
+def exps(x, cur):
+    return [valu("v_exp_f32", cur + i, cur + i, kind="trans") for i in range(8)]
 
 
 def cvt(x, cur):
@@ -265,6 +280,9 @@ def skew_reads(x, par):
 
 
 def next_scores(x, nxt):
+    if PACK:
+        return [I(f"v_pk_add_f32 {R(nxt + 2 * j, 2)}, {R(AS(x) + 2 * j, 2)}, {R(SK(x) + 2 * j, 2)}", "valu",
+                  {AS(x) + 2 * j, AS(x) + 2 * j + 1, SK(x) + 2 * j, SK(x) + 2 * j + 1}, {nxt + 2 * j, nxt + 2 * j + 1}) for j in range(4)]
     return [valu("v_add_f32", nxt + i, AS(x) + i, SK(x) + i) for i in range(8)]
 
 
@@ -368,8 +386,13 @@ def path_steady(r6):
     kr = k_reads(stg_a)
     items += [(0, softmax_top(0, S(0, cur))), (0, kr[0:4]), (1, softmax_top(1, S(1, cur))), (1, kr[4:8]), (2, ptr_steps())]
     # exp2 of block r-1: fma of element k beside exp of element k-1 (the dependent pair is never back to back), p~ pack two groups later
-    fe = [p for x in range(2) for p in exp_pairs(x, S(x, cur))]
-    exg = [[fe[0][0]]] + [[fe[k][0], fe[k - 1][1]] for k in range(1, 16)] + [[fe[15][1]]]
+    if PACK:   # pk[m] = elements 2 m, 2 m + 1 (element e = 8 x + i): group 2 m holds pk[m] beside the exp of element 2 m - 1, group 2 m + 1 the exp of 2 m
+        pk = [q for x in range(2) for q in exp_pk(x, S(x, cur))]
+        ex = [q for x in range(2) for q in exps(x, S(x, cur))]
+        exg = [[pk[0]]] + [([pk[k // 2]] if k % 2 == 0 else []) + [ex[k - 1]] for k in range(1, 16)] + [[ex[15]]]
+    else:
+        fe = [p for x in range(2) for p in exp_pairs(x, S(x, cur))]
+        exg = [[fe[0][0]]] + [[fe[k][0], fe[k - 1][1]] for k in range(1, 16)] + [[fe[15][1]]]
     cvs = {x: cvt(x, S(x, cur)) for x in range(2)}
     d = dma(r6)
     for k, grp in enumerate(exg):                                # slots 3 .. 19
@@ -402,7 +425,8 @@ def path_steady(r6):
     for x in range(2):
         bm = block_max(x, S(x, nxt))
         ns = next_scores(x, S(x, nxt))
-        items += [(35 + 2 * x, ns[0:4]), (36 + 2 * x, ns[4:8]), (37 + 2 * x, mask_block(x, S(x, nxt))),
+        h = len(ns) // 2
+        items += [(35 + 2 * x, ns[0:h]), (36 + 2 * x, ns[h:]), (37 + 2 * x, mask_block(x, S(x, nxt))),
                   (39 + 2 * x, bm[0:4]), (42 + 2 * x, bm[4:7]), (45 + 2 * x, bm[7:10])]
     seq += schedule(rel + smf + pv, items, f"steady{r6}")
     return seq + tail(6 + 3, r6)
@@ -415,8 +439,11 @@ def path_last(r6):
     for x in range(2):
         seq += softmax_top(x, S(x, cur))
     for x in range(2):
-        for p in exp_pairs(x, S(x, cur)):
-            seq += p
+        if PACK:
+            seq += exp_pk(x, S(x, cur)) + exps(x, S(x, cur))
+        else:
+            for p in exp_pairs(x, S(x, cur)):
+                seq += p
     seq += cvt(0, S(0, cur)) + cvt(1, S(1, cur)) + stores()
     for db in range(8):
         for x in range(2):
