@@ -31,6 +31,15 @@ struct FlashArgs {
     float scale;
 };
 
+// The fragment images (p~ kept by the forward; P / dS of the scratch mode): 1 KiB per (key block jb of 32, 16-query tile qt) and (batch, head),
+// [64 lanes][8] bf16.  A tile exists only on or below the causal diagonal (qt >= 2 jb: every window the kernels support is inside it), so the
+// tiles of a (batch, head) are stored as a TRIANGLE, key block major: index = qt + jb (NT - 1 - jb), NT = L / 16 -- row jb starts where row
+// jb - 1 ended, tiles of one key block stay adjacent in qt.  1056 instead of 2048 tiles at L = 1024: 25 instead of 49 GiB of kept
+// probabilities for DB1-1.3B at 64 x 1024 tokens (round 6).  A read of a tile above the diagonal (the key-side kernels' prefetch at the edge
+// of their walk) lands on some other tile of the same buffer: finite or NaN garbage that the edge blocks SELECT away, as before.
+static __host__ __device__ inline int64_t flash_pt_tiles(int L) { const int64_t nkb = L / FA_BK, nt = L / 16; return nkb * nt - nkb * (nkb - 1); }
+static __host__ __device__ inline int64_t flash_pt_index(int jb, int qt, int nt) { return (int64_t)qt + (int64_t)jb * (nt - 1 - jb); }
+
 // {lse[i0 .. i0+32), delta[i0 .. i0+32)} -> 64 floats in LDS, one 4-byte LDS-DMA per lane of ONE wave
 __device__ __forceinline__ void glds_stat(const float* lse, const float* delta, int i0, float* dst_lds, int lane) {
     const float* src = (lane < 32 ? lse : delta - 32) + i0 + lane;

@@ -80,8 +80,8 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int64_t sv_tile = (((int64_t)b * H + h) * (L / FA_BK) * (L / 16) + (iw / 16)) * 512 + lane * 8;   // + jb * (L / 16) * 512
-    const int64_t sv_step = (int64_t)(L / 16) * 512;
+    const int64_t sv_tile = (((int64_t)b * H + h) * flash_pt_tiles(L) + (iw / 16)) * 512 + lane * 8;   // + jb (NT - 1 - jb) * 512: the triangle of relattn_flash.h
+    const int sv_nt = L / 16;
     float* mrow = SAVE ? p.mblk + ((int64_t)b * H + h) * (L / FA_BK) * L + iw + a : nullptr;                   // + jb * L
     bool have_prev = false;  // did this wave process the previous key block?  (wave-uniform)
     auto block = [&](auto STG, auto PARC, int jb) __attribute__((always_inline)) {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_fwd_kernel(FlashArgs p) 
             for (int r = 0; r < 8; r++) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, mc)); l_i += s[r]; }
             const bf16x8_t pb = pack8(s);
             if (SAVE) {
-                *reinterpret_cast<bf16x8_t*>(p.pt + sv_tile + jb * sv_step) = pb;
+                *reinterpret_cast<bf16x8_t*>(p.pt + sv_tile + (int64_t)jb * (sv_nt - 1 - jb) * 512) = pb;
                 if (g == 0) mrow[(int64_t)jb * L] = -mc;
             }
 #pragma unroll
@@ -195,9 +195,9 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
     for (int t = 0; t < 2; t++) { dsw[t] = dw0 + a * W16_DP + (14 - kk16(t, g) / 2) * 4; W16_OPAQUE(dsw[t]); }
     dsr = dw0 + (lane >> 4) * W16_DP + (lane & 15) * 4;  // + it * 4 rows
     W16_OPAQUE(dsr);
-    // fragment image of tile (key block jb, query tile iw / 16): + jb * (L / 16) * 512 elements
-    const int64_t sv_tile = (((int64_t)b * p.H + h) * (p.L / FA_BK) * (p.L / 16) + (iw / 16)) * 512 + lane * 8;
-    const int64_t sv_step = (int64_t)(p.L / 16) * 512;
+    // fragment image of tile (key block jb, query tile iw / 16): + jb (NT - 1 - jb) * 512 elements (the triangle of relattn_flash.h)
+    const int64_t sv_tile = (((int64_t)b * p.H + h) * flash_pt_tiles(p.L) + (iw / 16)) * 512 + lane * 8;
+    const int sv_nt = p.L / 16;
 
     bf16x8_t fqu[4], fqv[4], fdo[4];
 #pragma unroll
@@ -291,13 +291,13 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q_kernel(FlashArgs p
                         ds[t * 4 + r] = ((j <= i) && (j > i - p.shift)) ? ds[t * 4 + r] : 0.f;
                     }
             }
-            if (SAVE) *reinterpret_cast<bf16x8_t*>(p.pbuf + sv_tile + jb * sv_step) = pack8(ds);
+            if (SAVE) *reinterpret_cast<bf16x8_t*>(p.pbuf + sv_tile + (int64_t)jb * (sv_nt - 1 - jb) * 512) = pack8(ds);
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) ds[t * 4 + r] = ds[t * 4 + r] * (acc_dp[t][r] - delta_a) * p.scale;
             const bf16x8_t db8 = pack8(ds);
-            if (SAVE) *reinterpret_cast<bf16x8_t*>(p.dsbuf + sv_tile + jb * sv_step) = db8;
+            if (SAVE) *reinterpret_cast<bf16x8_t*>(p.dsbuf + sv_tile + (int64_t)jb * (sv_nt - 1 - jb) * 512) = db8;
 #pragma unroll
             for (int db = 0; db < 8; db++) acc_dq[db] = MFMA16(kt[db], db8, acc_dq[db]);  // dq^T[d][query] += K^T . dS^T
             // dT: element 31 - key of row a; the pairs are (key+1, key) in memory order
@@ -387,8 +387,9 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q2_kernel(FlashArgs 
     const unsigned dwrow = dw0 + a * DTR_PITCH;            // ring row of this lane's query
     const unsigned drrow = dw0 + (lane >> 2) * DTR_PITCH;  // flush: row lane >> 2, 16-byte piece lane & 3
     for (int o = lane * 4; o < 16 * DTR_PITCH; o += 256) *(lds_u32_ptr)(size_t)(dw0 + o) = 0u;
-    const int64_t sv_tile = (((int64_t)b * H + h) * (L / FA_BK) * (L / 16) + (iw / 16)) * 512 + lane * 8;   // + jb * (L / 16) * 512
-    const int64_t sv_step = (int64_t)(L / 16) * 512;
+    const int64_t sv_tile = (((int64_t)b * H + h) * flash_pt_tiles(L) + (iw / 16)) * 512 + lane * 8;   // + jb (NT - 1 - jb) * 512
+    const int sv_nt = L / 16;
+    auto sv_off = [&](int jb) __attribute__((always_inline)) { return (int64_t)jb * (sv_nt - 1 - jb) * 512; };
     const int64_t mrow = ((int64_t)b * H + h) * (L / FA_BK) * L + iw + a;                                     // + jb * L
 
     bf16x8_t fdo[4];
@@ -419,10 +420,10 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q2_kernel(FlashArgs 
     if (jb_lo + 1 <= jb_hi) w16_stage_kv(sg, 1, wave);
     bf16x8_t ptq[2];   // p~ of the current / next block (slot = position in the loop & 1), m likewise
     float mq[2];
-    ptq[0] = Q2_NT_LOAD(reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + jb_lo * sv_step));
+    ptq[0] = Q2_NT_LOAD(reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + sv_off(jb_lo)));
     mq[0] = p.mblk[mrow + (int64_t)jb_lo * L];
     if (jb_lo + 1 <= jb_hi) {
-        ptq[1] = Q2_NT_LOAD(reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + (jb_lo + 1) * sv_step));
+        ptq[1] = Q2_NT_LOAD(reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + sv_off(jb_lo + 1)));
         mq[1] = p.mblk[mrow + (int64_t)(jb_lo + 1) * L];
     }
     f32x4 acc_dq[8];
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_q2_kernel(FlashArgs 
         const float m2 = mq[par];
         if (pf) {   // block jb+2: K / V tiles (two LDS-DMA pieces), then its p~ image and maxima into the slot just read
             w16_stage_kv(sg, (stg + 2) % W16_STAGES, wave);
-            ptq[par] = Q2_NT_LOAD(reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + (jb + 2) * sv_step));
+            ptq[par] = Q2_NT_LOAD(reinterpret_cast<const bf16x8_t*>(p.pt + sv_tile + sv_off(jb + 2)));
             mq[par] = p.mblk[mrow + (int64_t)(jb + 2) * L];
         }
         int cur_sure = 0;
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv2_kernel(FlashArgs
     const bf16_t* quptr = p.qu + ((int64_t)b * L + ib_lo * FA_BK + srow) * HD + h * FA_D + schunk;
     const bf16_t* doptr = p.dout + ((int64_t)b * L + ib_lo * FA_BK + srow) * HD + h * FA_D + schunk;
     // this wave copies image (key block j0 / 32 + (wave >> 1), query tile 2 ib + (wave & 1)); LDS chunk `lane` takes source chunk pos^-1 = pos
-    const int64_t img = ((((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + (wave >> 1)) * (L / 16) + 2 * ib_lo + (wave & 1)) * 512 +
+    const int64_t img = (((int64_t)b * H + h) * flash_pt_tiles(L) + flash_pt_index(j0 / FA_BK + (wave >> 1), 2 * ib_lo + (wave & 1), L / 16)) * 512 +
                         kv2_chunk_pos(lane, wave & 1) * 8;
     const bf16_t* pptr = (FACT ? p.pt : p.pbuf) + img;
     const bf16_t* sptr = p.dsbuf + img;
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(512, 1) void relattn_flash_bwd_kv3_kernel(FlashArgs
     const bf16_t* quptr = p.qu + ((int64_t)b * L + ib_hi * FA_BK + srow) * HD + h * FA_D + schunk;
     const bf16_t* doptr = p.dout + ((int64_t)b * L + ib_hi * FA_BK + srow) * HD + h * FA_D + schunk;
     // this wave copies the images (key block j0 / 32 + wave, query tiles 2 ib and 2 ib + 1): adjacent in memory
-    const int64_t img = ((((int64_t)b * H + h) * (L / FA_BK) + j0 / FA_BK + wave) * (L / 16) + 2 * ib_hi) * 512;
+    const int64_t img = (((int64_t)b * H + h) * flash_pt_tiles(L) + flash_pt_index(j0 / FA_BK + wave, 2 * ib_hi, L / 16)) * 512;
     const bf16_t* pptr0 = p.pt + img + kv2_chunk_pos(lane, 0) * 8;
     const bf16_t* pptr1 = p.pt + img + 512 + kv2_chunk_pos(lane, 1) * 8;
     const int64_t q_step = (int64_t)FA_BK * HD;
@@ -1069,8 +1070,11 @@ extern "C" int db1_relattn_flash_fwd(const void* qu, const void* qv, const void*
     return DB1_OK;
 }
 
+extern "C" int64_t db1_relattn_flash_probs_bytes(int B, int L, int H) {
+    return (B > 0 && H > 0 && L > 0 && (L % FA_BK) == 0) ? (int64_t)B * H * flash_pt_tiles(L) * 512 * (int64_t)sizeof(bf16_t) : 0;
+}
 extern "C" int64_t db1_relattn_flash_bwd_workspace_bytes(int B, int L, int H, int have_probs) {
-    const int64_t img = (int64_t)B * H * L * L * (int64_t)sizeof(bf16_t);   // one set of fragment images, [B*H][L/32][L/16][64][8] bf16
+    const int64_t img = (int64_t)B * H * flash_pt_tiles(L) * 512 * (int64_t)sizeof(bf16_t);   // one set of fragment images, [B*H][triangle of (key block, query tile)][64][8] bf16
     if (have_probs) return ((int64_t)B * H * (L / FA_BK) * L + 64) * (int64_t)sizeof(float);   // the factors f, [B*H][L/32][L] floats (+ the over-read of the last row)
     return 2 * img;                                                                                  // P and dS
 }
@@ -1129,7 +1133,7 @@ extern "C" int db1_relattn_flash_bwd(const void* qu, const void* qv, const void*
     if (ws && ws_bytes >= need && db1_aligned16(ws)) {
         // stored-probabilities backward: the query side leaves P and dS in the workspace, the key side is two contractions over them
         a.pbuf = (bf16_t*)ws;
-        a.dsbuf = a.pbuf + (int64_t)B * H * L * L;
+        a.dsbuf = a.pbuf + (int64_t)B * H * flash_pt_tiles(L) * 512;
         relattn_flash_bwd_q_kernel<true><<<grid, 512, W16_BQ_LDS, s>>>(a);
         DB1_CHECK_LAUNCH("relattn_flash_bwd_q");
         relattn_flash_bwd_kv2_kernel<false><<<grid, 512, KV2_LDS, s>>>(a);

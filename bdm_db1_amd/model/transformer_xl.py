@@ -490,7 +490,7 @@ class TransformerXL(nn.Module):
         key = (B, L, self.flash_probs_budget)
         mode = self._probs_mode_cache.get(key)
         if mode is None:
-            need = self.n_layer * B * self.n_head * L * (L * 2 + (L // 32) * 4)
+            need = self.n_layer * B * self.n_head * (ops.relattn_flash_probs_tiles(L) * 1024 + L * (L // 32) * 4)
             total = torch.cuda.get_device_properties(self.dev).total_memory
             # ... and only if it FITS beside what this process (weights, optimizer state, the data-parallel staging arena) and any other
             # process on the device already hold, plus the activations this shape keeps (~64 KB per token and layer) and the
@@ -954,7 +954,7 @@ class TransformerXL(nn.Module):
             lse = self._keep(("lse", i), B, H, Lq, dtype=torch.float32)
             probs = mblk = None
             if c is not None and self.use_flash_bwd and self._probs_mode(B * (self.bwd_window_ga if self._win_on else 1), Lq) == "forward":
-                probs = self._keep(("probs", i), B * H, Lq // 32, Lq // 16, 512)
+                probs = self._keep(("probs", i), B * H, ops.relattn_flash_probs_tiles(Lq), 512)    # (the causal triangle of (key block, query tile) images)
                 mblk = self._keep(("mblk", i), B * H, Lq // 32, Lq, dtype=torch.float32)
             ops.relattn_flash_fwd(qu, qv, qkv.view(B, Lk, 3, H, D), R, av, lse, B, Lq, H, D, shift, 1.0 / math.sqrt(D), probs=probs, mblk=mblk)
             if c is not None:

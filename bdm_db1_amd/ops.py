@@ -775,10 +775,28 @@ def relattn_flash_supported(B, L, H, D, dtype) -> bool:
     return bool(lib.load().db1_relattn_flash_supported(B, L, H, D, dt_code(dtype)))
 
 
+def relattn_flash_probs_tiles(L: int) -> int:
+    """1 KiB fragment images per (batch, head) of the kept probabilities: the tiles (key block of 32, 16-query tile) on or below the causal
+    diagonal, stored as a triangle (db1_relattn_flash_probs_bytes)"""
+    return int(lib.load().db1_relattn_flash_probs_bytes(1, int(L), 1)) // 1024
+
+
+def relattn_flash_probs_full(probs, L: int):
+    """(tests / tools) the triangle of kept-probability images [B*H, tiles, 512] expanded to [B*H, L/32, L/16, 512]; tiles above the causal
+    diagonal, which do not exist, read NaN"""
+    nkb, nt = L // 32, L // 16
+    full = torch.full((probs.shape[0], nkb, nt, 512), float("nan"), device=probs.device, dtype=probs.dtype)
+    for jb in range(nkb):
+        i0 = 2 * jb + jb * (nt - 1 - jb)
+        full[:, jb, 2 * jb:] = probs[:, i0:i0 + nt - 2 * jb]
+    return full
+
+
 def relattn_flash_fwd(qu, qv, qkv5, R, out, lse, B, L, H, D, shift, scale, probs=None, mblk=None):
     """qkv5: the packed activations viewed [B, L, 3, H, D]; k / v are addressed inside it by stride.
-    probs [B*H, L/32, L/16, 512] bf16 + mblk [B*H, L/32, L] f32 (optional): the unnormalised probabilities and their reference maxima,
-    kept for the stored-probabilities backward."""
+    probs [B*H, relattn_flash_probs_tiles(L), 512] bf16 + mblk [B*H, L/32, L] f32 (optional): the unnormalised probabilities (a triangle of
+    fragment images, see the header) and their reference maxima, kept for the stored-probabilities backward."""
+    assert probs is None or probs.numel() * 2 == int(lib.load().db1_relattn_flash_probs_bytes(B, L, H)), "probs: db1_relattn_flash_probs_bytes(B, L, H) bytes"
     k, v = qkv5[:, :, 1], qkv5[:, :, 2]
     vis = L * (L + 1) / 2 if shift >= L else (shift * (shift + 1) / 2 + (L - shift) * shift)   # visible (query, key) pairs
     _timed("flash_fwd", 3 * 2.0 * B * H * vis * D,   # (q+u).k, (q+v).R, P.v over the visible pairs (SURVEY 8d)

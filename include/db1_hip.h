@@ -353,8 +353,11 @@ int db1_relattn_flash_supported(int B, int L, int H, int D, int dt);
 /* qu = q + u, qv = q + v_bias: [B,L,H,D] contiguous (db1_relattn_add_head_bias); k, v: pointers INTO the packed
  * qkv activations with their row / batch strides in elements.
  * probs / mblk (optional, both or neither): keep the unnormalised probabilities p~ = exp2((s - m_blk) c2), c2 = scale log2 e, as bf16 MFMA
- * fragment images [B*H][L/32 key blocks][L/16 query tiles][64 lanes][8] and the running maxima m_blk c2 they refer to [B*H][L/32][L] f32,
- * for db1_relattn_flash_bwd (entries of blocks outside the window are not written). */
+ * fragment images [64 lanes][8] per (key block jb of 32, 16-query tile qt) and the running maxima m_blk c2 they refer to [B*H][L/32][L] f32,
+ * for db1_relattn_flash_bwd.  Only tiles on or below the causal diagonal exist (qt >= 2 jb); per (batch, head) they are stored as a triangle,
+ * key block major: tile index qt + jb (L/16 - 1 - jb) -- db1_relattn_flash_probs_bytes(B, L, H) bytes in all (round 6: 25 instead of 49 GiB
+ * for DB1-1.3B at 64 x 1024 tokens).  Tiles of blocks outside a sliding window are not written. */
+int64_t db1_relattn_flash_probs_bytes(int B, int L, int H);
 int db1_relattn_flash_fwd(const void* qu, const void* qv, const void* k, const void* v, int64_t kv_row_stride,
                           int64_t kv_batch_stride, const void* R, void* out, float* lse,
                           int B, int L, int H, int D, int shift, float scale, void* probs, float* mblk, void* stream);

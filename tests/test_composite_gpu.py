@@ -92,7 +92,7 @@ def test_relattn_composites_match_the_per_op_path_and_the_oracle(keep_probs):
 
     def composite():
         qu, qv, out, lse = new(B, L, H, D), new(B, L, H, D), new(B, L, H, D), new(B, H, L, dt=torch.float32)
-        probs = torch.full((B * H, L // 32, L // 16, 512), float("nan"), device=DEV, dtype=torch.bfloat16) if keep_probs else None
+        probs = torch.full((B * H, ops.relattn_flash_probs_tiles(L), 512), float("nan"), device=DEV, dtype=torch.bfloat16) if keep_probs else None
         mblk = torch.full((B * H, L // 32, L), float("nan"), device=DEV) if keep_probs else None
         lib.call("db1_relattn_fwd", ops.P(QKV), ops.P(U), ops.P(VB), ops.P(Rd), ops.P(qu), ops.P(qv), ops.P(out), ops.P(lse),
                  ops.P(probs) if keep_probs else vp0, ops.P(mblk) if keep_probs else vp0, B, L, H, D, L, scale, ops.stream())
@@ -109,7 +109,7 @@ def test_relattn_composites_match_the_per_op_path_and_the_oracle(keep_probs):
     def per_op():
         qu, qv, out, lse = new(B, L, H, D), new(B, L, H, D), new(B, L, H, D), new(B, H, L, dt=torch.float32)
         ops.relattn_add_head_bias(QKV, U, VB, qu, qv, B, L, L, H, D)
-        probs = torch.full((B * H, L // 32, L // 16, 512), float("nan"), device=DEV, dtype=torch.bfloat16) if keep_probs else None
+        probs = torch.full((B * H, ops.relattn_flash_probs_tiles(L), 512), float("nan"), device=DEV, dtype=torch.bfloat16) if keep_probs else None
         mblk = torch.full((B * H, L // 32, L), float("nan"), device=DEV) if keep_probs else None
         ops.relattn_flash_fwd(qu, qv, QKV, Rd, out, lse, B, L, H, D, L, scale, probs=probs, mblk=mblk)
         dqkv, dR = torch.full((B, L, 3, H, D), 3.0, device=DEV, dtype=torch.bfloat16), new(L, H, D)

@@ -134,7 +134,7 @@ def test_flash_backward_matches_oracle(B, L, H, shift, mode):
     lse = torch.empty(B, H, L, device=DEV, dtype=torch.float32)
     probs = mblk = None
     if mode == "fwd_probs":
-        probs = torch.full((B * H, L // 32, L // 16, 512), float("nan"), device=DEV, dtype=torch.bfloat16)
+        probs = torch.full((B * H, ops.relattn_flash_probs_tiles(L), 512), float("nan"), device=DEV, dtype=torch.bfloat16)
         mblk = torch.full((B * H, L // 32, L), float("nan"), device=DEV, dtype=torch.float32)
     ops.relattn_flash_fwd(qu, qv, QKV, Rd, out, lse, B, L, H, D, shift, scale, probs=probs, mblk=mblk)
     # the key side of the stored-probabilities backward has two kernels -- 32 keys per wave (L % 256 == 0 and enough workgroups: the
@@ -272,11 +272,11 @@ def test_hand_scheduled_forward_matches_compiled_loop(B, L, H, mode):
             ops.flash_fwd2(m)
             out = torch.full((B, L, H, D), 7.0, device=DEV, dtype=torch.bfloat16)
             lse = torch.full((B, H, L), 3.0, device=DEV, dtype=torch.float32)
-            probs = torch.full((B * H, L // 32, L // 16, 512), float("nan"), device=DEV, dtype=torch.bfloat16)
+            probs = torch.full((B * H, ops.relattn_flash_probs_tiles(L), 512), float("nan"), device=DEV, dtype=torch.bfloat16)
             mblk = torch.full((B * H, L // 32, L), float("nan"), device=DEV, dtype=torch.float32)
             ops.relattn_flash_fwd(qu, qv, QKV, Rd, out, lse, B, L, H, D, L, scale, probs=probs, mblk=mblk)
             torch.cuda.synchronize()
-            res.append((out.float().cpu(), lse.cpu(), probs.float().cpu(), mblk.cpu()))
+            res.append((out.float().cpu(), lse.cpu(), ops.relattn_flash_probs_full(probs, L).float().cpu(), mblk.cpu()))    # (the triangle of images, expanded)
     finally:
         ops.flash_fwd2(1)
 

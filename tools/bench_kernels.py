@@ -47,7 +47,7 @@ def flash(B=16, L=1024, H=16, D=128):
     unit = 2.0 * B * H * (L * (L + 1) / 2) * D  # one causal-counted L x L x D contraction
     t = timeit(lambda: ops.relattn_flash_fwd(qu, qv, qkv, R, out, lse, B, L, H, D, L, scale))
     print(f"flash fwd  B={B}: {t * 1e3:8.1f} us   {3 * unit / t / 1e9:7.1f} TFLOP/s algorithmic (3 contractions)")
-    probs = torch.empty(B * H, L // 32, L // 16, 512, device=DEV, dtype=torch.bfloat16)
+    probs = torch.empty(B * H, ops.relattn_flash_probs_tiles(L), 512, device=DEV, dtype=torch.bfloat16)
     mblk = torch.empty(B * H, L // 32, L, device=DEV, dtype=torch.float32)
     t = timeit(lambda: ops.relattn_flash_fwd(qu, qv, qkv, R, out, lse, B, L, H, D, L, scale, probs=probs, mblk=mblk))
     print(f"flash fwd  B={B} (+ stored p~): {t * 1e3:8.1f} us")

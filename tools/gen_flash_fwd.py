@@ -320,6 +320,7 @@ def stores():
     return [I(f"global_store_dwordx4 {vr(PP, 2)}, {vr(PB, 4)}, off", "vmem", set(rng(PB, 4)) | {PP, PP + 1}, ()),
             I(f"v_mul_f32 {vr(T0 + 6)}, {sr(S_C2)}, {vr(MI)}", "valu", {MI}, {T0 + 6}),
             I(f"v_lshl_add_u64 {vr(PP, 2)}, {vr(PP, 2)}, 0, {sr(S_PST, 2)}", "valu", {PP, PP + 1}, {PP, PP + 1}),
+            salu(f"s_sub_u32 {sr(S_PST)}, {sr(S_PST)}, 2048"),       # the p~ images are a triangle (relattn_flash.h): the row of the next key block is two tiles shorter
             salu("s_mov_b64 exec, 0xffff"),
             I(f"global_store_dword {vr(MP, 2)}, {vr(T0 + 6)}, off", "vmem", {MP, MP + 1, T0 + 6}, ()),
             salu("s_mov_b64 exec, -1"),
@@ -457,7 +458,7 @@ def path_steady(r6):
     skr = skew_reads(par)
     st = stores()
     fill = [lc[0:6] + vtr[0:2], lc[6:12] + vtr[2:4], sw[0:2] + vtr[4:6], sw[2:4] + vtr[6:8],
-            skr[0:4] + vtr[8:10], skr[4:8] + vtr[10:12], st[0:3] + vtr[12:14], st[3:7] + vtr[14:16]]
+            skr[0:4] + vtr[8:10], skr[4:8] + vtr[10:12], st[0:4] + vtr[12:14], st[4:8] + vtr[14:16]]
     seq += interleave(smf, fill, list(range(8)))
     # P.V MFMAs; behind them: the next block's scores, its mask (diagonal block only) and its maximum
     pv = [mfma(O + 4 * db, VT + 4 * db, PB, O + 4 * db) for db in range(8)]

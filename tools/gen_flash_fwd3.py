@@ -260,6 +260,7 @@ def stores():
     o = [I(f"global_store_dwordx4 {R(PP, 2)}, {R(PB(0), 4)}, off", "vmem", set(rng(PB(0), 4)) | {PP, PP + 1}, ()),
          I(f"global_store_dwordx4 {R(PP, 2)}, {R(PB(1), 4)}, off offset:1024", "vmem", set(rng(PB(1), 4)) | {PP, PP + 1}, ()),
          I(f"v_lshl_add_u64 {R(PP, 2)}, {R(PP, 2)}, 0, {sr(S_PST, 2)}", "valu", {PP, PP + 1}, {PP, PP + 1}),
+         salu(f"s_sub_u32 {sr(S_PST)}, {sr(S_PST)}, 2048"),       # the p~ images are a triangle (relattn_flash.h): the row of the next key block is two tiles shorter
          salu("s_mov_b64 exec, 0xffff"),
          I(f"v_mul_f32 {R(T0 + 14)}, {sr(S_C2)}, {R(MI)}", "valu", {MI}, {T0 + 14}),
          salu("s_mov_b64 exec, 0xffff0000"),
@@ -415,7 +416,7 @@ def path_steady(r6):
     for grp in d[4:6]:                                           # ring requests: the address VALU part and the scalar / issue part separately
         k = next(i for i, z in enumerate(grp) if z.kind == "salu")
         ring += [grp[:k], grp[k:]]
-    sts = [st[0:1], st[1:3], st[3:10], st[10:11]]               # (the exec window stays in one piece)
+    sts = [st[0:1], st[1:4], st[4:11], st[11:12]]               # (the exec window stays in one piece)
     for j in range(8):                                           # V^T fragments of d-block j: two slots ahead of their first MFMA at the latest
         items.append((24 + (3 * j) // 2, vtr[2 * j:2 * j + 2]))
         if j % 2 == 0:
