@@ -143,6 +143,48 @@ def test_layernorm_residual_with_fused_dropout(dtype, d):
     assert np.abs(dg.double().cpu().numpy() - (dy * xh).sum(0)).max() <= tol * np.abs((dy * xh).sum(0)).max() + 1e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,d", [("f32", 96), ("bf16", 2048)])
+def test_layernorm_backward_regenerates_dropout_by_row_block(dtype, d):
+    """round 6 (`drop_rows_per_step`): ONE LayerNorm backward over the rows of three micro-steps -- row r takes the keep decisions of step
+    step0 + r // rows_per_step, elements counted from the first row of its block -- against the ORACLE's mask function evaluated per
+    micro-step, and bit-for-bit against three calls on the row blocks (dr, ds; the parameter gradients to summation order).  Also on a
+    device step counter with a negative host offset, the form the boundary of a captured accumulation window uses."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bdm_db1_amd import ops
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    rng = np.random.default_rng(12)
+    ga, T, eps = 3, 20, 1e-5
+    rows = ga * T
+    s_ = _dev(rng.standard_normal((rows, d)), td)
+    dy = _dev(rng.standard_normal((rows, d)), td)
+    gam = _dev(1 + 0.1 * rng.standard_normal(d), td)
+    sq = s_.double()
+    mean = sq.mean(1).float().contiguous()
+    rstd = (1.0 / torch.sqrt(sq.var(1, unbiased=False) + eps)).float().contiguous()
+    site, seed, step0, p = O.site_of(1, 1), 4321, 17, 0.1
+    ds, dr = torch.empty_like(s_), torch.empty_like(s_)
+    dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    ops.layernorm_residual_bwd(dy, s_, gam, mean, rstd, ds, dg, db, dr_out=dr, drop=(p, seed, site, step0, None, T))
+    mask = np.concatenate([O.dropout_scale(T * d, p, seed, site, step0 + m).reshape(T, d) for m in range(ga)], 0)
+    dsq = ds.double().cpu().numpy()
+    assert np.array_equal(dr.double().cpu().numpy() == 0, (mask == 0) | (dsq == 0)), "keep decisions are not the per-micro-step ones"
+    assert np.abs(dr.double().cpu().numpy() - dsq * mask).max() <= (1e-6 if dtype == "f32" else 8e-3) * np.abs(dsq).max()
+    ds2, dr2 = torch.empty_like(s_), torch.empty_like(s_)
+    dg2, db2 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    for m in range(ga):
+        sl = slice(m * T, (m + 1) * T)
+        ops.layernorm_residual_bwd(dy[sl], s_[sl], gam, mean[sl], rstd[sl], ds2[sl], dg2, db2, dr_out=dr2[sl], drop=(p, seed, site, step0 + m))
+    assert torch.equal(ds, ds2) and torch.equal(dr, dr2)
+    assert float((dg - dg2).abs().max()) <= 1e-4 * float(dg2.abs().max()) and float((db - db2).abs().max()) <= 1e-4 * float(db2.abs().max())
+    # device counter = step of the LAST block; the host passes the distance back to the first one (modulo 2^32)
+    ctr = torch.tensor([step0 + ga - 1], dtype=torch.int32, device=DEV)
+    ds3, dr3 = torch.empty_like(s_), torch.empty_like(s_)
+    ops.layernorm_residual_bwd(dy, s_, gam, mean, rstd, ds3, torch.zeros(d, device=DEV), torch.zeros(d, device=DEV), dr_out=dr3, drop=(p, seed, site, -(ga - 1), ctr, T))
+    assert torch.equal(dr3, dr) and torch.equal(ds3, ds)
+
+
 def _build(name, over, dtype):
     from bdm_db1_amd import TransformerXL
     seed = 100 + list(CASES).index(name)

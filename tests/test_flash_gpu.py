@@ -252,6 +252,38 @@ def test_dq_r_stream_kernel_matches_the_batched_gemm(B, L, H):
     assert torch.equal(dqkv2[:, :, 0], dqkv[:, :, 0]) and torch.equal(du2, du) and torch.equal(dv2, dv)
 
 
+@pytest.mark.parametrize("B,L,H,ng", [(8, 256, 4, 4), (4, 1024, 16, 2), (16, 128, 16, 16)])
+def test_dq_r_stream_with_one_R_per_group_of_sequences(B, L, H, ng):
+    """db1_relattn_dqr_fused_groups (round 6): the batch is `ng` blocks of sequences and block g has its OWN R (every micro-step of an
+    accumulation window draws its own position-table dropout) -- one launch for all of them, bit-identical in dq to `ng` launches on the blocks
+    (every output row is the same MFMA sequence either way), the u / v column sums equal to summation order, and dq against fp32 arithmetic"""
+    from bdm_db1_amd import ops
+    D = 128
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + L + ng)
+    dT = (torch.randn(H, B, L, L, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    ii = torch.arange(L, device=DEV)
+    dT = (dT * (ii[None, :] <= ii[:, None]).to(torch.bfloat16)).contiguous()
+    # R of group g sits inside a larger [ng, layers = 3, L, H D] tensor (the model's batched r_net output): a strided [ng, L, H D] view
+    Rall = torch.randn(ng, 3, L, H * D, generator=g).to(torch.bfloat16).to(DEV)
+    Rg = Rall[:, 1]
+    assert ops.relattn_dqr_groups_supported(B, L, H, D, torch.bfloat16, ng)
+    dqkv = (torch.randn(B, L, 3, H, D, generator=g) * 0.3).to(torch.bfloat16).to(DEV)
+    dqkv2 = dqkv.clone()
+    dq_k = dqkv[:, :, 0].float().clone()
+    du, dv = torch.full((H * D,), 0.25, device=DEV), torch.full((H * D,), -0.5, device=DEV)
+    ops.relattn_dqr_fused_groups(dT, Rg, dqkv[:, :, 0], du, dv)
+    du2, dv2 = torch.full((H * D,), 0.25, device=DEV), torch.full((H * D,), -0.5, device=DEV)
+    Bm = B // ng
+    for k in range(ng):
+        ops.relattn_dqr_fused(dT[:, k * Bm:(k + 1) * Bm].contiguous(), Rg[k], dqkv2[k * Bm:(k + 1) * Bm, :, 0], du2, dv2)
+    assert torch.equal(dqkv, dqkv2), "one launch over the groups differs from a launch per group"
+    assert float((du - du2).abs().max()) <= 1e-4 * float(du2.abs().max()) and float((dv - dv2).abs().max()) <= 1e-3 * float(dv2.abs().max())
+    ref = torch.cat([torch.einsum("hbik,khd->bihd", dT[:, k * Bm:(k + 1) * Bm].float(), Rg[k].reshape(L, H, D).float()) for k in range(ng)], 0)
+    want = dq_k + ref
+    assert float((dqkv[:, :, 0].float() - want).abs().max() / want.abs().max()) < 6e-3
+    assert not ops.relattn_dqr_groups_supported(B, L, H, D, torch.bfloat16, 3)       # (3 divides neither B nor the head's workgroup count)
+
+
 @pytest.mark.parametrize("B,L,H", [(1, 128, 1), (2, 256, 2), (1, 384, 1), (1, 1024, 2)])
 @pytest.mark.parametrize("mode", [1, 2])
 def test_hand_scheduled_forward_matches_compiled_loop(B, L, H, mode):
