@@ -518,7 +518,10 @@ def rocprof_crosscheck(family_kernels_note: str):
     """the newest committed per-kernel table of a rocprofv3 kernel trace cut to the timed steps of THIS command (tools/prof_step.sh ->
     tools/prof_table.py -> profiles/r*_step_table.json): the same GEMM-family fraction, computed from the profiler's kernel durations"""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_table.json")))
+    import re
+    # rNN[x]_step_table.json only: tables of other workloads carry the workload in their name (r06k_rl_step_table.json)
+    cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_step_table.json"))
+                   if re.fullmatch(r"r\d+[a-z]?_step_table\.json", os.path.basename(f)))
     if not cands:
         return None
     try:
