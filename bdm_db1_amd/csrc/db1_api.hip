@@ -16,7 +16,7 @@ void db1_set_error(const char* fmt, ...) {
 static thread_local int g_knob_val[DB1_KNOB_COUNT];
 static thread_local bool g_knob_set[DB1_KNOB_COUNT];
 static const char* const g_knob_names[DB1_KNOB_COUNT] = {"gemm_tile", "gemm_splitk", "pp32_stages", "linear_decode_splitk", "w4",
-                                                         "flash_fwd2", "flash_kv3", "conv_wgrad_ks", "geglu_epi", "gemm_halfwave", "w4n", "conv_patch"};
+                                                         "flash_fwd2", "flash_kv3", "conv_wgrad_ks", "geglu_epi", "gemm_halfwave", "w4n", "conv_patch", "tri_split"};
 int db1_knob(int id, int dflt) { return (id >= 0 && id < DB1_KNOB_COUNT && g_knob_set[id]) ? g_knob_val[id] : dflt; }
 extern "C" int db1_test_set_knob(const char* name, int value) {
     for (int i = 0; i < DB1_KNOB_COUNT; i++)

@@ -26,7 +26,7 @@ void db1_set_error(const char* fmt, ...);
 // A/B knobs for measurements and parity tests (include/db1_hip_test.h: db1_test_set_knob): THREAD-LOCAL, unset by default, never read
 // from the environment -- the library has no process-level mutable state.  db1_knob(id, dflt) = the calling thread's value.
 enum Db1Knob { DB1_KNOB_GEMM_TILE = 0, DB1_KNOB_GEMM_SPLITK, DB1_KNOB_PP32_STAGES, DB1_KNOB_LINEAR_DECODE_SPLITK, DB1_KNOB_W4,
-               DB1_KNOB_FLASH_FWD2, DB1_KNOB_FLASH_KV3, DB1_KNOB_CONV_WGRAD_KS, DB1_KNOB_GEGLU_EPI, DB1_KNOB_GEMM_HALFWAVE, DB1_KNOB_W4N, DB1_KNOB_CONV_PATCH, DB1_KNOB_COUNT };
+               DB1_KNOB_FLASH_FWD2, DB1_KNOB_FLASH_KV3, DB1_KNOB_CONV_WGRAD_KS, DB1_KNOB_GEGLU_EPI, DB1_KNOB_GEMM_HALFWAVE, DB1_KNOB_W4N, DB1_KNOB_CONV_PATCH, DB1_KNOB_TRI_SPLIT, DB1_KNOB_COUNT };
 int db1_knob(int id, int dflt);
 
 #define DB1_FAIL(code, ...)           \

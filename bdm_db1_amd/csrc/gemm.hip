@@ -233,7 +233,7 @@ static GemmTileArgs tile_args(const GemmShape& g, const GemmPlan& pl) {
     t.M = g.M; t.N = g.N; t.K = g.K; t.lda = pl.lda; t.ldb = pl.ldb; t.ldc = g.c_rs;
     t.batch1 = g.batch1; t.a_bs0 = g.a_bs0; t.a_bs1 = g.a_bs1; t.b_bs0 = g.b_bs0; t.b_bs1 = g.b_bs1; t.c_bs0 = g.c_bs0; t.c_bs1 = g.c_bs1;
     t.alpha = 1.f; t.beta = g.beta; t.tiles_m = (g.M + TBM - 1) / TBM; t.tiles_n = (g.N + TBN - 1) / TBN; t.ksplit = 1;
-    t.tri_mode = g_tri_mode; t.tri_period = g_tri_period;
+    t.tri_mode = g_tri_mode; t.tri_period = g_tri_period; t.tri_walk = db1_knob(DB1_KNOB_TRI_SPLIT, 1) != 0;
     t.split_n = 0; t.Cu = nullptr; t.Cv = nullptr; t.bias_u = nullptr; t.bias_v = nullptr; t.ld_uv = 0;
     if (t.tri_mode == 2 && (t.tri_period <= 0 || (t.tri_period % TBK) || (g.K % t.tri_period))) t.tri_mode = 0;
     return t;
@@ -294,8 +294,16 @@ static GemmPlan gemm_plan(const GemmShape& g, bool aligned, int64_t ws_bytes) {
     if (tile_pref == 0 && splitk_on && g.batch1 == 1 && (pp_shape || (t256_shape && fb == 1)) && g.c_cs == 1) {
         const int64_t wg = pp_shape ? (int64_t)(M / 256) * (N / 256) * batch : (int64_t)(M / 256) * (N / TBN) * batch;
         int S = 0;
+        // structural-zero hint 2 on one column of tiles (the per-head dR, 64 tiles): the tile rows do 16 : 12 : 8 : 4 of the contraction, so
+        // one slice set that fills the chip (4 slices: 256 workgroups) waits for its heaviest row; with 8 slices and the heavy-first walk of the
+        // 4-wave kernel the light rows run behind the heavy ones (knob "tri_split": 0 = the plain rule)
+        const bool tri_shape = !pp_shape && (int64_t)(N / TBN) == 1 && db1_knob(DB1_KNOB_TRI_SPLIT, 1) == 1;   // (2: the walk alone)
+        const bool tri_rows = tri_shape && g_tri_mode == 2 && g_tri_period > 0;
+        // (the workspace query does not know the hint: it prices the shape as if it came with one -- the larger slice count)
+        const int64_t wg_cap = (tri_rows || (tri_shape && ws_bytes < 0)) ? 512 : 288;
         for (int cand = 8; cand >= 2; cand >>= 1)
-            if (wg * cand <= 288 && (K / TBK) % cand == 0 && (K / TBK) / cand >= 16) { S = cand; break; }   // (16: micro-batches of 4 sequences, K = 4096)
+            if (wg * cand <= wg_cap && (K / TBK) % cand == 0 && (K / TBK) / cand >= 16 && (!tri_rows || (K / cand) % g_tri_period == 0) &&
+                (ws_bytes < 0 || splitk_bytes(g, cand, M) <= ws_bytes)) { S = cand; break; }   // (16: micro-batches of 4 sequences, K = 4096)
         // half a wave of 256x256 tiles (128 of them) in two slices.  Round 1 measured the weight gradients of 64-sequence batches (ff2 dW: nothing
         // at K = 16 384, 1184 -> 978 us at K = 65 536).  Round 4, micro-batches of 4 sequences (T = 4096, tools/bench_kernels.py gemm 4, 4-wave
         // kernels): the data gradients with long contractions gain most -- dqkv NN K = 6144: 112 -> 92 us, dff1 NN K = 8192: 163 -> 119 us --, ff2 dW

@@ -27,6 +27,7 @@ struct GemmTileArgs {
     //   1: A[m, k] == 0 for k > m                      -> k-tiles beyond the tile's last row are skipped (dq_r = dT . R)
     //   2: A[m, k] == 0 for (k mod tri_period) < m     -> per period only the k-tiles from the tile's first row on (dR = dT^T . qv)
     int tri_mode, tri_period;
+    int tri_walk;   // mode 2 on one column of tiles: hand the tile rows out heaviest first (gemm_w4.hip; only read when tri_mode == 2)
     // head-bias epilogue of the attention input projection (ping-pong NT kernel only): columns n < split_n are written TWICE, as
     // acc + bias_u[n] to Cu and acc + bias_v[n] to Cv (row stride ld_uv) instead of to C: q + r_w_bias and q + r_r_bias straight from
     // the accumulators (db1_gemm_nt_headbias); 0 = off

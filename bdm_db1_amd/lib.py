@@ -84,7 +84,7 @@ def load():
 # the library itself).  Tuning scripts under tools/ keep their old switches by calling this once: DB1_W4=0 python tools/exp/exp_w4.py ...
 KNOB_ENV = {"DB1_GEMM_TILE": "gemm_tile", "DB1_GEMM_SPLITK": "gemm_splitk", "DB1_GEMM_PP32_STAGES": "pp32_stages",
             "DB1_LINEAR_DECODE_SPLITK": "linear_decode_splitk", "DB1_W4": "w4", "DB1_FLASH_FWD2": "flash_fwd2", "DB1_FLASH_KV3": "flash_kv3",
-            "DB1_CONV_WGRAD_KS": "conv_wgrad_ks", "DB1_GEGLU_EPI": "geglu_epi", "DB1_GEMM_HALFWAVE": "gemm_halfwave", "DB1_W4N": "w4n", "DB1_CONV_PATCH": "conv_patch"}
+            "DB1_CONV_WGRAD_KS": "conv_wgrad_ks", "DB1_GEGLU_EPI": "geglu_epi", "DB1_GEMM_HALFWAVE": "gemm_halfwave", "DB1_W4N": "w4n", "DB1_CONV_PATCH": "conv_patch", "DB1_TRI_SPLIT": "tri_split"}
 
 
 def set_knob(name: str, value: int):

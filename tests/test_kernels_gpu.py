@@ -226,6 +226,53 @@ def test_gemm_structural_zero_hint_by_period_at_model_length(ops):
     assert torch.equal(outs[1], outs[2])
 
 
+def test_gemm_structural_zero_hint_heavy_rows_first(ops):
+    """the per-head dR with its tile rows handed out heaviest first (the 4-wave kernel's walk for hint 2 on one column of tiles: the (row,
+    batch x slice) pair of a workgroup comes from its linear id, rows first): a bijection, so the same partial sums in the same slices as
+    the plain walk -- bit-identical outputs with the walk on (knob tri_split 1 / 2) and off (0) at equal slice counts, NaNs above the
+    diagonal never read, against the fp32 product; and the 8-slice rule (16 heads x 16 sequences: 64 tiles, 512 workgroups) against the
+    4-slice one to fp32 round-off of the partial sums"""
+    from bdm_db1_amd import lib as db1lib
+    rng = np.random.default_rng(29)
+    L, D = 1024, 128
+    i = np.arange(L)[:, None]; dd = np.arange(L)[None, :]
+
+    def run(H, B, dTd, qvd, knob, dtype):
+        db1lib.set_knob("tri_split", knob)
+        ops._ws_query_cache.clear()          # (the workspace query depends on the knob)
+        try:
+            dR = torch.full((L, H * D), float("nan"), device=DEV, dtype=dtype)
+            ops.gemm_batched(dTd.view(H, B * L, L).transpose(1, 2).unsqueeze(1), qvd.view(B * L, H, D).permute(1, 0, 2).unsqueeze(1),
+                             dR.view(L, H, D).permute(1, 0, 2).unsqueeze(1), tri=(2, L))
+            return dR
+        finally:
+            db1lib.load().db1_test_clear_knobs()
+            ops._ws_query_cache.clear()
+
+    H, B = 3, 8                              # 12 tiles x 8 slices either way (the plain rule takes 8 slices up to 36 tiles)
+    dT = (bf(rng.standard_normal((H, B, L, L))) * (dd <= i)).astype(np.float32)
+    qv = bf(rng.standard_normal((B, L, H, D))).astype(np.float32)
+    ref = np.einsum("hbik,bihd->khd", dT, qv, optimize=True)
+    dT[..., (i // 64) * 64 + 63 < (dd // 256) * 256] = np.nan
+    dTd, qvd = dev16(dT), dev16(qv)
+    outs = [run(H, B, dTd, qvd, k, torch.float32) for k in (0, 1, 2)]
+    close(outs[0].view(L, H, D), ref, 2e-5, name="dR, plain walk")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "the heavy-first walk changed the result"
+
+    H, B = 16, 16                            # the model's heads: 64 tiles; 8 slices of 2 sequences (walk) against 4 slices of 4
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    dTd = torch.randn(H, B, L, L, device=DEV, generator=g).to(torch.bfloat16)
+    dTd.masked_fill_(torch.from_numpy((dd > i)).to(DEV), 0)
+    dTd.masked_fill_(torch.from_numpy(((i // 64) * 64 + 63 < (dd // 256) * 256)).to(DEV), float("nan"))
+    qvd = torch.randn(B, L, H, D, device=DEV, generator=g).to(torch.bfloat16)
+    a, b_, c = (run(H, B, dTd, qvd, k, torch.float32) for k in (0, 1, 1))
+    assert torch.isfinite(a).all() and torch.isfinite(b_).all()
+    assert torch.equal(b_, c), "two runs of the 8-slice form differ"
+    assert not torch.equal(a, b_), "the 8-slice rule did not apply (same bits as 4 slices)"
+    err = (a - b_).abs().max().item() / a.abs().max().item()
+    assert err < 5e-6, f"8 slices against 4: {err:.2e} of the largest value"
+
+
 @pytest.mark.parametrize("case", ["weight_grad", "per_head_batched"])
 def test_gemm_bf16_workspace_split_k(ops, case):
     """small outputs over a long contraction take the deterministic workspace split-K (partials + fixed-order reduce):
