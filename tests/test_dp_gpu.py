@@ -139,6 +139,23 @@ def test_two_ranks_rccl(reduce_dtype, tol):
     _two_ranks_vs_one("nccl", reduce_dtype, tol)
 
 
+def test_rccl_one_rank_runs_the_bucket_path():
+    """RCCL itself on the one GPU of the test box, ONE rank (`tools/rccl_one_rank.py`, its own process): the engine's initialiser
+    (high-priority communication stream, communicator bound to the device), then GradSync's bucket path against the real library -- bf16 staging
+    cast, async all-reduce, the per-bucket norm on the side stream behind the collective's stream-level wait, finish(), fp32 buckets, barrier --
+    with the world size reported as 2 so that nothing is skipped (a sum over one rank is the identity: the reduced copy must equal the cast
+    gradient bit for bit, the per-bucket norms their one-pass sum)"""
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_one_rank.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL one-rank path ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "backend nccl" in r.stdout
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun around it must start two ranks itself and print ONE JSON line from rank 0
     (the bare command exited non-zero).  Two GPUs -> RCCL; one GPU -> DB1_DIST_BACKEND=gloo with both ranks on it."""
