@@ -156,6 +156,62 @@ def test_rccl_one_rank_runs_the_bucket_path():
     assert "backend nccl" in r.stdout
 
 
+def _worker_one_rank_rccl(port, q, reduce_dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from bdm_db1_amd import engine as E, mpu
+    E.init_distributed(dist_backend="nccl")
+    mpu.initialize_model_parallel()
+    cfg, model = _make()
+    real = dist.get_world_size
+    dist.get_world_size = lambda group=None: 2          # (read while the engine is built: it plans buckets, staging and the 1 / world scale for two ranks)
+    try:
+        from bdm_db1_amd import initialize
+        engine, _, _, _ = initialize(SimpleNamespace(grad_reduce_dtype=reduce_dtype, **ARGS), model, mpu=mpu)
+    finally:
+        dist.get_world_size = real
+    assert engine.dp_world == 2 and engine.sync.world == 2 and engine.sync._side is not None
+    plain_backward = model.backward                      # the "other rank's" half: the one-rank sum is g where two ranks would deliver 2 g
+    model.backward = lambda grad_scale=1.0, **kw: plain_backward(grad_scale=2.0 * grad_scale, **kw)
+    engine.train()
+    losses = []
+    for _ in range(3):
+        logits, loss = engine([_batch(cfg, [0, 1, 2, 3])])
+        engine.backward(loss)
+        engine.step()
+        losses.append(float(loss))
+    q.put((losses, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, str(dist.get_backend())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("reduce_dtype,tol", [("fp32", 2e-4), ("bf16", 3e-3)])
+def test_engine_steps_over_rccl_with_one_rank(reduce_dtype, tol):
+    """three optimizer steps of the engine with its gradients going through RCCL itself (one rank on the box's one GPU, the world size read as 2
+    while the engine is built, so the hooks launch every bucket's all-reduce from the backward, the norm is taken per bucket behind the
+    collectives and Adam reads the reduced copy).  A sum over one rank is the gradient itself where two ranks would deliver twice that, so the
+    worker doubles the loss-gradient scale (exact in binary): clip, norm and Adam (a large eps: not scale-invariant) then see what the plain
+    single-rank run sees, and the parameters must follow it (the tolerances of the two-rank tests)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_one_rank_rccl, args=(_free_port(), q, reduce_dtype))
+    p.start()
+    losses, sd, backend = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and backend == "nccl"
+    cfg, model = _make()
+    ref_losses = _train(model, cfg, [0, 1, 2, 3])
+    ltol = 2e-5 if reduce_dtype == "fp32" else 2e-3
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) < ltol * max(1.0, abs(b)), (losses, ref_losses)
+    worst = 0.0
+    for k, v in model.state_dict().items():
+        ref = v.detach().cpu().numpy().astype(np.float64)
+        worst = max(worst, float(np.abs(sd[k] - ref).max() / (np.abs(ref).max() + 1e-30)))
+    assert worst < tol, f"parameters after 3 steps over RCCL differ from the plain single-rank run: {worst:.2e}"
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun around it must start two ranks itself and print ONE JSON line from rank 0
     (the bare command exited non-zero).  Two GPUs -> RCCL; one GPU -> DB1_DIST_BACKEND=gloo with both ranks on it."""
