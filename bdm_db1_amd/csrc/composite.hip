@@ -248,7 +248,7 @@ extern "C" int db1_patch_embed_bwd(const void* demb, const void* const* weights,
     CK(db1_colsum_acc(t1, grads[9], s.rows, 64, 64, bf, gws, gws_b, stream));
     CK(db1_conv_weight_permute_t(weights[8], wt, 64, 64, bf, bf, stream));
     CK(db1_conv3x3_implicit_fwd(t1, wt, nullptr, t2, s.N, -1, 0, stream));                  // t2 = da1
-    CK(db1_groupnorm_gelu_nhwc_bwd(t2, c2, weights[6], weights[7], m1, r1, t3, grads[6], grads[7], s.N, 64, hw, 32, bf, bf, gws, gws_b, stream));   // t3 = dc2
+    CK(db1_groupnorm_gelu_nhwc_bwd(t2, c2, weights[6], weights[7], m1, r1, t3, nullptr, grads[6], grads[7], s.N, 64, hw, 32, bf, bf, gws, gws_b, stream));   // t3 = dc2
     // conv2 (residual_path.2)
     if (hipMemsetAsync(gp, 0, 64 * 576 * 4, st) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "patch_embed_bwd: memset");
     CK(db1_conv3x3_implicit_wgrad(t3, a0, gp, nullptr, s.N, gws, gws_b, stream));
@@ -256,8 +256,7 @@ extern "C" int db1_patch_embed_bwd(const void* demb, const void* const* weights,
     CK(db1_colsum_acc(t3, grads[5], s.rows, 64, 64, bf, gws, gws_b, stream));
     CK(db1_conv_weight_permute_t(weights[4], wt, 64, 64, bf, bf, stream));
     CK(db1_conv3x3_implicit_fwd(t3, wt, nullptr, t2, s.N, -1, 0, stream));                  // t2 = da0
-    CK(db1_groupnorm_gelu_nhwc_bwd(t2, c1, weights[2], weights[3], m0, r0, t3, grads[2], grads[3], s.N, 64, hw, 32, bf, bf, gws, gws_b, stream));   // t3 = dc1 (GroupNorm branch)
-    CK(db1_add(t3, t1, t3, s.rows * 64, bf, stream));                                       // + the residual branch
+    CK(db1_groupnorm_gelu_nhwc_bwd(t2, c1, weights[2], weights[3], m0, r0, t3, t1, grads[2], grads[3], s.N, 64, hw, 32, bf, bf, gws, gws_b, stream));   // t3 = dc1: GroupNorm branch + the residual branch (t1) in one pass
     // conv1: weight / bias gradients only (the pixels need none)
     if (hipMemsetAsync(gp1, 0, 64 * s.kp1 * 4, st) != hipSuccess) DB1_FAIL(DB1_ERR_HIP, "patch_embed_bwd: memset");
     CK(db1_gemm_strided(t3, cols1, gp1, nullptr, 64, (int)s.kp1, (int)s.rows, bf, bf, DB1_F32, 0, 1, 64, s.kp1, 1, s.kp1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1.f, 1.f, gws, gws_b, stream));

@@ -490,7 +490,8 @@ template <typename T, typename TP, bool BWD>
 __global__ __launch_bounds__(256) void gn_gelu_nhwc_kernel(const T* __restrict__ x, const T* __restrict__ dy, const TP* __restrict__ gamma,
                                                            const TP* __restrict__ beta, T* __restrict__ out, float* __restrict__ mean,
                                                            float* __restrict__ rstd, float* dgamma, float* dbeta, int cpg, float eps,
-                                                           float* __restrict__ pgrad) {   // bwd: per-sample (dgamma | dbeta) rows [N][128], or null (atomics)
+                                                           float* __restrict__ pgrad,     // bwd: per-sample (dgamma | dbeta) rows [N][128]
+                                                           const T* __restrict__ res) {   // bwd: added to dx in fp32 before the one rounding (the residual branch's gradient), or null
     __shared__ float part[256][8];
     __shared__ float stat[2][GNV_C];   // per channel: (mean, rstd) fwd / (c1, c2) bwd, replicated over the channels of a group
     const int t = threadIdx.x, chunk = t & 7, prow = t >> 3;
@@ -598,11 +599,16 @@ __global__ __launch_bounds__(256) void gn_gelu_nhwc_kernel(const T* __restrict__
         }
         __syncthreads();
         T* dxs = out + n * GNV_HW * GNV_C + chunk * 8;
+        const T* rss = res ? res + n * GNV_HW * GNV_C + chunk * 8 : nullptr;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            Vec16<T> o;
+            Vec16<T> o, r;
+            if (rss) r.load(rss + (int64_t)(prow + 32 * k) * GNV_C);
 #pragma unroll
-            for (int j = 0; j < 8; j++) o.v[j] = rs[j] * (dh[k][j] * gm[j] - cg[0][chunk * 8 + j] - v[k][j] * cg[1][chunk * 8 + j]);
+            for (int j = 0; j < 8; j++) {
+                const float g = rs[j] * (dh[k][j] * gm[j] - cg[0][chunk * 8 + j] - v[k][j] * cg[1][chunk * 8 + j]);
+                o.v[j] = rss ? g + (float)r.v[j] : g;
+            }
             o.store(dxs + (int64_t)(prow + 32 * k) * GNV_C);
         }
     }
@@ -612,8 +618,8 @@ extern "C" int db1_groupnorm_gelu_nhwc_fwd(const void* x, const void* gamma, con
     if (dt != DB1_BF16 || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "groupnorm_gelu_nhwc_fwd: bf16 activations only");
     if (N <= 0 || C != GNV_C || hw != GNV_HW || groups <= 0 || C % groups) DB1_FAIL(DB1_ERR_UNSUPPORTED, "groupnorm_gelu_nhwc_fwd: needs C=64, hw=256 (got %d, %d)", C, hw);
     hipStream_t st = (hipStream_t)stream;
-    if (dtParam == DB1_BF16) gn_gelu_nhwc_kernel<bf16_t, bf16_t, false><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, nullptr, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, mean, rstd, nullptr, nullptr, C / groups, eps, nullptr);
-    else gn_gelu_nhwc_kernel<bf16_t, float, false><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, nullptr, (const float*)gamma, (const float*)beta, (bf16_t*)y, mean, rstd, nullptr, nullptr, C / groups, eps, nullptr);
+    if (dtParam == DB1_BF16) gn_gelu_nhwc_kernel<bf16_t, bf16_t, false><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, nullptr, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, mean, rstd, nullptr, nullptr, C / groups, eps, nullptr, nullptr);
+    else gn_gelu_nhwc_kernel<bf16_t, float, false><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, nullptr, (const float*)gamma, (const float*)beta, (bf16_t*)y, mean, rstd, nullptr, nullptr, C / groups, eps, nullptr, nullptr);
     DB1_CHECK_LAUNCH("groupnorm_gelu_nhwc_fwd");
     return DB1_OK;
 }
@@ -621,7 +627,7 @@ extern "C" int64_t db1_groupnorm_gelu_nhwc_bwd_workspace_bytes(int64_t N) {   //
     return N > 0 ? ((N * 2 * GNV_C * (int64_t)sizeof(float) + 255) & ~(int64_t)255) + db1_colsum_acc_workspace_bytes(N, 2 * GNV_C) : 0;
 }
 extern "C" int db1_groupnorm_gelu_nhwc_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean, const float* rstd,
-                                           void* dx, float* dgamma_acc, float* dbeta_acc, int64_t N, int C, int hw, int groups, int dt,
+                                           void* dx, const void* res, float* dgamma_acc, float* dbeta_acc, int64_t N, int C, int hw, int groups, int dt,
                                            int dtParam, void* ws, int64_t ws_bytes, void* stream) {
     if (dt != DB1_BF16 || !db1_dt_ok(dtParam)) DB1_FAIL(DB1_ERR_UNSUPPORTED_DTYPE, "groupnorm_gelu_nhwc_bwd: bf16 activations only");
     if (N <= 0 || C != GNV_C || hw != GNV_HW || groups <= 0 || C % groups) DB1_FAIL(DB1_ERR_UNSUPPORTED, "groupnorm_gelu_nhwc_bwd: needs C=64, hw=256 (got %d, %d)", C, hw);
@@ -631,8 +637,8 @@ extern "C" int db1_groupnorm_gelu_nhwc_bwd(const void* dy, const void* x, const 
     const int64_t rows_b = (N * 2 * GNV_C * (int64_t)sizeof(float) + 255) & ~(int64_t)255;
     DB1_NEED_WS(ws, ws_bytes, db1_groupnorm_gelu_nhwc_bwd_workspace_bytes(N), "groupnorm_gelu_nhwc_bwd");
     float* pgrad = (float*)ws;
-    if (dtParam == DB1_BF16) gn_gelu_nhwc_kernel<bf16_t, bf16_t, true><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)dx, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma_acc, dbeta_acc, C / groups, 0.f, pgrad);
-    else gn_gelu_nhwc_kernel<bf16_t, float, true><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, (const float*)gamma, (const float*)beta, (bf16_t*)dx, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma_acc, dbeta_acc, C / groups, 0.f, pgrad);
+    if (dtParam == DB1_BF16) gn_gelu_nhwc_kernel<bf16_t, bf16_t, true><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)dx, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma_acc, dbeta_acc, C / groups, 0.f, pgrad, (const bf16_t*)res);
+    else gn_gelu_nhwc_kernel<bf16_t, float, true><<<(unsigned)N, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, (const float*)gamma, (const float*)beta, (bf16_t*)dx, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma_acc, dbeta_acc, C / groups, 0.f, pgrad, (const bf16_t*)res);
     if (pgrad) {
         DB1_CHECK_LAUNCH("groupnorm_gelu_nhwc_bwd");
         void* cws = (char*)ws + rows_b;

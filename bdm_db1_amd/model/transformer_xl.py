@@ -724,8 +724,8 @@ class TransformerXL(nn.Module):
         da0 = self._conv3x3_bwd_cl(dc2, c.cols2, pe + "residual_path.2.weight", pe + "residual_path.2.bias", N, 64, True)
         dc1 = self._new(N * hw, 64)
         ops.groupnorm_gelu_nhwc_bwd(da0, c.c1, self.W(pe + "residual_path.0.weight"), self.W(pe + "residual_path.0.bias"), c.m0, c.r0, dc1,
-                                    self.G(pe + "residual_path.0.weight"), self.G(pe + "residual_path.0.bias"), N, 64, hw)
-        ops.add(dc1, dy_cl, dc1)                               # residual branch
+                                    self.G(pe + "residual_path.0.weight"), self.G(pe + "residual_path.0.bias"), N, 64, hw,
+                                    res=dy_cl.view(N * hw, 64))    # + the residual branch's gradient, in the same pass
         self._conv3x3_bwd_cl(dc1, c.cols1, pe + "conv1.weight", pe + "conv1.bias", N, c.C, False)
 
     def _vision_fwd(self, pixels: torch.Tensor, row_ids=None, col_ids=None):

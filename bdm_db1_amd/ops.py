@@ -904,9 +904,11 @@ def groupnorm_gelu_nhwc_fwd(x, gamma, beta, y, mean, rstd, N, C, hw, groups=32, 
              dt_code(x), dt_code(gamma), stream())
 
 
-def groupnorm_gelu_nhwc_bwd(dy, x, gamma, beta, mean, rstd, dx, dgamma_acc, dbeta_acc, N, C, hw, groups=32):
+def groupnorm_gelu_nhwc_bwd(dy, x, gamma, beta, mean, rstd, dx, dgamma_acc, dbeta_acc, N, C, hw, groups=32, res=None):
+    """``res``: added to dx in fp32 before its rounding (the residual branch's gradient), instead of a separate add pass"""
+    assert res is None or (res.shape == dx.shape and res.dtype == dx.dtype and res.is_contiguous() and res.data_ptr() != dx.data_ptr())
     ws, wsn = _ws("db1_groupnorm_gelu_nhwc_bwd_workspace_bytes", (int(N),), x.device)   # per-sample rows, summed in a fixed order (no atomics)
-    lib.call("db1_groupnorm_gelu_nhwc_bwd", P(dy), P(x), P(gamma), P(beta), P(mean), P(rstd), P(dx), P(dgamma_acc), P(dbeta_acc),
+    lib.call("db1_groupnorm_gelu_nhwc_bwd", P(dy), P(x), P(gamma), P(beta), P(mean), P(rstd), P(dx), P(res) if res is not None else _vp(0), P(dgamma_acc), P(dbeta_acc),
              N, C, hw, groups, dt_code(x), dt_code(gamma), ws, wsn, stream())
 
 

@@ -447,8 +447,10 @@ int db1_conv3x3_implicit_wgrad(const void* dy, const void* x, float* gp_acc, flo
 int db1_groupnorm_gelu_nhwc_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                                 int64_t N, int C, int hw, int groups, float eps, int dt, int dtParam, void* stream);
 int64_t db1_groupnorm_gelu_nhwc_bwd_workspace_bytes(int64_t N);   /* per-sample parameter-gradient rows, summed in a fixed order (required) */
+/* res (nullable): a tensor of dx's shape added to dx in fp32 before its one rounding -- the gradient that reaches x past the block
+   (PatchEmbeddings' residual sum, vision_embedding.py:65-86), so that no separate add pass runs; res must not overlap dx */
 int db1_groupnorm_gelu_nhwc_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean,
-                                const float* rstd, void* dx, float* dgamma_acc, float* dbeta_acc,
+                                const float* rstd, void* dx, const void* res, float* dgamma_acc, float* dbeta_acc,
                                 int64_t N, int C, int hw, int groups, int dt, int dtParam, void* ws, int64_t ws_bytes, void* stream);
 /* layout shuffles between GEMM output [N*p*p, C] ("NHWC") and [N, C, p, p] ("NCHW") */
 int db1_nhwc_to_nchw(const void* x, void* y, int64_t N, int C, int hw, int dt, void* stream);

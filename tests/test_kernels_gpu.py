@@ -940,6 +940,13 @@ def test_channels_last_vision_kernels(ops):
     close(dxx.view(N, 256, 64), cl(dx_ref), 8e-3, name="gn+gelu dx (channels-last)")
     close(dga, dgam, 2e-4, name="gn dgamma (channels-last)")
     close(dbe, dbet, 2e-4, name="gn dbeta (channels-last)")
+    # ... with the residual branch's gradient added in the same pass (fp32, one rounding): parameter gradients unchanged bit for bit
+    resid = bf(rng.standard_normal((N, 64, 16, 16)))
+    dxr = torch.full((N * 256, 64), float("nan"), device=DEV, dtype=torch.bfloat16)
+    dga2, dbe2 = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    ops.groupnorm_gelu_nhwc_bwd(dev16(cl(dy)), dev16(cl(xg)), dev16(gam), dev16(bet), mean, rstd, dxr, dga2, dbe2, N, 64, 256, res=dev16(cl(resid)).view(N * 256, 64))
+    close(dxr.view(N, 256, 64), cl(dx_ref + resid), 6e-3, name="gn+gelu dx + residual (channels-last)")
+    assert torch.equal(dga, dga2) and torch.equal(dbe, dbe2)
 
 
 def test_implicit_3x3_convolutions(ops):
