@@ -346,7 +346,7 @@ static GemmPlan gemm_plan(const GemmShape& g, bool aligned, int64_t ws_bytes) {
     // to the 128x128 kernel for more workgroups made them 15-20 % slower, so form alone decides)
     // N a multiple of 128 but not of 256 with at least three quarters of a wave of 256 x 128 tiles: the 4-wave kernel's 256 x 128 form instead of the
     // 3-stage tile kernel (the per-head dR of an accumulation window, two batch levels, 1024 tiles: 404-409 -> 377-380 us with the heavy-first walk, profiles/r06q_dr_window_w4n.txt)
-    // (not under hint 1, which only the tile kernel honours: there the skipped k-tiles may hold anything)
+    // (not under hint 1: only the tile kernel skips those k-tiles -- half the product -- so that form stays where it is)
     if (w4n_shape && w4n_mode >= 3 && !pp_shape && wg128 >= 192 && g_tri_mode != 1) { pl.kind = GK_W4N; return pl; }
     const bool want256 = tile_pref == 256 || (tile_pref == 0 && fb == 1);
     if (want256 && t256_shape) { pl.kind = GK_TILE256; return pl; }
